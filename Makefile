@@ -1,0 +1,37 @@
+# Build recipes for the CMDA gfx950 kernel library, the CPU emulator build of the same
+# sources (test infrastructure) -- see __graft_entry__.build().
+ROCM      ?= /opt/rocm
+HIPCC     ?= $(ROCM)/bin/hipcc
+CLANGXX   ?= $(ROCM)/lib/llvm/bin/clang++
+CSRC      := cmda_amd/csrc
+SRCS      := $(wildcard $(CSRC)/*.hip)
+HIP_OBJS  := $(patsubst $(CSRC)/%.hip,build/hip/%.o,$(SRCS))
+EMU_OBJS  := $(patsubst $(CSRC)/%.hip,build/emu/%.o,$(SRCS)) build/emu/hip_emu.o
+HIPFLAGS  := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$(CSRC) -Iinclude -Wno-unused-result
+EMUFLAGS  := -x c++ -std=c++17 -O2 -g -fPIC -DCMDA_EMU -Itests/emu -I$(CSRC) -Iinclude -pthread -ffp-contract=off -Wno-unknown-pragmas -Wno-pass-failed
+
+all: hip emu
+hip: cmda_amd/libcmda_hip.so
+emu: tests/emu/libcmda_emu.so
+
+build/hip/%.o: $(CSRC)/%.hip $(CSRC)/common.h
+	@mkdir -p build/hip
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+cmda_amd/libcmda_hip.so: $(HIP_OBJS)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(HIP_OBJS)
+
+build/emu/%.o: $(CSRC)/%.hip $(CSRC)/common.h tests/emu/hip_emu.h
+	@mkdir -p build/emu
+	$(CLANGXX) $(EMUFLAGS) -c $< -o $@
+
+build/emu/hip_emu.o: tests/emu/hip_emu.cpp tests/emu/hip_emu.h
+	@mkdir -p build/emu
+	$(CLANGXX) $(EMUFLAGS) -c $< -o $@
+
+tests/emu/libcmda_emu.so: $(EMU_OBJS)
+	$(CLANGXX) -shared -fPIC -pthread -o $@ $(EMU_OBJS)
+
+clean:
+	rm -rf build cmda_amd/libcmda_hip.so tests/emu/libcmda_emu.so
+.PHONY: all hip emu clean

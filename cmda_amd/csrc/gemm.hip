@@ -1,0 +1,297 @@
+// gemm.hip -- MFMA tile GEMM with implicit-im2col operand views and fused epilogues.
+//
+// One kernel family serves every dense contraction of the CMDA hot path (SURVEY.md K1,K3,K5,K6,K8,K10,K11,K16):
+//   nn.Linear q/kv/proj/fc1/fc2 fwd/dgrad/wgrad   mmseg/models/backbones/mix_transformer.py:31-44,62-66,80-102
+//   sr / patch-embed / ASPP / bottleneck convs     mix_transformer.py:73-76,169-173; decode_heads/daformer_head.py:63-79
+//   attention QK^T, PV and their gradients (batched, strided heads)   mix_transformer.py:97-101
+//   CycleGAN generator convs                       mmseg/models/cyclegan/cyclegan_model.py:339-374
+//
+// C[m,n] = epilogue( alpha * sum_k A(m,k) * B(n,k) ).  Each operand is a *view* V(r,c) that is either a plain
+// row-major matrix or an im2col view of an NHWC tensor (r = (b,oh,ow), c = (kh,kw,ci)); no im2col buffer is ever
+// materialised.  An operand is used either "K-contiguous" (r = free index, c = k) or "K-strided" (r = k, c = free
+// index): the LDS tile always keeps the view's natural orientation so HBM reads stay 16-byte coalesced, and the
+// K-strided bf16 fragments come out of LDS through ds_read_b64_tr_b16.
+//
+// gfx950 tiling: 256 threads = 4 waves (2x2); each wave owns (16*TM)x(16*TN) of the block tile as TMxTN MFMA
+// 16x16 accumulators; bf16 uses v_mfma_f32_16x16x32_bf16 (BK=32), f32 uses v_mfma_f32_16x16x4_f32 (BK=16, exact
+// fp32 -- the parity mode).  Global->register prefetch of tile k+1 overlaps the MFMAs of tile k.
+// Roofline: MFMA-bound for K,N >= 256; HBM-bound below (stage-1/2 Linear layers, C=64/128).
+#include "common.h"
+#include "../../include/cmda_hip.h"
+
+namespace {
+
+typedef cmda_view_t GemmView;
+typedef cmda_gemm_params_t GemmParams;
+
+static __device__ __forceinline__ int reflect_idx(int i, int n) {
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * (n - 1) - i;
+  return i;
+}
+
+// Returns the element offset of V(r, c) or -1 when the element is structural zero (padding / out of range).
+static __device__ __forceinline__ long view_offset(const GemmView& v, long r, long c) {
+  if (r >= v.R || c >= v.Cc) return -1;
+  if (!v.conv) return r * v.ld + c;
+  const int ohw = v.OH * v.OW;
+  const int b = (int)(r / ohw);
+  const int rem = (int)(r - (long)b * ohw);
+  const int oh = rem / v.OW;
+  const int ow = rem - oh * v.OW;
+  const int cell = (int)(c / v.C);
+  const int ci = (int)(c - (long)cell * v.C);
+  const int kh = cell / v.KW;
+  const int kw = cell - kh * v.KW;
+  int ih = oh * v.stride - v.pad + kh * v.dil;
+  int iw = ow * v.stride - v.pad + kw * v.dil;
+  if (v.in_dil > 1) {  // transposed conv: input is zero-inserted by in_dil
+    if (ih < 0 || iw < 0 || (ih % v.in_dil) || (iw % v.in_dil)) return -1;
+    ih /= v.in_dil;
+    iw /= v.in_dil;
+  }
+  if (v.reflect) {
+    ih = reflect_idx(ih, v.H);
+    iw = reflect_idx(iw, v.W);
+  } else if (ih < 0 || ih >= v.H || iw < 0 || iw >= v.W) {
+    return -1;
+  }
+  return ((long)(b * v.H + ih) * v.W + iw) * v.C + ci;
+}
+
+template <typename T>
+static __device__ __forceinline__ uint4 load_chunk(const GemmView& v, const T* base, long r, long c) {
+  constexpr int CH = Num<T>::kChunk;
+  uint4 out = make_uint4(0u, 0u, 0u, 0u);
+  if (r >= v.R || c >= v.Cc) return out;
+  if (v.vec_ok && c + CH <= v.Cc) {
+    const long off = view_offset(v, r, c);
+    if (off >= 0) out = *reinterpret_cast<const uint4*>(base + off);
+    return out;
+  }
+  T tmp[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) {
+    const long off = view_offset(v, r, c + j);
+    tmp[j] = off >= 0 ? base[off] : (T)0;
+  }
+  __builtin_memcpy(&out, tmp, 16);
+  return out;
+}
+
+template <typename T, int TM, int TN, bool AKS, bool BKS>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+  constexpr int CH = Num<T>::kChunk;
+  constexpr int BM = 32 * TM, BN = 32 * TN, BK = 4 * CH;
+  constexpr int ROWS_A = AKS ? BK : BM, COLS_A = AKS ? BM : BK, PITCH_A = COLS_A + CH;
+  constexpr int ROWS_B = BKS ? BK : BN, COLS_B = BKS ? BN : BK, PITCH_B = COLS_B + CH;
+  constexpr int CPR_A = COLS_A / CH, CPR_B = COLS_B / CH;
+  constexpr int NCH_A = ROWS_A * CPR_A / 256, NCH_B = ROWS_B * CPR_B / 256;
+  static_assert(NCH_A >= 1 && NCH_B >= 1, "tile too small for 256 threads");
+
+  __shared__ __attribute__((aligned(16))) T sA[ROWS_A * PITCH_A];
+  __shared__ __attribute__((aligned(16))) T sB[ROWS_B * PITCH_B];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int g = lane >> 4, l15 = lane & 15;
+
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int bt = blockIdx.x;
+  const long m0 = (long)(bt % tiles_m) * BM;
+  const long n0 = (long)(bt / tiles_m) * BN;
+  const int z = blockIdx.z;
+  const int batch = z / p.splits;
+  const int split = z - batch * p.splits;
+  const int nkt = (p.K + BK - 1) / BK;
+  const int kt_per = (nkt + p.splits - 1) / p.splits;
+  const int kt0 = split * kt_per;
+  const int kt1 = min(nkt, kt0 + kt_per);
+
+  const T* baseA = reinterpret_cast<const T*>(p.A.ptr) + (long)batch * p.A.batch_stride;
+  const T* baseB = reinterpret_cast<const T*>(p.B.ptr) + (long)batch * p.B.batch_stride;
+
+  uint4 ra[NCH_A], rb[NCH_B];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < NCH_A; ++i) {
+      const int id = tid + i * 256;
+      const int row = id / CPR_A, cc = id - row * CPR_A;
+      const long r = AKS ? (long)kt * BK + row : m0 + row;
+      const long c = AKS ? m0 + cc * CH : (long)kt * BK + cc * CH;
+      ra[i] = load_chunk<T>(p.A, baseA, r, c);
+    }
+#pragma unroll
+    for (int i = 0; i < NCH_B; ++i) {
+      const int id = tid + i * 256;
+      const int row = id / CPR_B, cc = id - row * CPR_B;
+      const long r = BKS ? (long)kt * BK + row : n0 + row;
+      const long c = BKS ? n0 + cc * CH : (long)kt * BK + cc * CH;
+      rb[i] = load_chunk<T>(p.B, baseB, r, c);
+    }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < NCH_A; ++i) {
+      const int id = tid + i * 256;
+      const int row = id / CPR_A, cc = id - row * CPR_A;
+      *reinterpret_cast<uint4*>(&sA[row * PITCH_A + cc * CH]) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NCH_B; ++i) {
+      const int id = tid + i * 256;
+      const int row = id / CPR_B, cc = id - row * CPR_B;
+      *reinterpret_cast<uint4*>(&sB[row * PITCH_B + cc * CH]) = rb[i];
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (kt0 < kt1) {
+    gload(kt0);
+    sstore();
+  }
+  __syncthreads();
+  for (int kt = kt0; kt < kt1; ++kt) {
+    if (kt + 1 < kt1) gload(kt + 1);  // in flight behind the MFMAs below
+    if constexpr (sizeof(T) == 2) {
+      u16x8 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int mr = wm * 16 * TM + i * 16;
+        if constexpr (!AKS) {
+          fa[i] = *reinterpret_cast<const u16x8*>(&sA[(mr + l15) * PITCH_A + 8 * g]);
+        } else {
+          const int q = l15 >> 2, pp = l15 & 3;
+          const u16x4 lo = lds_read_tr16(reinterpret_cast<const bf16_t*>(&sA[(8 * g + q) * PITCH_A + mr + 4 * pp]));
+          const u16x4 hi = lds_read_tr16(reinterpret_cast<const bf16_t*>(&sA[(8 * g + 4 + q) * PITCH_A + mr + 4 * pp]));
+          fa[i] = u16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int nr = wn * 16 * TN + j * 16;
+        if constexpr (!BKS) {
+          fb[j] = *reinterpret_cast<const u16x8*>(&sB[(nr + l15) * PITCH_B + 8 * g]);
+        } else {
+          const int q = l15 >> 2, pp = l15 & 3;
+          const u16x4 lo = lds_read_tr16(reinterpret_cast<const bf16_t*>(&sB[(8 * g + q) * PITCH_B + nr + 4 * pp]));
+          const u16x4 hi = lds_read_tr16(reinterpret_cast<const bf16_t*>(&sB[(8 * g + 4 + q) * PITCH_B + nr + 4 * pp]));
+          fb[j] = u16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16_16x16x32(fa[i], fb[j], acc[i][j]);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < BK / 4; ++ks) {
+        float fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int mr = wm * 16 * TM + i * 16;
+          fa[i] = AKS ? sA[(ks * 4 + g) * PITCH_A + mr + l15] : sA[(mr + l15) * PITCH_A + ks * 4 + g];
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int nr = wn * 16 * TN + j * 16;
+          fb[j] = BKS ? sB[(ks * 4 + g) * PITCH_B + nr + l15] : sB[(nr + l15) * PITCH_B + ks * 4 + g];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = mfma_f32_16x16x4(fa[i], fb[j], acc[i][j]);
+      }
+    }
+    __syncthreads();
+    if (kt + 1 < kt1) {
+      sstore();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: C/D map col = lane&15 (n), row = 4*(lane>>4)+r (m) ----
+  if (kt0 >= kt1 && p.splits > 1) return;  // empty split contributes nothing
+  const long cb = (long)batch * p.c_batch_stride;
+  const long rb_off = (long)batch * p.res_batch_stride;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const long n = n0 + wn * 16 * TN + j * 16 + l15;
+      if (n >= p.N) continue;
+      const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long m = m0 + wm * 16 * TM + i * 16 + 4 * g + r;
+        if (m >= p.M) continue;
+        float v = p.alpha * acc[i][j][r];
+        const long ci = cb + m * p.ldc + n;
+        if (p.atomic) {
+          atomicAdd(reinterpret_cast<float*>(p.C) + ci, v);
+          continue;
+        }
+        v += bias;
+        if (p.act == 1) v = fmaxf(v, 0.f);
+        else if (p.act == 2) v = gelu_erf(v);
+        if (p.rowscale) v *= p.rowscale[m / p.rows_per_scale];
+        if (p.res) v += ldf(reinterpret_cast<const T*>(p.res) + rb_off + m * p.ldres + n);
+        if (p.out_f32) {
+          float* cp = reinterpret_cast<float*>(p.C) + ci;
+          if (p.beta != 0.f) v += p.beta * *cp;
+          *cp = v;
+        } else {
+          T* cp = reinterpret_cast<T*>(p.C) + ci;
+          if (p.beta != 0.f) v += p.beta * ldf(cp);
+          stf(cp, v);
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int TM, int TN>
+int launch_tile(const GemmParams& p, void* stream) {
+  constexpr int BM = 32 * TM, BN = 32 * TN;
+  const long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  if (tiles > 0x7fffffffL || (long)p.batch * p.splits > 65535) return CMDA_ERR_SHAPE;
+  dim3 grid((unsigned)tiles, 1, (unsigned)(p.batch * p.splits));
+  const bool aks = p.a_kstrided != 0, bks = p.b_kstrided != 0;
+  if (!aks && !bks) CMDA_LAUNCH((gemm_kernel<T, TM, TN, false, false>), grid, dim3(256), 0, stream, p);
+  else if (!aks && bks) CMDA_LAUNCH((gemm_kernel<T, TM, TN, false, true>), grid, dim3(256), 0, stream, p);
+  else if (aks && bks) CMDA_LAUNCH((gemm_kernel<T, TM, TN, true, true>), grid, dim3(256), 0, stream, p);
+  else CMDA_LAUNCH((gemm_kernel<T, TM, TN, true, false>), grid, dim3(256), 0, stream, p);
+  CMDA_CHECK_LAUNCH();
+}
+
+template <typename T>
+int launch_dtype(const GemmParams& p, void* stream) {
+  // tile choice: fill >= 256 CUs when the problem allows it, never waste half a tile on N <= 64
+  const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.batch * p.splits;
+  const long t12864 = (long)((p.M + 127) / 128) * ((p.N + 63) / 64) * p.batch * p.splits;
+  if (p.N > 64 && t128 >= 512) return launch_tile<T, 4, 4>(p, stream);
+  if (t12864 >= 512) return launch_tile<T, 4, 2>(p, stream);
+  return launch_tile<T, 2, 2>(p, stream);
+}
+
+}  // namespace
+
+extern "C" int cmda_gemm(const cmda_gemm_params_t* pp, void* stream) {
+  if (!pp) return CMDA_ERR_SHAPE;
+  GemmParams p = *pp;
+  if (p.M <= 0 || p.N <= 0 || p.batch <= 0) return CMDA_OK;
+  if (p.K <= 0 || p.splits <= 0) return CMDA_ERR_SHAPE;
+  if (p.atomic && !p.out_f32) return CMDA_ERR_UNSUPPORTED;
+  if (p.splits > 1 && !p.atomic) return CMDA_ERR_UNSUPPORTED;
+  if (p.atomic && (p.bias || p.act || p.res || p.rowscale)) return CMDA_ERR_UNSUPPORTED;
+  if (p.dtype == CMDA_F32) return launch_dtype<float>(p, stream);
+  if (p.dtype == CMDA_BF16) return launch_dtype<bf16_t>(p, stream);
+  return CMDA_ERR_DTYPE;
+}

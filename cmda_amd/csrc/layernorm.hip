@@ -1,0 +1,181 @@
+// layernorm.hip -- row LayerNorm over the channel dim of NLC activations.
+//
+// Reference ops replaced: nn.LayerNorm in mmseg/models/backbones/mix_transformer.py:123,136
+// (Block norm1/norm2, eps 1e-6), :175 (OverlapPatchEmbed.norm, eps 1e-5), :76 (Attention.norm,
+// eps 1e-5), :270-318 (per-stage norm, eps 1e-6).
+//
+// HBM-bound: one wave per row, 16-byte (f32) / 8-byte (bf16) lane accesses, wave-shuffle
+// reductions, statistics in fp32.  Algorithmic bytes: fwd 2*rows*C*sizeof(T); bwd 3*rows*C*sizeof(T)
+// (+ rows*C*sizeof(T) when a residual gradient is fused in).
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxVec = 4;  // 4 * 64 lanes * 4 elems = C up to 1024
+
+template <typename T>
+__global__ void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                              T* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out, long rows,
+                              int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  const int wpb = blockDim.x >> 6;
+  const int nvec = C >> 2;
+  for (long row = (long)blockIdx.x * wpb + wid; row < rows; row += (long)gridDim.x * wpb) {
+    const T* xr = x + row * C;
+    float v[kMaxVec][4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxVec; ++i) {
+      const int vi = i * 64 + lane;
+      if (vi < nvec) {
+        ld4(xr + vi * 4, v[i]);
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+      } else {
+        v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
+      }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxVec; ++i) {
+      const int vi = i * 64 + lane;
+      if (vi < nvec) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float d = v[i][j] - mean;
+          q += d * d;
+        }
+      }
+    }
+    const float var = wave_sum(q) / (float)C;
+    const float rstd = rsqrtf(var + eps);
+#pragma unroll
+    for (int i = 0; i < kMaxVec; ++i) {
+      const int vi = i * 64 + lane;
+      if (vi < nvec) {
+        float g[4], b[4], o[4];
+        ld4(gamma + vi * 4, g);
+        ld4(beta + vi * 4, b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
+        st4(y + row * C + vi * 4, o);
+      }
+    }
+    if (lane == 0) {
+      if (mean_out) mean_out[row] = mean;
+      if (rstd_out) rstd_out[row] = rstd;
+    }
+  }
+}
+
+// dx = [dres +] rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
+// dgamma += sum_rows dy * xhat ; dbeta += sum_rows dy   (fp32 atomics, one set per block)
+template <typename T>
+__global__ void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
+                              const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                              const T* __restrict__ dres, T* __restrict__ dx, float* __restrict__ dgamma,
+                              float* __restrict__ dbeta, long rows, int C) {
+  __shared__ float red[2][4][1024];  // [gamma/beta][wave][channel]  (32 KiB)
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  const int wpb = blockDim.x >> 6;
+  const int nvec = C >> 2;
+  float ag[kMaxVec][4], ab[kMaxVec][4];
+#pragma unroll
+  for (int i = 0; i < kMaxVec; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ag[i][j] = ab[i][j] = 0.f;
+
+  for (long row = (long)blockIdx.x * wpb + wid; row < rows; row += (long)gridDim.x * wpb) {
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    float xh[kMaxVec][4], g[kMaxVec][4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxVec; ++i) {
+      const int vi = i * 64 + lane;
+      if (vi < nvec) {
+        float xv[4], dv[4], gm[4];
+        ld4(x + row * C + vi * 4, xv);
+        ld4(dy + row * C + vi * 4, dv);
+        ld4(gamma + vi * 4, gm);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          xh[i][j] = (xv[j] - mean) * rstd;
+          g[i][j] = dv[j] * gm[j];
+          s1 += g[i][j];
+          s2 += g[i][j] * xh[i][j];
+          ag[i][j] += dv[j] * xh[i][j];
+          ab[i][j] += dv[j];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)C;
+    s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int i = 0; i < kMaxVec; ++i) {
+      const int vi = i * 64 + lane;
+      if (vi < nvec) {
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = rstd * (g[i][j] - s1 - xh[i][j] * s2);
+        if (dres) {
+          float r[4];
+          ld4(dres + row * C + vi * 4, r);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] += r[j];
+        }
+        st4(dx + row * C + vi * 4, o);
+      }
+    }
+  }
+  // cross-wave reduce of the parameter gradients, then one atomic per channel per block
+#pragma unroll
+  for (int i = 0; i < kMaxVec; ++i) {
+    const int vi = i * 64 + lane;
+    if (vi < nvec) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        red[0][wid][vi * 4 + j] = ag[i][j];
+        red[1][wid][vi * 4 + j] = ab[i][j];
+      }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float sg = 0.f, sb = 0.f;
+    for (int w = 0; w < wpb; ++w) {
+      sg += red[0][w][c];
+      sb += red[1][w][c];
+    }
+    atomicAdd(dgamma + c, sg);
+    atomicAdd(dbeta + c, sb);
+  }
+}
+
+}  // namespace
+
+extern "C" int cmda_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                                  float* rstd, int64_t rows, int C, float eps, int dtype, void* stream) {
+  if (rows <= 0) return CMDA_OK;
+  if (C <= 0 || (C & 3) || C > kMaxVec * 256) return CMDA_ERR_SHAPE;
+  const int wpb = 4;
+  const int grid = (int)std::min<long>((rows + wpb - 1) / wpb, 4096);
+  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((ln_fwd_kernel<T>), dim3(grid), dim3(64 * wpb), 0, stream, (const T*)x, gamma,
+                                         beta, (T*)y, mean, rstd, (long)rows, C, eps));
+  CMDA_CHECK_LAUNCH();
+}
+
+// dgamma / dbeta are ACCUMULATED into (caller zeroes them once per optimizer step).
+extern "C" int cmda_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                                  const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
+                                  int64_t rows, int C, int dtype, void* stream) {
+  if (rows <= 0) return CMDA_OK;
+  if (C <= 0 || (C & 3) || C > kMaxVec * 256) return CMDA_ERR_SHAPE;
+  const int wpb = 4;
+  const int grid = (int)std::min<long>((rows + wpb - 1) / wpb, 512);
+  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((ln_bwd_kernel<T>), dim3(grid), dim3(64 * wpb), 0, stream, (const T*)dy,
+                                         (const T*)x, gamma, mean, rstd, (const T*)dres, (T*)dx, dgamma, dbeta,
+                                         (long)rows, C));
+  CMDA_CHECK_LAUNCH();
+}

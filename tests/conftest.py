@@ -1,0 +1,70 @@
+"""Test configuration.
+
+Two execution targets share every kernel-level test:
+  * ``emu`` (runs everywhere, not marked gpu): the HIP kernel sources compiled for x86 under
+    tests/emu/hip_emu.h and driven through the same C ABI -- checks indexing/semantics on CPU;
+  * ``gpu`` (marked ``gpu``): the real libcmda_hip.so on an MI355X.
+The checker is always plain torch fp32 on CPU or the oracle/ restatement.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+EMU_LIB = os.path.join(ROOT, 'tests', 'emu', 'libcmda_emu.so')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
+    config.addinivalue_line('markers', 'slow: long-running CPU test')
+
+
+def _ensure_emu():
+    srcs = [os.path.join(ROOT, 'cmda_amd', 'csrc', f) for f in os.listdir(os.path.join(ROOT, 'cmda_amd', 'csrc'))]
+    srcs += [os.path.join(ROOT, 'tests', 'emu', f) for f in ('hip_emu.h', 'hip_emu.cpp')]
+    srcs.append(os.path.join(ROOT, 'include', 'cmda_hip.h'))
+    if os.path.exists(EMU_LIB) and all(os.path.getmtime(s) <= os.path.getmtime(EMU_LIB) for s in srcs):
+        return
+    subprocess.check_call(['make', '-j8', 'emu'], cwd=ROOT, stdout=subprocess.DEVNULL)
+
+
+class Target:
+    def __init__(self, kind):
+        self.kind = kind
+        self.device = torch.device('cuda:0' if kind == 'gpu' else 'cpu')
+
+    def to(self, t):
+        return t.to(self.device) if t is not None else None
+
+    def __repr__(self):
+        return self.kind
+
+
+@pytest.fixture(params=[pytest.param('emu'), pytest.param('gpu', marks=pytest.mark.gpu)])
+def tgt(request):
+    from cmda_amd import _lib
+    if request.param == 'emu':
+        _ensure_emu()
+        _lib._bind_for_tests(EMU_LIB)
+    else:
+        _lib._unbind_for_tests()
+        assert torch.cuda.is_available(), 'gpu test without a GPU'
+    yield Target(request.param)
+    if request.param == 'gpu':
+        torch.cuda.synchronize()
+    _lib._unbind_for_tests()
+
+
+def assert_close(got, ref, rtol, atol=0.0, name=''):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, f'{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}'
+    err = (got - ref).abs().max().item() if got.numel() else 0.0
+    scale = ref.abs().max().item() if ref.numel() else 0.0
+    assert err <= atol + rtol * max(scale, 1e-30), f'{name}: max err {err:.3e} vs scale {scale:.3e} (rtol {rtol}, atol {atol})'

@@ -1,0 +1,90 @@
+"""MFMA GEMM / implicit-GEMM conv (cmda_amd/csrc/gemm.hip) against plain torch fp32."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from cmda_amd import ops
+from conftest import assert_close
+
+DT = [(torch.float32, 0, 2e-5), (torch.bfloat16, 1, 1.5e-2)]
+
+
+@pytest.mark.parametrize('dt,tag,tol', DT)
+@pytest.mark.parametrize('M,N,K', [(70, 50, 40), (130, 19, 147), (256, 128, 64), (33, 200, 8), (300, 260, 96)])
+def test_gemm_layouts(tgt, dt, tag, tol, M, N, K):
+    torch.manual_seed(M * 7 + N)
+    a, b = torch.randn(M, K).to(dt), torch.randn(N, K).to(dt)
+    bias, res = torch.randn(N), torch.randn(M, N).to(dt)
+    ref = a.float() @ b.float().t()
+    ad, bd, biasd, resd = map(tgt.to, (a, b, bias, res))
+    out = torch.empty(M, N, dtype=dt, device=tgt.device)
+    ops.gemm(ops.plain_view(ad, M, K), ops.plain_view(bd, N, K), out, M, N, K, dtype=tag)
+    assert_close(out, ref, tol, name='NT')
+    out = torch.empty(M, N, dtype=dt, device=tgt.device)
+    ops.gemm(ops.plain_view(ad, M, K), ops.plain_view(bd, N, K), out, M, N, K, dtype=tag, bias=biasd, act='gelu', res=resd)
+    assert_close(out, F.gelu(ref + bias) + res.float(), tol, name='NT+bias+gelu+res')
+    out = torch.empty(M, N, dtype=dt, device=tgt.device)
+    ops.gemm(ops.plain_view(ad, M, K), ops.plain_view(bd, N, K), out, M, N, K, dtype=tag, bias=biasd, act='relu')
+    assert_close(out, F.relu(ref + bias), tol, name='NT+bias+relu')
+    btd = tgt.to(b.t().contiguous())
+    out = torch.empty(M, N, dtype=dt, device=tgt.device)
+    ops.gemm(ops.plain_view(ad, M, K), ops.plain_view(btd, K, N), out, M, N, K, b_kstrided=True, dtype=tag)
+    assert_close(out, ref, tol, name='NN')
+    atd = tgt.to(a.t().contiguous())
+    out = torch.zeros(M, N, dtype=torch.float32, device=tgt.device)
+    ops.gemm(ops.plain_view(atd, K, M), ops.plain_view(btd, K, N), out, M, N, K, a_kstrided=True, b_kstrided=True,
+             dtype=tag, atomic=True, splits=3)
+    assert_close(out, ref, 1e-5, name='TN split-K atomic')
+    out = torch.ones(M, N, dtype=dt, device=tgt.device)
+    ops.gemm(ops.plain_view(atd, K, M), ops.plain_view(bd, N, K), out, M, N, K, a_kstrided=True, dtype=tag, beta=1.0)
+    assert_close(out, ref + 1, tol, name='TT-ish (A k-strided, B k-contig) beta=1')
+
+
+@pytest.mark.parametrize('dt,tag,tol', DT)
+def test_gemm_batched_heads(tgt, dt, tag, tol):
+    torch.manual_seed(1)
+    Bn, Nq, Nk, h, hd = 2, 40, 24, 2, 16
+    C = h * hd
+    q, kv = torch.randn(Bn, Nq, C).to(dt), torch.randn(Bn, Nk, 2 * C).to(dt)
+    qd, kvd = tgt.to(q), tgt.to(kv)
+    S = torch.empty(Bn, h, Nq, Nk, dtype=dt, device=tgt.device)
+    for hh in range(h):
+        ops.gemm(ops.plain_view(qd, Nq, hd, ld=C, batch_stride=Nq * C, offset=hh * hd),
+                 ops.plain_view(kvd, Nk, hd, ld=2 * C, batch_stride=Nk * 2 * C, offset=hh * hd),
+                 S, Nq, Nk, hd, batch=Bn, c_batch_stride=h * Nq * Nk, c_offset=hh * Nq * Nk, dtype=tag, alpha=0.25)
+    qr = q.float().view(Bn, Nq, h, hd).permute(0, 2, 1, 3)
+    kr = kv.float()[..., :C].reshape(Bn, Nk, h, hd).permute(0, 2, 1, 3)
+    assert_close(S, 0.25 * qr @ kr.transpose(-1, -2), tol, name='batched QK^T')
+
+
+CONVS = [(2, 9, 11, 8, 24, 3, 1, 1, 1), (1, 16, 16, 3, 16, 7, 4, 3, 1), (1, 12, 12, 16, 8, 3, 2, 1, 1),
+         (1, 14, 14, 8, 8, 3, 1, 2, 2), (1, 8, 8, 16, 32, 2, 2, 0, 1), (1, 11, 13, 8, 8, 3, 2, 1, 1)]
+
+
+@pytest.mark.parametrize('dt,tag,tol', DT)
+@pytest.mark.parametrize('Bc,H,W,Ci,Co,KH,st,pd,dl', CONVS)
+def test_conv_implicit_gemm(tgt, dt, tag, tol, Bc, H, W, Ci, Co, KH, st, pd, dl):
+    torch.manual_seed(H + Ci)
+    x, w = torch.randn(Bc, H, W, Ci).to(dt), torch.randn(Co, Ci, KH, KH).to(dt)
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w.float().requires_grad_(True)
+    yref = F.conv2d(xr, wr, stride=st, padding=pd, dilation=dl)
+    OH, OW = yref.shape[2:]
+    dy = torch.randn(Bc, OH, OW, Co).to(dt)
+    yref.backward(dy.float().permute(0, 3, 1, 2))
+    xd, dyd = tgt.to(x), tgt.to(dy)
+    wg = tgt.to(w.permute(0, 2, 3, 1).contiguous().view(Co, -1))
+    K = KH * KH * Ci
+    out = torch.empty(Bc, OH, OW, Co, dtype=dt, device=tgt.device)
+    ops.gemm(ops.conv_view(xd, Bc, H, W, Ci, KH, KH, st, pd, dl), ops.plain_view(wg, Co, K), out, Bc * OH * OW, Co, K, dtype=tag)
+    assert_close(out, yref.permute(0, 2, 3, 1), tol * 2, name='conv fwd')
+    dW = torch.zeros(Co, K, device=tgt.device)
+    ops.gemm(ops.plain_view(dyd, Bc * OH * OW, Co), ops.conv_view(xd, Bc, H, W, Ci, KH, KH, st, pd, dl), dW, Co, K,
+             Bc * OH * OW, a_kstrided=True, b_kstrided=True, dtype=tag, atomic=True, splits=2)
+    assert_close(dW.view(Co, KH, KH, Ci).permute(0, 3, 1, 2), wr.grad, 1e-5, name='conv wgrad')
+    if st == 1:
+        wd = tgt.to(w.flip(2, 3).permute(1, 2, 3, 0).contiguous().view(Ci, -1))
+        dx = torch.empty(Bc, H, W, Ci, dtype=dt, device=tgt.device)
+        ops.gemm(ops.conv_view(dyd, Bc, OH, OW, Co, KH, KH, 1, dl * (KH - 1) - pd, dl, OH=H, OW=W),
+                 ops.plain_view(wd, Ci, KH * KH * Co), dx, Bc * H * W, Ci, KH * KH * Co, dtype=tag)
+        assert_close(dx, xr.grad.permute(0, 2, 3, 1), tol * 2, name='conv dgrad')
