@@ -1,0 +1,229 @@
+// ce_loss.hip -- fused "bilinear x-up-sample + per-pixel cross-entropy (+ top-1 accuracy)" and the teacher's
+// fused "up-sample + softmax + max + confidence count" (pseudo-labels).
+//
+// Reference:
+//   BaseDecodeHead(Fusion).losses   decode_heads/decode_head.py:588-606
+//     resize(seg_logit -> label size)                         ops/wrappers.py:9-28
+//     F.cross_entropy(reduction='none', ignore_index=255)     losses/cross_entropy_loss.py:21-26
+//     * weight, .mean() over ALL B*H*W pixels (ignored ones included in the denominator)  losses/utils.py:60-69
+//     accuracy(): 100 * #(argmax == label) / numel            losses/accuracy.py:40-50
+//   DACS teacher: encode_decode's resize + softmax + max + ge(0.968)   segmentors/encoder_decoder.py:733-745,
+//     uda/dacs.py:674-682,702-705
+//
+// The 19 x H x W up-sampled logits are never materialised (the reference makes three passes over that 40 MB
+// tensor): logits stay NHWC fp32 at 1/4 resolution (L2 resident, 1.2 MB per sample) and each thread rebuilds the 19
+// class scores of one full-resolution pixel on the fly.  HBM-bound; algorithmic bytes per sample:
+// fwd  19*h*w*4 + H*W*(8 label + 4 weight + 4 lse out); bwd the same + 19*h*w*4 written.
+// Backward is a deterministic gather over the 1/4-resolution grid (no atomics).
+#include "bilinear.h"
+
+namespace {
+constexpr int kMaxClasses = 32;
+
+template <int NC_MAX>
+static __device__ __forceinline__ void upsample_scores(const float* __restrict__ lg, int b, int h, int w, int nc,
+                                                       const BilinTap& ty, const BilinTap& tx, float (&s)[NC_MAX]) {
+  const float* p00 = lg + ((long)(b * h + ty.i0) * w + tx.i0) * nc;
+  const float* p01 = lg + ((long)(b * h + ty.i0) * w + tx.i1) * nc;
+  const float* p10 = lg + ((long)(b * h + ty.i1) * w + tx.i0) * nc;
+  const float* p11 = lg + ((long)(b * h + ty.i1) * w + tx.i1) * nc;
+#pragma unroll
+  for (int c = 0; c < NC_MAX; ++c)
+    if (c < nc) s[c] = bilin_mix(p00[c], p01[c], p10[c], p11[c], tx.l0, tx.l1, ty.l0, ty.l1);
+}
+
+// acc[0] += sum_pix weight*nll ; acc[1] += #correct ; lse[pix] saved for the backward
+__global__ void ce_fwd_kernel(const float* __restrict__ logits, const long long* __restrict__ label,
+                              const float* __restrict__ weight, float* __restrict__ lse_out, float* __restrict__ acc,
+                              int B, int h, int w, int H, int W, int nc, int ignore_index) {
+  __shared__ float red[2][4];
+  const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+  const long total = (long)B * H * W;
+  float lsum = 0.f, csum = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int X = (int)(i % W);
+    const long t = i / W;
+    const int Y = (int)(t % H);
+    const int b = (int)(t / H);
+    const BilinTap ty = bilin_tap(Y, h, H, sh), tx = bilin_tap(X, w, W, sw);
+    float s[kMaxClasses];
+    upsample_scores<kMaxClasses>(logits, b, h, w, nc, ty, tx, s);
+    float mx = -INFINITY;
+    int am = 0;
+#pragma unroll
+    for (int c = 0; c < kMaxClasses; ++c)
+      if (c < nc && s[c] > mx) { mx = s[c]; am = c; }
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < kMaxClasses; ++c)
+      if (c < nc) se += __expf(s[c] - mx);
+    const float lse = mx + __logf(se);
+    if (lse_out) lse_out[i] = lse;
+    const long long lab = label[i];
+    if (lab != ignore_index && lab >= 0 && lab < nc) {
+      float sl = 0.f;
+#pragma unroll
+      for (int c = 0; c < kMaxClasses; ++c)
+        if (c == (int)lab) sl = s[c];
+      const float wgt = weight ? weight[i] : 1.f;
+      lsum += wgt * (lse - sl);
+    }
+    csum += ((long long)am == lab) ? 1.f : 0.f;
+  }
+  lsum = wave_sum(lsum);
+  csum = wave_sum(csum);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wid] = lsum; red[1][wid] = csum; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(acc + 0, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    atomicAdd(acc + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+  }
+}
+
+// dlogits[b,y,x,c] = gscale * sum over full-res pixels (Y,X) touching (y,x) of
+//                    wy*wx * weight[Y,X] * (softmax_c(Y,X) - [c == label])          (0 for ignored pixels)
+// one thread per low-res pixel, all classes in registers.
+__global__ void ce_bwd_kernel(const float* __restrict__ logits, const long long* __restrict__ label,
+                              const float* __restrict__ weight, const float* __restrict__ lse,
+                              const float* __restrict__ gscale_ptr, float gscale_mul, float* __restrict__ dlogits, int B,
+                              int h, int w, int H, int W, int nc, int ignore_index) {
+  const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+  const float ish = (float)H / (float)h, isw = (float)W / (float)w;
+  const float gscale = (gscale_ptr ? *gscale_ptr : 1.f) * gscale_mul;
+  const long total = (long)B * h * w;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % w);
+    const long t = i / w;
+    const int y = (int)(t % h);
+    const int b = (int)(t / h);
+    int Y0 = (int)floorf(((float)y - 0.5f) * ish - 0.5f) - 1, Y1 = (int)ceilf(((float)y + 1.5f) * ish - 0.5f) + 1;
+    int X0 = (int)floorf(((float)x - 0.5f) * isw - 0.5f) - 1, X1 = (int)ceilf(((float)x + 1.5f) * isw - 0.5f) + 1;
+    if (y == 0) Y0 = 0;
+    if (x == 0) X0 = 0;
+    if (y == h - 1) Y1 = H - 1;
+    if (x == w - 1) X1 = W - 1;
+    Y0 = max(Y0, 0); X0 = max(X0, 0);
+    Y1 = min(Y1, H - 1); X1 = min(X1, W - 1);
+    float g[kMaxClasses];
+#pragma unroll
+    for (int c = 0; c < kMaxClasses; ++c) g[c] = 0.f;
+    for (int Y = Y0; Y <= Y1; ++Y) {
+      const BilinTap ty = bilin_tap(Y, h, H, sh);
+      const float wy = (ty.i0 == y ? ty.l0 : 0.f) + (ty.i1 == y ? ty.l1 : 0.f);
+      if (wy == 0.f) continue;
+      for (int X = X0; X <= X1; ++X) {
+        const BilinTap tx = bilin_tap(X, w, W, sw);
+        const float wx = (tx.i0 == x ? tx.l0 : 0.f) + (tx.i1 == x ? tx.l1 : 0.f);
+        if (wx == 0.f) continue;
+        const long pi = ((long)b * H + Y) * W + X;
+        const long long lab = label[pi];
+        if (lab == ignore_index || lab < 0 || lab >= nc) continue;
+        const float coef = wy * wx * (weight ? weight[pi] : 1.f);
+        if (coef == 0.f) continue;
+        float s[kMaxClasses];
+        upsample_scores<kMaxClasses>(logits, b, h, w, nc, ty, tx, s);
+        const float l = lse[pi];
+#pragma unroll
+        for (int c = 0; c < kMaxClasses; ++c)
+          if (c < nc) g[c] += coef * (__expf(s[c] - l) - (c == (int)lab ? 1.f : 0.f));
+      }
+    }
+    float* o = dlogits + i * nc;
+#pragma unroll
+    for (int c = 0; c < kMaxClasses; ++c)
+      if (c < nc) o[c] = gscale * g[c];
+  }
+}
+
+// label = first arg-max of the up-sampled scores; prob = 1 / sum exp(s - max); count += (prob >= thr)
+__global__ void pseudo_label_kernel(const float* __restrict__ logits, long long* __restrict__ label_out,
+                                    float* __restrict__ prob_out, int* __restrict__ count, int B, int h, int w, int H,
+                                    int W, int nc, float thr) {
+  __shared__ int red[4];
+  const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+  const long total = (long)B * H * W;
+  int cnt = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int X = (int)(i % W);
+    const long t = i / W;
+    const int Y = (int)(t % H);
+    const int b = (int)(t / H);
+    const BilinTap ty = bilin_tap(Y, h, H, sh), tx = bilin_tap(X, w, W, sw);
+    float s[kMaxClasses];
+    upsample_scores<kMaxClasses>(logits, b, h, w, nc, ty, tx, s);
+    float mx = -INFINITY;
+    int am = 0;
+#pragma unroll
+    for (int c = 0; c < kMaxClasses; ++c)
+      if (c < nc && s[c] > mx) { mx = s[c]; am = c; }
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < kMaxClasses; ++c)
+      if (c < nc) se += __expf(s[c] - mx);
+    const float prob = 1.f / se;
+    label_out[i] = am;
+    if (prob_out) prob_out[i] = prob;
+    cnt += prob >= thr ? 1 : 0;
+  }
+  float cf = wave_sum((float)cnt);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) red[wid] = (int)cf;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(count, red[0] + red[1] + red[2] + red[3]);
+}
+
+// weight[b,y,x] = (count / total) with the first `top` and last `bottom` rows zeroed (dacs.py:702-711)
+__global__ void pseudo_weight_kernel(const int* __restrict__ count, float* __restrict__ weight, int B, int H, int W,
+                                     int top, int bottom) {
+  const long total = (long)B * H * W;
+  const float v = (float)((double)(*count) / (double)total);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int Y = (int)((i / W) % H);
+    weight[i] = (Y < top || Y >= H - bottom) ? 0.f : v;
+  }
+}
+
+static inline int grid_for(long n) { return (int)std::max<long>(1, std::min<long>((n + 255) / 256, 4096)); }
+}  // namespace
+
+// logits: fp32 NHWC [B,h,w,nc]; label int64 [B,H,W]; weight fp32 [B,H,W] or NULL; lse_out fp32 [B,H,W];
+// acc: fp32[2], ACCUMULATED (caller zeroes): acc[0] = sum w*nll, acc[1] = #(argmax == label).
+extern "C" int cmda_ce_upsample_fwd(const float* logits, const int64_t* label, const float* weight, float* lse_out,
+                                    float* acc, int B, int h, int w, int H, int W, int nc, int ignore_index,
+                                    void* stream) {
+  if ((long)B * H * W <= 0) return CMDA_OK;
+  if (nc <= 0 || nc > kMaxClasses) return CMDA_ERR_SHAPE;
+  CMDA_LAUNCH(ce_fwd_kernel, dim3(grid_for((long)B * H * W)), dim3(256), 0, stream, logits, (const long long*)label,
+              weight, lse_out, acc, B, h, w, H, W, nc, ignore_index);
+  CMDA_CHECK_LAUNCH();
+}
+
+// dlogits (fp32 NHWC [B,h,w,nc]) = (*gscale_ptr) * gscale_mul * d(sum w*nll)/dlogits; gscale_ptr may be NULL (=1).
+extern "C" int cmda_ce_upsample_bwd(const float* logits, const int64_t* label, const float* weight, const float* lse,
+                                    const float* gscale_ptr, float gscale_mul, float* dlogits, int B, int h, int w,
+                                    int H, int W, int nc, int ignore_index, void* stream) {
+  if ((long)B * h * w <= 0) return CMDA_OK;
+  if (nc <= 0 || nc > kMaxClasses) return CMDA_ERR_SHAPE;
+  CMDA_LAUNCH(ce_bwd_kernel, dim3(grid_for((long)B * h * w)), dim3(256), 0, stream, logits, (const long long*)label,
+              weight, lse, gscale_ptr, gscale_mul, dlogits, B, h, w, H, W, nc, ignore_index);
+  CMDA_CHECK_LAUNCH();
+}
+
+// count: int32[1], ACCUMULATED (caller zeroes).
+extern "C" int cmda_pseudo_label(const float* logits, int64_t* label_out, float* prob_out, int* count, int B, int h,
+                                 int w, int H, int W, int nc, float thr, void* stream) {
+  if ((long)B * H * W <= 0) return CMDA_OK;
+  if (nc <= 0 || nc > kMaxClasses) return CMDA_ERR_SHAPE;
+  CMDA_LAUNCH(pseudo_label_kernel, dim3(grid_for((long)B * H * W)), dim3(256), 0, stream, logits,
+              (long long*)label_out, prob_out, count, B, h, w, H, W, nc, thr);
+  CMDA_CHECK_LAUNCH();
+}
+
+extern "C" int cmda_pseudo_weight(const int* count, float* weight, int B, int H, int W, int top, int bottom,
+                                  void* stream) {
+  if ((long)B * H * W <= 0) return CMDA_OK;
+  CMDA_LAUNCH(pseudo_weight_kernel, dim3(grid_for((long)B * H * W)), dim3(256), 0, stream, count, weight, B, H, W, top,
+              bottom);
+  CMDA_CHECK_LAUNCH();
+}

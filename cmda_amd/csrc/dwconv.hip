@@ -1,0 +1,232 @@
+// dwconv.hip -- depthwise 3x3 convolution (optionally dilated) on NHWC activations.
+//
+// Reference ops replaced:
+//   DWConv (3x3, pad 1, bias, groups=C) + GELU inside MixFFN   mix_transformer.py:37-44,443-455
+//   depthwise half of DepthwiseSeparableConvModule (3x3, dilation 6/12/18, no bias) in the sep-ASPP
+//   decode_heads/sep_aspp_head.py:18-27 (mmcv DepthwiseSeparableConvModule.depthwise_conv)
+//
+// HBM-bound stencils: a thread owns 4 adjacent channels of one pixel, lanes run along C so every tap is a
+// coalesced 8/16-byte access; neighbouring pixels' taps hit L1/L2.  Algorithmic bytes per pixel-channel:
+// fwd 2*sizeof(T); gelu-bwd-prep 3*sizeof(T); bwd-data 2*sizeof(T); bwd-weight 2*sizeof(T).
+// Depthwise weights/bias stay fp32 ([C,9] = the reference's [C,1,3,3] parameter, no repack).
+#include "common.h"
+
+namespace {
+
+template <typename T>
+static __device__ __forceinline__ void dw_accum(const T* __restrict__ x, const float* __restrict__ w, int b, int h,
+                                                int wx, int c, int H, int W, int C, int dil, float (&acc)[4]) {
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int ih = h + (kh - 1) * dil;
+    if (ih < 0 || ih >= H) continue;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int iw = wx + (kw - 1) * dil;
+      if (iw < 0 || iw >= W) continue;
+      float xv[4];
+      ld4(x + ((long)(b * H + ih) * W + iw) * C + c, xv);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] += xv[j] * w[(c + j) * 9 + kh * 3 + kw];
+    }
+  }
+}
+
+// y = act(dwconv(x) + bias)
+template <typename T>
+__global__ void dw_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                              T* __restrict__ y, int B, int H, int W, int C, int dil, int act) {
+  const int cg = C >> 2;
+  const long total = (long)B * H * W * cg;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cg) * 4;
+    long pix = i / cg;
+    const int wx = (int)(pix % W);
+    pix /= W;
+    const int h = (int)(pix % H);
+    const int b = (int)(pix / H);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = bias[c + j];
+    }
+    dw_accum(x, w, b, h, wx, c, H, W, C, dil, acc);
+    if (act == 2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = gelu_erf(acc[j]);
+    }
+    st4(y + ((long)(b * H + h) * W + wx) * C + c, acc);
+  }
+}
+
+// dz = da * gelu'(dwconv(x) + bias)   (recomputes the pre-activation instead of saving it)
+template <typename T>
+__global__ void dw_gelu_bwd_prep_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                        const float* __restrict__ bias, const T* __restrict__ da, T* __restrict__ dz,
+                                        int B, int H, int W, int C, int dil) {
+  const int cg = C >> 2;
+  const long total = (long)B * H * W * cg;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cg) * 4;
+    long pix = i / cg;
+    const int wx = (int)(pix % W);
+    pix /= W;
+    const int h = (int)(pix % H);
+    const int b = (int)(pix / H);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = bias[c + j];
+    }
+    dw_accum(x, w, b, h, wx, c, H, W, C, dil, acc);
+    const long o = ((long)(b * H + h) * W + wx) * C + c;
+    float g[4];
+    ld4(da + o, g);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g[j] *= gelu_erf_grad(acc[j]);
+    st4(dz + o, g);
+  }
+}
+
+// dx[b,h,w,c] = sum_taps dy[b, h-(kh-1)d, w-(kw-1)d, c] * w[c,kh,kw]
+template <typename T>
+__global__ void dw_bwd_data_kernel(const T* __restrict__ dy, const float* __restrict__ w, T* __restrict__ dx, int B,
+                                   int H, int W, int C, int dil) {
+  const int cg = C >> 2;
+  const long total = (long)B * H * W * cg;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cg) * 4;
+    long pix = i / cg;
+    const int wx = (int)(pix % W);
+    pix /= W;
+    const int h = (int)(pix % H);
+    const int b = (int)(pix / H);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int oh = h - (kh - 1) * dil;
+      if (oh < 0 || oh >= H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ow = wx - (kw - 1) * dil;
+        if (ow < 0 || ow >= W) continue;
+        float gv[4];
+        ld4(dy + ((long)(b * H + oh) * W + ow) * C + c, gv);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += gv[j] * w[(c + j) * 9 + kh * 3 + kw];
+      }
+    }
+    st4(dx + ((long)(b * H + h) * W + wx) * C + c, acc);
+  }
+}
+
+// dw[c,tap] += sum_pix dz[pix,c] * x[pix+tap,c];  dbias[c] += sum_pix dz[pix,c]
+// block = 64 channel-groups x 4 pixel lanes; each block owns `pix_per_block` pixels; LDS reduce over the 4 pixel
+// lanes, then one fp32 atomic per (channel, tap) per block.
+template <typename T>
+__global__ void dw_bwd_weight_kernel(const T* __restrict__ dz, const T* __restrict__ x, float* __restrict__ dw,
+                                     float* __restrict__ dbias, int B, int H, int W, int C, int dil,
+                                     int pix_per_block) {
+  __shared__ float red[4][64][41];
+  const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + cx) * 4;
+  const long npix = (long)B * H * W;
+  const long p0 = (long)blockIdx.y * pix_per_block;
+  const long p1 = min(npix, p0 + pix_per_block);
+  float acc[9][4], accb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[t][j] = 0.f;
+  if (c < C) {
+    for (long pix = p0 + py; pix < p1; pix += 4) {
+      const int wx = (int)(pix % W);
+      const long t2 = pix / W;
+      const int h = (int)(t2 % H);
+      const int b = (int)(t2 / H);
+      float g[4];
+      ld4(dz + pix * C + c, g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) accb[j] += g[j];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int ih = h + (kh - 1) * dil;
+        if (ih < 0 || ih >= H) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int iw = wx + (kw - 1) * dil;
+          if (iw < 0 || iw >= W) continue;
+          float xv[4];
+          ld4(x + ((long)(b * H + ih) * W + iw) * C + c, xv);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[kh * 3 + kw][j] += g[j] * xv[j];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[py][cx][t * 4 + j] = acc[t][j];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) red[py][cx][36 + j] = accb[j];
+  __syncthreads();
+  // 64 channel groups x 40 values, summed over the 4 pixel lanes
+  for (int k = threadIdx.x; k < 64 * 40; k += blockDim.x) {
+    const int gx = k / 40, v = k - gx * 40;
+    const int cc = (blockIdx.x * 64 + gx) * 4;
+    if (cc >= C) continue;
+    const float s = red[0][gx][v] + red[1][gx][v] + red[2][gx][v] + red[3][gx][v];
+    if (v < 36) {
+      const int t = v >> 2, j = v & 3;
+      atomicAdd(dw + (cc + j) * 9 + t, s);
+    } else if (dbias) {
+      atomicAdd(dbias + cc + (v - 36), s);
+    }
+  }
+}
+
+static inline int grid_for(long n) { return (int)std::max<long>(1, std::min<long>((n + 255) / 256, 8192)); }
+
+}  // namespace
+
+extern "C" int cmda_dwconv3x3_fwd(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C,
+                                  int dil, int act, int dtype, void* stream) {
+  if ((long)B * H * W * C <= 0) return CMDA_OK;
+  if (C & 3) return CMDA_ERR_SHAPE;
+  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((dw_fwd_kernel<T>), dim3(grid_for((long)B * H * W * (C / 4))), dim3(256), 0,
+                                         stream, (const T*)x, w, bias, (T*)y, B, H, W, C, dil, act));
+  CMDA_CHECK_LAUNCH();
+}
+
+extern "C" int cmda_dwconv3x3_gelu_bwd_prep(const void* x, const float* w, const float* bias, const void* da, void* dz,
+                                            int B, int H, int W, int C, int dil, int dtype, void* stream) {
+  if ((long)B * H * W * C <= 0) return CMDA_OK;
+  if (C & 3) return CMDA_ERR_SHAPE;
+  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((dw_gelu_bwd_prep_kernel<T>), dim3(grid_for((long)B * H * W * (C / 4))),
+                                         dim3(256), 0, stream, (const T*)x, w, bias, (const T*)da, (T*)dz, B, H, W, C, dil));
+  CMDA_CHECK_LAUNCH();
+}
+
+extern "C" int cmda_dwconv3x3_bwd_data(const void* dy, const float* w, void* dx, int B, int H, int W, int C, int dil,
+                                       int dtype, void* stream) {
+  if ((long)B * H * W * C <= 0) return CMDA_OK;
+  if (C & 3) return CMDA_ERR_SHAPE;
+  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((dw_bwd_data_kernel<T>), dim3(grid_for((long)B * H * W * (C / 4))), dim3(256),
+                                         0, stream, (const T*)dy, w, (T*)dx, B, H, W, C, dil));
+  CMDA_CHECK_LAUNCH();
+}
+
+extern "C" int cmda_dwconv3x3_bwd_weight(const void* dz, const void* x, float* dw, float* dbias, int B, int H, int W,
+                                         int C, int dil, int dtype, void* stream) {
+  const long npix = (long)B * H * W;
+  if (npix * C <= 0) return CMDA_OK;
+  if (C & 3) return CMDA_ERR_SHAPE;
+  const int gx = (C / 4 + 63) / 64;
+  int ppb = 512;
+  while (ppb > 32 && (npix + ppb - 1) / ppb * gx < 512) ppb >>= 1;
+  dim3 grid(gx, (unsigned)((npix + ppb - 1) / ppb));
+  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((dw_bwd_weight_kernel<T>), grid, dim3(256), 0, stream, (const T*)dz,
+                                         (const T*)x, dw, dbias, B, H, W, C, dil, ppb));
+  CMDA_CHECK_LAUNCH();
+}

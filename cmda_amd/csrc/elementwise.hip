@@ -1,0 +1,238 @@
+// elementwise.hip -- HBM-bound data movement / pointwise kernels.
+//
+//  cmda_permute4     : 4-D permute + cast (+flip, +accumulate).  Replaces the NLC<->NCHW `.permute().contiguous()`
+//                      copies of mix_transformer.py:406,414,422,430 at the module boundary only, and repacks conv
+//                      weights between the reference's [Co,Ci,KH,KW] parameter layout and the GEMM layouts.
+//  cmda_colsum       : bias gradient (column sum of dY), fp32 accumulate.
+//  cmda_axpby        : out = a*x + b*y  (feature averaging, attention_avg_fusion.py:49).
+//  cmda_ema_update   : EMA teacher update, dacs.py:261-272.
+//  cmda_adamw_step   : fused AdamW over a flat parameter segment (torch.optim.AdamW semantics,
+//                      configs/_base_/schedules/adamw.py), optionally emitting the bf16 compute copy.
+//  cmda_class_mix    : ClassMix of image / events / label / weight, dacs_transforms.py:101-131, dacs.py:716-771.
+#include "common.h"
+
+namespace {
+
+template <typename TS, typename TD>
+__global__ void permute4_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int d0, int d1, int d2, int d3,
+                                int p0, int p1, int p2, int p3, int flipmask, int accumulate) {
+  const int sd[4] = {d0, d1, d2, d3};
+  const long ss[4] = {(long)d1 * d2 * d3, (long)d2 * d3, (long)d3, 1};
+  const int pp[4] = {p0, p1, p2, p3};
+  const long total = (long)d0 * d1 * d2 * d3;
+  const int e1 = sd[pp[1]], e2 = sd[pp[2]], e3 = sd[pp[3]];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long t = i;
+    int idx[4];
+    idx[3] = (int)(t % e3); t /= e3;
+    idx[2] = (int)(t % e2); t /= e2;
+    idx[1] = (int)(t % e1); t /= e1;
+    idx[0] = (int)t;
+    long so = 0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      int v = idx[a];
+      const int ax = pp[a];
+      if ((flipmask >> ax) & 1) v = sd[ax] - 1 - v;
+      so += (long)v * ss[ax];
+    }
+    float v = ldf(src + so);
+    if (accumulate) v += ldf(dst + i);
+    stf(dst + i, v);
+  }
+}
+
+// column sum of x[M,N] (row-major) accumulated into out[N] (fp32 atomics, one per block per column)
+template <typename T>
+__global__ void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, long M, int N, int rows_per_block) {
+  __shared__ float red[256];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cx;
+  const long r0 = (long)blockIdx.y * rows_per_block;
+  const long r1 = min(M, r0 + rows_per_block);
+  float s = 0.f;
+  if (col < N)
+    for (long r = r0 + ry; r < r1; r += 4) s += ldf(x + r * N + col);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (ry == 0 && col < N) atomicAdd(out + col, red[cx] + red[64 + cx] + red[128 + cx] + red[192 + cx]);
+}
+
+template <typename T>
+__global__ void axpby_kernel(const T* __restrict__ x, const T* __restrict__ y, T* __restrict__ out, float a, float b,
+                             long n) {
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
+    if (i + 4 <= n) {
+      float xv[4], yv[4], o[4];
+      ld4(x + i, xv);
+      if (y) ld4(y + i, yv); else yv[0] = yv[1] = yv[2] = yv[3] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = a * xv[j] + b * yv[j];
+      st4(out + i, o);
+    } else {
+      for (long j = i; j < n; ++j) stf(out + j, a * ldf(x + j) + (y ? b * ldf(y + j) : 0.f));
+    }
+  }
+}
+
+__global__ void ema_kernel(float* __restrict__ ema, const float* __restrict__ p, float alpha, long n) {
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
+    if (i + 4 <= n) {
+      float e[4], v[4];
+      ld4(ema + i, e);
+      ld4(p + i, v);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) e[j] = alpha * e[j] + (1.f - alpha) * v[j];
+      st4(ema + i, e);
+    } else {
+      for (long j = i; j < n; ++j) ema[j] = alpha * ema[j] + (1.f - alpha) * p[j];
+    }
+  }
+}
+
+// torch.optim.AdamW (amsgrad=False): p *= 1 - lr*wd; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+// p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, bf16_t* __restrict__ p_bf16, long n, float lr, float b1, float b2,
+                             float eps, float wd, float bc1, float bc2_sqrt) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float pv = p[i];
+    const float gv = g[i];
+    pv *= 1.f - lr * wd;
+    const float mv = b1 * m[i] + (1.f - b1) * gv;
+    const float vv = b2 * v[i] + (1.f - b2) * gv * gv;
+    m[i] = mv;
+    v[i] = vv;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    pv -= (lr / bc1) * (mv / denom);
+    p[i] = pv;
+    if (p_bf16) p_bf16[i] = f2bf(pv);
+  }
+}
+
+// ClassMix for one tensor pair: out = m*src + (1-m)*tgt, mask m[b,h,w] = 1 where the source label is one of the
+// chosen classes (dacs_transforms.py:121-131).  `classes` holds the chosen class ids per sample, padded with -1.
+template <typename T>
+__global__ void class_mix_kernel(const T* __restrict__ src, const T* __restrict__ tgt, T* __restrict__ out,
+                                 const long long* __restrict__ src_label, const long long* __restrict__ classes,
+                                 int max_classes, int B, int HW, int Cch, int channels_last) {
+  const long total = (long)B * HW * Cch;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long b, pix;
+    if (channels_last) {
+      const long bp = i / Cch;
+      b = bp / HW;
+      pix = bp - b * HW;
+    } else {
+      b = i / ((long)Cch * HW);
+      pix = i % HW;
+    }
+    const long long lab = src_label[b * HW + pix];
+    int msk = 0;
+    for (int k = 0; k < max_classes; ++k) msk += (classes[b * max_classes + k] == lab) ? 1 : 0;
+    const float mf = (float)msk;
+    stf(out + i, mf * ldf(src + i) + (1.f - mf) * ldf(tgt + i));
+  }
+}
+
+__global__ void class_mix_label_kernel(const long long* __restrict__ src, const long long* __restrict__ tgt,
+                                       long long* __restrict__ out, const long long* __restrict__ src_label,
+                                       const long long* __restrict__ classes, int max_classes, int B, int HW) {
+  const long total = (long)B * HW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / HW;
+    const long long lab = src_label[i];
+    long long msk = 0;
+    for (int k = 0; k < max_classes; ++k) msk += (classes[b * max_classes + k] == lab) ? 1 : 0;
+    out[i] = msk * src[i] + (1 - msk) * tgt[i];
+  }
+}
+
+static inline int grid_for(long n, int per_thread = 1) {
+  long blocks = (n + 256L * per_thread - 1) / (256L * per_thread);
+  return (int)std::max<long>(1, std::min<long>(blocks, 2048));
+}
+
+template <typename TS, typename TD>
+int launch_permute(const void* src, void* dst, const int* d, const int* p, int flipmask, int accumulate, void* stream) {
+  const long total = (long)d[0] * d[1] * d[2] * d[3];
+  CMDA_LAUNCH((permute4_kernel<TS, TD>), dim3(grid_for(total)), dim3(256), 0, stream, (const TS*)src, (TD*)dst, d[0],
+              d[1], d[2], d[3], p[0], p[1], p[2], p[3], flipmask, accumulate);
+  CMDA_CHECK_LAUNCH();
+}
+
+}  // namespace
+
+// dst dims = (d[p0], d[p1], d[p2], d[p3]); dst[i0..i3] = src[...] with src axis p_a indexed by i_a
+// (reversed when bit p_a of flipmask is set); accumulate: dst += instead of dst =.
+extern "C" int cmda_permute4(const void* src, void* dst, int d0, int d1, int d2, int d3, int p0, int p1, int p2, int p3,
+                             int flipmask, int accumulate, int src_dtype, int dst_dtype, void* stream) {
+  const int d[4] = {d0, d1, d2, d3}, p[4] = {p0, p1, p2, p3};
+  if ((long)d0 * d1 * d2 * d3 <= 0) return CMDA_OK;
+  int seen = 0;
+  for (int a = 0; a < 4; ++a) {
+    if (p[a] < 0 || p[a] > 3) return CMDA_ERR_SHAPE;
+    seen |= 1 << p[a];
+  }
+  if (seen != 15) return CMDA_ERR_SHAPE;
+  if (src_dtype == CMDA_F32 && dst_dtype == CMDA_F32) return launch_permute<float, float>(src, dst, d, p, flipmask, accumulate, stream);
+  if (src_dtype == CMDA_F32 && dst_dtype == CMDA_BF16) return launch_permute<float, bf16_t>(src, dst, d, p, flipmask, accumulate, stream);
+  if (src_dtype == CMDA_BF16 && dst_dtype == CMDA_F32) return launch_permute<bf16_t, float>(src, dst, d, p, flipmask, accumulate, stream);
+  if (src_dtype == CMDA_BF16 && dst_dtype == CMDA_BF16) return launch_permute<bf16_t, bf16_t>(src, dst, d, p, flipmask, accumulate, stream);
+  return CMDA_ERR_DTYPE;
+}
+
+extern "C" int cmda_colsum(const void* x, float* out, int64_t M, int N, int dtype, void* stream) {
+  if (M <= 0 || N <= 0) return CMDA_OK;
+  const int rpb = 256;
+  dim3 grid((N + 63) / 64, (unsigned)((M + rpb - 1) / rpb));
+  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((colsum_kernel<T>), grid, dim3(256), 0, stream, (const T*)x, out, (long)M, N, rpb));
+  CMDA_CHECK_LAUNCH();
+}
+
+extern "C" int cmda_axpby(const void* x, const void* y, void* out, float a, float b, int64_t n, int dtype, void* stream) {
+  if (n <= 0) return CMDA_OK;
+  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((axpby_kernel<T>), dim3(grid_for(n, 4)), dim3(256), 0, stream, (const T*)x,
+                                         (const T*)y, (T*)out, a, b, (long)n));
+  CMDA_CHECK_LAUNCH();
+}
+
+extern "C" int cmda_ema_update(float* ema, const float* param, float alpha, int64_t n, void* stream) {
+  if (n <= 0) return CMDA_OK;
+  CMDA_LAUNCH(ema_kernel, dim3(grid_for(n, 4)), dim3(256), 0, stream, ema, param, alpha, (long)n);
+  CMDA_CHECK_LAUNCH();
+}
+
+extern "C" int cmda_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
+                               float beta1, float beta2, float eps, float weight_decay, int step, void* stream) {
+  if (n <= 0) return CMDA_OK;
+  if (step < 1) return CMDA_ERR_SHAPE;
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2 = 1.f - powf(beta2, (float)step);
+  CMDA_LAUNCH(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p_bf16, (long)n, lr, beta1,
+              beta2, eps, weight_decay, bc1, sqrtf(bc2));
+  CMDA_CHECK_LAUNCH();
+}
+
+// src/tgt/out: [B,Cch,H,W] (channels_last=0) or [B,H,W,Cch] (channels_last=1); src_label [B,H*W] int64;
+// classes [B,max_classes] int64 padded with -1.
+extern "C" int cmda_class_mix(const void* src, const void* tgt, void* out, const int64_t* src_label,
+                              const int64_t* classes, int max_classes, int B, int HW, int Cch, int channels_last,
+                              int dtype, void* stream) {
+  const long total = (long)B * HW * Cch;
+  if (total <= 0) return CMDA_OK;
+  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((class_mix_kernel<T>), dim3(grid_for(total)), dim3(256), 0, stream,
+                                         (const T*)src, (const T*)tgt, (T*)out, (const long long*)src_label,
+                                         (const long long*)classes, max_classes, B, HW, Cch, channels_last));
+  CMDA_CHECK_LAUNCH();
+}
+
+extern "C" int cmda_class_mix_label(const int64_t* src, const int64_t* tgt, int64_t* out, const int64_t* src_label,
+                                    const int64_t* classes, int max_classes, int B, int HW, void* stream) {
+  const long total = (long)B * HW;
+  if (total <= 0) return CMDA_OK;
+  CMDA_LAUNCH(class_mix_label_kernel, dim3(grid_for(total)), dim3(256), 0, stream, (const long long*)src,
+              (const long long*)tgt, (long long*)out, (const long long*)src_label, (const long long*)classes,
+              max_classes, B, HW);
+  CMDA_CHECK_LAUNCH();
+}

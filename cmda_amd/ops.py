@@ -89,3 +89,187 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None):
     call('cmda_layernorm_bwd', ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dgamma),
          ptr(dbeta), c_i64(rows), c_i32(C), dtype_tag(x), stream_of(x))
     return dx
+
+
+def permute4(src, dst, dims, perm, flipmask=0, accumulate=False):
+    """dst (contiguous, dims[perm]) = permute(src viewed as `dims`), with optional axis flips / accumulate."""
+    check_dev(src, dst)
+    d = list(dims) + [1] * (4 - len(dims))
+    p = list(perm) + list(range(len(perm), 4))
+    call('cmda_permute4', ptr(src), ptr(dst), *[c_i32(v) for v in d], *[c_i32(v) for v in p], c_i32(flipmask),
+         c_i32(int(accumulate)), dtype_tag(src), dtype_tag(dst), stream_of(src))
+    return dst
+
+
+def cast(src, dtype):
+    if src.dtype == dtype:
+        return src
+    dst = torch.empty(src.shape, dtype=dtype, device=src.device)
+    return permute4(src, dst, (src.numel(), 1, 1, 1), (0, 1, 2, 3))
+
+
+def colsum(x, out, M, N):
+    check_dev(x, out)
+    call('cmda_colsum', ptr(x), ptr(out), c_i64(M), c_i32(N), dtype_tag(x), stream_of(x))
+    return out
+
+
+def axpby(x, y, a, b, out=None):
+    check_dev(x, y)
+    out = torch.empty_like(x) if out is None else out
+    call('cmda_axpby', ptr(x), ptr(y), ptr(out), c_f32(a), c_f32(b), c_i64(x.numel()), dtype_tag(x), stream_of(x))
+    return out
+
+
+def ema_update(ema, param, alpha):
+    check_dev(ema, param)
+    call('cmda_ema_update', ptr(ema), ptr(param), c_f32(alpha), c_i64(ema.numel()), stream_of(ema))
+
+
+def adamw_step(p, g, m, v, lr, beta1, beta2, eps, wd, step, p_bf16=None):
+    check_dev(p, g, m, v, p_bf16)
+    call('cmda_adamw_step', ptr(p), ptr(g), ptr(m), ptr(v), ptr(p_bf16), c_i64(p.numel()), c_f32(lr), c_f32(beta1),
+         c_f32(beta2), c_f32(eps), c_f32(wd), c_i32(step), stream_of(p))
+
+
+def class_mix(src, tgt, src_label, classes, channels_last=False):
+    """src/tgt [B,C,H,W] (or [B,H,W,C]); src_label int64 [B,H,W]; classes int64 [B,K] padded with -1."""
+    check_dev(src, tgt, src_label, classes)
+    out = torch.empty_like(src)
+    B = src.shape[0]
+    HW = src_label.shape[-2] * src_label.shape[-1]
+    Cch = src.numel() // (B * HW)
+    call('cmda_class_mix', ptr(src), ptr(tgt), ptr(out), ptr(src_label), ptr(classes), c_i32(classes.shape[1]), c_i32(B),
+         c_i32(HW), c_i32(Cch), c_i32(int(channels_last)), dtype_tag(src), stream_of(src))
+    return out
+
+
+def class_mix_label(src, tgt, src_label, classes):
+    check_dev(src, tgt, src_label, classes)
+    out = torch.empty_like(src)
+    B = src.shape[0]
+    call('cmda_class_mix_label', ptr(src), ptr(tgt), ptr(out), ptr(src_label), ptr(classes), c_i32(classes.shape[1]),
+         c_i32(B), c_i32(src.numel() // B), stream_of(src))
+    return out
+
+
+def softmax_fwd_(s, rows, L, alpha):
+    check_dev(s)
+    call('cmda_softmax_fwd', ptr(s), c_i64(rows), c_i32(L), c_f32(alpha), dtype_tag(s), stream_of(s))
+    return s
+
+
+def softmax_bwd_(p, dp, rows, L, alpha):
+    check_dev(p, dp)
+    call('cmda_softmax_bwd', ptr(p), ptr(dp), c_i64(rows), c_i32(L), c_f32(alpha), dtype_tag(p), stream_of(p))
+    return dp
+
+
+def dwconv_fwd(x, w, bias, B, H, W, C, dil=1, act=None):
+    check_dev(x, w, bias)
+    y = torch.empty_like(x)
+    call('cmda_dwconv3x3_fwd', ptr(x), ptr(w), ptr(bias), ptr(y), c_i32(B), c_i32(H), c_i32(W), c_i32(C), c_i32(dil),
+         c_i32(ACT[act]), dtype_tag(x), stream_of(x))
+    return y
+
+
+def dwconv_gelu_bwd_prep(x, w, bias, da, B, H, W, C, dil=1):
+    check_dev(x, w, bias, da)
+    dz = torch.empty_like(x)
+    call('cmda_dwconv3x3_gelu_bwd_prep', ptr(x), ptr(w), ptr(bias), ptr(da), ptr(dz), c_i32(B), c_i32(H), c_i32(W),
+         c_i32(C), c_i32(dil), dtype_tag(x), stream_of(x))
+    return dz
+
+
+def dwconv_bwd_data(dy, w, B, H, W, C, dil=1):
+    check_dev(dy, w)
+    dx = torch.empty_like(dy)
+    call('cmda_dwconv3x3_bwd_data', ptr(dy), ptr(w), ptr(dx), c_i32(B), c_i32(H), c_i32(W), c_i32(C), c_i32(dil),
+         dtype_tag(dy), stream_of(dy))
+    return dx
+
+
+def dwconv_bwd_weight(dz, x, dw, dbias, B, H, W, C, dil=1):
+    check_dev(dz, x, dw, dbias)
+    call('cmda_dwconv3x3_bwd_weight', ptr(dz), ptr(x), ptr(dw), ptr(dbias), c_i32(B), c_i32(H), c_i32(W), c_i32(C),
+         c_i32(dil), dtype_tag(x), stream_of(x))
+
+
+def bilinear_fwd(x, y, B, IH, IW, OH, OW, C, ldy=None, coff=0):
+    check_dev(x, y)
+    call('cmda_bilinear_fwd', ptr(x), ptr(y), c_i32(B), c_i32(IH), c_i32(IW), c_i32(OH), c_i32(OW), c_i32(C),
+         c_i32(C if ldy is None else ldy), c_i32(coff), dtype_tag(x), stream_of(x))
+    return y
+
+
+def bilinear_bwd(dy, dx, B, IH, IW, OH, OW, C, ldy=None, coff=0):
+    check_dev(dy, dx)
+    call('cmda_bilinear_bwd', ptr(dy), ptr(dx), c_i32(B), c_i32(IH), c_i32(IW), c_i32(OH), c_i32(OW), c_i32(C),
+         c_i32(C if ldy is None else ldy), c_i32(coff), dtype_tag(dy), stream_of(dy))
+    return dx
+
+
+def bn_train_fwd(x, gamma, beta, y, running_mean, running_var, M, C, eps, momentum, relu, ldy=None, coff=0):
+    check_dev(x, gamma, beta, y, running_mean, running_var)
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+    call('cmda_bn_train_fwd', ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), ptr(running_mean),
+         ptr(running_var), ptr(ws), c_i64(M), c_i32(C), c_f32(eps), c_f32(momentum), c_i32(int(relu)),
+         c_i32(C if ldy is None else ldy), c_i32(coff), dtype_tag(x), stream_of(x))
+    return mean, rstd
+
+
+def bn_apply(x, mean, rstd, gamma, beta, y, M, C, relu, ldy=None, coff=0):
+    check_dev(x, mean, rstd, gamma, beta, y)
+    call('cmda_bn_apply', ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(y), c_i64(M), c_i32(C),
+         c_i32(int(relu)), c_i32(C if ldy is None else ldy), c_i32(coff), dtype_tag(x), stream_of(x))
+
+
+def bn_train_bwd(dy, x, mean, rstd, gamma, beta, dgamma, dbeta, M, C, relu, lddy=None, coff=0):
+    check_dev(dy, x, mean, rstd, gamma, beta, dgamma, dbeta)
+    dx = torch.empty_like(x)
+    ws = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+    call('cmda_bn_train_bwd', ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(dx), ptr(dgamma),
+         ptr(dbeta), ptr(ws), c_i64(M), c_i32(C), c_i32(int(relu)), c_i32(C if lddy is None else lddy), c_i32(coff),
+         dtype_tag(x), stream_of(x))
+    return dx
+
+
+def ce_upsample_fwd(logits, label, weight, H, W, ignore_index=255):
+    """logits fp32 NHWC [B,h,w,nc]; returns (acc[2] = (sum w*nll, #correct), lse[B,H,W])."""
+    check_dev(logits, label, weight)
+    B, h, w, nc = logits.shape
+    lse = torch.empty(B, H, W, dtype=torch.float32, device=logits.device)
+    acc = torch.zeros(2, dtype=torch.float32, device=logits.device)
+    call('cmda_ce_upsample_fwd', ptr(logits), ptr(label), ptr(weight), ptr(lse), ptr(acc), c_i32(B), c_i32(h), c_i32(w),
+         c_i32(H), c_i32(W), c_i32(nc), c_i32(ignore_index), stream_of(logits))
+    return acc, lse
+
+
+def ce_upsample_bwd(logits, label, weight, lse, gscale, gscale_mul, H, W, ignore_index=255):
+    check_dev(logits, label, weight, lse, gscale)
+    B, h, w, nc = logits.shape
+    dl = torch.empty_like(logits)
+    call('cmda_ce_upsample_bwd', ptr(logits), ptr(label), ptr(weight), ptr(lse), ptr(gscale), c_f32(gscale_mul), ptr(dl),
+         c_i32(B), c_i32(h), c_i32(w), c_i32(H), c_i32(W), c_i32(nc), c_i32(ignore_index), stream_of(logits))
+    return dl
+
+
+def pseudo_label(logits, H, W, thr, want_prob=True):
+    check_dev(logits)
+    B, h, w, nc = logits.shape
+    label = torch.empty(B, H, W, dtype=torch.int64, device=logits.device)
+    prob = torch.empty(B, H, W, dtype=torch.float32, device=logits.device) if want_prob else None
+    count = torch.zeros(1, dtype=torch.int32, device=logits.device)
+    call('cmda_pseudo_label', ptr(logits), ptr(label), ptr(prob), ptr(count), c_i32(B), c_i32(h), c_i32(w), c_i32(H),
+         c_i32(W), c_i32(nc), c_f32(thr), stream_of(logits))
+    return label, prob, count
+
+
+def pseudo_weight(count, B, H, W, top=0, bottom=0):
+    check_dev(count)
+    wgt = torch.empty(B, H, W, dtype=torch.float32, device=count.device)
+    call('cmda_pseudo_weight', ptr(count), ptr(wgt), c_i32(B), c_i32(H), c_i32(W), c_i32(top), c_i32(bottom),
+         stream_of(count))
+    return wgt

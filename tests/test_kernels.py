@@ -1,0 +1,220 @@
+"""Kernel-level parity of the HBM-bound kernels against plain torch fp32 (emu on CPU, real lib on GPU)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from cmda_amd import ops
+from conftest import assert_close
+
+DT = [(torch.float32, 3e-5), (torch.bfloat16, 1.6e-2)]
+
+
+@pytest.mark.parametrize('dt,tol', DT)
+@pytest.mark.parametrize('C', [64, 320, 1024])
+def test_layernorm(tgt, dt, tol, C):
+    torch.manual_seed(C)
+    rows = 37
+    x = torch.randn(rows, C).to(dt)
+    g, b = torch.randn(C), torch.randn(C)
+    dy, dres = torch.randn(rows, C).to(dt), torch.randn(rows, C).to(dt)
+    xr = x.float().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (C,), gr, br, 1e-6)
+    ref.backward(dy.float())
+    xd, gd, bd, dyd, dresd = map(tgt.to, (x, g, b, dy, dres))
+    y, mean, rstd = ops.layernorm_fwd(xd, gd, bd, 1e-6)
+    assert_close(y, ref, tol, name='ln fwd')
+    dg, db = torch.zeros(C, device=tgt.device), torch.zeros(C, device=tgt.device)
+    dx = ops.layernorm_bwd(dyd, xd, gd, mean, rstd, dg, db, dres=dresd)
+    assert_close(dx, xr.grad + dres.float(), tol, name='ln dx')
+    assert_close(dg, gr.grad, 2e-5, name='ln dgamma')
+    assert_close(db, br.grad, 2e-5, name='ln dbeta')
+
+
+@pytest.mark.parametrize('dt,tol', DT)
+def test_permute_cast_colsum_axpby(tgt, dt, tol):
+    torch.manual_seed(0)
+    w = torch.randn(6, 5, 3, 3)
+    wd = tgt.to(w)
+    out = torch.empty(6, 3, 3, 5, dtype=dt, device=tgt.device)
+    ops.permute4(wd, out, (6, 5, 3, 3), (0, 2, 3, 1))
+    assert_close(out, w.permute(0, 2, 3, 1), 4e-3 if dt == torch.bfloat16 else 0, name='permute')
+    out = torch.empty(5, 3, 3, 6, dtype=dt, device=tgt.device)
+    ops.permute4(wd, out, (6, 5, 3, 3), (1, 2, 3, 0), flipmask=0b1100)
+    assert_close(out, w.flip(2, 3).permute(1, 2, 3, 0), 4e-3 if dt == torch.bfloat16 else 0, name='permute+flip')
+    g = torch.randn(6, 3, 3, 5)
+    acc = tgt.to(w.clone())
+    ops.permute4(tgt.to(g), acc, (6, 3, 3, 5), (0, 3, 1, 2), accumulate=True)
+    assert_close(acc, w + g.permute(0, 3, 1, 2), 1e-6, name='permute accumulate')
+    x = torch.randn(1000, 52).to(dt)
+    s = torch.zeros(52, device=tgt.device)
+    ops.colsum(tgt.to(x), s, 1000, 52)
+    assert_close(s, x.float().sum(0), 1e-5, name='colsum')
+    a, b = torch.randn(1003).to(dt), torch.randn(1003).to(dt)
+    o = ops.axpby(tgt.to(a), tgt.to(b), 0.5, 0.5)
+    assert_close(o, 0.5 * a.float() + 0.5 * b.float(), tol, name='axpby')
+
+
+@pytest.mark.parametrize('dt,tol', DT)
+@pytest.mark.parametrize('L', [24, 256, 280])
+def test_softmax(tgt, dt, tol, L):
+    torch.manual_seed(L)
+    rows = 19
+    s = (torch.randn(rows, L) * 3).to(dt)
+    sr = s.float().requires_grad_(True)
+    ref = torch.softmax(0.125 * sr, -1)
+    dp = torch.randn(rows, L).to(dt)
+    ref.backward(dp.float())
+    p = ops.softmax_fwd_(tgt.to(s.clone()), rows, L, 0.125)
+    assert_close(p, ref, tol, name='softmax fwd')
+    ds = ops.softmax_bwd_(tgt.to(ref.detach().to(dt)), tgt.to(dp.clone()), rows, L, 0.125)
+    assert_close(ds, sr.grad, tol, atol=2e-4 if dt == torch.bfloat16 else 0, name='softmax bwd')
+
+
+@pytest.mark.parametrize('dt,tol', DT)
+@pytest.mark.parametrize('dil,act', [(1, 'gelu'), (1, None), (6, None)])
+def test_dwconv(tgt, dt, tol, dil, act):
+    torch.manual_seed(dil)
+    B, H, W, C = 2, 13, 9, 24
+    x = torch.randn(B, H, W, C).to(dt)
+    w, b = torch.randn(C, 1, 3, 3) * 0.3, torch.randn(C)
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    z = F.conv2d(xr, wr, br if act else None, padding=dil, dilation=dil, groups=C)
+    ref = F.gelu(z) if act == 'gelu' else z
+    dy = torch.randn(B, H, W, C).to(dt)
+    ref.backward(dy.float().permute(0, 3, 1, 2))
+    xd, wd, bd, dyd = tgt.to(x), tgt.to(w.view(C, 9).contiguous()), tgt.to(b) if act else None, tgt.to(dy)
+    y = ops.dwconv_fwd(xd, wd, bd, B, H, W, C, dil, act)
+    assert_close(y, ref.permute(0, 2, 3, 1), tol, name='dw fwd')
+    dz = ops.dwconv_gelu_bwd_prep(xd, wd, bd, dyd, B, H, W, C, dil) if act == 'gelu' else dyd
+    dx = ops.dwconv_bwd_data(dz, wd, B, H, W, C, dil)
+    assert_close(dx, xr.grad.permute(0, 2, 3, 1), tol * 2, name='dw dx')
+    dw = torch.zeros(C, 9, device=tgt.device)
+    db = torch.zeros(C, device=tgt.device) if act else None
+    ops.dwconv_bwd_weight(dz, xd, dw, db, B, H, W, C, dil)
+    assert_close(dw, wr.grad.view(C, 9), tol, name='dw dweight')
+    if act:
+        assert_close(db, br.grad, tol, name='dw dbias')
+
+
+@pytest.mark.parametrize('dt,tol', DT)
+@pytest.mark.parametrize('IH,IW,OH,OW', [(8, 8, 32, 32), (4, 6, 32, 48), (16, 16, 32, 32), (14, 20, 110, 160), (9, 7, 9, 7)])
+def test_bilinear(tgt, dt, tol, IH, IW, OH, OW):
+    torch.manual_seed(IH)
+    B, C, ld, coff = 2, 8, 24, 12
+    x = torch.randn(B, IH, IW, C).to(dt)
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    ref = F.interpolate(xr, size=(OH, OW), mode='bilinear', align_corners=False)
+    dy = torch.randn(B, OH, OW, ld).to(dt)
+    ref.backward(dy.float()[..., coff:coff + C].permute(0, 3, 1, 2))
+    y = torch.zeros(B, OH, OW, ld, dtype=dt, device=tgt.device)
+    ops.bilinear_fwd(tgt.to(x), y, B, IH, IW, OH, OW, C, ld, coff)
+    assert_close(y[..., coff:coff + C], ref.permute(0, 2, 3, 1), tol if dt == torch.bfloat16 else 2e-6, name='resize fwd')
+    assert y[..., :coff].abs().max().item() == 0 and y[..., coff + C:].abs().max().item() == 0
+    dx = torch.empty(B, IH, IW, C, dtype=dt, device=tgt.device)
+    ops.bilinear_bwd(tgt.to(dy), dx, B, IH, IW, OH, OW, C, ld, coff)
+    assert_close(dx, xr.grad.permute(0, 2, 3, 1), tol, name='resize bwd')
+
+
+@pytest.mark.parametrize('dt,tol', DT)
+@pytest.mark.parametrize('relu', [True, False])
+def test_batchnorm(tgt, dt, tol, relu):
+    torch.manual_seed(3)
+    M, C, ld, coff = 600, 36, 48, 8
+    x = (torch.randn(M, C) * 2 + 3).to(dt)
+    g, b = torch.rand(C) + 0.5, torch.randn(C) * 0.2
+    rm, rv = torch.randn(C), torch.rand(C) + 0.5
+    bn = torch.nn.BatchNorm1d(C)
+    bn.weight.data.copy_(g), bn.bias.data.copy_(b), bn.running_mean.copy_(rm), bn.running_var.copy_(rv)
+    xr = x.float().requires_grad_(True)
+    ref = bn(xr)
+    ref = F.relu(ref) if relu else ref
+    dy = torch.randn(M, ld).to(dt)
+    ref.backward(dy.float()[:, coff:coff + C])
+    xd, gd, bd, rmd, rvd = map(tgt.to, (x, g, b, rm.clone(), rv.clone()))
+    y = torch.zeros(M, ld, dtype=dt, device=tgt.device)
+    mean, rstd = ops.bn_train_fwd(xd, gd, bd, y, rmd, rvd, M, C, 1e-5, 0.1, relu, ld, coff)
+    assert_close(y[:, coff:coff + C], ref, tol, name='bn fwd')
+    assert_close(rmd, bn.running_mean, 1e-5, name='running_mean')
+    assert_close(rvd, bn.running_var, 1e-5, name='running_var')
+    dg, db = torch.zeros(C, device=tgt.device), torch.zeros(C, device=tgt.device)
+    dx = ops.bn_train_bwd(tgt.to(dy), xd, mean, rstd, gd, bd, dg, db, M, C, relu, ld, coff)
+    assert_close(dx, xr.grad, tol * 2, name='bn dx')
+    assert_close(dg, bn.weight.grad, 1e-4, name='bn dgamma')
+    assert_close(db, bn.bias.grad, 1e-4, name='bn dbeta')
+
+
+@pytest.mark.parametrize('h,w,H,W', [(8, 8, 32, 32), (6, 10, 24, 40), (7, 5, 28, 20)])
+@pytest.mark.parametrize('use_weight', [True, False])
+def test_ce_upsample(tgt, h, w, H, W, use_weight):
+    torch.manual_seed(h * 3 + w)
+    B, nc = 2, 19
+    logits = torch.randn(B, h, w, nc) * 2
+    label = torch.randint(0, nc, (B, H, W))
+    label[torch.rand(B, H, W) < 0.1] = 255
+    weight = torch.rand(B, H, W) if use_weight else None
+    lr = logits.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    up = F.interpolate(lr, size=(H, W), mode='bilinear', align_corners=False)
+    loss_px = F.cross_entropy(up, label, reduction='none', ignore_index=255)
+    if use_weight:
+        loss_px = loss_px * weight
+    loss = loss_px.mean()
+    (loss * 0.7).backward()
+    acc_ref = (up.argmax(1) == label).float().sum()
+    acc, lse = ops.ce_upsample_fwd(tgt.to(logits), tgt.to(label), tgt.to(weight), H, W)
+    n = B * H * W
+    assert_close(acc[0] / n, loss, 2e-6, name='ce loss')
+    assert acc[1].item() == acc_ref.item()
+    gs = tgt.to(torch.tensor([0.7]))
+    dl = ops.ce_upsample_bwd(tgt.to(logits), tgt.to(label), tgt.to(weight), lse, gs, 1.0 / n, H, W)
+    assert_close(dl, lr.grad.permute(0, 2, 3, 1), 2e-5, name='ce dlogits')
+
+
+def test_pseudo_label(tgt):
+    torch.manual_seed(5)
+    B, h, w, H, W, nc = 2, 8, 12, 32, 48, 19
+    logits = torch.randn(B, h, w, nc) * 4
+    up = F.interpolate(logits.permute(0, 3, 1, 2), size=(H, W), mode='bilinear', align_corners=False)
+    prob_ref, lab_ref = torch.softmax(up, 1).max(1)
+    lab, prob, cnt = ops.pseudo_label(tgt.to(logits), H, W, 0.968)
+    top2 = up.topk(2, 1).values
+    near_tie = (top2[:, 0] - top2[:, 1]) < 1e-5
+    assert bool(((lab.cpu() == lab_ref) | near_tie).all())
+    assert_close(prob, prob_ref, 1e-5, name='pseudo prob')
+    assert abs(cnt.item() - int((prob_ref >= 0.968).sum())) <= 2
+    wgt = ops.pseudo_weight(cnt, B, H, W, top=3, bottom=5)
+    exp = torch.full((B, H, W), cnt.item() / (B * H * W))
+    exp[:, :3] = 0
+    exp[:, H - 5:] = 0
+    assert_close(wgt, exp, 1e-7, name='pseudo weight')
+
+
+def test_classmix_ema_adamw(tgt):
+    torch.manual_seed(7)
+    B, C, H, W = 2, 3, 8, 10
+    src, tg = torch.randn(B, C, H, W), torch.randn(B, C, H, W)
+    lab = torch.randint(0, 5, (B, H, W))
+    classes = torch.tensor([[1, 3, -1], [0, 2, 4]])
+    mask = torch.stack([(lab[i][None] == classes[i][classes[i] >= 0][:, None, None]).sum(0) for i in range(B)]).float()
+    out = ops.class_mix(tgt.to(src), tgt.to(tg), tgt.to(lab), tgt.to(classes))
+    assert_close(out, mask[:, None] * src + (1 - mask[:, None]) * tg, 0, name='classmix')
+    plab = torch.randint(0, 19, (B, H, W))
+    ol = ops.class_mix_label(tgt.to(lab), tgt.to(plab), tgt.to(lab), tgt.to(classes))
+    assert torch.equal(ol.cpu(), (mask.long() * lab + (1 - mask.long()) * plab))
+    p, e = torch.randn(1001), torch.randn(1001)
+    ed = tgt.to(e.clone())
+    ops.ema_update(ed, tgt.to(p), 0.9)
+    assert_close(ed, 0.9 * e + 0.1 * p, 1e-6, name='ema')
+    prm = torch.nn.Parameter(torch.randn(777))
+    opt = torch.optim.AdamW([prm], lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    pd = tgt.to(prm.data.clone())
+    m, v = torch.zeros(777, device=tgt.device), torch.zeros(777, device=tgt.device)
+    pb = torch.empty(777, dtype=torch.bfloat16, device=tgt.device)
+    for step in (1, 2, 3):
+        gr = torch.randn(777)
+        prm.grad = gr.clone()
+        opt.step()
+        ops.adamw_step(pd, tgt.to(gr), m, v, 1e-2, 0.9, 0.999, 1e-8, 0.01, step, p_bf16=pb)
+    assert_close(pd, prm.data, 2e-6, name='adamw')
+    assert_close(pb, prm.data, 8e-3, name='adamw bf16 copy')
