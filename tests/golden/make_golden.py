@@ -1,0 +1,267 @@
+"""Generates tests/golden/*.npz from the reference's OWN modules (imported unmodified from /root/reference through
+tests/golden/ref_shim.py).  Runs only in the authoring container; the fixtures (inputs/seeds + expected outputs) are
+committed, the reference never ships.  Usage: python tests/golden/make_golden.py [case ...]
+"""
+import json
+import os
+import sys
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_shim  # noqa: E402
+from weights import sample_grad, seeded_fill, seeded_randn  # noqa: E402
+
+torch.set_num_threads(8)
+ns = ref_shim.load_hotpath()
+CASES = {}
+
+
+def case(fn):
+    CASES[fn.__name__] = fn
+    return fn
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print('wrote', name, {k: tuple(v.shape) for k, v in out.items()})
+
+
+def param_grads(module, n=2048):
+    return {'grad.' + k: sample_grad(p.grad, n) for k, p in module.named_parameters() if p.grad is not None}
+
+
+BLOCK_CFGS = {'s1': (64, 1, 8, 16, 16), 's2': (128, 2, 4, 8, 16), 's3': (320, 5, 2, 8, 8), 's4': (512, 8, 1, 4, 4),
+              'f1': (128, 1, 4, 8, 8)}
+
+
+@case
+def block():
+    for tag, (dim, heads, sr, H, W) in BLOCK_CFGS.items():
+        m = ns.mit.Block(dim=dim, num_heads=heads, mlp_ratio=4, qkv_bias=True, drop_path=0.0,
+                         norm_layer=partial(nn.LayerNorm, eps=1e-6), sr_ratio=sr)
+        seeded_fill(m, 11)
+        m.train()
+        x = seeded_randn((2, H * W, dim), 11, 'x').requires_grad_(True)
+        y = m(x, H, W)
+        y.backward(seeded_randn(y.shape, 11, 'dy'))
+        save(f'block_{tag}', y=y, dx=x.grad, **param_grads(m))
+
+
+@case
+def mit_b5_64():
+    m = ns.mit.mit_b5(style='pytorch', in_chans=3)
+    seeded_fill(m, 21)
+    m.eval()
+    with torch.no_grad():
+        outs = m(seeded_randn((1, 3, 64, 64), 21, 'img'))
+    save('mit_b5_64', **{f'out{i}': o for i, o in enumerate(outs)})
+
+
+@case
+def mit_small_train():
+    m = ns.mit.MixVisionTransformer(patch_size=4, embed_dims=[64, 128, 320, 512], num_heads=[1, 2, 5, 8],
+                                    mlp_ratios=[4, 4, 4, 4], qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6),
+                                    depths=[1, 1, 1, 1], sr_ratios=[8, 4, 2, 1], drop_path_rate=0.0)
+    seeded_fill(m, 22)
+    m.train()
+    outs = m(seeded_randn((2, 3, 64, 96), 22, 'img'))
+    loss = sum((o * seeded_randn(o.shape, 22, f'dy{i}')).sum() for i, o in enumerate(outs))
+    loss.backward()
+    save('mit_small_train', **{f'out{i}': o for i, o in enumerate(outs)}, **param_grads(m))
+
+
+HEAD_CFG = dict(in_channels=[64, 128, 320, 512], in_index=[0, 1, 2, 3], channels=256, dropout_ratio=0.0, num_classes=19,
+                norm_cfg=dict(type='BN', requires_grad=True), align_corners=False,
+                loss_decode=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0))
+
+
+def _decoder_params(**extra):
+    d = dict(embed_dims=256, embed_cfg=dict(type='mlp', act_cfg=None, norm_cfg=None),
+             embed_neck_cfg=dict(type='mlp', act_cfg=None, norm_cfg=None),
+             fusion_cfg=dict(type='aspp', sep=True, dilations=(1, 6, 12, 18), pool=False, act_cfg=dict(type='ReLU'),
+                             norm_cfg=dict(type='BN', requires_grad=True)))
+    d.update(extra)
+    return d
+
+
+def _feats(B, H, W, seed, tag):
+    return [seeded_randn((B, c, H // s, W // s), seed, f'{tag}{i}').requires_grad_(True)
+            for i, (c, s) in enumerate(zip([64, 128, 320, 512], [4, 8, 16, 32]))]
+
+
+def _label(B, H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    lab = torch.randint(0, 19, (B, 1, H // 8, W // 8), generator=g).repeat_interleave(8, 2).repeat_interleave(8, 3)
+    lab[torch.rand((B, 1, H, W), generator=g) < 0.05] = 255
+    return lab
+
+
+@case
+def head_train():
+    head = ns.daformer_head.DAFormerHead(**HEAD_CFG, decoder_params=_decoder_params())
+    seeded_fill(head, 31)
+    head.train()
+    B, H, W = 2, 64, 96
+    feats = _feats(B, H, W, 31, 'f')
+    gt = _label(B, H, W, 31)
+    weight = torch.rand((B, H, W), generator=torch.Generator().manual_seed(32))
+    losses, logits = head.forward_train(feats, None, gt, None, weight)
+    (losses['loss_seg'] * 1.7).backward()
+    bn = {k: v for k, v in head.state_dict().items() if 'running' in k}
+    save('head_train', logits=logits, loss_seg=losses['loss_seg'], acc_seg=losses['acc_seg'], gt=gt, weight=weight,
+         **{f'dfeat{i}': f.grad for i, f in enumerate(feats)}, **param_grads(head), **{'bn.' + k: v for k, v in bn.items()})
+
+
+@case
+def head_fusion_train():
+    head = ns.daformer_head.DAFormerHeadFusion(
+        **HEAD_CFG, decoder_params=_decoder_params(train_type='cs2dsec_image+events_together', share_decoder=True))
+    seeded_fill(head, 41)
+    head.train()
+    B, H, W = 1, 64, 64
+    inputs = {k: _feats(B, H, W, 41, k) for k in ('f_image', 'f_events', 'f_fusion', 'f_img_self_res')}
+    gt = _label(B, H, W, 41)
+    cfg = dict(loss_weight={'image': 0.5, 'events': 0.5, 'fusion': 0.5, 'img_self_res': 0.25}, gradual_rate=0.0)
+    losses, logits = head.forward_train(inputs, None, gt, None, None, cfg)
+    losses['loss_seg'].backward()
+    save('head_fusion_train', loss_seg=losses['loss_seg'], acc_seg=losses['acc_seg'], gt=gt,
+         **{k: v for k, v in logits.items()}, **{f'd{k}{i}': f.grad for k, fs in inputs.items() for i, f in enumerate(fs)},
+         **param_grads(head))
+    with open(os.path.join(HERE, 'head_fusion_keys.json'), 'w') as f:
+        json.dump(sorted(head.state_dict().keys()), f, indent=0)
+
+
+@case
+def isr():
+    from PIL import Image
+    g = torch.Generator().manual_seed(51)
+    H, W = 40, 56
+    base = torch.rand((H // 4, W // 4, 3), generator=g).repeat_interleave(4, 0).repeat_interleave(4, 1)
+    img = ((base * 0.8 + 0.2 * torch.rand((H, W, 3), generator=g)) * 255).to(torch.uint8).numpy()
+    pil = Image.fromarray(img)
+    out = {'img': img, 'gray': np.array(pil.convert('L'))}
+    params = {'dsec': dict(val_range=[0.01, 1.01], _threshold=0.005, _clip_range=0.1, shift_pixel=1),
+              'dz': dict(val_range=[1, 100], _threshold=0.01, _clip_range=0.1, shift_pixel=3)}
+    for pn, p in params.items():
+        for d in ('rightdown', 'rightup', 'leftdown', 'leftup', 'all'):
+            out[f'{pn}_{d}'] = ns.ds_utils.get_image_change_from_pil(pil, width=W, height=H, auto_threshold=None,
+                                                                       shift_direction=d, **p)
+    save('isr', **out)
+
+
+@case
+def voxel():
+    dsec = ref_shim.load('mmseg.datasets.dsec')
+    g = torch.Generator().manual_seed(61)
+    N, W, H = 5000, 64, 48
+    out = {}
+    for bins in (1, 5):
+        t = torch.sort(torch.rand(N, generator=g))[0] * 1e5
+        x = torch.rand(N, generator=g) * (W + 2) - 1
+        y = torch.rand(N, generator=g) * (H + 2) - 1
+        x, y = x.clamp(0, W - 0.001), y.clamp(0, H - 0.001)
+        p = (torch.rand(N, generator=g) > 0.5).float()
+        vg = dsec.events_to_voxel_grid(t, x, y, p, W, H, bins, normalize_flag=False)
+        out.update({f't{bins}': t, f'x{bins}': x, f'y{bins}': y, f'p{bins}': p, f'vg{bins}': vg,
+                    f'norm{bins}': dsec.events_norm(vg.clone(), clip_range=(N / 500000) * 1.5 * 100, final_range=1.0,
+                                                     enforce_no_events_zero=True)})
+    save('voxel', **out)
+
+
+@case
+def classmix():
+    tr = ns.dacs_transforms
+    g = torch.Generator().manual_seed(71)
+    B, H, W = 2, 24, 32
+    lab = torch.randint(0, 6, (B, 1, H // 4, W // 4), generator=g).repeat_interleave(4, 2).repeat_interleave(4, 3)
+    lab[0, 0, :4] = 255
+    np.random.seed(71)
+    masks = tr.get_class_masks(lab)
+    np.random.seed(71)  # replay the draw to record the chosen classes
+    classes = torch.unique(lab)
+    n = classes.shape[0]
+    chosen = [classes[torch.Tensor(np.random.choice(n, int((n + n % 2) / 2), replace=False)).long()] for _ in range(B)]
+    a, b = torch.randn((B, 3, H, W), generator=g), torch.randn((B, 3, H, W), generator=g)
+    pl = torch.randint(0, 19, (B, H, W), generator=g)
+    mixed, mixed_l = [], []
+    for i in range(B):
+        d, _ = tr.one_mix(masks[i], data=torch.stack((a[i], b[i])))
+        _, t = tr.one_mix(masks[i], target=torch.stack((lab[i][0], pl[i])))
+        mixed.append(d), mixed_l.append(t)
+    K = max(len(c) for c in chosen)
+    cls = torch.full((B, K), -1, dtype=torch.long)
+    for i, c in enumerate(chosen):
+        cls[i, :len(c)] = c
+    save('classmix', label=lab, a=a, b=b, pl=pl, classes=cls, masks=torch.cat(masks), mixed=torch.cat(mixed),
+         mixed_label=torch.cat(mixed_l))
+
+
+@case
+def generator():
+    G = ns.cyclegan.ResnetGenerator(1, 1, 64, norm_layer=partial(nn.InstanceNorm2d, affine=False, track_running_stats=False),
+                                    use_dropout=False, n_blocks=9)
+    seeded_fill(G, 81)
+    G.eval()
+    with torch.no_grad():
+        y = G(seeded_randn((2, 1, 32, 48), 81, 'x'))
+    save('generator', y=y)
+    with open(os.path.join(HERE, 'generator_keys.json'), 'w') as f:
+        json.dump(sorted(G.state_dict().keys()), f, indent=0)
+
+
+@case
+def fusion_modules():
+    feats_i = [f.detach() for f in _feats(1, 64, 64, 91, 'i')]
+    feats_e = [f.detach() for f in _feats(1, 64, 64, 91, 'e')]
+    for name, cls in (('avg', ns.avg_fusion.AttentionAvgFusion), ('cat', ns.att_fusion.AttentionFusion)):
+        m = cls(drop_path_rate=0.0)
+        seeded_fill(m, 91)
+        m.train()
+        outs = m(feats_i, feats_e)
+        save(f'fusion_{name}', **{f'out{i}': o for i, o in enumerate(outs)})
+
+
+@case
+def segmentor_train():
+    cfg = dict(type='FusionEncoderDecoder', pretrained=None,
+               backbone_image=dict(type='mit_b5', style='pytorch', in_chans=3, drop_path_rate=0.0),
+               backbone_events=dict(type='mit_b5', style='pytorch', in_chans=3, drop_path_rate=0.0),
+               fusion_module=dict(type='AttentionAvgFusion', drop_path_rate=0.0),
+               decode_head=dict(type='DAFormerHeadFusion', **HEAD_CFG,
+                                decoder_params=_decoder_params(train_type='cs2dsec_image+events_together', share_decoder=True)),
+               train_type='cs2dsec_image+events_together', train_cfg=dict(), test_cfg=dict(mode='whole'))
+    model = ns.builder.build_segmentor(cfg)
+    seeded_fill(model, 101)
+    model.train()
+    B, H, W = 1, 64, 64
+    inputs = {k: seeded_randn((B, 3, H, W), 101, k) for k in ('image', 'events', 'img_self_res')}
+    gt = _label(B, H, W, 101)
+    fcfg = dict(loss_weight={'image': 0.5, 'events': 0.5, 'fusion': 0.5, 'img_self_res': 0.25}, gradual_rate=0.0)
+    losses, pred = model.forward_train(inputs, gt, return_feat=True, cfg=fcfg)
+    losses.pop('features')
+    losses['decode.loss_seg'].backward()
+    save('segmentor_train', loss_seg=losses['decode.loss_seg'], acc_seg=losses['decode.acc_seg'], gt=gt,
+         **{k: v for k, v in pred.items()}, **param_grads(model, 96))
+    model.eval()
+    with torch.no_grad():
+        out = model.encode_decode(inputs['image'], inputs['events'], output_features=True, test_cfg=fcfg)
+    save('segmentor_teacher', **{k: v for k, v in out.items() if v is not None})
+    with open(os.path.join(HERE, 'segmentor_keys.json'), 'w') as f:
+        json.dump(sorted(model.state_dict().keys()), f, indent=0)
+
+
+if __name__ == '__main__':
+    names = sys.argv[1:] or list(CASES)
+    for n in names:
+        print('==', n)
+        CASES[n]()

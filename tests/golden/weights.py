@@ -1,0 +1,43 @@
+"""Deterministic, construction-order-independent weights/inputs shared by make_golden.py and the tests: every tensor
+is drawn from a torch CPU generator seeded by (seed, crc32(name)), so fixtures need not store any weights."""
+import zlib
+
+import torch
+
+
+def _gen(seed, name):
+    return torch.Generator().manual_seed((seed * 1000003 + zlib.crc32(name.encode())) % (2 ** 31))
+
+
+def seeded_randn(shape, seed, name='x', scale=1.0):
+    return torch.randn(tuple(shape), generator=_gen(seed, name)) * scale
+
+
+def seeded_fill(module, seed):
+    """Fill every parameter/buffer of `module` (keyed by state_dict name) with seeded values of sane magnitude."""
+    sd = module.state_dict()
+    with torch.no_grad():
+        for name in sorted(sd.keys()):
+            t = sd[name]
+            g = _gen(seed, name)
+            if name.endswith('num_batches_tracked'):
+                t.zero_()
+            elif name.endswith('running_var'):
+                t.copy_(torch.rand(t.shape, generator=g) + 0.5)
+            elif name.endswith('running_mean'):
+                t.copy_(torch.randn(t.shape, generator=g) * 0.1)
+            elif t.dim() == 1 and name.endswith('weight'):
+                t.copy_(1.0 + 0.1 * torch.randn(t.shape, generator=g))
+            elif t.dim() == 1:
+                t.copy_(0.05 * torch.randn(t.shape, generator=g))
+            else:
+                fan_in = t[0].numel()
+                t.copy_(torch.randn(t.shape, generator=g) * (1.0 / fan_in ** 0.5))
+    return module
+
+
+def sample_grad(g, n=2048):
+    """Compact fingerprint of a gradient tensor: strided sample + sum + abs-sum."""
+    f = g.detach().flatten().float()
+    stride = max(1, f.numel() // n)
+    return torch.cat([f[::stride][:n], f.sum()[None], f.abs().sum()[None]])
