@@ -20,7 +20,7 @@ F32, BF16 = 0, 1
 
 
 class View(ctypes.Structure):
-    _fields_ = [('ptr', c_vp), ('ld', c_i64), ('R', c_i64), ('Cc', c_i64), ('batch_stride', c_i64),
+    _fields_ = [('ptr', c_vp), ('ld', c_i64), ('R', c_i64), ('Cc', c_i64), ('batch_stride', c_i64), ('batch2_stride', c_i64),
                 ('conv', c_i32), ('H', c_i32), ('W', c_i32), ('C', c_i32), ('OH', c_i32), ('OW', c_i32),
                 ('KH', c_i32), ('KW', c_i32), ('stride', c_i32), ('pad', c_i32), ('dil', c_i32),
                 ('in_dil', c_i32), ('reflect', c_i32), ('vec_ok', c_i32)]
@@ -28,9 +28,9 @@ class View(ctypes.Structure):
 
 class GemmParams(ctypes.Structure):
     _fields_ = [('A', View), ('B', View), ('a_kstrided', c_i32), ('b_kstrided', c_i32), ('C', c_vp),
-                ('ldc', c_i64), ('c_batch_stride', c_i64), ('M', c_i32), ('N', c_i32), ('K', c_i32),
-                ('batch', c_i32), ('splits', c_i32), ('alpha', c_f32), ('beta', c_f32), ('bias', c_vp),
-                ('act', c_i32), ('res', c_vp), ('ldres', c_i64), ('res_batch_stride', c_i64),
+                ('ldc', c_i64), ('c_batch_stride', c_i64), ('c_batch2_stride', c_i64), ('M', c_i32), ('N', c_i32),
+                ('K', c_i32), ('batch', c_i32), ('batch2', c_i32), ('splits', c_i32), ('alpha', c_f32), ('beta', c_f32), ('bias', c_vp),
+                ('act', c_i32), ('res', c_vp), ('ldres', c_i64), ('res_batch_stride', c_i64), ('res_batch2_stride', c_i64),
                 ('rowscale', c_vp), ('rows_per_scale', c_i32), ('out_f32', c_i32), ('atomic', c_i32),
                 ('dtype', c_i32)]
 

@@ -103,15 +103,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   const long m0 = (long)(bt % tiles_m) * BM;
   const long n0 = (long)(bt / tiles_m) * BN;
   const int z = blockIdx.z;
-  const int batch = z / p.splits;
-  const int split = z - batch * p.splits;
+  const int bz = z / p.splits;
+  const int split = z - bz * p.splits;
+  const int batch = bz / p.batch2;
+  const int batch2 = bz - batch * p.batch2;
   const int nkt = (p.K + BK - 1) / BK;
   const int kt_per = (nkt + p.splits - 1) / p.splits;
   const int kt0 = split * kt_per;
   const int kt1 = min(nkt, kt0 + kt_per);
 
-  const T* baseA = reinterpret_cast<const T*>(p.A.ptr) + (long)batch * p.A.batch_stride;
-  const T* baseB = reinterpret_cast<const T*>(p.B.ptr) + (long)batch * p.B.batch_stride;
+  const T* baseA = reinterpret_cast<const T*>(p.A.ptr) + (long)batch * p.A.batch_stride + (long)batch2 * p.A.batch2_stride;
+  const T* baseB = reinterpret_cast<const T*>(p.B.ptr) + (long)batch * p.B.batch_stride + (long)batch2 * p.B.batch2_stride;
 
   uint4 ra[NCH_A], rb[NCH_B];
   auto gload = [&](int kt) {
@@ -219,8 +221,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 
   // ---- epilogue: C/D map col = lane&15 (n), row = 4*(lane>>4)+r (m) ----
   if (kt0 >= kt1 && p.splits > 1) return;  // empty split contributes nothing
-  const long cb = (long)batch * p.c_batch_stride;
-  const long rb_off = (long)batch * p.res_batch_stride;
+  const long cb = (long)batch * p.c_batch_stride + (long)batch2 * p.c_batch2_stride;
+  const long rb_off = (long)batch * p.res_batch_stride + (long)batch2 * p.res_batch2_stride;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -261,8 +263,8 @@ template <typename T, int TM, int TN>
 int launch_tile(const GemmParams& p, void* stream) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
   const long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  if (tiles > 0x7fffffffL || (long)p.batch * p.splits > 65535) return CMDA_ERR_SHAPE;
-  dim3 grid((unsigned)tiles, 1, (unsigned)(p.batch * p.splits));
+  if (tiles > 0x7fffffffL || (long)p.batch * p.batch2 * p.splits > 65535) return CMDA_ERR_SHAPE;
+  dim3 grid((unsigned)tiles, 1, (unsigned)(p.batch * p.batch2 * p.splits));
   const bool aks = p.a_kstrided != 0, bks = p.b_kstrided != 0;
   if (!aks && !bks) CMDA_LAUNCH((gemm_kernel<T, TM, TN, false, false>), grid, dim3(256), 0, stream, p);
   else if (!aks && bks) CMDA_LAUNCH((gemm_kernel<T, TM, TN, false, true>), grid, dim3(256), 0, stream, p);
@@ -274,8 +276,8 @@ int launch_tile(const GemmParams& p, void* stream) {
 template <typename T>
 int launch_dtype(const GemmParams& p, void* stream) {
   // tile choice: fill >= 256 CUs when the problem allows it, never waste half a tile on N <= 64
-  const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.batch * p.splits;
-  const long t12864 = (long)((p.M + 127) / 128) * ((p.N + 63) / 64) * p.batch * p.splits;
+  const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.batch * p.batch2 * p.splits;
+  const long t12864 = (long)((p.M + 127) / 128) * ((p.N + 63) / 64) * p.batch * p.batch2 * p.splits;
   if (p.N > 64 && t128 >= 512) return launch_tile<T, 4, 4>(p, stream);
   if (t12864 >= 512) return launch_tile<T, 4, 2>(p, stream);
   return launch_tile<T, 2, 2>(p, stream);
@@ -286,6 +288,7 @@ int launch_dtype(const GemmParams& p, void* stream) {
 extern "C" int cmda_gemm(const cmda_gemm_params_t* pp, void* stream) {
   if (!pp) return CMDA_ERR_SHAPE;
   GemmParams p = *pp;
+  if (p.batch2 <= 0) p.batch2 = 1;
   if (p.M <= 0 || p.N <= 0 || p.batch <= 0) return CMDA_OK;
   if (p.K <= 0 || p.splits <= 0) return CMDA_ERR_SHAPE;
   if (p.atomic && !p.out_f32) return CMDA_ERR_UNSUPPORTED;

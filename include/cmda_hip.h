@@ -41,7 +41,8 @@ typedef struct cmda_view_t {
   const void* ptr;
   int64_t ld;           /* plain: elements between consecutive r */
   int64_t R, Cc;        /* extent of r and c */
-  int64_t batch_stride; /* elements between batch entries (grid z) */
+  int64_t batch_stride; /* elements between batch entries (grid z, outer) */
+  int64_t batch2_stride; /* elements between inner batch entries (e.g. attention heads) */
   int32_t conv;         /* 0 plain, 1 im2col view */
   int32_t H, W, C;      /* conv: input height/width/channels (NHWC) */
   int32_t OH, OW;       /* conv: output height/width */
@@ -56,13 +57,13 @@ typedef struct cmda_gemm_params_t {
   int32_t a_kstrided;   /* 0: A view is (r=m, c=k); 1: (r=k, c=m) */
   int32_t b_kstrided;   /* 0: B view is (r=n, c=k); 1: (r=k, c=n) */
   void* C;
-  int64_t ldc, c_batch_stride;
-  int32_t M, N, K, batch, splits;
+  int64_t ldc, c_batch_stride, c_batch2_stride;
+  int32_t M, N, K, batch, batch2, splits; /* grid z = (batch*batch2)*splits */
   float alpha, beta;
   const float* bias;    /* [N] or NULL */
   int32_t act;          /* 0 none, 1 ReLU, 2 GELU(erf) */
   const void* res;      /* residual, activation dtype, or NULL */
-  int64_t ldres, res_batch_stride;
+  int64_t ldres, res_batch_stride, res_batch2_stride;
   const float* rowscale; /* per-sample drop-path scale or NULL; index m / rows_per_scale */
   int32_t rows_per_scale;
   int32_t out_f32;      /* C is fp32 regardless of dtype */
