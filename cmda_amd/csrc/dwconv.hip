@@ -91,7 +91,7 @@ __global__ void dw_gelu_bwd_prep_kernel(const T* __restrict__ x, const float* __
 // dx[b,h,w,c] = sum_taps dy[b, h-(kh-1)d, w-(kw-1)d, c] * w[c,kh,kw]
 template <typename T>
 __global__ void dw_bwd_data_kernel(const T* __restrict__ dy, const float* __restrict__ w, T* __restrict__ dx, int B,
-                                   int H, int W, int C, int dil) {
+                                   int H, int W, int C, int dil, int accumulate) {
   const int cg = C >> 2;
   const long total = (long)B * H * W * cg;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -116,7 +116,14 @@ __global__ void dw_bwd_data_kernel(const T* __restrict__ dy, const float* __rest
         for (int j = 0; j < 4; ++j) acc[j] += gv[j] * w[(c + j) * 9 + kh * 3 + kw];
       }
     }
-    st4(dx + ((long)(b * H + h) * W + wx) * C + c, acc);
+    T* o = dx + ((long)(b * H + h) * W + wx) * C + c;
+    if (accumulate) {
+      float prev[4];
+      ld4(o, prev);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] += prev[j];
+    }
+    st4(o, acc);
   }
 }
 
@@ -209,11 +216,11 @@ extern "C" int cmda_dwconv3x3_gelu_bwd_prep(const void* x, const float* w, const
 }
 
 extern "C" int cmda_dwconv3x3_bwd_data(const void* dy, const float* w, void* dx, int B, int H, int W, int C, int dil,
-                                       int dtype, void* stream) {
+                                       int accumulate, int dtype, void* stream) {
   if ((long)B * H * W * C <= 0) return CMDA_OK;
   if (C & 3) return CMDA_ERR_SHAPE;
   CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((dw_bwd_data_kernel<T>), dim3(grid_for((long)B * H * W * (C / 4))), dim3(256),
-                                         0, stream, (const T*)dy, w, (T*)dx, B, H, W, C, dil));
+                                         0, stream, (const T*)dy, w, (T*)dx, B, H, W, C, dil, accumulate));
   CMDA_CHECK_LAUNCH();
 }
 

@@ -44,7 +44,7 @@ __global__ void permute4_kernel(const TS* __restrict__ src, TD* __restrict__ dst
 
 // column sum of x[M,N] (row-major) accumulated into out[N] (fp32 atomics, one per block per column)
 template <typename T>
-__global__ void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, long M, int N, int rows_per_block) {
+__global__ void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, long M, int N, long ld, int rows_per_block) {
   __shared__ float red[256];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + cx;
@@ -52,7 +52,7 @@ __global__ void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, 
   const long r1 = min(M, r0 + rows_per_block);
   float s = 0.f;
   if (col < N)
-    for (long r = r0 + ry; r < r1; r += 4) s += ldf(x + r * N + col);
+    for (long r = r0 + ry; r < r1; r += 4) s += ldf(x + r * ld + col);
   red[threadIdx.x] = s;
   __syncthreads();
   if (ry == 0 && col < N) atomicAdd(out + col, red[cx] + red[64 + cx] + red[128 + cx] + red[192 + cx]);
@@ -72,6 +72,22 @@ __global__ void axpby_kernel(const T* __restrict__ x, const T* __restrict__ y, T
     } else {
       for (long j = i; j < n; ++j) stf(out + j, a * ldf(x + j) + (y ? b * ldf(y + j) : 0.f));
     }
+  }
+}
+
+// out[b, i, c] = x[b, i, c] * scale[b * sstride + (c if per_channel)]  (DropPath per-sample scale, Dropout2d per
+// (sample, channel) mask; timm DropPath mix_transformer.py:134,145-146, nn.Dropout2d decode_head.py:565-566)
+template <typename T>
+__global__ void sample_scale_kernel(const T* __restrict__ x, const float* __restrict__ scale, T* __restrict__ out,
+                                    long per_sample, int C, int per_channel, long n) {
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
+    const long b = i / per_sample;
+    const int c = (int)(i % C);
+    float v[4];
+    ld4(x + i, v);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] *= per_channel ? scale[b * C + c + j] : scale[b];
+    st4(out + i, v);
   }
 }
 
@@ -182,11 +198,11 @@ extern "C" int cmda_permute4(const void* src, void* dst, int d0, int d1, int d2,
   return CMDA_ERR_DTYPE;
 }
 
-extern "C" int cmda_colsum(const void* x, float* out, int64_t M, int N, int dtype, void* stream) {
+extern "C" int cmda_colsum(const void* x, float* out, int64_t M, int N, int64_t ld, int dtype, void* stream) {
   if (M <= 0 || N <= 0) return CMDA_OK;
   const int rpb = 256;
   dim3 grid((N + 63) / 64, (unsigned)((M + rpb - 1) / rpb));
-  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((colsum_kernel<T>), grid, dim3(256), 0, stream, (const T*)x, out, (long)M, N, rpb));
+  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((colsum_kernel<T>), grid, dim3(256), 0, stream, (const T*)x, out, (long)M, N, (long)ld, rpb));
   CMDA_CHECK_LAUNCH();
 }
 
@@ -194,6 +210,17 @@ extern "C" int cmda_axpby(const void* x, const void* y, void* out, float a, floa
   if (n <= 0) return CMDA_OK;
   CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((axpby_kernel<T>), dim3(grid_for(n, 4)), dim3(256), 0, stream, (const T*)x,
                                          (const T*)y, (T*)out, a, b, (long)n));
+  CMDA_CHECK_LAUNCH();
+}
+
+// x/out: [B, per_sample] with per_sample = HW*C, C % 4 == 0; scale: [B] (per_channel=0) or [B,C] (per_channel=1)
+extern "C" int cmda_sample_scale(const void* x, const float* scale, void* out, int B, int64_t per_sample, int C,
+                                 int per_channel, int dtype, void* stream) {
+  const long n = (long)B * per_sample;
+  if (n <= 0) return CMDA_OK;
+  if ((C & 3) || (per_sample % C)) return CMDA_ERR_SHAPE;
+  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((sample_scale_kernel<T>), dim3(grid_for(n, 4)), dim3(256), 0, stream,
+                                         (const T*)x, scale, (T*)out, (long)per_sample, C, per_channel, n));
   CMDA_CHECK_LAUNCH();
 }
 

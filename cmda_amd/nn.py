@@ -1,0 +1,206 @@
+"""Hand-scheduled forward/backward composites over the HIP kernels (no torch autograd inside).
+
+Activations are 2-D [tokens, channels] tensors (NLC / NHWC flattened) in the compute dtype.  Every `*_fwd` returns
+its outputs plus whatever the matching `*_bwd` needs; parameter gradients are accumulated by the kernels into
+`param.grad` (fp32) through cmda_amd.runtime.grad().
+"""
+import torch
+
+from . import ops
+from . import runtime as rt
+from .ops import conv_view, plain_view
+
+
+def _wgrad_splits(out_rows, out_cols, contraction):
+    tiles = ((out_rows + 63) // 64) * ((out_cols + 63) // 64)
+    s = max(1, 512 // max(tiles, 1))
+    s = min(s, max(1, contraction // 256), 128)
+    return s
+
+
+# ------------------------------------------------------------------ Linear
+def linear_fwd(x, weight, bias, M, K, *, act=None, res=None, rowscale=None, rows_per_scale=1, out=None, ldc=None,
+               c_offset=0, out_dtype=None, x_ld=None, x_off=0):
+    """y[M,N] = act(x[M,K] @ W[N,K]^T + b) (* rowscale) (+ res)"""
+    N = weight.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=out_dtype or rt.compute_dtype(), device=x.device)
+    ops.gemm(plain_view(x, M, K, ld=x_ld, offset=x_off), plain_view(rt.w(weight), N, K), out, M, N, K, dtype=rt.tag(),
+             bias=bias, act=act, res=res, rowscale=rowscale, rows_per_scale=rows_per_scale, ldc=ldc, c_offset=c_offset)
+    return out
+
+
+def linear_bwd(dy, x, weight, bias, M, K, *, need_dx=True, dx_out=None, dx_beta=0.0, dy_ld=None, dy_off=0, x_ld=None,
+               x_off=0):
+    """dW += dy^T x, db += colsum(dy), returns dx = dy @ W (optionally accumulated into dx_out)."""
+    N = weight.shape[0]
+    dyv_k = plain_view(dy, M, N, ld=dy_ld, offset=dy_off)  # (r = token, c = n)
+    ops.gemm(dyv_k, plain_view(x, M, K, ld=x_ld, offset=x_off), rt.grad(weight), N, K, M, a_kstrided=True,
+             b_kstrided=True, dtype=rt.tag(), atomic=True, splits=_wgrad_splits(N, K, M))
+    if bias is not None:
+        ops.colsum(dy, rt.grad(bias), M, N, ld=dy_ld, offset=dy_off)
+    if not need_dx:
+        return None
+    dx = dx_out if dx_out is not None else torch.empty(M, K, dtype=rt.compute_dtype(), device=dy.device)
+    ops.gemm(dyv_k, plain_view(rt.w(weight), N, K), dx, M, K, N, b_kstrided=True, dtype=rt.tag(), beta=dx_beta)
+    return dx
+
+
+# ------------------------------------------------------------------ Conv2d as implicit GEMM (NHWC)
+def conv_out_size(H, W, k, stride, pad, dil=1):
+    return (H + 2 * pad - dil * (k - 1) - 1) // stride + 1, (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+def conv_fwd(x, weight, bias, B, H, W, stride, pad, dil=1, *, act=None, out=None, reflect=0):
+    Co, Ci, KH, KW = weight.shape
+    OH, OW = conv_out_size(H, W, KH, stride, pad, dil)
+    M, K = B * OH * OW, KH * KW * Ci
+    if out is None:
+        out = torch.empty(M, Co, dtype=rt.compute_dtype(), device=x.device)
+    ops.gemm(conv_view(x, B, H, W, Ci, KH, KW, stride, pad, dil, OH=OH, OW=OW, reflect=reflect),
+             plain_view(rt.wconv(weight), Co, K), out, M, Co, K, dtype=rt.tag(), bias=bias, act=act)
+    return out, OH, OW
+
+
+def conv_bwd(dy, x, weight, bias, B, H, W, stride, pad, dil=1, *, need_dx=True, dx_out=None, dx_beta=0.0):
+    Co, Ci, KH, KW = weight.shape
+    OH, OW = conv_out_size(H, W, KH, stride, pad, dil)
+    M, K = B * OH * OW, KH * KW * Ci
+    dwg = torch.zeros(Co, K, dtype=torch.float32, device=dy.device)
+    ops.gemm(plain_view(dy, M, Co), conv_view(x, B, H, W, Ci, KH, KW, stride, pad, dil, OH=OH, OW=OW), dwg, Co, K, M,
+             a_kstrided=True, b_kstrided=True, dtype=rt.tag(), atomic=True, splits=_wgrad_splits(Co, K, M))
+    ops.permute4(dwg, rt.grad(weight), (Co, KH, KW, Ci), (0, 3, 1, 2), accumulate=True)
+    if bias is not None:
+        ops.colsum(dy, rt.grad(bias), M, Co)
+    if not need_dx:
+        return None
+    dx = dx_out if dx_out is not None else torch.empty(B * H * W, Ci, dtype=rt.compute_dtype(), device=dy.device)
+    if KH == stride and pad == 0 and dil == 1 and H % stride == 0 and W % stride == 0:
+        # non-overlapping patches (spatial-reduction conv): dcol = dy @ W, then un-patchify (pure permutation)
+        dcol = torch.empty(M, K, dtype=rt.compute_dtype(), device=dy.device)
+        ops.gemm(plain_view(dy, M, Co), plain_view(rt.wconv(weight), Co, K), dcol, M, K, Co, b_kstrided=True, dtype=rt.tag())
+        if dx_beta == 0.0:
+            ops.permute4(dcol, dx, (B * OH, OW, KH, KW * Ci), (0, 2, 1, 3))
+        else:
+            ops.permute4(dcol, dx, (B * OH, OW, KH, KW * Ci), (0, 2, 1, 3), accumulate=True)
+        return dx
+    ops.gemm(conv_view(dy, B, OH, OW, Co, KH, KW, 1, dil * (KH - 1) - pad, dil, OH=H, OW=W, in_dil=stride),
+             plain_view(rt.wconv(weight, 'dgrad'), Ci, KH * KW * Co), dx, B * H * W, Ci, KH * KW * Co, dtype=rt.tag(),
+             beta=dx_beta)
+    return dx
+
+
+# ------------------------------------------------------------------ attention (scores materialised; v0 path)
+def attention_fwd(q, kv, B, N, Nk, heads, C, scale):
+    """q [B*N,C], kv [B*Nk,2C] -> o [B*N,C]; returns (o, P) with P [B,heads,N,Nk] saved for the backward."""
+    hd = C // heads
+    dev = q.device
+    P = torch.empty(B, heads, N, Nk, dtype=rt.compute_dtype(), device=dev)
+    ops.gemm(plain_view(q, N, hd, ld=C, batch_stride=N * C, batch2_stride=hd),
+             plain_view(kv, Nk, hd, ld=2 * C, batch_stride=Nk * 2 * C, batch2_stride=hd),
+             P, N, Nk, hd, batch=B, batch2=heads, c_batch_stride=heads * N * Nk, c_batch2_stride=N * Nk, dtype=rt.tag())
+    ops.softmax_fwd_(P, B * heads * N, Nk, scale)
+    o = torch.empty(B * N, C, dtype=rt.compute_dtype(), device=dev)
+    ops.gemm(plain_view(P, N, Nk, batch_stride=heads * N * Nk, batch2_stride=N * Nk),
+             plain_view(kv, Nk, hd, ld=2 * C, batch_stride=Nk * 2 * C, batch2_stride=hd, offset=C),
+             o, N, hd, Nk, b_kstrided=True, batch=B, batch2=heads, ldc=C, c_batch_stride=N * C, c_batch2_stride=hd,
+             dtype=rt.tag())
+    return o, P
+
+
+def attention_bwd(do, q, kv, P, B, N, Nk, heads, C, scale):
+    """returns (dq [B*N,C], dkv [B*Nk,2C]) in the compute dtype."""
+    hd = C // heads
+    dev = do.device
+    tag = rt.tag()
+    dkv32 = torch.zeros(B * Nk, 2 * C, dtype=torch.float32, device=dev)
+    Pv = dict(batch_stride=heads * N * Nk, batch2_stride=N * Nk)
+    sp = _wgrad_splits(Nk, hd, N)
+    sp = max(1, min(sp, 65535 // max(1, B * heads)))
+    # dV_h = P_h^T dO_h
+    ops.gemm(plain_view(P, N, Nk, **Pv), plain_view(do, N, hd, ld=C, batch_stride=N * C, batch2_stride=hd),
+             dkv32, Nk, hd, N, a_kstrided=True, b_kstrided=True, batch=B, batch2=heads, ldc=2 * C,
+             c_batch_stride=Nk * 2 * C, c_batch2_stride=hd, c_offset=C, dtype=tag, atomic=True, splits=sp)
+    # dP_h = dO_h V_h^T
+    dP = torch.empty_like(P)
+    ops.gemm(plain_view(do, N, hd, ld=C, batch_stride=N * C, batch2_stride=hd),
+             plain_view(kv, Nk, hd, ld=2 * C, batch_stride=Nk * 2 * C, batch2_stride=hd, offset=C),
+             dP, N, Nk, hd, batch=B, batch2=heads, c_batch_stride=heads * N * Nk, c_batch2_stride=N * Nk, dtype=tag)
+    ops.softmax_bwd_(P, dP, B * heads * N, Nk, scale)  # dP now holds dS (scale folded in)
+    # dQ_h = dS_h K_h
+    dq = torch.empty(B * N, C, dtype=rt.compute_dtype(), device=dev)
+    ops.gemm(plain_view(dP, N, Nk, **Pv), plain_view(kv, Nk, hd, ld=2 * C, batch_stride=Nk * 2 * C, batch2_stride=hd),
+             dq, N, hd, Nk, b_kstrided=True, batch=B, batch2=heads, ldc=C, c_batch_stride=N * C, c_batch2_stride=hd,
+             dtype=tag)
+    # dK_h = dS_h^T Q_h
+    ops.gemm(plain_view(dP, N, Nk, **Pv), plain_view(q, N, hd, ld=C, batch_stride=N * C, batch2_stride=hd),
+             dkv32, Nk, hd, N, a_kstrided=True, b_kstrided=True, batch=B, batch2=heads, ldc=2 * C,
+             c_batch_stride=Nk * 2 * C, c_batch2_stride=hd, dtype=tag, atomic=True, splits=sp)
+    dkv = dkv32 if rt.compute_dtype() == torch.float32 else ops.cast(dkv32, rt.compute_dtype())
+    return dq, dkv
+
+
+# ------------------------------------------------------------------ MiT Block (mix_transformer.py:108-148)
+def block_fwd(x, p, B, H, W, C, heads, sr, *, eps=1e-6, dp1=None, dp2=None, save=True):
+    """x [B*H*W, C].  p: the Block module (norm1, attn.{q,kv,proj,sr,norm}, norm2, mlp.{fc1,dwconv.dwconv,fc2}).
+    dp1/dp2: per-sample DropPath scales (fp32 [B]) or None."""
+    N = H * W
+    M = B * N
+    a = p.attn
+    xn, m1, r1 = ops.layernorm_fwd(x, p.norm1.weight, p.norm1.bias, eps)
+    q = linear_fwd(xn, a.q.weight, a.q.bias, M, C)
+    if sr > 1:
+        xs_pre, OH, OW = conv_fwd(xn, a.sr.weight, a.sr.bias, B, H, W, sr, 0)
+        Nk = OH * OW
+        xs, ms, rs = ops.layernorm_fwd(xs_pre, a.norm.weight, a.norm.bias, 1e-5)
+    else:
+        xs_pre, ms, rs, xs, Nk = None, None, None, xn, N
+    kv = linear_fwd(xs, a.kv.weight, a.kv.bias, B * Nk, C)
+    hd = C // heads
+    o, P = attention_fwd(q, kv, B, N, Nk, heads, C, hd ** -0.5)
+    x1 = linear_fwd(o, a.proj.weight, a.proj.bias, M, C, res=x, rowscale=dp1, rows_per_scale=N)
+    xn2, m2, r2 = ops.layernorm_fwd(x1, p.norm2.weight, p.norm2.bias, eps)
+    hidden = p.mlp.fc1.weight.shape[0]
+    h = linear_fwd(xn2, p.mlp.fc1.weight, p.mlp.fc1.bias, M, C)
+    dw = p.mlp.dwconv.dwconv
+    act = ops.dwconv_fwd(h, dw.weight.data.view(hidden, 9), dw.bias, B, H, W, hidden, 1, 'gelu')
+    Cout = p.mlp.fc2.weight.shape[0]
+    x2 = linear_fwd(act, p.mlp.fc2.weight, p.mlp.fc2.bias, M, hidden, res=x1 if Cout == C else None, rowscale=dp2,
+                    rows_per_scale=N)
+    saved = (x, m1, r1, xn, q, xs_pre, ms, rs, xs, kv, P, o, x1, m2, r2, xn2, h, act, Nk, dp1, dp2) if save else None
+    return x2, saved
+
+
+def mlp_bwd(dy, mlp, xin, h, act, B, H, W, Cin, dps=None):
+    """Backward of Mlp (fc1 -> dwconv3x3 -> GELU -> fc2); returns d(xin)."""
+    M = B * H * W
+    hidden = mlp.fc1.weight.shape[0]
+    dys = dy if dps is None else ops.sample_scale(dy, dps, B, dy.shape[1])
+    da = linear_bwd(dys, act, mlp.fc2.weight, mlp.fc2.bias, M, hidden)
+    dw = mlp.dwconv.dwconv
+    w9 = dw.weight.data.view(hidden, 9)
+    dz = ops.dwconv_gelu_bwd_prep(h, w9, dw.bias, da, B, H, W, hidden, 1)
+    ops.dwconv_bwd_weight(dz, h, rt.grad(dw.weight).view(hidden, 9), rt.grad(dw.bias), B, H, W, hidden, 1)
+    dh = ops.dwconv_bwd_data(dz, w9, B, H, W, hidden, 1, out=da)
+    return linear_bwd(dh, xin, mlp.fc1.weight, mlp.fc1.bias, M, Cin)
+
+
+def block_bwd(dy, p, saved, B, H, W, C, heads, sr, *, eps=1e-6):
+    (x, m1, r1, xn, q, xs_pre, ms, rs, xs, kv, P, o, x1, m2, r2, xn2, h, act, Nk, dp1, dp2) = saved
+    N = H * W
+    M = B * N
+    a = p.attn
+    hd = C // heads
+    dxn2 = mlp_bwd(dy, p.mlp, xn2, h, act, B, H, W, C, dp2)
+    dx1 = ops.layernorm_bwd(dxn2, x1, p.norm2.weight, m2, r2, rt.grad(p.norm2.weight), rt.grad(p.norm2.bias), dres=dy)
+    dps = dx1 if dp1 is None else ops.sample_scale(dx1, dp1, B, C)
+    do = linear_bwd(dps, o, a.proj.weight, a.proj.bias, M, C)
+    dq, dkv = attention_bwd(do, q, kv, P, B, N, Nk, heads, C, hd ** -0.5)
+    dxs = linear_bwd(dkv, xs, a.kv.weight, a.kv.bias, B * Nk, C)
+    if sr > 1:
+        dxs_pre = ops.layernorm_bwd(dxs, xs_pre, a.norm.weight, ms, rs, rt.grad(a.norm.weight), rt.grad(a.norm.bias))
+        dxn = conv_bwd(dxs_pre, xn, a.sr.weight, a.sr.bias, B, H, W, sr, 0)
+    else:
+        dxn = dxs
+    linear_bwd(dq, xn, a.q.weight, a.q.bias, M, C, dx_out=dxn, dx_beta=1.0)
+    return ops.layernorm_bwd(dxn, x, p.norm1.weight, m1, r1, rt.grad(p.norm1.weight), rt.grad(p.norm1.bias), dres=dx1)

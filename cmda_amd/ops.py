@@ -109,9 +109,11 @@ def cast(src, dtype):
     return permute4(src, dst, (src.numel(), 1, 1, 1), (0, 1, 2, 3))
 
 
-def colsum(x, out, M, N):
+def colsum(x, out, M, N, ld=None, offset=0):
+    """out[N] += column sums of the [M,N] matrix at element `offset` of x with row pitch ld."""
     check_dev(x, out)
-    call('cmda_colsum', ptr(x), ptr(out), c_i64(M), c_i32(N), dtype_tag(x), stream_of(x))
+    call('cmda_colsum', L.c_vp(x.data_ptr() + offset * _ESIZE[x.dtype]), ptr(out), c_i64(M), c_i32(N),
+         c_i64(N if ld is None else ld), dtype_tag(x), stream_of(x))
     return out
 
 
@@ -182,11 +184,11 @@ def dwconv_gelu_bwd_prep(x, w, bias, da, B, H, W, C, dil=1):
     return dz
 
 
-def dwconv_bwd_data(dy, w, B, H, W, C, dil=1):
-    check_dev(dy, w)
-    dx = torch.empty_like(dy)
+def dwconv_bwd_data(dy, w, B, H, W, C, dil=1, out=None, accumulate=False):
+    check_dev(dy, w, out)
+    dx = torch.empty_like(dy) if out is None else out
     call('cmda_dwconv3x3_bwd_data', ptr(dy), ptr(w), ptr(dx), c_i32(B), c_i32(H), c_i32(W), c_i32(C), c_i32(dil),
-         dtype_tag(dy), stream_of(dy))
+         c_i32(int(accumulate)), dtype_tag(dy), stream_of(dy))
     return dx
 
 
@@ -274,3 +276,12 @@ def pseudo_weight(count, B, H, W, top=0, bottom=0):
     call('cmda_pseudo_weight', ptr(count), ptr(wgt), c_i32(B), c_i32(H), c_i32(W), c_i32(top), c_i32(bottom),
          stream_of(count))
     return wgt
+
+
+def sample_scale(x, scale, B, C, per_channel=False, out=None):
+    """x viewed as [B, HW*C]; scale fp32 [B] or [B,C]."""
+    check_dev(x, scale, out)
+    out = torch.empty_like(x) if out is None else out
+    call('cmda_sample_scale', ptr(x), ptr(scale), ptr(out), c_i32(B), c_i64(x.numel() // B), c_i32(C),
+         c_i32(int(per_channel)), dtype_tag(x), stream_of(x))
+    return out

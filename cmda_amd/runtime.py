@@ -1,0 +1,88 @@
+"""Runtime policy shared by the cmda_amd modules: compute dtype, compute-layout copies of the fp32 master
+parameters, and the fp32 gradient buffers the HIP kernels accumulate into.
+
+Parameters keep the reference's names, shapes and fp32 storage (state_dict compatible with mit_b5.pth / CMDA
+checkpoints).  Kernels consume *compute copies*:
+  Linear  weight [N,K]          -> same layout, compute dtype (no copy in fp32 mode)
+  Conv2d  weight [Co,Ci,KH,KW]  -> 'khwc'  [Co,KH,KW,Ci]           (implicit-GEMM forward / wgrad layout)
+                                -> 'dgrad' [Ci,KH,KW,Co], taps flipped (implicit-GEMM data gradient)
+The copies are cached and must be dropped with `invalidate()` after every optimizer step (the fused AdamW kernel
+writes the masters without touching torch's version counters).
+Parameter gradients are accumulated by the kernels straight into `param.grad` (fp32, allocated zero on first use):
+autograd never sees them, which is what lets two backward passes per step accumulate with no extra traffic.
+"""
+import torch
+
+from . import ops
+
+_state = {'dtype': torch.float32}
+_cache = {}
+
+
+def set_compute_dtype(dtype):
+    assert dtype in (torch.float32, torch.bfloat16)
+    _state['dtype'] = dtype
+    invalidate()
+
+
+def compute_dtype():
+    return _state['dtype']
+
+
+def tag():
+    return 0 if _state['dtype'] == torch.float32 else 1
+
+
+def invalidate():
+    _cache.clear()
+
+
+def w(param):
+    """Linear weight [N,K] in the compute dtype."""
+    if _state['dtype'] == torch.float32:
+        return param.data
+    key = (id(param), 'w')
+    t = _cache.get(key)
+    if t is None:
+        t = ops.cast(param.data, _state['dtype'])
+        _cache[key] = t
+    return t
+
+
+def wconv(param, kind='khwc'):
+    """Conv weight [Co,Ci,KH,KW] repacked for the implicit GEMM (see module docstring)."""
+    key = (id(param), kind)
+    t = _cache.get(key)
+    if t is None:
+        Co, Ci, KH, KW = param.shape
+        if kind == 'khwc':
+            t = torch.empty(Co, KH * KW * Ci, dtype=_state['dtype'], device=param.device)
+            ops.permute4(param.data, t, (Co, Ci, KH, KW), (0, 2, 3, 1))
+        else:
+            t = torch.empty(Ci, KH * KW * Co, dtype=_state['dtype'], device=param.device)
+            ops.permute4(param.data, t, (Co, Ci, KH, KW), (1, 2, 3, 0), flipmask=0b1100)
+        _cache[key] = t
+    return t
+
+
+def grad(param):
+    if param.grad is None:
+        param.grad = torch.zeros_like(param.data)
+    return param.grad
+
+
+def act_empty(*shape, device):
+    return torch.empty(*shape, dtype=_state['dtype'], device=device)
+
+
+_anchors = {}
+
+
+def anchor(device):
+    """A grad-requiring scalar passed into the autograd bridges so that their backward always runs: parameter
+    gradients are produced by side effect (see module docstring), so autograd cannot know the outputs depend on them."""
+    a = _anchors.get(device)
+    if a is None:
+        a = torch.zeros(1, device=device, requires_grad=True)
+        _anchors[device] = a
+    return a

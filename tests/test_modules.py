@@ -1,0 +1,75 @@
+"""Module-level parity of the cmda_amd modules (HIP kernels through the C ABI) against the oracle and the golden
+fixtures produced by the reference's own modules.  fp32 compute mode: tolerance 1e-3 relative (north star) -- in
+practice ~1e-5; bf16 mode: documented looser bound."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, 'golden'))
+from weights import sample_grad, seeded_fill, seeded_randn  # noqa: E402
+
+import cmda_amd.runtime as rt  # noqa: E402
+from cmda_amd import backbones as bb  # noqa: E402
+from conftest import assert_close  # noqa: E402
+
+
+def gold(name):
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(HERE, 'golden', name + '.npz')).items()}
+
+
+def check_grads(module, g, rtol, n=2048, atol=1e-6):
+    seen = 0
+    for name, p in module.named_parameters():
+        key = 'grad.' + name
+        if key in g:
+            assert p.grad is not None, name
+            assert_close(sample_grad(p.grad, n), g[key], rtol, atol=atol, name=key)
+            seen += 1
+    assert seen == sum(k.startswith('grad.') for k in g)
+
+
+@pytest.fixture
+def mode(request, tgt):
+    dt = getattr(request, 'param', torch.float32)
+    rt.set_compute_dtype(dt)
+    yield dt
+    rt.set_compute_dtype(torch.float32)
+
+
+BLOCK_CFGS = {'s1': (64, 1, 8, 16, 16), 's2': (128, 2, 4, 8, 16), 's3': (320, 5, 2, 8, 8), 's4': (512, 8, 1, 4, 4),
+              'f1': (128, 1, 4, 8, 8)}
+
+
+@pytest.mark.parametrize('mode', [torch.float32, torch.bfloat16], indirect=True)
+@pytest.mark.parametrize('tag', list(BLOCK_CFGS))
+def test_block_golden(tgt, mode, tag):
+    from functools import partial
+    dim, heads, sr, H, W = BLOCK_CFGS[tag]
+    g = gold('block_' + tag)
+    m = bb.Block(dim, heads, 4, True, drop_path=0.0, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), sr_ratio=sr)
+    seeded_fill(m, 11).train().to(tgt.device)
+    x = tgt.to(seeded_randn((2, H * W, dim), 11, 'x')).requires_grad_(True)
+    y = m(x, H, W)
+    y.backward(tgt.to(seeded_randn(y.shape, 11, 'dy')))
+    f32 = mode == torch.float32
+    assert_close(y, g['y'], 1e-4 if f32 else 3e-2, name='y')
+    assert_close(x.grad, g['dx'], 1e-4 if f32 else 4e-2, name='dx')
+    check_grads(m, g, 2e-4 if f32 else 6e-2, atol=1e-6 if f32 else 1e-3)
+
+
+@pytest.mark.parametrize('mode', [torch.float32], indirect=True)
+def test_mit_small_train_golden(tgt, mode):
+    g = gold('mit_small_train')
+    m = bb.MixVisionTransformer(patch_size=4, embed_dims=[64, 128, 320, 512], num_heads=[1, 2, 5, 8], qkv_bias=True,
+                                norm_layer=__import__('functools').partial(torch.nn.LayerNorm, eps=1e-6),
+                                depths=[1, 1, 1, 1], sr_ratios=[8, 4, 2, 1], drop_path_rate=0.0)
+    seeded_fill(m, 22).train().to(tgt.device)
+    outs = m(tgt.to(seeded_randn((2, 3, 64, 96), 22, 'img')))
+    sum((o * tgt.to(seeded_randn(o.shape, 22, f'dy{i}'))).sum() for i, o in enumerate(outs)).backward()
+    for i, o in enumerate(outs):
+        assert_close(o, g[f'out{i}'], 1e-4, name=f'out{i}')
+    check_grads(m, g, 5e-4)
