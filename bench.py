@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training images/s of the CMDA hot path on MI355X (BASELINE.json metric).
+
+Workload at N=1 = BASELINE.json configs[1]: MiT-B5 + DAFormer (sep-ASPP) head forward/backward (+ fused AdamW step),
+synthetic 512x512 inputs, bf16 activations / fp32 accumulate, random-init weights of the real architecture.
+N>1: one process per GPU (torchrun), weak scaling (per-GPU batch fixed), gradients all-reduced (mean) with RCCL.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel family = the MFMA GEMM, HIP-event timed on the launch
+stream) and, at N=1, `cpu_baseline` (the oracle restatement timed on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+GFLOP_PER_IMAGE_FWD = 252.6     # MiT-B5 138.8 + DAFormer head 113.8
+
+
+def build_model(dev, drop_path_rate=0.1, dropout_ratio=0.1):
+    import cmda_amd  # noqa: F401
+    from cmda_amd.registry import build_segmentor
+    cfg = dict(type='EncoderDecoder',
+               backbone=dict(type='mit_b5', style='pytorch', drop_path_rate=drop_path_rate),
+               decode_head=dict(type='DAFormerHead', in_channels=[64, 128, 320, 512], in_index=[0, 1, 2, 3], channels=256,
+                                dropout_ratio=dropout_ratio, num_classes=19, norm_cfg=dict(type='BN', requires_grad=True),
+                                align_corners=False,
+                                decoder_params=dict(embed_dims=256, embed_cfg=dict(type='mlp', act_cfg=None, norm_cfg=None),
+                                                    embed_neck_cfg=dict(type='mlp', act_cfg=None, norm_cfg=None),
+                                                    fusion_cfg=dict(type='aspp', sep=True, dilations=(1, 6, 12, 18),
+                                                                    pool=False, act_cfg=dict(type='ReLU'),
+                                                                    norm_cfg=dict(type='BN', requires_grad=True))),
+                                loss_decode=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0)),
+               train_cfg=dict(), test_cfg=dict(mode='whole'))
+    model = build_segmentor(cfg)
+    model.init_weights()
+    return model.to(dev).train()
+
+
+def synthetic_batch(B, size, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randn(B, 3, size, size, generator=g)
+    lab = torch.randint(0, 19, (B, 1, size // 32, size // 32), generator=g)
+    lab = lab.repeat_interleave(32, 2).repeat_interleave(32, 3)
+    lab[torch.rand(B, 1, size, size, generator=g) < 0.05] = 255
+    return img.to(dev), lab.to(dev)
+
+
+def cpu_baseline(size):
+    """Oracle (port of the reference algorithm, oracle/) timed on the host cores: one fwd+bwd of MiT-B5 + DAFormer
+    head on ONE image (bounded sample of the same workload)."""
+    from oracle import head as ohd, mit as omit, segmentor as oseg
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    ref = oseg.EncoderDecoder(omit.mit_b5(drop_path_rate=0.1), ohd.DAFormerHead(dropout_ratio=0.1)).train()
+    ref.backbone.init_weights()
+    img = torch.randn(1, 3, size, size)
+    gt = torch.randint(0, 19, (1, 1, size, size))
+    t0 = time.time()
+    losses, _ = ref.forward_train(img, gt)
+    losses['decode.loss_seg'].backward()
+    dt = time.time() - t0
+    return {'value': round(1.0 / dt, 4), 'unit': 'img/s', 'cores': cores, 'kind': 'port',
+            'sample': f'1 image {size}x{size}, one fwd+bwd of MiT-B5+DAFormerHead in fp32 on {cores} host threads, {dt:.1f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=int(os.environ.get('CMDA_BENCH_BATCH', 8)), help='images per GPU')
+    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X (the HIP path has no CPU fallback)'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    import cmda_amd.runtime as rt
+    from cmda_amd import ops, optim
+    rt.set_compute_dtype(torch.bfloat16 if args.dtype == 'bf16' else torch.float32)
+    torch.manual_seed(1234)  # identical initial weights on every rank
+    model = build_model(dev)
+    opt = optim.FlatAdamW(model, lr=6e-5, weight_decay=0.01,
+                          custom_keys=dict(head=dict(lr_mult=10.0), pos_block=dict(decay_mult=0.0), norm=dict(decay_mult=0.0)))
+    torch.manual_seed(1000 + rank)  # per-rank DropPath / Dropout streams
+    img, gt = synthetic_batch(args.batch, args.size, rank, dev)
+    it = [0]
+
+    def step():
+        opt.zero_grad()
+        losses, _ = model.forward_train(img, None, gt)
+        losses['decode.loss_seg'].backward()
+        if world > 1:
+            dist.all_reduce(opt.flat_g)
+            opt.flat_g.div_(world)
+        opt.step(optim.poly_warm_scale(it[0]))
+        it[0] += 1
+        return losses['decode.loss_seg']
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    loss_val = float(loss.item())
+
+    # roofline leg: one more step with every GEMM launch bracketed by events on the launch stream
+    ops.GEMM_PROFILE = []
+    step()
+    torch.cuda.synchronize()
+    prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+    gemm_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in prof)
+    gemm_flops = sum(f for f, _, _ in prof)
+    achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    roofline = {'bound': 'mfma', 'kernel': 'gemm_kernel (bf16 MFMA 16x16x32 tile GEMM / implicit-GEMM conv family)',
+                'achieved': round(achieved, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,
+                'launches_per_step': len(prof), 'avg_launch_us': round(gemm_ms * 1e3 / max(len(prof), 1), 2),
+                'gemm_ms_per_step': round(gemm_ms, 3), 'algorithmic_gflop_per_step': round(gemm_flops / 1e9, 1)}
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = args.batch * world * args.steps / dt
+        out = {'metric': 'training images/sec (512x512, MiT-B5 + DAFormer head fwd/bwd + AdamW step)', 'value': round(value, 3),
+               'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+               'dtype': 'bf16' if args.dtype == 'bf16' else 'f32', 'data': 'synthetic',
+               'config': {'workload': 'BASELINE.json configs[1]: MiT-B5 + DAFormer(sep-ASPP) head fwd/bwd, random '
+                                      f'{args.size}x{args.size}, HIP kernels', 'global_batch': args.batch * world,
+                          'per_gpu_batch': args.batch, 'image_size': args.size, 'parallelism': f'dp{world}',
+                          'drop_path_rate': 0.1, 'dropout_ratio': 0.1, 'optimizer': 'AdamW (fused, flat buffers)'},
+               'final_loss': round(loss_val, 5),
+               'model_gflop_per_image_fwd_bwd': round(3 * GFLOP_PER_IMAGE_FWD, 1),
+               'model_tflops_achieved': round(3 * GFLOP_PER_IMAGE_FWD * value / 1e3 / world, 2),
+               'roofline': roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args.size)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,5 @@
+"""cmda_amd -- MI355X (gfx950) implementation of CMDA's dense-segmentation training hot path.
+
+Importing the package registers the modules under the reference's registry keys (cmda_amd.registry)."""
+from . import registry  # noqa: F401
+from . import backbones, decode_heads, segmentors  # noqa: F401,E402

@@ -173,6 +173,25 @@ __global__ void pseudo_label_kernel(const float* __restrict__ logits, long long*
   if (threadIdx.x == 0) atomicAdd(count, red[0] + red[1] + red[2] + red[3]);
 }
 
+// out[b,c,Y,X] (NCHW fp32) = bilinear up-sample of NHWC logits: encode_decode's resize (encoder_decoder.py:733-745)
+__global__ void upsample_logits_nchw_kernel(const float* __restrict__ logits, float* __restrict__ out, int B, int h,
+                                            int w, int H, int W, int nc) {
+  const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+  const long total = (long)B * H * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int X = (int)(i % W);
+    const long t = i / W;
+    const int Y = (int)(t % H);
+    const int b = (int)(t / H);
+    const BilinTap ty = bilin_tap(Y, h, H, sh), tx = bilin_tap(X, w, W, sw);
+    float s[kMaxClasses];
+    upsample_scores<kMaxClasses>(logits, b, h, w, nc, ty, tx, s);
+#pragma unroll
+    for (int c = 0; c < kMaxClasses; ++c)
+      if (c < nc) out[(((long)b * nc + c) * H + Y) * W + X] = s[c];
+  }
+}
+
 // weight[b,y,x] = (count / total) with the first `top` and last `bottom` rows zeroed (dacs.py:702-711)
 __global__ void pseudo_weight_kernel(const int* __restrict__ count, float* __restrict__ weight, int B, int H, int W,
                                      int top, int bottom) {
@@ -225,5 +244,14 @@ extern "C" int cmda_pseudo_weight(const int* count, float* weight, int B, int H,
   if ((long)B * H * W <= 0) return CMDA_OK;
   CMDA_LAUNCH(pseudo_weight_kernel, dim3(grid_for((long)B * H * W)), dim3(256), 0, stream, count, weight, B, H, W, top,
               bottom);
+  CMDA_CHECK_LAUNCH();
+}
+
+extern "C" int cmda_upsample_logits_nchw(const float* logits, float* out, int B, int h, int w, int H, int W, int nc,
+                                         void* stream) {
+  if ((long)B * H * W <= 0) return CMDA_OK;
+  if (nc <= 0 || nc > kMaxClasses) return CMDA_ERR_SHAPE;
+  CMDA_LAUNCH(upsample_logits_nchw_kernel, dim3(grid_for((long)B * H * W)), dim3(256), 0, stream, logits, out, B, h, w,
+              H, W, nc);
   CMDA_CHECK_LAUNCH();
 }

@@ -1,0 +1,316 @@
+"""DAFormer decode heads on the HIP kernels -- registry keys `DAFormerHead`, `DAFormerHeadFusion`, `CrossEntropyLoss`.
+
+Mirrors mmseg/models/decode_heads/daformer_head.py (DAFormerHead :136-197, DAFormerHeadFusion :200-322),
+decode_head.py (BaseDecodeHead(.Fusion): ctor :49-97 / :275-343, cls_seg* :563-586, losses :588-606,
+forward_train :423-534), aspp_head.py / sep_aspp_head.py (ASPP modules) and losses/cross_entropy_loss.py:140-200.
+Parameter names equal the reference's state_dict keys (mmcv ConvModule: `.conv` / `.bn`).
+
+Data layout: every feature map is NHWC flattened to [B*H*W, C]; the four embeds are written straight into their
+channel slice of one [B*H*W, 1024] buffer (no torch.cat), the four ASPP branches likewise into the bottleneck's input;
+logits stay fp32 NHWC and the 19 x H x W up-sampled tensor of losses() is never materialised (ce_loss.hip).
+"""
+import torch
+import torch.nn as nn
+
+from . import nn as K
+from . import ops
+from . import runtime as rt
+from .registry import HEADS, LOSSES, build_loss
+
+
+# ---------------------------------------------------------------------------------------------- containers
+class ConvModule(nn.Module):
+    """Parameter container with mmcv.cnn.ConvModule's naming: conv (no bias when a norm follows) + bn (+ReLU)."""
+
+    def __init__(self, cin, cout, k, padding=0, dilation=1, groups=1, norm=True):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, padding=padding, dilation=dilation, groups=groups, bias=not norm)
+        self.bn = nn.BatchNorm2d(cout) if norm else None
+        nn.init.kaiming_normal_(self.conv.weight, a=0, mode='fan_out', nonlinearity='relu')
+        if self.conv.bias is not None:
+            nn.init.zeros_(self.conv.bias)
+        self.k, self.padding, self.dilation, self.groups = k, padding, dilation, groups
+
+
+class DepthwiseSeparableConvModule(nn.Module):
+    def __init__(self, cin, cout, k, padding, dilation):
+        super().__init__()
+        self.depthwise_conv = ConvModule(cin, cin, k, padding=padding, dilation=dilation, groups=cin)
+        self.pointwise_conv = ConvModule(cin, cout, 1)
+
+
+class MLP(nn.Module):
+    def __init__(self, input_dim=2048, embed_dim=768):
+        super().__init__()
+        self.proj = nn.Linear(input_dim, embed_dim)
+
+
+def _bn_fwd(bn, x, y, M, C, relu, ldy=None, coff=0):
+    """train: batch stats + running-stat update; eval: running stats.  Returns what the backward needs."""
+    if bn.training:
+        mean, rstd = ops.bn_train_fwd(x, bn.weight, bn.bias, y, bn.running_mean, bn.running_var, M, C, bn.eps,
+                                      bn.momentum, relu, ldy, coff)
+    else:
+        mean, rstd = bn.running_mean, torch.rsqrt(bn.running_var + bn.eps)
+        ops.bn_apply(x, mean, rstd, bn.weight, bn.bias, y, M, C, relu, ldy, coff)
+    return mean, rstd
+
+
+def _bn_bwd(bn, dy, x, stats, M, C, relu, lddy=None, coff=0):
+    mean, rstd = stats
+    return ops.bn_train_bwd(dy, x, mean, rstd, bn.weight, bn.bias, rt.grad(bn.weight), rt.grad(bn.bias), M, C, relu,
+                            lddy, coff)
+
+
+class ASPPWrapper(nn.Module):
+    """daformer_head.py:15-79 with pool=False, no context layer (configs/_base_/models/daformer_sepaspp_mitb5.py)."""
+
+    def __init__(self, in_channels, channels, sep, dilations, pool=False, norm_cfg=None, act_cfg=None,
+                 align_corners=False, context_cfg=None):
+        super().__init__()
+        assert not pool and context_cfg is None, 'only the configuration CMDA uses is implemented'
+        assert sep, 'CMDA uses the depthwise-separable ASPP'
+        self.dilations = tuple(dilations)
+        self.in_channels, self.channels = in_channels, channels
+        mods = []
+        for d in self.dilations:
+            mods.append(ConvModule(in_channels, channels, 1) if d == 1 else
+                        DepthwiseSeparableConvModule(in_channels, channels, 3, padding=d, dilation=d))
+        self.aspp_modules = nn.ModuleList(mods)
+        self.bottleneck = ConvModule(len(self.dilations) * channels, channels, 3, padding=1)
+
+    def fwd(self, x, B, H, W):
+        """x [M, Cin] -> feat [M, channels]"""
+        M, Cin, Ch = B * H * W, self.in_channels, self.channels
+        nb = len(self.dilations)
+        cat = torch.empty(M, nb * Ch, dtype=rt.compute_dtype(), device=x.device)
+        saved = []
+        for j, (d, m) in enumerate(zip(self.dilations, self.aspp_modules)):
+            if d == 1:
+                z = K.linear_fwd(x, m.conv.weight, None, M, Cin)
+                st = _bn_fwd(m.bn, z, cat, M, Ch, True, nb * Ch, j * Ch)
+                saved.append((z, st))
+            else:
+                dwm, pwm = m.depthwise_conv, m.pointwise_conv
+                u = ops.dwconv_fwd(x, dwm.conv.weight.data.view(Cin, 9), None, B, H, W, Cin, d, None)
+                ub = torch.empty_like(u)
+                st_u = _bn_fwd(dwm.bn, u, ub, M, Cin, True)
+                z = K.linear_fwd(ub, pwm.conv.weight, None, M, Cin)
+                st_z = _bn_fwd(pwm.bn, z, cat, M, Ch, True, nb * Ch, j * Ch)
+                saved.append((u, st_u, ub, z, st_z))
+        zb, _, _ = K.conv_fwd(cat, self.bottleneck.conv.weight, None, B, H, W, 1, 1)
+        feat = torch.empty_like(zb)
+        st_b = _bn_fwd(self.bottleneck.bn, zb, feat, M, Ch, True)
+        return feat, (x, cat, saved, zb, st_b)
+
+    def bwd(self, sv, dfeat, B, H, W):
+        x, cat, saved, zb, st_b = sv
+        M, Cin, Ch = B * H * W, self.in_channels, self.channels
+        nb = len(self.dilations)
+        dzb = _bn_bwd(self.bottleneck.bn, dfeat, zb, st_b, M, Ch, True)
+        dcat = K.conv_bwd(dzb, cat, self.bottleneck.conv.weight, None, B, H, W, 1, 1)
+        dx = torch.empty(M, Cin, dtype=rt.compute_dtype(), device=x.device)
+        first = True
+        for j, (d, m) in enumerate(zip(self.dilations, self.aspp_modules)):
+            if d == 1:
+                z, st = saved[j]
+                dz = _bn_bwd(m.bn, dcat, z, st, M, Ch, True, nb * Ch, j * Ch)
+                K.linear_bwd(dz, x, m.conv.weight, None, M, Cin, dx_out=dx, dx_beta=0.0 if first else 1.0)
+            else:
+                u, st_u, ub, z, st_z = saved[j]
+                dwm, pwm = m.depthwise_conv, m.pointwise_conv
+                dz = _bn_bwd(pwm.bn, dcat, z, st_z, M, Ch, True, nb * Ch, j * Ch)
+                dub = K.linear_bwd(dz, ub, pwm.conv.weight, None, M, Cin)
+                du = _bn_bwd(dwm.bn, dub, u, st_u, M, Cin, True)
+                ops.dwconv_bwd_weight(du, x, rt.grad(dwm.conv.weight).view(Cin, 9), None, B, H, W, Cin, d)
+                ops.dwconv_bwd_data(du, dwm.conv.weight.data.view(Cin, 9), B, H, W, Cin, d, out=dx, accumulate=not first)
+            first = False
+        return dx
+
+
+def build_layer(in_channels, out_channels, type, **kwargs):
+    """daformer_head.py:82-116 (the layer types CMDA's configs use)."""
+    if type == 'id':
+        return nn.Identity()
+    if type == 'mlp':
+        return MLP(input_dim=in_channels, embed_dim=out_channels)
+    if type == 'aspp':
+        return ASPPWrapper(in_channels=in_channels, channels=out_channels, **kwargs)
+    raise NotImplementedError(type)
+
+
+@LOSSES.register_module()
+class CrossEntropyLoss(nn.Module):
+    """losses/cross_entropy_loss.py:140-200, softmax path (use_sigmoid=False, use_mask=False, no class weights)."""
+
+    def __init__(self, use_sigmoid=False, use_mask=False, reduction='mean', class_weight=None, loss_weight=1.0):
+        super().__init__()
+        assert not use_sigmoid and not use_mask, 'only the softmax cross-entropy of configs/fusion/* is implemented'
+        assert reduction == 'mean'
+        self.use_sigmoid, self.use_mask, self.reduction = use_sigmoid, use_mask, reduction
+        self.loss_weight, self.class_weight = loss_weight, class_weight
+
+
+def ce_losses_fwd(logits, seg_label, seg_weight, ignore_index, loss_weight):
+    """losses(): logits fp32 NHWC [B,h,w,nc]; label [B,1,H,W] int64.  Returns (loss, acc%, saved)."""
+    B, _, H, W = seg_label.shape
+    label = seg_label.view(B, H, W)
+    wgt = seg_weight.float().contiguous() if seg_weight is not None else None
+    acc, lse = ops.ce_upsample_fwd(logits, label, wgt, H, W, ignore_index)
+    n = float(B * H * W)
+    loss = acc[0] * (loss_weight / n)
+    accuracy = acc[1:2] * (100.0 / n)
+    return loss, accuracy, (logits, label, wgt, lse, H, W, n)
+
+
+def ce_losses_bwd(saved, gscale, mul, ignore_index, loss_weight):
+    """d(loss)/d(logits) * gscale (fp32 device scalar or None) * mul"""
+    logits, label, wgt, lse, H, W, n = saved
+    return ops.ce_upsample_bwd(logits, label, wgt, lse, gscale, mul * loss_weight / n, H, W, ignore_index)
+
+
+# ---------------------------------------------------------------------------------------------- heads
+class _HeadBase(nn.Module):
+    def __init__(self, in_channels, channels, *, num_classes, dropout_ratio=0.1, conv_cfg=None, norm_cfg=None,
+                 act_cfg=dict(type='ReLU'), in_index=-1, input_transform=None,
+                 loss_decode=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0), decoder_params=None,
+                 ignore_index=255, sampler=None, align_corners=False, init_cfg=None):
+        super().__init__()
+        assert input_transform == 'multiple_select' and sampler is None
+        assert isinstance(in_channels, (list, tuple)) and isinstance(in_index, (list, tuple))
+        assert len(in_channels) == len(in_index)
+        assert not align_corners
+        self.in_channels, self.in_index, self.channels = list(in_channels), list(in_index), channels
+        self.num_classes, self.dropout_ratio, self.ignore_index = num_classes, dropout_ratio, ignore_index
+        self.norm_cfg, self.act_cfg, self.align_corners = norm_cfg, act_cfg, align_corners
+        self.input_transform = input_transform
+        self.loss_decode = build_loss(loss_decode)
+        self.conv_seg = nn.Conv2d(channels, num_classes, kernel_size=1)
+        nn.init.normal_(self.conv_seg.weight, std=0.01)
+        nn.init.zeros_(self.conv_seg.bias)
+        dp = decoder_params
+        embed_dims = dp['embed_dims']
+        self.embed_dims = [embed_dims] * len(self.in_index) if isinstance(embed_dims, int) else list(embed_dims)
+        embed_cfg, neck_cfg = dp['embed_cfg'], dp['embed_neck_cfg']
+        self._embed_cfg = dict(embed_cfg)
+        self._neck_cfg = dict(embed_cfg if neck_cfg == 'same_as_embed_cfg' else neck_cfg)
+        self._fusion_cfg = dict(dp['fusion_cfg'])
+        for cfg in (self._embed_cfg, self._neck_cfg, self._fusion_cfg):
+            if 'aspp' in cfg['type']:
+                cfg['align_corners'] = self.align_corners
+
+    def init_weights(self):
+        pass  # constructors already apply the reference's initialisers
+
+    def _make_branch(self):
+        embeds = {}
+        for i, cin, e in zip(self.in_index, self.in_channels, self.embed_dims):
+            cfg = self._neck_cfg if i == self.in_index[-1] else self._embed_cfg
+            embeds[str(i)] = build_layer(cin, e, **cfg)
+        return nn.ModuleDict(embeds), build_layer(sum(self.embed_dims), self.channels, **self._fusion_cfg)
+
+    # one decoder branch: embeds -> resize+concat -> fuse layer
+    def _branch_fwd(self, embeds, fuse, feats, B):
+        f0, H, W = feats[self.in_index[0]]
+        M = B * H * W
+        tot = sum(self.embed_dims)
+        cat = torch.empty(M, tot, dtype=rt.compute_dtype(), device=f0.device)
+        off = 0
+        for i, e in zip(self.in_index, self.embed_dims):
+            f, h, w = feats[i]
+            lin = embeds[str(i)].proj
+            if (h, w) == (H, W):
+                K.linear_fwd(f, lin.weight, lin.bias, B * h * w, f.shape[1], out=cat, ldc=tot, c_offset=off)
+            else:
+                emb = K.linear_fwd(f, lin.weight, lin.bias, B * h * w, f.shape[1])
+                ops.bilinear_fwd(emb, cat, B, h, w, H, W, e, tot, off)
+            off += e
+        feat, sv = fuse.fwd(cat, B, H, W)
+        return feat, (sv, feats, H, W)
+
+    def _branch_bwd(self, embeds, fuse, saved, dfeat, B):
+        sv, feats, H, W = saved
+        tot = sum(self.embed_dims)
+        dcat = fuse.bwd(sv, dfeat, B, H, W)
+        dfs = {}
+        off = 0
+        for i, e in zip(self.in_index, self.embed_dims):
+            f, h, w = feats[i]
+            lin = embeds[str(i)].proj
+            if (h, w) == (H, W):
+                dfs[i] = K.linear_bwd(dcat, f, lin.weight, lin.bias, B * h * w, f.shape[1], dy_ld=tot, dy_off=off)
+            else:
+                demb = torch.empty(B * h * w, e, dtype=rt.compute_dtype(), device=dcat.device)
+                ops.bilinear_bwd(dcat, demb, B, h, w, H, W, e, tot, off)
+                dfs[i] = K.linear_bwd(demb, f, lin.weight, lin.bias, B * h * w, f.shape[1])
+            off += e
+        return dfs
+
+    # classifier: (Dropout2d) -> 1x1 conv, logits fp32 NHWC
+    def _cls_fwd(self, feat, B, H, W, with_dropout=True):
+        M, Ch = B * H * W, self.channels
+        mask = None
+        if with_dropout and self.training and self.dropout_ratio > 0:
+            keep = 1.0 - self.dropout_ratio
+            mask = (torch.rand(B, Ch, device=feat.device) < keep).float().div_(keep)
+            featd = ops.sample_scale(feat, mask, B, Ch, per_channel=True)
+        else:
+            featd = feat
+        logits = K.linear_fwd(featd, self.conv_seg.weight, self.conv_seg.bias, M, Ch,
+                              out_dtype=torch.float32)
+        return logits.view(B, H, W, self.num_classes), (featd, mask)
+
+    def _cls_bwd(self, saved, dlogits, B, H, W):
+        featd, mask = saved
+        M, Ch = B * H * W, self.channels
+        dl = dlogits.view(M, self.num_classes)
+        dl = dl if rt.compute_dtype() == torch.float32 else ops.cast(dl, rt.compute_dtype())
+        dfeat = K.linear_bwd(dl, featd, self.conv_seg.weight, self.conv_seg.bias, M, Ch)
+        if mask is not None:
+            dfeat = ops.sample_scale(dfeat, mask, B, Ch, per_channel=True, out=dfeat)
+        return dfeat
+
+    @staticmethod
+    def _to_feats(inputs):
+        """NCHW list (reference interface) -> [(NLC tensor, H, W)] in the compute dtype."""
+        out = []
+        for x in inputs:
+            B, C, H, W = x.shape
+            t = torch.empty(B * H * W, C, dtype=rt.compute_dtype(), device=x.device)
+            ops.permute4(x.contiguous(), t, (B, C, H, W), (0, 2, 3, 1))
+            out.append((t, H, W))
+        return out
+
+
+@HEADS.register_module()
+class DAFormerHead(_HeadBase):
+    def __init__(self, **kwargs):
+        super().__init__(input_transform='multiple_select', **kwargs)
+        self.embed_layers, self.fuse_layer = self._make_branch()
+
+    def fwd(self, feats, B):
+        feat, sv_b = self._branch_fwd(self.embed_layers, self.fuse_layer, feats, B)
+        H, W = sv_b[2], sv_b[3]
+        logits, sv_c = self._cls_fwd(feat, B, H, W)
+        return logits, (sv_b, sv_c, H, W)
+
+    def bwd(self, saved, dlogits, B):
+        sv_b, sv_c, H, W = saved
+        dfeat = self._cls_bwd(sv_c, dlogits, B, H, W)
+        return self._branch_bwd(self.embed_layers, self.fuse_layer, sv_b, dfeat, B)
+
+    def fwd_train(self, feats, B, gt, seg_weight=None):
+        logits, sv = self.fwd(feats, B)
+        loss, acc, sv_l = ce_losses_fwd(logits, gt, seg_weight, self.ignore_index, self.loss_decode.loss_weight)
+        return {'loss_seg': loss, 'acc_seg': acc}, logits, (sv, sv_l)
+
+    def bwd_train(self, saved, B, gscale=None, mul=1.0):
+        sv, sv_l = saved
+        dlogits = ce_losses_bwd(sv_l, gscale, mul, self.ignore_index, self.loss_decode.loss_weight)
+        return self.bwd(sv, dlogits, B)
+
+    def forward(self, inputs):
+        """Reference signature: list of NCHW maps -> logits [B,nc,h,w] (fp32, NCHW view). Inference-style (no grad)."""
+        B = inputs[0].shape[0]
+        logits, _ = self.fwd(self._to_feats([inputs[i] for i in range(len(inputs))]), B)
+        return logits.permute(0, 3, 1, 2)

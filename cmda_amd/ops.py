@@ -40,6 +40,9 @@ def conv_view(x, B, H, W, C, KH, KW, stride, pad, dil=1, OH=None, OW=None, in_di
 
 ACT = {None: 0, 'none': 0, 'relu': 1, 'gelu': 2}
 
+# bench.py's roofline leg: when a list is installed here every GEMM launch is bracketed by events on the launch stream
+GEMM_PROFILE = None
+
 
 def gemm(A, B, out, M, N, K, *, a_kstrided=False, b_kstrided=False, ldc=None, batch=1, c_batch_stride=0,
          batch2=1, c_batch2_stride=0, res_batch2_stride=0, splits=1, alpha=1.0, beta=0.0, bias=None, act=None, res=None, ldres=None, res_batch_stride=0,
@@ -66,6 +69,13 @@ def gemm(A, B, out, M, N, K, *, a_kstrided=False, b_kstrided=False, ldc=None, ba
     p.out_f32 = int(out_f32)
     assert out_f32 or not atomic
     p.atomic = int(atomic)
+    if GEMM_PROFILE is not None and out.is_cuda:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        call('cmda_gemm', ctypes.byref(p), stream_of(out))
+        e1.record()
+        GEMM_PROFILE.append((2.0 * M * N * K * batch * batch2, e0, e1))
+        return out
     call('cmda_gemm', ctypes.byref(p), stream_of(out))
     return out
 
@@ -284,4 +294,14 @@ def sample_scale(x, scale, B, C, per_channel=False, out=None):
     out = torch.empty_like(x) if out is None else out
     call('cmda_sample_scale', ptr(x), ptr(scale), ptr(out), c_i32(B), c_i64(x.numel() // B), c_i32(C),
          c_i32(int(per_channel)), dtype_tag(x), stream_of(x))
+    return out
+
+
+def upsample_logits_nchw(logits, H, W):
+    """fp32 NHWC [B,h,w,nc] -> fp32 NCHW [B,nc,H,W] (bilinear, align_corners=False)."""
+    check_dev(logits)
+    B, h, w, nc = logits.shape
+    out = torch.empty(B, nc, H, W, dtype=torch.float32, device=logits.device)
+    call('cmda_upsample_logits_nchw', ptr(logits), ptr(out), c_i32(B), c_i32(h), c_i32(w), c_i32(H), c_i32(W), c_i32(nc),
+         stream_of(logits))
     return out

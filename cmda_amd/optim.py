@@ -1,0 +1,74 @@
+"""Flat-buffer parameter store + fused AdamW (the optimiser of configs/_base_/schedules/adamw.py with the paramwise
+rules of configs/fusion/*: `head` lr x10, `pos_block` / `norm` weight-decay 0; mmcv DefaultOptimizerConstructor
+semantics restated in SURVEY.md appendix D) and the poly(1.0) + linear warm-up schedule (schedules/poly10warm.py).
+
+All trainable parameters of a model are re-homed into ONE fp32 buffer (grouped by (lr_mult, decay_mult)), their
+gradients into a second one, so that zero_grad is one memset, the data-parallel gradient exchange is a handful of
+large RCCL calls over contiguous memory, and the AdamW update is one kernel launch per group (cmda_adamw_step).
+"""
+import torch
+
+from . import ops
+from . import runtime as rt
+
+
+def _group_of(name, custom_keys):
+    for key in sorted(sorted(custom_keys.keys()), key=len, reverse=True):
+        if key in name:
+            return (custom_keys[key].get('lr_mult', 1.0), custom_keys[key].get('decay_mult', 1.0))
+    return (1.0, 1.0)
+
+
+class FlatAdamW:
+    def __init__(self, model, lr=6e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, custom_keys=None,
+                 name_prefix=''):
+        custom_keys = custom_keys or {}
+        named = [(name_prefix + n, p) for n, p in model.named_parameters() if p.requires_grad]
+        seen, uniq = set(), []
+        for n, p in named:
+            if id(p) not in seen:
+                seen.add(id(p))
+                uniq.append((n, p))
+        groups = {}
+        for n, p in uniq:
+            groups.setdefault(_group_of(n, custom_keys), []).append(p)
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        dev = uniq[0][1].device
+        total = sum((p.numel() + 3) // 4 * 4 for _, p in uniq)
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.segments = []  # (start, end, lr_mult, decay_mult)
+        off = 0
+        with torch.no_grad():
+            for (lm, dm), ps in sorted(groups.items()):
+                start = off
+                for p in ps:
+                    n = p.numel()
+                    self.flat_p[off:off + n].copy_(p.data.reshape(-1))
+                    p.data = self.flat_p[off:off + n].view(p.shape)
+                    p.grad = self.flat_g[off:off + n].view(p.shape)
+                    off += (n + 3) // 4 * 4
+                self.segments.append((start, off, lm, dm))
+        self.step_count = 0
+        rt.invalidate()
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+
+    def step(self, lr_scale=1.0):
+        self.step_count += 1
+        for start, end, lm, dm in self.segments:
+            ops.adamw_step(self.flat_p[start:end], self.flat_g[start:end], self.flat_m[start:end], self.flat_v[start:end],
+                           self.lr * lm * lr_scale, self.betas[0], self.betas[1], self.eps, self.weight_decay * dm,
+                           self.step_count)
+        rt.invalidate()
+
+
+def poly_warm_scale(it, max_iters=40000, power=1.0, warmup_iters=1500, warmup_ratio=1e-6):
+    """lr(it) / base_lr for poly(power) decay to 0 with linear warm-up (mmcv PolyLrUpdaterHook + 'linear' warmup)."""
+    s = (1 - it / max_iters) ** power
+    if it < warmup_iters:
+        s *= 1 - (1 - it / warmup_iters) * (1 - warmup_ratio)
+    return s

@@ -73,3 +73,50 @@ def test_mit_small_train_golden(tgt, mode):
     for i, o in enumerate(outs):
         assert_close(o, g[f'out{i}'], 1e-4, name=f'out{i}')
     check_grads(m, g, 5e-4)
+
+
+def feats_nlc(tgt, B, H, W, seed, tag):
+    out = []
+    for i, (c, s) in enumerate(zip([64, 128, 320, 512], [4, 8, 16, 32])):
+        f = seeded_randn((B, c, H // s, W // s), seed, f'{tag}{i}')
+        out.append((tgt.to(f.permute(0, 2, 3, 1).reshape(-1, c).contiguous().to(rt.compute_dtype())), H // s, W // s))
+    return out
+
+
+HEAD_KW = dict(in_channels=[64, 128, 320, 512], in_index=[0, 1, 2, 3], channels=256, dropout_ratio=0.0, num_classes=19,
+               norm_cfg=dict(type='BN', requires_grad=True), align_corners=False,
+               loss_decode=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0))
+
+
+def decoder_params(**extra):
+    d = dict(embed_dims=256, embed_cfg=dict(type='mlp', act_cfg=None, norm_cfg=None),
+             embed_neck_cfg=dict(type='mlp', act_cfg=None, norm_cfg=None),
+             fusion_cfg=dict(type='aspp', sep=True, dilations=(1, 6, 12, 18), pool=False, act_cfg=dict(type='ReLU'),
+                             norm_cfg=dict(type='BN', requires_grad=True)))
+    d.update(extra)
+    return d
+
+
+@pytest.mark.parametrize('mode', [torch.float32, torch.bfloat16], indirect=True)
+def test_head_train_golden(tgt, mode):
+    from cmda_amd import decode_heads as dh
+    g = gold('head_train')
+    head = dh.DAFormerHead(**HEAD_KW, decoder_params=decoder_params())
+    seeded_fill(head, 31).train().to(tgt.device)
+    B, H, W = 2, 64, 96
+    feats = feats_nlc(tgt, B, H, W, 31, 'f')
+    losses, logits, saved = head.fwd_train(feats, B, tgt.to(g['gt']), tgt.to(g['weight']))
+    dfs = head.bwd_train(saved, B, gscale=tgt.to(torch.tensor([1.7])))
+    f32 = mode == torch.float32
+    assert_close(logits.permute(0, 3, 1, 2), g['logits'], 1e-4 if f32 else 4e-2, name='logits')
+    assert_close(losses['loss_seg'], g['loss_seg'], 1e-5 if f32 else 5e-3, name='loss')
+    assert_close(losses['acc_seg'], g['acc_seg'], 1e-6 if f32 else 0.3, name='acc')
+    for i in range(4):
+        c = dfs[i].shape[1]
+        ref = g[f'dfeat{i}'].permute(0, 2, 3, 1).reshape(-1, c)
+        assert_close(dfs[i], ref, 3e-4 if f32 else 0.25, atol=1e-8 if f32 else 2e-6, name=f'dfeat{i}')  # bf16: 3 train-mode BNs amplify rounding
+    check_grads(head, g, 5e-4 if f32 else 0.25, atol=1e-6 if f32 else 2e-3)
+    if f32:
+        for k, v in head.state_dict().items():
+            if 'running' in k:
+                assert_close(v, g['bn.' + k], 1e-4, name=k)
