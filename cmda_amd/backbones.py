@@ -37,7 +37,7 @@ class Mlp(nn.Module):
         hidden = self.fc1.weight.shape[0]
         h = K.linear_fwd(x, self.fc1.weight, self.fc1.bias, M, Cin)
         dw = self.dwconv.dwconv
-        act = ops.dwconv_fwd(h, dw.weight.data.view(hidden, 9), dw.bias, B, H, W, hidden, 1, 'gelu')
+        act = ops.dwconv_fwd(h, rt.wdw(dw.weight), dw.bias, B, H, W, hidden, 1, 'gelu')
         y = K.linear_fwd(act, self.fc2.weight, self.fc2.bias, M, hidden)
         return y, (x, h, act)
 

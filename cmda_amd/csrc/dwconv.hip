@@ -8,7 +8,9 @@
 // HBM-bound stencils: a thread owns 4 adjacent channels of one pixel, lanes run along C so every tap is a
 // coalesced 8/16-byte access; neighbouring pixels' taps hit L1/L2.  Algorithmic bytes per pixel-channel:
 // fwd 2*sizeof(T); gelu-bwd-prep 3*sizeof(T); bwd-data 2*sizeof(T); bwd-weight 2*sizeof(T).
-// Depthwise weights/bias stay fp32 ([C,9] = the reference's [C,1,3,3] parameter, no repack).
+// Depthwise weights/bias stay fp32.  The stencil kernels read a tap-major [9][C] copy of the reference's [C,1,3,3]
+// parameter (rt.wdw: one tiny permute per optimizer step) so that the 4 channel weights of a lane are one coalesced
+// 16-byte load per tap; the weight-gradient kernel still accumulates in the parameter's own [C,9] layout.
 #include "common.h"
 
 namespace {
@@ -24,10 +26,11 @@ static __device__ __forceinline__ void dw_accum(const T* __restrict__ x, const f
     for (int kw = 0; kw < 3; ++kw) {
       const int iw = wx + (kw - 1) * dil;
       if (iw < 0 || iw >= W) continue;
-      float xv[4];
+      float xv[4], wv[4];
       ld4(x + ((long)(b * H + ih) * W + iw) * C + c, xv);
+      ld4(w + (kh * 3 + kw) * C + c, wv);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] += xv[j] * w[(c + j) * 9 + kh * 3 + kw];
+      for (int j = 0; j < 4; ++j) acc[j] += xv[j] * wv[j];
     }
   }
 }
@@ -39,12 +42,13 @@ __global__ void dw_fwd_kernel(const T* __restrict__ x, const float* __restrict__
   const int cg = C >> 2;
   const long total = (long)B * H * W * cg;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % cg) * 4;
-    long pix = i / cg;
-    const int wx = (int)(pix % W);
-    pix /= W;
-    const int h = (int)(pix % H);
-    const int b = (int)(pix / H);
+    const unsigned iu = (unsigned)i;  // launchers guarantee total < 2^32
+    const int c = (int)(iu % (unsigned)cg) * 4;
+    unsigned pix = iu / (unsigned)cg;
+    const int wx = (int)(pix % (unsigned)W);
+    pix /= (unsigned)W;
+    const int h = (int)(pix % (unsigned)H);
+    const int b = (int)(pix / (unsigned)H);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     if (bias) {
 #pragma unroll
@@ -67,12 +71,13 @@ __global__ void dw_gelu_bwd_prep_kernel(const T* __restrict__ x, const float* __
   const int cg = C >> 2;
   const long total = (long)B * H * W * cg;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % cg) * 4;
-    long pix = i / cg;
-    const int wx = (int)(pix % W);
-    pix /= W;
-    const int h = (int)(pix % H);
-    const int b = (int)(pix / H);
+    const unsigned iu = (unsigned)i;  // launchers guarantee total < 2^32
+    const int c = (int)(iu % (unsigned)cg) * 4;
+    unsigned pix = iu / (unsigned)cg;
+    const int wx = (int)(pix % (unsigned)W);
+    pix /= (unsigned)W;
+    const int h = (int)(pix % (unsigned)H);
+    const int b = (int)(pix / (unsigned)H);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     if (bias) {
 #pragma unroll
@@ -95,12 +100,13 @@ __global__ void dw_bwd_data_kernel(const T* __restrict__ dy, const float* __rest
   const int cg = C >> 2;
   const long total = (long)B * H * W * cg;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % cg) * 4;
-    long pix = i / cg;
-    const int wx = (int)(pix % W);
-    pix /= W;
-    const int h = (int)(pix % H);
-    const int b = (int)(pix / H);
+    const unsigned iu = (unsigned)i;  // launchers guarantee total < 2^32
+    const int c = (int)(iu % (unsigned)cg) * 4;
+    unsigned pix = iu / (unsigned)cg;
+    const int wx = (int)(pix % (unsigned)W);
+    pix /= (unsigned)W;
+    const int h = (int)(pix % (unsigned)H);
+    const int b = (int)(pix / (unsigned)H);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
@@ -110,10 +116,11 @@ __global__ void dw_bwd_data_kernel(const T* __restrict__ dy, const float* __rest
       for (int kw = 0; kw < 3; ++kw) {
         const int ow = wx - (kw - 1) * dil;
         if (ow < 0 || ow >= W) continue;
-        float gv[4];
+        float gv[4], wv[4];
         ld4(dy + ((long)(b * H + oh) * W + ow) * C + c, gv);
+        ld4(w + (kh * 3 + kw) * C + c, wv);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] += gv[j] * w[(c + j) * 9 + kh * 3 + kw];
+        for (int j = 0; j < 4; ++j) acc[j] += gv[j] * wv[j];
       }
     }
     T* o = dx + ((long)(b * H + h) * W + wx) * C + c;
@@ -193,14 +200,15 @@ __global__ void dw_bwd_weight_kernel(const T* __restrict__ dz, const T* __restri
   }
 }
 
-static inline int grid_for(long n) { return (int)std::max<long>(1, std::min<long>((n + 255) / 256, 8192)); }
+static inline int grid_for(long n) { return (int)std::max<long>(1, std::min<long>((n + 255) / 256, 16384)); }
+static inline bool too_big(long n) { return n >= (1L << 32); }
 
 }  // namespace
 
 extern "C" int cmda_dwconv3x3_fwd(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C,
                                   int dil, int act, int dtype, void* stream) {
   if ((long)B * H * W * C <= 0) return CMDA_OK;
-  if (C & 3) return CMDA_ERR_SHAPE;
+  if ((C & 3) || too_big((long)B * H * W * (C / 4))) return CMDA_ERR_SHAPE;
   CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((dw_fwd_kernel<T>), dim3(grid_for((long)B * H * W * (C / 4))), dim3(256), 0,
                                          stream, (const T*)x, w, bias, (T*)y, B, H, W, C, dil, act));
   CMDA_CHECK_LAUNCH();
@@ -209,7 +217,7 @@ extern "C" int cmda_dwconv3x3_fwd(const void* x, const float* w, const float* bi
 extern "C" int cmda_dwconv3x3_gelu_bwd_prep(const void* x, const float* w, const float* bias, const void* da, void* dz,
                                             int B, int H, int W, int C, int dil, int dtype, void* stream) {
   if ((long)B * H * W * C <= 0) return CMDA_OK;
-  if (C & 3) return CMDA_ERR_SHAPE;
+  if ((C & 3) || too_big((long)B * H * W * (C / 4))) return CMDA_ERR_SHAPE;
   CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((dw_gelu_bwd_prep_kernel<T>), dim3(grid_for((long)B * H * W * (C / 4))),
                                          dim3(256), 0, stream, (const T*)x, w, bias, (const T*)da, (T*)dz, B, H, W, C, dil));
   CMDA_CHECK_LAUNCH();
@@ -218,7 +226,7 @@ extern "C" int cmda_dwconv3x3_gelu_bwd_prep(const void* x, const float* w, const
 extern "C" int cmda_dwconv3x3_bwd_data(const void* dy, const float* w, void* dx, int B, int H, int W, int C, int dil,
                                        int accumulate, int dtype, void* stream) {
   if ((long)B * H * W * C <= 0) return CMDA_OK;
-  if (C & 3) return CMDA_ERR_SHAPE;
+  if ((C & 3) || too_big((long)B * H * W * (C / 4))) return CMDA_ERR_SHAPE;
   CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((dw_bwd_data_kernel<T>), dim3(grid_for((long)B * H * W * (C / 4))), dim3(256),
                                          0, stream, (const T*)dy, w, (T*)dx, B, H, W, C, dil, accumulate));
   CMDA_CHECK_LAUNCH();

@@ -274,12 +274,31 @@ int launch_tile(const GemmParams& p, void* stream) {
 }
 
 template <typename T>
-int launch_dtype(const GemmParams& p, void* stream) {
-  // tile choice: fill >= 256 CUs when the problem allows it, never waste half a tile on N <= 64
-  const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.batch * p.batch2 * p.splits;
-  const long t12864 = (long)((p.M + 127) / 128) * ((p.N + 63) / 64) * p.batch * p.batch2 * p.splits;
-  if (p.N > 64 && t128 >= 512) return launch_tile<T, 4, 4>(p, stream);
-  if (t12864 >= 512) return launch_tile<T, 4, 2>(p, stream);
+int launch_dtype(GemmParams& p, void* stream) {
+  // Tile / split-K choice.  256 CUs want >= ~2 blocks each; never waste half a tile on N <= 64.
+  const long zb = (long)p.batch * p.batch2;
+  auto blocks = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * zb; };
+  constexpr int BK = 4 * Num<T>::kChunk;
+  const int nkt = (p.K + BK - 1) / BK;
+  int tile;  // 0: 128x128, 1: 128x64, 2: 64x64
+  if (p.atomic && p.splits <= 0) {
+    // accumulate-by-atomics GEMMs (weight gradients): few output tiles, very long contraction -> largest tile that
+    // fits the output, then split K until the grid fills the chip
+    tile = (p.M > 64 && p.N > 64) ? 0 : (p.M > 64 ? 1 : 2);
+    const long b = tile == 0 ? blocks(128, 128) : tile == 1 ? blocks(128, 64) : blocks(64, 64);
+    long s = (1024 + b - 1) / b;
+    s = std::min<long>(s, std::max(1, nkt / 4));
+    s = std::min<long>(s, std::max<long>(1, 65535 / std::max<long>(zb, 1)));
+    p.splits = (int)std::max<long>(1, s);
+  } else {
+    if (p.splits <= 0) p.splits = 1;
+    const long sp = p.splits;
+    if (p.N > 64 && blocks(128, 128) * sp >= 256) tile = 0;
+    else if (blocks(128, 64) * sp >= 256) tile = 1;
+    else tile = 2;
+  }
+  if (tile == 0) return launch_tile<T, 4, 4>(p, stream);
+  if (tile == 1) return launch_tile<T, 4, 2>(p, stream);
   return launch_tile<T, 2, 2>(p, stream);
 }
 
@@ -290,7 +309,7 @@ extern "C" int cmda_gemm(const cmda_gemm_params_t* pp, void* stream) {
   GemmParams p = *pp;
   if (p.batch2 <= 0) p.batch2 = 1;
   if (p.M <= 0 || p.N <= 0 || p.batch <= 0) return CMDA_OK;
-  if (p.K <= 0 || p.splits <= 0) return CMDA_ERR_SHAPE;
+  if (p.K <= 0) return CMDA_ERR_SHAPE;
   if (p.atomic && !p.out_f32) return CMDA_ERR_UNSUPPORTED;
   if (p.splits > 1 && !p.atomic) return CMDA_ERR_UNSUPPORTED;
   if (p.atomic && (p.bias || p.act || p.res || p.rowscale)) return CMDA_ERR_UNSUPPORTED;

@@ -92,7 +92,7 @@ class ASPPWrapper(nn.Module):
                 saved.append((z, st))
             else:
                 dwm, pwm = m.depthwise_conv, m.pointwise_conv
-                u = ops.dwconv_fwd(x, dwm.conv.weight.data.view(Cin, 9), None, B, H, W, Cin, d, None)
+                u = ops.dwconv_fwd(x, rt.wdw(dwm.conv.weight), None, B, H, W, Cin, d, None)
                 ub = torch.empty_like(u)
                 st_u = _bn_fwd(dwm.bn, u, ub, M, Cin, True)
                 z = K.linear_fwd(ub, pwm.conv.weight, None, M, Cin)
@@ -123,7 +123,7 @@ class ASPPWrapper(nn.Module):
                 dub = K.linear_bwd(dz, ub, pwm.conv.weight, None, M, Cin)
                 du = _bn_bwd(dwm.bn, dub, u, st_u, M, Cin, True)
                 ops.dwconv_bwd_weight(du, x, rt.grad(dwm.conv.weight).view(Cin, 9), None, B, H, W, Cin, d)
-                ops.dwconv_bwd_data(du, dwm.conv.weight.data.view(Cin, 9), B, H, W, Cin, d, out=dx, accumulate=not first)
+                ops.dwconv_bwd_data(du, rt.wdw(dwm.conv.weight), B, H, W, Cin, d, out=dx, accumulate=not first)
             first = False
         return dx
 

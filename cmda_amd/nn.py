@@ -11,13 +11,6 @@ from . import runtime as rt
 from .ops import conv_view, plain_view
 
 
-def _wgrad_splits(out_rows, out_cols, contraction):
-    tiles = ((out_rows + 63) // 64) * ((out_cols + 63) // 64)
-    s = max(1, 512 // max(tiles, 1))
-    s = min(s, max(1, contraction // 256), 128)
-    return s
-
-
 # ------------------------------------------------------------------ Linear
 def linear_fwd(x, weight, bias, M, K, *, act=None, res=None, rowscale=None, rows_per_scale=1, out=None, ldc=None,
                c_offset=0, out_dtype=None, x_ld=None, x_off=0):
@@ -36,7 +29,7 @@ def linear_bwd(dy, x, weight, bias, M, K, *, need_dx=True, dx_out=None, dx_beta=
     N = weight.shape[0]
     dyv_k = plain_view(dy, M, N, ld=dy_ld, offset=dy_off)  # (r = token, c = n)
     ops.gemm(dyv_k, plain_view(x, M, K, ld=x_ld, offset=x_off), rt.grad(weight), N, K, M, a_kstrided=True,
-             b_kstrided=True, dtype=rt.tag(), atomic=True, splits=_wgrad_splits(N, K, M))
+             b_kstrided=True, dtype=rt.tag(), atomic=True, splits=0)
     if bias is not None:
         ops.colsum(dy, rt.grad(bias), M, N, ld=dy_ld, offset=dy_off)
     if not need_dx:
@@ -68,7 +61,7 @@ def conv_bwd(dy, x, weight, bias, B, H, W, stride, pad, dil=1, *, need_dx=True, 
     M, K = B * OH * OW, KH * KW * Ci
     dwg = torch.zeros(Co, K, dtype=torch.float32, device=dy.device)
     ops.gemm(plain_view(dy, M, Co), conv_view(x, B, H, W, Ci, KH, KW, stride, pad, dil, OH=OH, OW=OW), dwg, Co, K, M,
-             a_kstrided=True, b_kstrided=True, dtype=rt.tag(), atomic=True, splits=_wgrad_splits(Co, K, M))
+             a_kstrided=True, b_kstrided=True, dtype=rt.tag(), atomic=True, splits=0)
     ops.permute4(dwg, rt.grad(weight), (Co, KH, KW, Ci), (0, 3, 1, 2), accumulate=True)
     if bias is not None:
         ops.colsum(dy, rt.grad(bias), M, Co)
@@ -115,8 +108,7 @@ def attention_bwd(do, q, kv, P, B, N, Nk, heads, C, scale):
     tag = rt.tag()
     dkv32 = torch.zeros(B * Nk, 2 * C, dtype=torch.float32, device=dev)
     Pv = dict(batch_stride=heads * N * Nk, batch2_stride=N * Nk)
-    sp = _wgrad_splits(Nk, hd, N)
-    sp = max(1, min(sp, 65535 // max(1, B * heads)))
+    sp = 0  # auto split-K
     # dV_h = P_h^T dO_h
     ops.gemm(plain_view(P, N, Nk, **Pv), plain_view(do, N, hd, ld=C, batch_stride=N * C, batch2_stride=hd),
              dkv32, Nk, hd, N, a_kstrided=True, b_kstrided=True, batch=B, batch2=heads, ldc=2 * C,
@@ -163,7 +155,7 @@ def block_fwd(x, p, B, H, W, C, heads, sr, *, eps=1e-6, dp1=None, dp2=None, save
     hidden = p.mlp.fc1.weight.shape[0]
     h = linear_fwd(xn2, p.mlp.fc1.weight, p.mlp.fc1.bias, M, C)
     dw = p.mlp.dwconv.dwconv
-    act = ops.dwconv_fwd(h, dw.weight.data.view(hidden, 9), dw.bias, B, H, W, hidden, 1, 'gelu')
+    act = ops.dwconv_fwd(h, rt.wdw(dw.weight), dw.bias, B, H, W, hidden, 1, 'gelu')
     Cout = p.mlp.fc2.weight.shape[0]
     x2 = linear_fwd(act, p.mlp.fc2.weight, p.mlp.fc2.bias, M, hidden, res=x1 if Cout == C else None, rowscale=dp2,
                     rows_per_scale=N)
@@ -178,7 +170,7 @@ def mlp_bwd(dy, mlp, xin, h, act, B, H, W, Cin, dps=None):
     dys = dy if dps is None else ops.sample_scale(dy, dps, B, dy.shape[1])
     da = linear_bwd(dys, act, mlp.fc2.weight, mlp.fc2.bias, M, hidden)
     dw = mlp.dwconv.dwconv
-    w9 = dw.weight.data.view(hidden, 9)
+    w9 = rt.wdw(dw.weight)
     dz = ops.dwconv_gelu_bwd_prep(h, w9, dw.bias, da, B, H, W, hidden, 1)
     ops.dwconv_bwd_weight(dz, h, rt.grad(dw.weight).view(hidden, 9), rt.grad(dw.bias), B, H, W, hidden, 1)
     dh = ops.dwconv_bwd_data(dz, w9, B, H, W, hidden, 1, out=da)

@@ -65,6 +65,18 @@ def wconv(param, kind='khwc'):
     return t
 
 
+def wdw(param):
+    """Depthwise 3x3 weight [C,1,3,3] -> tap-major fp32 [9,C] (coalesced per-tap reads in dwconv.hip)."""
+    key = (id(param), 'dw')
+    t = _cache.get(key)
+    if t is None:
+        C = param.shape[0]
+        t = torch.empty(9, C, dtype=torch.float32, device=param.device)
+        ops.permute4(param.data, t, (C, 9, 1, 1), (1, 0, 2, 3))
+        _cache[key] = t
+    return t
+
+
 def grad(param):
     if param.grad is None:
         param.grad = torch.zeros_like(param.data)

@@ -58,7 +58,7 @@ typedef struct cmda_gemm_params_t {
   int32_t b_kstrided;   /* 0: B view is (r=n, c=k); 1: (r=k, c=n) */
   void* C;
   int64_t ldc, c_batch_stride, c_batch2_stride;
-  int32_t M, N, K, batch, batch2, splits; /* grid z = (batch*batch2)*splits */
+  int32_t M, N, K, batch, batch2, splits; /* grid z = (batch*batch2)*splits; splits <= 0 with atomic=1: auto */
   float alpha, beta;
   const float* bias;    /* [N] or NULL */
   int32_t act;          /* 0 none, 1 ReLU, 2 GELU(erf) */

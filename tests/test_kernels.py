@@ -84,7 +84,7 @@ def test_dwconv(tgt, dt, tol, dil, act):
     ref = F.gelu(z) if act == 'gelu' else z
     dy = torch.randn(B, H, W, C).to(dt)
     ref.backward(dy.float().permute(0, 3, 1, 2))
-    xd, wd, bd, dyd = tgt.to(x), tgt.to(w.view(C, 9).contiguous()), tgt.to(b) if act else None, tgt.to(dy)
+    xd, wd, bd, dyd = tgt.to(x), tgt.to(w.view(C, 9).t().contiguous()), tgt.to(b) if act else None, tgt.to(dy)  # tap-major [9,C]
     y = ops.dwconv_fwd(xd, wd, bd, B, H, W, C, dil, act)
     assert_close(y, ref.permute(0, 2, 3, 1), tol, name='dw fwd')
     dz = ops.dwconv_gelu_bwd_prep(xd, wd, bd, dyd, B, H, W, C, dil) if act == 'gelu' else dyd

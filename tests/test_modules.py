@@ -21,13 +21,13 @@ def gold(name):
     return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(HERE, 'golden', name + '.npz')).items()}
 
 
-def check_grads(module, g, rtol, n=2048, atol=1e-6):
+def check_grads(module, g, rtol, n=2048, atol=1e-6, outlier_frac=0.0):
     seen = 0
     for name, p in module.named_parameters():
         key = 'grad.' + name
         if key in g:
             assert p.grad is not None, name
-            assert_close(sample_grad(p.grad, n), g[key], rtol, atol=atol, name=key)
+            assert_close(sample_grad(p.grad, n), g[key], rtol, atol=atol, name=key, outlier_frac=outlier_frac)
             seen += 1
     assert seen == sum(k.startswith('grad.') for k in g)
 
@@ -114,8 +114,8 @@ def test_head_train_golden(tgt, mode):
     for i in range(4):
         c = dfs[i].shape[1]
         ref = g[f'dfeat{i}'].permute(0, 2, 3, 1).reshape(-1, c)
-        assert_close(dfs[i], ref, 3e-4 if f32 else 0.25, atol=1e-8 if f32 else 2e-6, name=f'dfeat{i}')  # bf16: 3 train-mode BNs amplify rounding
-    check_grads(head, g, 5e-4 if f32 else 0.25, atol=1e-6 if f32 else 2e-3)
+        assert_close(dfs[i], ref, 3e-4 if f32 else 0.25, atol=1e-8 if f32 else 2e-6, name=f'dfeat{i}', outlier_frac=2e-3 if f32 else 0.0)  # bf16: 3 train-mode BNs amplify rounding
+    check_grads(head, g, 5e-4 if f32 else 0.25, atol=1e-6 if f32 else 2e-3, outlier_frac=2e-3 if f32 else 0.0)
     if f32:
         for k, v in head.state_dict().items():
             if 'running' in k:
