@@ -284,10 +284,13 @@ int launch_dtype(GemmParams& p, void* stream) {
   if (p.atomic && p.splits <= 0) {
     // accumulate-by-atomics GEMMs (weight gradients): few output tiles, very long contraction -> largest tile that
     // fits the output, then split K until the grid fills the chip
-    tile = (p.M > 64 && p.N > 64) ? 0 : (p.M > 64 ? 1 : 2);
-    const long b = tile == 0 ? blocks(128, 128) : tile == 1 ? blocks(128, 64) : blocks(64, 64);
-    long s = (1024 + b - 1) / b;
-    s = std::min<long>(s, std::max(1, nkt / 4));
+    // Every split adds one fp32 atomic per output element (chip-wide ~1.3 TB/s), so splits stay small and the tile
+    // only grows to 128x128 when the output alone already has enough tiles.
+    tile = (p.M > 64 && p.N > 64 && blocks(128, 128) >= 64) ? 0 : 2;
+    const long b = tile == 0 ? blocks(128, 128) : blocks(64, 64);
+    long s = (512 + b - 1) / b;
+    s = std::min<long>(s, std::max(1, nkt / 8));
+    s = std::min<long>(s, 16);
     s = std::min<long>(s, std::max<long>(1, 65535 / std::max<long>(zb, 1)));
     p.splits = (int)std::max<long>(1, s);
   } else {

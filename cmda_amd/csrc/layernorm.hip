@@ -173,8 +173,7 @@ extern "C" int cmda_layernorm_bwd(const void* dy, const void* x, const float* ga
   if (rows <= 0) return CMDA_OK;
   if (C <= 0 || (C & 3) || C > kMaxVec * 256) return CMDA_ERR_SHAPE;
   const int wpb = 4;
-  // few blocks: every block ends with 2*C atomics on the same addresses (contention grows with the grid)
-  const int grid = (int)std::max<long>(1, std::min<long>(rows / (wpb * 16), 160));
+  const int grid = (int)std::min<long>((rows + wpb - 1) / wpb, 512);
   CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((ln_bwd_kernel<T>), dim3(grid), dim3(64 * wpb), 0, stream, (const T*)dy,
                                          (const T*)x, gamma, mean, rstd, (const T*)dres, (T*)dx, dgamma, dbeta,
                                          (long)rows, C));
