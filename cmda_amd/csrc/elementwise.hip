@@ -91,6 +91,21 @@ __global__ void sample_scale_kernel(const T* __restrict__ x, const float* __rest
   }
 }
 
+// strided 2-D copy (channel concat / split of NLC tensors: attention_fusion.py:52, torch.cat)
+template <typename T>
+__global__ void copy2d_kernel(const T* __restrict__ src, T* __restrict__ dst, long rows, int cols, long src_ld,
+                              long dst_ld) {
+  const int cg = cols >> 2;
+  const long total = rows * cg;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cg;
+    const int c = (int)(i - r * cg) * 4;
+    float v[4];
+    ld4(src + r * src_ld + c, v);
+    st4(dst + r * dst_ld + c, v);
+  }
+}
+
 __global__ void ema_kernel(float* __restrict__ ema, const float* __restrict__ p, float alpha, long n) {
   for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
     if (i + 4 <= n) {
@@ -221,6 +236,16 @@ extern "C" int cmda_sample_scale(const void* x, const float* scale, void* out, i
   if ((C & 3) || (per_sample % C)) return CMDA_ERR_SHAPE;
   CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((sample_scale_kernel<T>), dim3(grid_for(n, 4)), dim3(256), 0, stream,
                                          (const T*)x, scale, (T*)out, (long)per_sample, C, per_channel, n));
+  CMDA_CHECK_LAUNCH();
+}
+
+// src/dst already point at the first element; cols and both pitches must be multiples of 4
+extern "C" int cmda_copy2d(const void* src, void* dst, int64_t rows, int cols, int64_t src_ld, int64_t dst_ld, int dtype,
+                           void* stream) {
+  if (rows <= 0 || cols <= 0) return CMDA_OK;
+  if ((cols & 3) || (src_ld & 3) || (dst_ld & 3)) return CMDA_ERR_SHAPE;
+  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((copy2d_kernel<T>), dim3(grid_for(rows * (cols / 4))), dim3(256), 0, stream,
+                                         (const T*)src, (T*)dst, (long)rows, cols, (long)src_ld, (long)dst_ld));
   CMDA_CHECK_LAUNCH();
 }
 

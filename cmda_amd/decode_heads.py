@@ -314,3 +314,108 @@ class DAFormerHead(_HeadBase):
         B = inputs[0].shape[0]
         logits, _ = self.fwd(self._to_feats([inputs[i] for i in range(len(inputs))]), B)
         return logits.permute(0, 3, 1, 2)
+
+
+@HEADS.register_module()
+class DAFormerHeadFusion(_HeadBase):
+    """daformer_head.py:200-322 + BaseDecodeHeadFusion.forward_train decode_head.py:423-534 (the loss mix used by
+    configs/fusion/*: not `cal_confidence`, not the `_split` train types)."""
+
+    def __init__(self, **kwargs):
+        dp = kwargs['decoder_params']
+        assert 'train_type' in dp
+        self.train_type = dp['train_type']
+        assert self.train_type not in ('cs2dz_image+raw-isr_split', 'cs2dz_image+raw-isr_no-fusion'), \
+            'split-classifier train types are outside the hot path (SURVEY.md section 2, row 12)'
+        super().__init__(input_transform='multiple_select', **kwargs)
+        self.split_cls = False
+        self.share_decoder = bool(dp.get('share_decoder'))
+        self.half_share_decoder = bool(dp.get('half_share_decoder'))
+        assert not (self.share_decoder and self.half_share_decoder)
+        self.embed_layers_image, self.fuse_layer_image = self._make_branch()
+        self.embed_layers_events, self.fuse_layer_events = self._make_branch()
+        self.embed_layers_fusion, self.fuse_layer_fusion = self._make_branch()
+        if self.half_share_decoder:
+            self.fuse_layer_events = self.fuse_layer_image
+            self.fuse_layer_fusion = self.fuse_layer_image
+        elif self.share_decoder:
+            self.embed_layers_events = self.embed_layers_image
+            self.fuse_layer_events = self.fuse_layer_image
+            self.embed_layers_fusion = self.embed_layers_image
+            self.fuse_layer_fusion = self.fuse_layer_image
+
+    _BRANCHES = (('image_output', 'f_image', 'image', True), ('events_output', 'f_events', 'events', False),
+                 ('fusion_output', 'f_fusion', 'fusion', False), ('img_self_res_output', 'f_img_self_res', 'events', False))
+
+    def _layers(self, which):
+        return getattr(self, f'embed_layers_{which}'), getattr(self, f'fuse_layer_{which}')
+
+    def fwd(self, inputs, B):
+        """inputs: dict f_image / f_events / f_fusion / f_img_self_res -> list of (NLC tensor, H, W) or None."""
+        out, saved = {}, {}
+        for key, fkey, which, dropout in self._BRANCHES:
+            feats = inputs.get(fkey)
+            if feats is None:
+                out[key] = None
+                continue
+            emb, fuse = self._layers(which)
+            feat, sv_b = self._branch_fwd(emb, fuse, feats, B)
+            H, W = sv_b[2], sv_b[3]
+            logits, sv_c = self._cls_fwd(feat, B, H, W, with_dropout=dropout)
+            out[key] = logits
+            saved[key] = (sv_b, sv_c, H, W, which)
+        return out, saved
+
+    def bwd(self, saved, dlogits, B):
+        """dlogits: dict key -> gradient (or None).  Returns dict f_* -> {level: d feat}."""
+        dfeats = {}
+        for key, fkey, which, _ in self._BRANCHES:
+            if key not in saved or dlogits.get(key) is None:
+                continue
+            sv_b, sv_c, H, W, which = saved[key]
+            emb, fuse = self._layers(which)
+            dfeat = self._cls_bwd(sv_c, dlogits[key], B, H, W)
+            dfeats[fkey] = self._branch_bwd(emb, fuse, sv_b, dfeat, B)
+        return dfeats
+
+    def fwd_train(self, inputs, B, gt, seg_weight=None, cfg=None):
+        lw = cfg['loss_weight']
+        logits, saved = self.fwd(inputs, B)
+        ii, lwt = self.ignore_index, self.loss_decode.loss_weight
+        if seg_weight is None:
+            seg_weight = torch.ones(gt.shape[0], gt.shape[2], gt.shape[3], dtype=torch.float32, device=gt.device)
+        terms, sv_l = {}, {}
+        for key in ('image_output', 'events_output', 'fusion_output', 'img_self_res_output'):
+            if logits[key] is not None:
+                loss, acc, sv = ce_losses_fwd(logits[key], gt, seg_weight, ii, lwt)
+                terms[key] = (loss, acc)
+                sv_l[key] = sv
+        coef = {'image_output': lw['image']}
+        if 'fusion_output' in terms:
+            coef['fusion_output'] = lw['fusion']
+        if 'img_self_res_output' in terms:
+            coef['img_self_res_output'] = lw['img_self_res']
+            coef['events_output'] = lw['events'] / 2
+        else:
+            coef['events_output'] = lw['events']
+        # the reference accumulates fusion, image, then (isr, events): keep that order of fp32 additions
+        order = [k for k in ('fusion_output', 'image_output', 'img_self_res_output', 'events_output') if k in coef]
+        total = None
+        for k in order:
+            t = terms[k][0] * coef[k]
+            total = t if total is None else total + t
+        acc = terms['fusion_output'][1] if 'fusion_output' in terms else terms['image_output'][1]
+        return {'loss_seg': total, 'acc_seg': acc}, logits, (saved, sv_l, coef)
+
+    def bwd_train(self, saved_all, B, gscale=None, mul=1.0):
+        saved, sv_l, coef = saved_all
+        ii, lwt = self.ignore_index, self.loss_decode.loss_weight
+        dlogits = {k: ce_losses_bwd(sv_l[k], gscale, mul * coef[k], ii, lwt) for k in sv_l}
+        return self.bwd(saved, dlogits, B)
+
+    def forward(self, inputs, cfg=None):
+        """Reference signature: dict of NCHW feature lists -> dict of logits [B,nc,h,w] (no grad)."""
+        B = inputs['f_image'][0].shape[0]
+        feats = {k: (self._to_feats(v) if v is not None else None) for k, v in inputs.items()}
+        out, _ = self.fwd(feats, B)
+        return {k: (v.permute(0, 3, 1, 2) if v is not None else None) for k, v in out.items()}

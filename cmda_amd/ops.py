@@ -305,3 +305,11 @@ def upsample_logits_nchw(logits, H, W):
     call('cmda_upsample_logits_nchw', ptr(logits), ptr(out), c_i32(B), c_i32(h), c_i32(w), c_i32(H), c_i32(W), c_i32(nc),
          stream_of(logits))
     return out
+
+
+def copy2d(src, dst, rows, cols, src_ld, dst_ld, src_off=0, dst_off=0):
+    check_dev(src, dst)
+    es = _ESIZE[src.dtype]
+    call('cmda_copy2d', L.c_vp(src.data_ptr() + src_off * es), L.c_vp(dst.data_ptr() + dst_off * es), c_i64(rows),
+         c_i32(cols), c_i64(src_ld), c_i64(dst_ld), dtype_tag(src), stream_of(src))
+    return dst
