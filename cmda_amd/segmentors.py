@@ -116,3 +116,158 @@ class _Capture:
 
     def train_bwd(self, saved, gscale):
         return self.model.train_bwd(saved, gscale)
+
+
+def _sum_grads(a, b):
+    """element-wise sum of two per-level gradient lists/dicts (entries may be None)."""
+    out = []
+    for i in range(4):
+        x = a[i] if a is not None else None
+        y = b[i] if b is not None else None
+        if isinstance(a, dict):
+            x = a.get(i)
+        if isinstance(b, dict):
+            y = b.get(i)
+        out.append(y if x is None else (x if y is None else ops.axpby(x, y, 1.0, 1.0)))
+    return out
+
+
+@SEGMENTORS.register_module()
+class FusionEncoderDecoder(nn.Module):
+    """encoder_decoder.py:625-1003 for train types 'cs2dsec_image+events_together' / 'cs2dsec_image+events' /
+    'cs2dz_image+raw-isr' (the ones configs/fusion/* use)."""
+
+    TRAIN_TYPES = {'cs2dsec_image+events', 'cs2dz_image+d2n-isr', 'cs2dz_image+raw-isr', 'cs2dz_image+raw-isr_no-fusion',
+                   'cs2dz_image+raw-isr_split', 'cs2dsec_image+events_together'}
+
+    def __init__(self, backbone_image, backbone_events, fusion_module, decode_head, neck=None, auxiliary_head=None,
+                 train_cfg=None, test_cfg=None, pretrained=None, init_cfg=None, **kwargs):
+        super().__init__()
+        assert kwargs['train_type'] in self.TRAIN_TYPES
+        self.train_type = kwargs['train_type']
+        assert neck is None and auxiliary_head is None
+        if pretrained is not None:
+            assert backbone_events.get('pretrained') is None and backbone_image.get('pretrained') is None, \
+                'both backbone and segmentor set pretrained weight'
+            backbone_events = dict(backbone_events, pretrained=pretrained)
+            backbone_image = dict(backbone_image, pretrained=pretrained)
+        self.backbone_image = build_backbone(backbone_image)
+        self.backbone_events = build_backbone(backbone_events)
+        if self.train_type in {'cs2dsec_image+events', 'cs2dz_image+raw-isr', 'cs2dsec_image+events_together'}:
+            self.fusion_module = build_fusion(fusion_module)
+            fim = kwargs.get('fusion_isr_module')
+            if fim is not None and fim.get('type', '') != '':
+                self.fusion_isr_module = build_fusion(fim)
+        else:
+            self.fusion_module = None
+        self.decode_head = build_head(decode_head)
+        self.align_corners = self.decode_head.align_corners
+        self.num_classes = self.decode_head.num_classes
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+
+    def init_weights(self):
+        for m in (self.backbone_image, self.backbone_events, self.decode_head):
+            m.init_weights()
+
+    # -- feature extraction (extract_feat :698-721) --------------------------------------------------------------
+    def _extract(self, image, events, img_self_res, cfg, save):
+        cfg = cfg or {}
+        B = (image if image is not None else events).shape[0]
+        sv = {}
+        f_image = f_events = f_isr = None
+        if image is not None:
+            f_image, sv['image'] = self.backbone_image.fwd(image, save=save)
+        if events is not None:
+            f_events, sv['events'] = self.backbone_events.fwd(events, save=save)
+        if img_self_res is not None:
+            f_isr, sv['isr'] = self.backbone_events.fwd(img_self_res, save=save)
+        f_fusion = None
+        if cfg.get('no_fusion'):
+            pass
+        elif cfg.get('fusion_isr'):
+            second = 'events' if img_self_res is None else 'isr'
+            f_fusion, sv['fusion_isr'] = self.fusion_isr_module.fwd(f_image, f_events if second == 'events' else f_isr, B, save)
+            sv['fusion_isr_second'] = second
+        elif cfg.get('fusion_all'):
+            a, sv['fusion_isr'] = self.fusion_isr_module.fwd(f_image, f_isr, B, save)
+            sv['fusion_isr_second'] = 'isr'
+            b, sv['fusion'] = self.fusion_module.fwd(f_image, f_events, B, save)
+            f_fusion = [(ops.axpby(x[0], y[0], 0.5, 0.5), x[1], x[2]) for x, y in zip(a, b)]
+            sv['fusion_all'] = True
+        elif self.fusion_module is not None and events is not None:
+            f_fusion, sv['fusion'] = self.fusion_module.fwd(f_image, f_events, B, save)
+        feats = {'f_image': f_image, 'f_events': f_events, 'f_fusion': f_fusion, 'f_img_self_res': f_isr}
+        return feats, sv, B
+
+    def _extract_bwd(self, sv, dfeats, B):
+        d_img = dfeats.get('f_image')
+        d_evt = dfeats.get('f_events')
+        d_isr = dfeats.get('f_img_self_res')
+        d_fus = dfeats.get('f_fusion')
+        if d_fus is not None:
+            d_fus = [d_fus.get(i) for i in range(4)]
+            if sv.get('fusion_all'):
+                d_fus = [ops.axpby(d, None, 0.5, 0.0) if d is not None else None for d in d_fus]
+            if 'fusion' in sv:
+                di, de = self.fusion_module.bwd(sv['fusion'], d_fus, B)
+                d_img, d_evt = _sum_grads(d_img, di), _sum_grads(d_evt, de)
+            if 'fusion_isr' in sv:
+                di, de = self.fusion_isr_module.bwd(sv['fusion_isr'], d_fus, B)
+                d_img = _sum_grads(d_img, di)
+                if sv['fusion_isr_second'] == 'isr':
+                    d_isr = _sum_grads(d_isr, de)
+                else:
+                    d_evt = _sum_grads(d_evt, de)
+        as_list = lambda d: [d.get(i) for i in range(4)] if isinstance(d, dict) else d
+        if 'image' in sv and d_img is not None:
+            self.backbone_image.bwd(sv['image'], as_list(d_img))
+        if 'isr' in sv and d_isr is not None:
+            self.backbone_events.bwd(sv['isr'], as_list(d_isr))
+        if 'events' in sv and d_evt is not None:
+            self.backbone_events.bwd(sv['events'], as_list(d_evt))
+
+    # -- hand-scheduled training pass ---------------------------------------------------------------------------------
+    def train_fwd(self, inputs, gt, seg_weight, cfg):
+        feats, sv, B = self._extract(inputs['image'], inputs['events'], inputs.get('img_self_res'), cfg, True)
+        losses, logits, sv_h = self.decode_head.fwd_train(feats, B, gt, seg_weight, cfg)
+        return losses['loss_seg'], (losses, logits, feats), (sv, sv_h, B)
+
+    def train_bwd(self, saved, gscale):
+        sv, sv_h, B = saved
+        dfeats = self.decode_head.bwd_train(sv_h, B, gscale)
+        self._extract_bwd(sv, dfeats, B)
+
+    def forward_train(self, inputs, gt_semantic_seg, seg_weight=None, return_feat=False, cfg=None):
+        holder = {}
+        dev = inputs['image'].device
+        loss = _TrainFn.apply(_Capture(self, holder), rt.anchor(dev), (inputs, gt_semantic_seg, seg_weight, cfg))
+        losses, logits, feats = holder['aux']
+        out = {}
+        if return_feat:
+            out['features'] = feats
+        out.update(add_prefix({'loss_seg': loss, 'acc_seg': losses['acc_seg']}, 'decode'))
+        pred = {k: (v.permute(0, 3, 1, 2) if v is not None else None) for k, v in logits.items()}
+        return out, pred
+
+    # -- inference / teacher ---------------------------------------------------------------------------------------------
+    def encode_decode_lowres(self, img, events, img_self_res=None, test_cfg=None):
+        """dict of fp32 NHWC logits at 1/4 resolution (the fused kernels up-sample on the fly)."""
+        with torch.no_grad():
+            feats, _, B = self._extract(img, events, img_self_res, test_cfg, False)
+            out, _ = self.decode_head.fwd(feats, B)
+        return out
+
+    def encode_decode(self, img, events, img_self_res=None, output_features=False, test_cfg={'output_type': 'fusion'}):
+        out = self.encode_decode_lowres(img, events, img_self_res, test_cfg)
+        if events is None:
+            test_cfg = {'output_type': 'image'}
+        H, W = (img if img is not None else events).shape[2:]
+        if output_features:
+            return {k: (ops.upsample_logits_nchw(v, H, W) if v is not None else None) for k, v in out.items()}
+        return ops.upsample_logits_nchw(out[test_cfg['output_type'] + '_output'], H, W)
+
+    def simple_test(self, rescale=True, **kwargs):
+        img = kwargs['warp_image'] if 'warp_image' in kwargs else kwargs['image']
+        events = kwargs.get('events_vg') if self.train_type in {'cs2dsec_image+events', 'cs2dsec_image+events_together'} else None
+        logit = self.encode_decode(img, events, test_cfg=kwargs.get('test_cfg', {'output_type': 'fusion'}))
+        return list(torch.softmax(logit, dim=1).argmax(dim=1).cpu().numpy())

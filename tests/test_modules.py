@@ -183,3 +183,42 @@ def test_fusion_modules_golden(tgt, mode, name):
     for (n1, p), (n2, q) in zip(m.named_parameters(), ref.named_parameters()):
         assert n1 == n2
         assert_close(p.grad, q.grad, 5e-4, atol=1e-6, name=n1)
+
+
+SEG_CFG = dict(type='FusionEncoderDecoder', pretrained=None,
+               backbone_image=dict(type='mit_b5', style='pytorch', in_chans=3, drop_path_rate=0.0),
+               backbone_events=dict(type='mit_b5', style='pytorch', in_chans=3, drop_path_rate=0.0),
+               fusion_module=dict(type='AttentionAvgFusion', drop_path_rate=0.0),
+               decode_head=dict(type='DAFormerHeadFusion', **HEAD_KW,
+                                decoder_params=decoder_params(train_type='cs2dsec_image+events_together', share_decoder=True)),
+               train_type='cs2dsec_image+events_together', train_cfg=dict(), test_cfg=dict(mode='whole'))
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize('mode', [torch.float32], indirect=True)
+def test_fusion_segmentor_golden(tgt, mode):
+    """Full student (2 x MiT-B5 + fusion + 4 decoder passes + loss) and teacher pass vs the reference's own outputs."""
+    import json
+    import cmda_amd  # noqa: F401
+    from cmda_amd.registry import build_segmentor
+    if tgt.kind == 'emu' and not os.environ.get('CMDA_SLOW'):
+        pytest.skip('9 min in the CPU emulator (set CMDA_SLOW=1); always runs on the GPU')
+    g = gold('segmentor_train')
+    model = build_segmentor(SEG_CFG)
+    with open(os.path.join(HERE, 'golden', 'segmentor_keys.json')) as f:
+        assert sorted(model.state_dict().keys()) == json.load(f)
+    seeded_fill(model, 101).train().to(tgt.device)
+    inputs = {k: tgt.to(seeded_randn((1, 3, 64, 64), 101, k)) for k in ('image', 'events', 'img_self_res')}
+    fcfg = dict(loss_weight={'image': 0.5, 'events': 0.5, 'fusion': 0.5, 'img_self_res': 0.25})
+    losses, pred = model.forward_train(inputs, tgt.to(g['gt']), return_feat=True, cfg=fcfg)
+    losses['decode.loss_seg'].backward()
+    assert_close(losses['decode.loss_seg'], g['loss_seg'], 1e-4, name='loss')
+    assert_close(losses['decode.acc_seg'], g['acc_seg'], 1e-3, name='acc')
+    for k, v in pred.items():
+        assert_close(v, g[k], 1e-3, name=k)  # north-star bound: logits within 1e-3 relative
+    check_grads(model, g, 5e-2, n=96, atol=1e-5)
+    gt = gold('segmentor_teacher')
+    model.eval()
+    out = model.encode_decode(inputs['image'], inputs['events'], output_features=True, test_cfg=fcfg)
+    for k, v in gt.items():
+        assert_close(out[k], v, 1e-3, name=k)
