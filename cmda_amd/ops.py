@@ -313,3 +313,58 @@ def copy2d(src, dst, rows, cols, src_ld, dst_ld, src_off=0, dst_off=0):
     call('cmda_copy2d', L.c_vp(src.data_ptr() + src_off * es), L.c_vp(dst.data_ptr() + dst_off * es), c_i64(rows),
          c_i32(cols), c_i64(src_ld), c_i64(dst_ld), dtype_tag(src), stream_of(src))
     return dst
+
+
+_IMG_MEAN = (ctypes.c_float * 3)(123.675, 116.28, 103.53)
+_IMG_STD = (ctypes.c_float * 3)(58.395, 57.12, 57.375)
+_ISR_DIRS = {'rightdown': ((0, -1), (-1, 0)), 'rightup': ((0, -1), (1, 0)), 'leftdown': ((0, 1), (-1, 0)),
+             'leftup': ((0, 1), (1, 0)), 'all': ((1, 0), (0, 1), (-1, 0), (0, -1))}
+
+
+def isr_lut(val_range, device):
+    """float32 log-intensity of the 256 gray levels, computed exactly as datasets/utils.py:get_ic does (numpy fp32)."""
+    import numpy as np
+    g = np.arange(256, dtype=np.float32)
+    return torch.from_numpy(np.log(g / 255 * (val_range[1] - val_range[0]) + val_range[0]).astype(np.float32)).to(device)
+
+
+def isr_gray(img):
+    """normalised NCHW fp32 image [B,3,H,W] -> PIL-exact 'L' uint8 [B,H,W]"""
+    check_dev(img)
+    B, _, H, W = img.shape
+    gray = torch.empty(B, H, W, dtype=torch.uint8, device=img.device)
+    call('cmda_isr_gray', ptr(img), ptr(gray), c_i32(B), c_i32(H), c_i32(W), _IMG_MEAN, _IMG_STD, stream_of(img))
+    return gray
+
+
+def isr_from_gray(gray, val_range, threshold, clip_range, shift_pixel, shift_direction):
+    """get_image_change_from_pil after the gray conversion -> fp32 NCHW [B,3,H,W] in [-1,1]."""
+    import numpy as np
+    check_dev(gray)
+    B, H, W = gray.shape
+    span = np.log(val_range[1]) - np.log(val_range[0])
+    dirs = [(dy * shift_pixel, dx * shift_pixel) for dy, dx in _ISR_DIRS[shift_direction]]
+    dirs_t = torch.tensor(dirs, dtype=torch.int32).to(gray.device)
+    mm = torch.empty(B * len(dirs) * 4, dtype=torch.int32, device=gray.device)
+    out = torch.empty(B, 3, H, W, dtype=torch.float32, device=gray.device)
+    call('cmda_isr_from_gray', ptr(gray), ptr(isr_lut(val_range, gray.device)), ptr(dirs_t), c_i32(len(dirs)), ptr(mm),
+         ptr(out), c_i32(B), c_i32(H), c_i32(W), c_f32(float(np.float32(span * threshold))),
+         c_f32(float(np.float32(span * clip_range))), stream_of(gray))
+    return out
+
+
+def events_to_voxel_grid(t, x, y, pol, bins, H, W):
+    check_dev(t, x, y, pol)
+    grid = torch.empty(bins, H, W, dtype=torch.float32, device=t.device)
+    call('cmda_events_to_voxel_grid', ptr(t), ptr(x), ptr(y), ptr(pol), ptr(grid), c_i64(t.numel()), c_i32(bins), c_i32(H),
+         c_i32(W), stream_of(t))
+    return grid
+
+
+def events_norm(events, clip_range, final_range=1.0):
+    check_dev(events)
+    out = torch.empty_like(events)
+    ws = torch.empty(5, dtype=torch.float64, device=events.device)
+    call('cmda_events_norm', ptr(events), ptr(out), ptr(ws), c_i64(events.numel()), c_f32(clip_range), c_f32(final_range),
+         stream_of(events))
+    return out

@@ -147,6 +147,18 @@ static inline float atomicAdd(float* p, float v) {
     if (__atomic_compare_exchange_n(u, &old, nu, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) return f;
   }
 }
+static inline double atomicAdd(double* p, double v) {
+  uint64_t* u = reinterpret_cast<uint64_t*>(p);
+  uint64_t old = __atomic_load_n(u, __ATOMIC_RELAXED);
+  for (;;) {
+    double f;
+    memcpy(&f, &old, 8);
+    double nf = f + v;
+    uint64_t nu;
+    memcpy(&nu, &nf, 8);
+    if (__atomic_compare_exchange_n(u, &old, nu, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) return f;
+  }
+}
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) {

@@ -218,3 +218,39 @@ def test_classmix_ema_adamw(tgt):
         ops.adamw_step(pd, tgt.to(gr), m, v, 1e-2, 0.9, 0.999, 1e-8, 0.01, step, p_bf16=pb)
     assert_close(pd, prm.data, 2e-6, name='adamw')
     assert_close(pb, prm.data, 8e-3, name='adamw bf16 copy')
+
+
+def _gold(name):
+    import os
+    import numpy as np
+    here = os.path.dirname(os.path.abspath(__file__))
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(here, 'golden', name + '.npz')).items()}
+
+
+def test_isr_golden(tgt):
+    """On-device Image Content-Extractor vs the reference's get_image_change_from_pil outputs (tests/golden/isr.npz)."""
+    from oracle import uda as ouda
+    g = _gold('isr')
+    img_u8 = g['img']  # [H,W,3] uint8
+    # build the normalised image whose denorm*255 truncates back to img_u8 (as the step does with the mixed image)
+    mean = torch.tensor(ouda.IMG_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(ouda.IMG_STD).view(1, 3, 1, 1)
+    x = ((img_u8.permute(2, 0, 1)[None].float() + 0.5) - mean) / std
+    gray = ops.isr_gray(tgt.to(x.contiguous()))
+    assert torch.equal(gray.cpu()[0], g['gray'])
+    params = {'dsec': dict(val_range=[0.01, 1.01], threshold=0.005, clip_range=0.1, shift_pixel=1),
+              'dz': dict(val_range=[1, 100], threshold=0.01, clip_range=0.1, shift_pixel=3)}
+    for pn, p in params.items():
+        for d in ('rightdown', 'rightup', 'leftdown', 'leftup', 'all'):
+            out = ops.isr_from_gray(gray, shift_direction=d, **p)
+            assert_close(out[0, 0:1], g[f'{pn}_{d}'], 2e-6, atol=2e-7, name=f'isr {pn} {d}')
+            assert torch.equal(out[0, 0], out[0, 2])
+
+
+def test_voxel_golden(tgt):
+    g = _gold('voxel')
+    for bins in (1, 5):
+        vg = ops.events_to_voxel_grid(*[tgt.to(g[f'{k}{bins}']) for k in 'txyp'], bins, 48, 64)
+        assert_close(vg, g[f'vg{bins}'], 2e-6, atol=1e-6, name='voxel grid')
+        nrm = ops.events_norm(tgt.to(g[f'vg{bins}']), (5000 / 500000) * 1.5 * 100)
+        assert_close(nrm, g[f'norm{bins}'], 1e-5, name='events_norm')
