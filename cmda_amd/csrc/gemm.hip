@@ -243,6 +243,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
         v += bias;
         if (p.act == 1) v = fmaxf(v, 0.f);
         else if (p.act == 2) v = gelu_erf(v);
+        else if (p.act == 3) v = tanhf(v);
         if (p.rowscale) v *= p.rowscale[m / p.rows_per_scale];
         if (p.res) v += ldf(reinterpret_cast<const T*>(p.res) + rb_off + m * p.ldres + n);
         if (p.out_f32) {

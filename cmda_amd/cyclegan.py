@@ -1,0 +1,115 @@
+"""Image Motion-Extractor generator (CycleGAN ResNet-9 blocks, inference only) on the HIP kernels.
+
+Mirrors mmseg/models/cyclegan/cyclegan_model.py: define_G :119-160, ResnetGenerator :316-374, ResnetBlock :377-434, as
+DACS uses it (uda/dacs.py:96-103,400-404: define_G() = 1->1 channels, ngf 64, InstanceNorm2d(affine=False), reflect
+padding, 9 blocks, run frozen under no_grad on mean_c(img_time_res)).  Parameter names are the reference's
+`model.<idx>...` so `cityscapes_ICD_to_dsec_EN.pth` loads with load_state_dict.
+
+Every convolution is an implicit GEMM on the MFMA kernel (reflection padding and the transposed convolutions'
+zero insertion are address modes of the operand view, gemm.hip view_offset); InstanceNorm reuses the column-statistics
+kernels of batchnorm.hip per sample.
+"""
+import torch
+import torch.nn as nn
+
+from . import nn as K
+from . import ops
+from . import runtime as rt
+from .ops import conv_view, plain_view
+
+
+class ResnetBlock(nn.Module):
+    def __init__(self, dim, padding_type='reflect', norm_layer=None, use_dropout=False, use_bias=True):
+        super().__init__()
+        assert padding_type == 'reflect' and not use_dropout
+        self.conv_block = nn.Sequential(nn.ReflectionPad2d(1), nn.Conv2d(dim, dim, 3, bias=use_bias),
+                                        nn.InstanceNorm2d(dim), nn.ReLU(True), nn.ReflectionPad2d(1),
+                                        nn.Conv2d(dim, dim, 3, bias=use_bias), nn.InstanceNorm2d(dim))
+
+
+class ResnetGenerator(nn.Module):
+    def __init__(self, input_nc=1, output_nc=1, ngf=64, norm_layer=None, use_dropout=False, n_blocks=9,
+                 padding_type='reflect'):
+        super().__init__()
+        m = [nn.ReflectionPad2d(3), nn.Conv2d(input_nc, ngf, 7, bias=True), nn.InstanceNorm2d(ngf), nn.ReLU(True)]
+        for i in range(2):
+            c = ngf * 2 ** i
+            m += [nn.Conv2d(c, c * 2, 3, stride=2, padding=1, bias=True), nn.InstanceNorm2d(c * 2), nn.ReLU(True)]
+        m += [ResnetBlock(ngf * 4) for _ in range(n_blocks)]
+        for i in range(2):
+            c = ngf * 2 ** (2 - i)
+            m += [nn.ConvTranspose2d(c, c // 2, 3, stride=2, padding=1, output_padding=1, bias=True),
+                  nn.InstanceNorm2d(c // 2), nn.ReLU(True)]
+        m += [nn.ReflectionPad2d(3), nn.Conv2d(ngf, output_nc, 7), nn.Tanh()]
+        self.model = nn.Sequential(*m)
+        self.n_blocks = n_blocks
+
+    @staticmethod
+    def _inorm(x, B, HW, C, relu, res=None):
+        """InstanceNorm2d(affine=False, eps 1e-5) (+ReLU) (+residual) on NHWC-flat x [B*HW, C], per sample."""
+        one = torch.ones(C, dtype=torch.float32, device=x.device)
+        zero = torch.zeros(C, dtype=torch.float32, device=x.device)
+        y = torch.empty_like(x)
+        for b in range(B):
+            ops.bn_train_fwd(x[b * HW:(b + 1) * HW], one, zero, y[b * HW:(b + 1) * HW], None, None, HW, C, 1e-5, 0.0, relu)
+        return y if res is None else ops.axpby(y, res, 1.0, 1.0)
+
+    def _conv(self, x, conv, B, H, W, stride, pad, reflect, act=None):
+        y, OH, OW = K.conv_fwd(x, conv.weight, conv.bias, B, H, W, stride, pad, 1, act=act, reflect=reflect)
+        return y, OH, OW
+
+    def _convT(self, x, ct, B, H, W):
+        """ConvTranspose2d(k3, s2, p1, output_padding 1) = conv of the zero-inserted input with the flipped kernel."""
+        Ci, Co, KH, KW = ct.weight.shape
+        OH, OW = 2 * H, 2 * W
+        y = torch.empty(B * OH * OW, Co, dtype=rt.compute_dtype(), device=x.device)
+        ops.gemm(conv_view(x, B, H, W, Ci, KH, KW, 1, KH - 1 - 1, 1, OH=OH, OW=OW, in_dil=2),
+                 plain_view(rt.wconv(ct.weight, 'dgrad'), Co, KH * KW * Ci), y, B * OH * OW, Co, KH * KW * Ci,
+                 dtype=rt.tag(), bias=ct.bias)
+        return y, OH, OW
+
+    @torch.no_grad()
+    def forward(self, inp):
+        """inp fp32 NCHW [B,1,H,W] -> fp32 NCHW [B,1,H,W] (tanh)."""
+        B, Cin, H, W = inp.shape
+        m = self.model
+        x = torch.empty(B * H * W, Cin, dtype=rt.compute_dtype(), device=inp.device)
+        ops.permute4(inp.contiguous(), x, (B, Cin, H, W), (0, 2, 3, 1))
+        x, H1, W1 = self._conv(x, m[1], B, H, W, 1, 3, 1)
+        x = self._inorm(x, B, H1 * W1, m[1].out_channels, True)
+        x, H2, W2 = self._conv(x, m[4], B, H1, W1, 2, 1, 0)
+        x = self._inorm(x, B, H2 * W2, m[4].out_channels, True)
+        x, H3, W3 = self._conv(x, m[7], B, H2, W2, 2, 1, 0)
+        C = m[7].out_channels
+        x = self._inorm(x, B, H3 * W3, C, True)
+        for i in range(self.n_blocks):
+            cb = m[10 + i].conv_block
+            y, _, _ = self._conv(x, cb[1], B, H3, W3, 1, 1, 1)
+            y = self._inorm(y, B, H3 * W3, C, True)
+            y, _, _ = self._conv(y, cb[5], B, H3, W3, 1, 1, 1)
+            x = self._inorm(y, B, H3 * W3, C, False, res=x)
+        k = 10 + self.n_blocks
+        x, H4, W4 = self._convT(x, m[k], B, H3, W3)
+        x = self._inorm(x, B, H4 * W4, m[k].out_channels, True)
+        x, H5, W5 = self._convT(x, m[k + 3], B, H4, W4)
+        x = self._inorm(x, B, H5 * W5, m[k + 3].out_channels, True)
+        last = m[k + 7]
+        Co = last.out_channels
+        y = torch.empty(B * H5 * W5, Co, dtype=torch.float32, device=inp.device)
+        Ci = last.in_channels
+        ops.gemm(conv_view(x, B, H5, W5, Ci, 7, 7, 1, 3, 1, OH=H5, OW=W5, reflect=1),
+                 plain_view(rt.wconv(last.weight), Co, 49 * Ci), y, B * H5 * W5, Co, 49 * Ci, dtype=rt.tag(),
+                 bias=last.bias, act='tanh')
+        return y.view(B, H5, W5, Co).permute(0, 3, 1, 2)
+
+
+def define_G(input_nc=1, output_nc=1, ngf=64, netG='resnet_9blocks', norm='instance', use_dropout=False,
+             init_type='normal', init_gain=0.02, gpu_ids=[]):
+    assert netG in ('resnet_9blocks', 'resnet_6blocks') and norm == 'instance' and not use_dropout
+    net = ResnetGenerator(input_nc, output_nc, ngf, n_blocks=9 if netG == 'resnet_9blocks' else 6)
+    for mod in net.modules():
+        if isinstance(mod, (nn.Conv2d, nn.ConvTranspose2d)):
+            nn.init.normal_(mod.weight.data, 0.0, init_gain)
+            if mod.bias is not None:
+                nn.init.constant_(mod.bias.data, 0.0)
+    return net

@@ -38,7 +38,7 @@ def conv_view(x, B, H, W, C, KH, KW, stride, pad, dil=1, OH=None, OW=None, in_di
                 vec_ok=vec_ok)
 
 
-ACT = {None: 0, 'none': 0, 'relu': 1, 'gelu': 2}
+ACT = {None: 0, 'none': 0, 'relu': 1, 'gelu': 2, 'tanh': 3}
 
 # bench.py's roofline leg: when a list is installed here every GEMM launch is bracketed by events on the launch stream
 GEMM_PROFILE = None

@@ -61,7 +61,7 @@ typedef struct cmda_gemm_params_t {
   int32_t M, N, K, batch, batch2, splits; /* grid z = (batch*batch2)*splits; splits <= 0 with atomic=1: auto */
   float alpha, beta;
   const float* bias;    /* [N] or NULL */
-  int32_t act;          /* 0 none, 1 ReLU, 2 GELU(erf) */
+  int32_t act;          /* 0 none, 1 ReLU, 2 GELU(erf), 3 tanh */
   const void* res;      /* residual, activation dtype, or NULL */
   int64_t ldres, res_batch_stride, res_batch2_stride;
   const float* rowscale; /* per-sample drop-path scale or NULL; index m / rows_per_scale */

@@ -222,3 +222,16 @@ def test_fusion_segmentor_golden(tgt, mode):
     out = model.encode_decode(inputs['image'], inputs['events'], output_features=True, test_cfg=fcfg)
     for k, v in gt.items():
         assert_close(out[k], v, 1e-3, name=k)
+
+
+@pytest.mark.parametrize('mode', [torch.float32, torch.bfloat16], indirect=True)
+def test_generator_golden(tgt, mode):
+    import json
+    from cmda_amd import cyclegan as cg
+    g = gold('generator')
+    G = cg.ResnetGenerator()
+    with open(os.path.join(HERE, 'golden', 'generator_keys.json')) as f:
+        assert sorted(G.state_dict().keys()) == json.load(f)
+    seeded_fill(G, 81).eval().to(tgt.device)
+    y = G(tgt.to(seeded_randn((2, 1, 32, 48), 81, 'x')))
+    assert_close(y, g['y'], 1e-4 if mode == torch.float32 else 0.1, name='generator')  # bf16: 23 conv+InstanceNorm layers, random weights
