@@ -2,4 +2,4 @@
 
 Importing the package registers the modules under the reference's registry keys (cmda_amd.registry)."""
 from . import registry  # noqa: F401
-from . import backbones, decode_heads, fusion, segmentors  # noqa: F401,E402
+from . import backbones, decode_heads, fusion, segmentors, uda  # noqa: F401,E402

@@ -72,7 +72,7 @@ class Block(nn.Module):
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
 
     def _dp(self, B, device):
-        if not self.training or self.drop_path_rate == 0.:
+        if not self.training or self.drop_path_rate == 0. or not getattr(self, 'stochastic', True):
             return None
         keep = 1.0 - self.drop_path_rate
         return (keep + torch.rand(B, device=device)).floor_().div_(keep)

@@ -250,7 +250,7 @@ class _HeadBase(nn.Module):
     def _cls_fwd(self, feat, B, H, W, with_dropout=True):
         M, Ch = B * H * W, self.channels
         mask = None
-        if with_dropout and self.training and self.dropout_ratio > 0:
+        if with_dropout and self.training and self.dropout_ratio > 0 and getattr(self, 'stochastic', True):
             keep = 1.0 - self.dropout_ratio
             mask = (torch.rand(B, Ch, device=feat.device) < keep).float().div_(keep)
             featd = ops.sample_scale(feat, mask, B, Ch, per_channel=True)
