@@ -101,6 +101,8 @@ def main():
     model = build_model(dev)
     opt = optim.FlatAdamW(model, lr=6e-5, weight_decay=0.01,
                           custom_keys=dict(head=dict(lr_mult=10.0), pos_block=dict(decay_mult=0.0), norm=dict(decay_mult=0.0)))
+    from cmda_amd.parallel import GradAllReducer
+    reducer = GradAllReducer(opt.flat_g, wire_dtype=torch.bfloat16)  # no-op at world size 1
     torch.manual_seed(1000 + rank)  # per-rank DropPath / Dropout streams
     img, gt = synthetic_batch(args.batch, args.size, rank, dev)
     it = [0]
@@ -109,9 +111,7 @@ def main():
         opt.zero_grad()
         losses, _ = model.forward_train(img, None, gt)
         losses['decode.loss_seg'].backward()
-        if world > 1:
-            dist.all_reduce(opt.flat_g)
-            opt.flat_g.div_(world)
+        reducer.all_reduce_mean()
         opt.step(optim.poly_warm_scale(it[0]))
         it[0] += 1
         return losses['decode.loss_seg']

@@ -139,7 +139,7 @@ class MixVisionTransformer(nn.Module):
         self.depths, self.pretrained, self.init_cfg = list(depths), pretrained, init_cfg
         self.embed_dims, self.num_heads, self.sr_ratios = list(embed_dims), list(num_heads), list(sr_ratios)
         self.eps = getattr(norm_layer, 'keywords', None) and norm_layer.keywords.get('eps', 1e-5) or 1e-5
-        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, sum(depths))]
+        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, sum(depths), device='cpu')]
         cur = 0
         for s in range(4):
             cin = in_chans if s == 0 else embed_dims[s - 1]
@@ -184,7 +184,7 @@ class MixVisionTransformer(nn.Module):
         rt.invalidate()
 
     def reset_drop_path(self, drop_path_rate):
-        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, sum(self.depths))]
+        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, sum(self.depths), device='cpu')]
         cur = 0
         for s in range(4):
             for i, blk in enumerate(getattr(self, f'block{s + 1}')):
