@@ -73,12 +73,98 @@ typedef struct cmda_gemm_params_t {
 
 int cmda_gemm(const cmda_gemm_params_t* p, void* stream);
 
-/* ---- LayerNorm (mix_transformer.py:76,123,136,175,270-318) ---- */
+/* ---- LayerNorm -- nn.LayerNorm at mmseg/models/backbones/mix_transformer.py:76 (sr norm, eps 1e-5), :123,:136 (Block, 1e-6),
+ * :175 (patch embed, 1e-5), :270-318 (stage norms).  bwd: dx = [dres +] LN'(dy); dgamma/dbeta accumulated. */
 int cmda_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
-                       int64_t rows, int C, float eps, int dtype, void* stream);
-int cmda_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
-                       const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int C, int dtype,
-                       void* stream);
+    int64_t rows, int C, float eps, int dtype, void* stream);
+int cmda_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const
+    void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int C, int dtype, void* stream);
+
+/* ---- Row softmax of attention scores -- `attn.softmax(dim=-1)` mix_transformer.py:97-98 (in place, alpha = head_dim^-0.5);
+ * bwd writes dS = alpha * P * (dP - sum P dP) over dP. */
+int cmda_softmax_fwd(void* s, int64_t rows, int L, float alpha, int dtype, void* stream);
+int cmda_softmax_bwd(const void* p, void* dp, int64_t rows, int L, float alpha, int dtype, void* stream);
+
+/* ---- Depthwise 3x3 convolution, NHWC -- DWConv(+GELU) of MixFFN mix_transformer.py:37-44,443-455 and the dilated depthwise
+ * half of the sep-ASPP decode_heads/sep_aspp_head.py:18-27.  `w` is tap-major fp32 [9][C]; dw (gradient) is [C][9]. */
+int cmda_dwconv3x3_fwd(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int dil,
+    int act, int dtype, void* stream);
+int cmda_dwconv3x3_gelu_bwd_prep(const void* x, const float* w, const float* bias, const void* da, void* dz, int B,
+    int H, int W, int C, int dil, int dtype, void* stream);
+int cmda_dwconv3x3_bwd_data(const void* dy, const float* w, void* dx, int B, int H, int W, int C, int dil, int
+    accumulate, int dtype, void* stream);
+int cmda_dwconv3x3_bwd_weight(const void* dz, const void* x, float* dw, float* dbias, int B, int H, int W, int C, int
+    dil, int dtype, void* stream);
+
+/* ---- Bilinear resize (align_corners=False), fused with the channel-concat write -- resize() + torch.cat at
+ * decode_heads/daformer_head.py:263-275 (ops/wrappers.py:9-28).  y/dy is a channel slice [coff,coff+C) of rows of pitch ldy. */
+int cmda_bilinear_fwd(const void* x, void* y, int B, int IH, int IW, int OH, int OW, int C, int ldy, int coff, int
+    dtype, void* stream);
+int cmda_bilinear_bwd(const void* dy, void* dx, int B, int IH, int IW, int OH, int OW, int C, int ldy, int coff, int
+    dtype, void* stream);
+
+/* ---- Train-mode BatchNorm2d (+ReLU) -- mmcv ConvModule's norm/activate in decode_heads/daformer_head.py:46-62,
+ * aspp_head.py:33-43, sep_aspp_head.py:18-27 (batch statistics, running-stat update, eps 1e-5, momentum 0.1).
+ * Also used per sample as InstanceNorm2d for cyclegan/cyclegan_model.py:339-374.  ws: 2*C floats of scratch. */
+int cmda_bn_train_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, float*
+    running_mean, float* running_var, float* ws, int64_t M, int C, float eps, float momentum, int relu, int ldy, int
+    coff, int dtype, void* stream);
+int cmda_bn_apply(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, void* y,
+    int64_t M, int C, int relu, int ldy, int coff, int dtype, void* stream);
+int cmda_bn_train_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const
+    float* beta, void* dx, float* dgamma, float* dbeta, float* ws, int64_t M, int C, int relu, int lddy, int coff, int
+    dtype, void* stream);
+
+/* ---- Fused up-sample + cross-entropy + accuracy -- BaseDecodeHead(Fusion).losses decode_heads/decode_head.py:588-606
+ * (resize -> F.cross_entropy(reduction='none', ignore_index) losses/cross_entropy_loss.py:21-26 -> x weight -> mean over
+ * all pixels losses/utils.py:60-69; accuracy losses/accuracy.py:40-50).  acc[0] += sum w*nll, acc[1] += #correct.
+ * Teacher: fused up-sample + softmax-max + threshold count + pseudo-weight, uda/dacs.py:674-682,701-711;
+ * cmda_upsample_logits_nchw = encode_decode's final resize, segmentors/encoder_decoder.py:733-745. */
+int cmda_ce_upsample_fwd(const float* logits, const int64_t* label, const float* weight, float* lse_out, float* acc,
+    int B, int h, int w, int H, int W, int nc, int ignore_index, void* stream);
+int cmda_ce_upsample_bwd(const float* logits, const int64_t* label, const float* weight, const float* lse, const
+    float* gscale_ptr, float gscale_mul, float* dlogits, int B, int h, int w, int H, int W, int nc, int ignore_index,
+    void* stream);
+int cmda_pseudo_label(const float* logits, int64_t* label_out, float* prob_out, int* count, int B, int h, int w, int
+    H, int W, int nc, float thr, void* stream);
+int cmda_pseudo_weight(const int* count, float* weight, int B, int H, int W, int top, int bottom, void* stream);
+int cmda_upsample_logits_nchw(const float* logits, float* out, int B, int h, int w, int H, int W, int nc, void*
+    stream);
+
+/* ---- Data movement / pointwise -- permute+cast (NLC<->NCHW boundary copies mix_transformer.py:406-430 and conv-weight
+ * repacks), bias gradient, a*x+b*y (fusion/attention_avg_fusion.py:49), DropPath / Dropout2d scaling (timm DropPath
+ * mix_transformer.py:134,145-146; nn.Dropout2d decode_head.py:565-566), strided 2-D copy (torch.cat fusion/attention_fusion.py:52). */
+int cmda_permute4(const void* src, void* dst, int d0, int d1, int d2, int d3, int p0, int p1, int p2, int p3, int
+    flipmask, int accumulate, int src_dtype, int dst_dtype, void* stream);
+int cmda_colsum(const void* x, float* out, int64_t M, int N, int64_t ld, int dtype, void* stream);
+int cmda_axpby(const void* x, const void* y, void* out, float a, float b, int64_t n, int dtype, void* stream);
+int cmda_sample_scale(const void* x, const float* scale, void* out, int B, int64_t per_sample, int C, int per_channel,
+    int dtype, void* stream);
+int cmda_copy2d(const void* src, void* dst, int64_t rows, int cols, int64_t src_ld, int64_t dst_ld, int dtype, void*
+    stream);
+
+/* ---- Self-training state -- EMA teacher update uda/dacs.py:261-272; fused AdamW (torch.optim.AdamW semantics,
+ * configs/_base_/schedules/adamw.py; optional bf16 copy of the updated weights); ClassMix of image/events/weight and of
+ * labels, models/utils/dacs_transforms.py:101-131 (classes: int64 [B,max_classes] padded with -1). */
+int cmda_ema_update(float* ema, const float* param, float alpha, int64_t n, void* stream);
+int cmda_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,
+    float beta2, float eps, float weight_decay, int step, void* stream);
+int cmda_class_mix(const void* src, const void* tgt, void* out, const int64_t* src_label, const int64_t* classes, int
+    max_classes, int B, int HW, int Cch, int channels_last, int dtype, void* stream);
+int cmda_class_mix_label(const int64_t* src, const int64_t* tgt, int64_t* out, const int64_t* src_label, const
+    int64_t* classes, int max_classes, int B, int HW, void* stream);
+
+/* ---- Extractors -- Image Content-Extractor (ISR) datasets/utils.py:87-152 as called in the step uda/dacs.py:729-744
+ * (mean3/std3 are HOST pointers; lut = fp32[256] log table; dirs = int32[ndir][2] (dy,dx); mm = uint32[B*ndir*4] scratch)
+ * and the event voxel grid datasets/dsec.py:26-70 + events_norm :80-121 (ws = 40 bytes of scratch, 8-byte aligned). */
+int cmda_isr_gray(const float* img, uint8_t* gray, int B, int H, int W, const float* mean3, const float* std3, void*
+    stream);
+int cmda_isr_from_gray(const uint8_t* gray, const float* lut, const int* dirs, int ndir, uint32_t* mm, float* out, int
+    B, int H, int W, float threshold, float clip, void* stream);
+int cmda_events_to_voxel_grid(const float* t, const float* x, const float* y, const float* pol, float* grid, int64_t
+    N, int bins, int H, int W, void* stream);
+int cmda_events_norm(const float* events, float* out, void* ws, int64_t n, float clip_range, float final_range, void*
+    stream);
 
 #ifdef __cplusplus
 }
