@@ -56,7 +56,9 @@ def cpu_baseline(size):
     """Oracle (port of the reference algorithm, oracle/) timed on the host cores: one fwd+bwd of MiT-B5 + DAFormer
     head on ONE image (bounded sample of the same workload)."""
     from oracle import head as ohd, mit as omit, segmentor as oseg
-    cores = os.cpu_count() or 1
+    # 16 threads: torch's CPU kernels at these sizes stop scaling there (256 threads took 737 s for this sample on the
+    # GPU box's host, 8 threads take 11 s) -- `cores` reports the threads actually used
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     ref = oseg.EncoderDecoder(omit.mit_b5(drop_path_rate=0.1), ohd.DAFormerHead(dropout_ratio=0.1)).train()
