@@ -79,18 +79,74 @@ static __device__ __forceinline__ uint4 load_chunk(const GemmView& v, const T* b
   return out;
 }
 
+// Per-thread staging state of one operand: which (row, 16-byte chunk) pairs of the LDS tile this thread fills and, for
+// plain views, the running element offset of each (so the K loop only adds a constant instead of re-deriving addresses).
+template <typename T, int NCH, bool KS, int TILE, int BK>
+struct Stager {
+  static constexpr int CH = Num<T>::kChunk;
+  static constexpr int COLS = KS ? TILE : BK, CPR = COLS / CH, PITCH = COLS + CH;
+  long off[NCH];       // plain fast path: element offset of the chunk for the current k-tile
+  int rowcol[NCH];     // (row << 8) | chunk-in-row
+  uint4 reg[NCH];
+  bool fast;
+  long step;
+
+  __device__ __forceinline__ void init(const GemmView& v, int tid, long t0, int kt0) {
+    fast = v.vec_ok && !v.conv;
+    step = KS ? (long)BK * v.ld : (long)BK;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int id = tid + i * 256;
+      const int row = id / CPR, cc = id - row * CPR;
+      rowcol[i] = (row << 8) | cc;
+      const long r = KS ? (long)kt0 * BK + row : t0 + row;
+      const long c = KS ? t0 + cc * CH : (long)kt0 * BK + cc * CH;
+      off[i] = r * v.ld + c;
+    }
+  }
+  // r/c of chunk i for k-tile kt (t0 = first free-index of the block tile)
+  __device__ __forceinline__ void load(const GemmView& v, const T* base, long t0, int kt) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int row = rowcol[i] >> 8, cc = rowcol[i] & 255;
+      const long r = KS ? (long)kt * BK + row : t0 + row;
+      const long c = KS ? t0 + cc * CH : (long)kt * BK + cc * CH;
+      if (fast) {
+        if (r < v.R && c + CH <= v.Cc) reg[i] = *reinterpret_cast<const uint4*>(base + off[i]);
+        else if (r < v.R && c < v.Cc) reg[i] = load_chunk<T>(v, base, r, c);  // ragged last chunk
+        else reg[i] = make_uint4(0u, 0u, 0u, 0u);
+        off[i] += step;
+      } else {
+        reg[i] = load_chunk<T>(v, base, r, c);
+      }
+    }
+  }
+  __device__ __forceinline__ void store(T* lds) const {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int row = rowcol[i] >> 8, cc = rowcol[i] & 255;
+      *reinterpret_cast<uint4*>(&lds[row * PITCH + cc * CH]) = reg[i];
+    }
+  }
+};
+
 template <typename T, int TM, int TN, bool AKS, bool BKS>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   constexpr int CH = Num<T>::kChunk;
-  constexpr int BM = 32 * TM, BN = 32 * TN, BK = 4 * CH;
+  constexpr int BM = 32 * TM, BN = 32 * TN, BK = 8 * CH;  // BK = 64 (bf16) / 32 (f32)
   constexpr int ROWS_A = AKS ? BK : BM, COLS_A = AKS ? BM : BK, PITCH_A = COLS_A + CH;
   constexpr int ROWS_B = BKS ? BK : BN, COLS_B = BKS ? BN : BK, PITCH_B = COLS_B + CH;
-  constexpr int CPR_A = COLS_A / CH, CPR_B = COLS_B / CH;
-  constexpr int NCH_A = ROWS_A * CPR_A / 256, NCH_B = ROWS_B * CPR_B / 256;
+  constexpr int NCH_A = ROWS_A * (COLS_A / CH) / 256, NCH_B = ROWS_B * (COLS_B / CH) / 256;
   static_assert(NCH_A >= 1 && NCH_B >= 1, "tile too small for 256 threads");
+  constexpr int SZ_A = ROWS_A * PITCH_A, SZ_B = ROWS_B * PITCH_B;     // elements per stage
+  constexpr int PITCH_C = BN + 4;                                       // fp32 epilogue tile
+  constexpr size_t STAGE_BYTES = (size_t)2 * (SZ_A + SZ_B) * sizeof(T);
+  constexpr size_t EPI_BYTES = (size_t)BM * PITCH_C * sizeof(float);
+  constexpr size_t LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
 
-  __shared__ __attribute__((aligned(16))) T sA[ROWS_A * PITCH_A];
-  __shared__ __attribute__((aligned(16))) T sB[ROWS_B * PITCH_B];
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];  // ONE LDS object: 2 stages of A|B, reused by the epilogue
+  T* const sAbase = reinterpret_cast<T*>(smem);
+  T* const sBbase = sAbase + 2 * SZ_A;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -115,39 +171,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   const T* baseA = reinterpret_cast<const T*>(p.A.ptr) + (long)batch * p.A.batch_stride + (long)batch2 * p.A.batch2_stride;
   const T* baseB = reinterpret_cast<const T*>(p.B.ptr) + (long)batch * p.B.batch_stride + (long)batch2 * p.B.batch2_stride;
 
-  uint4 ra[NCH_A], rb[NCH_B];
-  auto gload = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < NCH_A; ++i) {
-      const int id = tid + i * 256;
-      const int row = id / CPR_A, cc = id - row * CPR_A;
-      const long r = AKS ? (long)kt * BK + row : m0 + row;
-      const long c = AKS ? m0 + cc * CH : (long)kt * BK + cc * CH;
-      ra[i] = load_chunk<T>(p.A, baseA, r, c);
-    }
-#pragma unroll
-    for (int i = 0; i < NCH_B; ++i) {
-      const int id = tid + i * 256;
-      const int row = id / CPR_B, cc = id - row * CPR_B;
-      const long r = BKS ? (long)kt * BK + row : n0 + row;
-      const long c = BKS ? n0 + cc * CH : (long)kt * BK + cc * CH;
-      rb[i] = load_chunk<T>(p.B, baseB, r, c);
-    }
-  };
-  auto sstore = [&]() {
-#pragma unroll
-    for (int i = 0; i < NCH_A; ++i) {
-      const int id = tid + i * 256;
-      const int row = id / CPR_A, cc = id - row * CPR_A;
-      *reinterpret_cast<uint4*>(&sA[row * PITCH_A + cc * CH]) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < NCH_B; ++i) {
-      const int id = tid + i * 256;
-      const int row = id / CPR_B, cc = id - row * CPR_B;
-      *reinterpret_cast<uint4*>(&sB[row * PITCH_B + cc * CH]) = rb[i];
-    }
-  };
+  Stager<T, NCH_A, AKS, BM, BK> stA;
+  Stager<T, NCH_B, BKS, BN, BK> stB;
+  stA.init(p.A, tid, m0, kt0);
+  stB.init(p.B, tid, n0, kt0);
 
   f32x4 acc[TM][TN];
 #pragma unroll
@@ -156,42 +183,53 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (kt0 < kt1) {
-    gload(kt0);
-    sstore();
+    stA.load(p.A, baseA, m0, kt0);
+    stB.load(p.B, baseB, n0, kt0);
+    stA.store(sAbase);
+    stB.store(sBbase);
   }
   __syncthreads();
+  int cur = 0;
   for (int kt = kt0; kt < kt1; ++kt) {
-    if (kt + 1 < kt1) gload(kt + 1);  // in flight behind the MFMAs below
+    const T* sA = sAbase + cur * SZ_A;
+    const T* sB = sBbase + cur * SZ_B;
+    if (kt + 1 < kt1) {  // next tile's HBM/L2 reads fly behind this tile's MFMAs
+      stA.load(p.A, baseA, m0, kt + 1);
+      stB.load(p.B, baseB, n0, kt + 1);
+    }
     if constexpr (sizeof(T) == 2) {
-      u16x8 fa[TM], fb[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int mr = wm * 16 * TM + i * 16;
-        if constexpr (!AKS) {
-          fa[i] = *reinterpret_cast<const u16x8*>(&sA[(mr + l15) * PITCH_A + 8 * g]);
-        } else {
-          const int q = l15 >> 2, pp = l15 & 3;
-          const u16x4 lo = lds_read_tr16(reinterpret_cast<const bf16_t*>(&sA[(8 * g + q) * PITCH_A + mr + 4 * pp]));
-          const u16x4 hi = lds_read_tr16(reinterpret_cast<const bf16_t*>(&sA[(8 * g + 4 + q) * PITCH_A + mr + 4 * pp]));
-          fa[i] = u16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      for (int kk = 0; kk < BK / 32; ++kk) {
+        u16x8 fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int mr = wm * 16 * TM + i * 16;
+          if constexpr (!AKS) {
+            fa[i] = *reinterpret_cast<const u16x8*>(&sA[(mr + l15) * PITCH_A + kk * 32 + 8 * g]);
+          } else {
+            const int q = l15 >> 2, pp = l15 & 3;
+            const u16x4 lo = lds_read_tr16(reinterpret_cast<const bf16_t*>(&sA[(kk * 32 + 8 * g + q) * PITCH_A + mr + 4 * pp]));
+            const u16x4 hi = lds_read_tr16(reinterpret_cast<const bf16_t*>(&sA[(kk * 32 + 8 * g + 4 + q) * PITCH_A + mr + 4 * pp]));
+            fa[i] = u16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          }
         }
-      }
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int nr = wn * 16 * TN + j * 16;
-        if constexpr (!BKS) {
-          fb[j] = *reinterpret_cast<const u16x8*>(&sB[(nr + l15) * PITCH_B + 8 * g]);
-        } else {
-          const int q = l15 >> 2, pp = l15 & 3;
-          const u16x4 lo = lds_read_tr16(reinterpret_cast<const bf16_t*>(&sB[(8 * g + q) * PITCH_B + nr + 4 * pp]));
-          const u16x4 hi = lds_read_tr16(reinterpret_cast<const bf16_t*>(&sB[(8 * g + 4 + q) * PITCH_B + nr + 4 * pp]));
-          fb[j] = u16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        for (int j = 0; j < TN; ++j) {
+          const int nr = wn * 16 * TN + j * 16;
+          if constexpr (!BKS) {
+            fb[j] = *reinterpret_cast<const u16x8*>(&sB[(nr + l15) * PITCH_B + kk * 32 + 8 * g]);
+          } else {
+            const int q = l15 >> 2, pp = l15 & 3;
+            const u16x4 lo = lds_read_tr16(reinterpret_cast<const bf16_t*>(&sB[(kk * 32 + 8 * g + q) * PITCH_B + nr + 4 * pp]));
+            const u16x4 hi = lds_read_tr16(reinterpret_cast<const bf16_t*>(&sB[(kk * 32 + 8 * g + 4 + q) * PITCH_B + nr + 4 * pp]));
+            fb[j] = u16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          }
         }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16_16x16x32(fa[i], fb[j], acc[i][j]);
       }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16_16x16x32(fa[i], fb[j], acc[i][j]);
     } else {
 #pragma unroll
       for (int ks = 0; ks < BK / 4; ++ks) {
@@ -212,49 +250,91 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
           for (int j = 0; j < TN; ++j) acc[i][j] = mfma_f32_16x16x4(fa[i], fb[j], acc[i][j]);
       }
     }
-    __syncthreads();
-    if (kt + 1 < kt1) {
-      sstore();
-      __syncthreads();
+    if (kt + 1 < kt1) {  // the other stage was last read one iteration ago, behind the barrier below
+      stA.store(sAbase + (cur ^ 1) * SZ_A);
+      stB.store(sBbase + (cur ^ 1) * SZ_B);
     }
+    __syncthreads();
+    cur ^= 1;
   }
 
-  // ---- epilogue: C/D map col = lane&15 (n), row = 4*(lane>>4)+r (m) ----
   if (kt0 >= kt1 && p.splits > 1) return;  // empty split contributes nothing
   const long cb = (long)batch * p.c_batch_stride + (long)batch2 * p.c_batch2_stride;
   const long rb_off = (long)batch * p.res_batch_stride + (long)batch2 * p.res_batch2_stride;
+
+  if (p.atomic) {  // split-K / gradient accumulation: fp32 atomics straight from the accumulators
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const long n = n0 + wn * 16 * TN + j * 16 + l15;
-      if (n >= p.N) continue;
-      const float bias = p.bias ? p.bias[n] : 0.f;
+      for (int j = 0; j < TN; ++j) {
+        const long n = n0 + wn * 16 * TN + j * 16 + l15;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const long m = m0 + wm * 16 * TM + i * 16 + 4 * g + r;
-        if (m >= p.M) continue;
-        float v = p.alpha * acc[i][j][r];
-        const long ci = cb + m * p.ldc + n;
-        if (p.atomic) {
-          atomicAdd(reinterpret_cast<float*>(p.C) + ci, v);
-          continue;
+        for (int r = 0; r < 4; ++r) {
+          const long m = m0 + wm * 16 * TM + i * 16 + 4 * g + r;
+          if (m < p.M && n < p.N) atomicAdd(reinterpret_cast<float*>(p.C) + cb + m * p.ldc + n, p.alpha * acc[i][j][r]);
         }
-        v += bias;
-        if (p.act == 1) v = fmaxf(v, 0.f);
-        else if (p.act == 2) v = gelu_erf(v);
-        else if (p.act == 3) v = tanhf(v);
-        if (p.rowscale) v *= p.rowscale[m / p.rows_per_scale];
-        if (p.res) v += ldf(reinterpret_cast<const T*>(p.res) + rb_off + m * p.ldres + n);
-        if (p.out_f32) {
-          float* cp = reinterpret_cast<float*>(p.C) + ci;
-          if (p.beta != 0.f) v += p.beta * *cp;
-          *cp = v;
-        } else {
-          T* cp = reinterpret_cast<T*>(p.C) + ci;
-          if (p.beta != 0.f) v += p.beta * ldf(cp);
-          stf(cp, v);
-        }
+      }
+    return;
+  }
+
+  // ---- epilogue through LDS: accumulators (C/D map col = lane&15, row = 4*(lane>>4)+r) -> fp32 tile -> every thread
+  //      finishes 4 adjacent columns of one row with vector loads/stores (bias, act, drop-path scale, residual, beta) ----
+  float* sC = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        sC[(wm * 16 * TM + i * 16 + 4 * g + r) * PITCH_C + wn * 16 * TN + j * 16 + l15] = acc[i][j][r];
+  __syncthreads();
+  const bool vec = p.c_vec_ok != 0;
+  constexpr int QPR = BN / 4;  // quads per tile row
+  for (int id = tid; id < BM * QPR; id += 256) {
+    const int row = id / QPR, q4 = (id - row * QPR) * 4;
+    const long m = m0 + row, n = n0 + q4;
+    if (m >= p.M || n >= p.N) continue;
+    const float4 t = *reinterpret_cast<const float4*>(&sC[row * PITCH_C + q4]);
+    float v[4] = {t.x, t.y, t.z, t.w};
+    const float rs = p.rowscale ? p.rowscale[m / p.rows_per_scale] : 1.f;
+    const long ci = cb + m * p.ldc + n;
+    const long ri = rb_off + m * p.ldres + n;
+    const bool full = vec && n + 4 <= p.N;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f}, rv[4] = {0.f, 0.f, 0.f, 0.f}, ov[4] = {0.f, 0.f, 0.f, 0.f};
+    if (full) {
+      if (p.bias) ld4(p.bias + n, bv);
+      if (p.res) ld4(reinterpret_cast<const T*>(p.res) + ri, rv);
+      if (p.beta != 0.f) {
+        if (p.out_f32) ld4(reinterpret_cast<const float*>(p.C) + ci, ov);
+        else ld4(reinterpret_cast<const T*>(p.C) + ci, ov);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (n + e >= p.N) continue;
+        if (p.bias) bv[e] = p.bias[n + e];
+        if (p.res) rv[e] = ldf(reinterpret_cast<const T*>(p.res) + ri + e);
+        if (p.beta != 0.f) ov[e] = p.out_f32 ? reinterpret_cast<const float*>(p.C)[ci + e] : ldf(reinterpret_cast<const T*>(p.C) + ci + e);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float x = p.alpha * v[e] + bv[e];
+      if (p.act == 1) x = fmaxf(x, 0.f);
+      else if (p.act == 2) x = gelu_erf(x);
+      else if (p.act == 3) x = tanhf(x);
+      x = x * rs + rv[e] + p.beta * ov[e];
+      v[e] = x;
+    }
+    if (full) {
+      if (p.out_f32) st4(reinterpret_cast<float*>(p.C) + ci, v);
+      else st4(reinterpret_cast<T*>(p.C) + ci, v);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (n + e >= p.N) continue;
+        if (p.out_f32) reinterpret_cast<float*>(p.C)[ci + e] = v[e];
+        else stf(reinterpret_cast<T*>(p.C) + ci + e, v[e]);
       }
     }
   }
@@ -279,7 +359,7 @@ int launch_dtype(GemmParams& p, void* stream) {
   // Tile / split-K choice.  256 CUs want >= ~2 blocks each; never waste half a tile on N <= 64.
   const long zb = (long)p.batch * p.batch2;
   auto blocks = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * zb; };
-  constexpr int BK = 4 * Num<T>::kChunk;
+  constexpr int BK = 8 * Num<T>::kChunk;
   const int nkt = (p.K + BK - 1) / BK;
   int tile;  // 0: 128x128, 1: 128x64, 2: 64x64
   if (p.atomic && p.splits <= 0) {

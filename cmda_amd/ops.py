@@ -69,6 +69,12 @@ def gemm(A, B, out, M, N, K, *, a_kstrided=False, b_kstrided=False, ldc=None, ba
     p.out_f32 = int(out_f32)
     assert out_f32 or not atomic
     p.atomic = int(atomic)
+    ok = (p.ldc % 4 == 0 and c_batch_stride % 4 == 0 and c_batch2_stride % 4 == 0 and p.C % 16 == 0)
+    if res is not None:
+        ok = ok and p.ldres % 4 == 0 and res_batch_stride % 4 == 0 and res_batch2_stride % 4 == 0 and res.data_ptr() % 16 == 0
+    if bias is not None:
+        ok = ok and bias.data_ptr() % 16 == 0
+    p.c_vec_ok = int(ok)
     if GEMM_PROFILE is not None and out.is_cuda:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -69,6 +69,7 @@ typedef struct cmda_gemm_params_t {
   int32_t out_f32;      /* C is fp32 regardless of dtype */
   int32_t atomic;       /* C += via fp32 atomics (split-K / gradient accumulation) */
   int32_t dtype;
+  int32_t c_vec_ok;     /* C, res and bias may be accessed 4 elements at a time (pitches, offsets % 4 == 0, 16-B bases) */
 } cmda_gemm_params_t;
 
 int cmda_gemm(const cmda_gemm_params_t* p, void* stream);
