@@ -42,20 +42,42 @@ __global__ void permute4_kernel(const TS* __restrict__ src, TD* __restrict__ dst
   }
 }
 
-// column sum of x[M,N] (row-major) accumulated into out[N] (fp32 atomics, one per block per column)
+// column sum of x[M,N] (row pitch ld) accumulated into out[N].  Block = 32 column-quads x 8 row lanes: lanes read 4
+// adjacent columns (8/16-byte accesses) of 8 different rows; LDS reduce over the row lanes, one fp32 atomic per column
+// per block.
 template <typename T>
-__global__ void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, long M, int N, long ld, int rows_per_block) {
-  __shared__ float red[256];
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + cx;
+__global__ void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, long M, int N, long ld, int rows_per_block,
+                              int vec) {
+  __shared__ float red[8][32][4];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int col = (blockIdx.x * 32 + cx) * 4;
   const long r0 = (long)blockIdx.y * rows_per_block;
   const long r1 = min(M, r0 + rows_per_block);
-  float s = 0.f;
-  if (col < N)
-    for (long r = r0 + ry; r < r1; r += 4) s += ldf(x + r * ld + col);
-  red[threadIdx.x] = s;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (vec && col + 4 <= N) {
+    for (long r = r0 + ry; r < r1; r += 8) {
+      float v[4];
+      ld4(x + r * ld + col, v);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s[j] += v[j];
+    }
+  } else if (col < N) {
+    for (long r = r0 + ry; r < r1; r += 8)
+      for (int j = 0; j < 4 && col + j < N; ++j) s[j] += ldf(x + r * ld + col + j);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) red[ry][cx][j] = s[j];
   __syncthreads();
-  if (ry == 0 && col < N) atomicAdd(out + col, red[cx] + red[64 + cx] + red[128 + cx] + red[192 + cx]);
+  if (ry == 0 && col < N) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (col + j >= N) break;
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += red[k][cx][j];
+      atomicAdd(out + col + j, t);
+    }
+  }
 }
 
 template <typename T>
@@ -215,9 +237,12 @@ extern "C" int cmda_permute4(const void* src, void* dst, int d0, int d1, int d2,
 
 extern "C" int cmda_colsum(const void* x, float* out, int64_t M, int N, int64_t ld, int dtype, void* stream) {
   if (M <= 0 || N <= 0) return CMDA_OK;
-  const int rpb = 256;
-  dim3 grid((N + 63) / 64, (unsigned)((M + rpb - 1) / rpb));
-  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((colsum_kernel<T>), grid, dim3(256), 0, stream, (const T*)x, out, (long)M, N, (long)ld, rpb));
+  const int vec = ((ld & 3) == 0) && (((uintptr_t)x) % 16 == 0);
+  int rpb = 512;
+  const int gx = (N + 127) / 128;
+  while (rpb > 64 && (M + rpb - 1) / rpb * gx < 256) rpb >>= 1;
+  dim3 grid(gx, (unsigned)((M + rpb - 1) / rpb));
+  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((colsum_kernel<T>), grid, dim3(256), 0, stream, (const T*)x, out, (long)M, N, (long)ld, rpb, vec));
   CMDA_CHECK_LAUNCH();
 }
 

@@ -87,12 +87,14 @@ struct Stager {
   static constexpr int COLS = KS ? TILE : BK, CPR = COLS / CH, PITCH = COLS + CH;
   long off[NCH];       // plain fast path: element offset of the chunk for the current k-tile
   int rowcol[NCH];     // (row << 8) | chunk-in-row
+  int ca[NCH], cb[NCH], cc_[NCH];  // conv fast path: per-chunk constants (see init)
   uint4 reg[NCH];
-  bool fast;
+  bool fast, cfast;
   long step;
 
   __device__ __forceinline__ void init(const GemmView& v, int tid, long t0, int kt0) {
     fast = v.vec_ok && !v.conv;
+    cfast = v.vec_ok && v.conv && v.in_dil <= 1 && !v.reflect && v.R < (1L << 31) && v.Cc < (1L << 31);
     step = KS ? (long)BK * v.ld : (long)BK;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
@@ -102,6 +104,30 @@ struct Stager {
       const long r = KS ? (long)kt0 * BK + row : t0 + row;
       const long c = KS ? t0 + cc * CH : (long)kt0 * BK + cc * CH;
       off[i] = r * v.ld + c;
+      ca[i] = cb[i] = cc_[i] = 0;
+      if (cfast) {
+        if (!KS) {  // the im2col ROW (b,oh,ow) of this chunk never changes: keep (b*H, oh*s-p, ow*s-p); -1 = row out of range
+          if (r < v.R) {
+            const unsigned ohw = (unsigned)(v.OH * v.OW), ru = (unsigned)r;
+            const unsigned b = ru / ohw, rem = ru - b * ohw, oh = rem / (unsigned)v.OW, ow = rem - oh * (unsigned)v.OW;
+            ca[i] = (int)b * v.H;
+            cb[i] = (int)oh * v.stride - v.pad;
+            cc_[i] = (int)ow * v.stride - v.pad;
+          } else {
+            ca[i] = -1;
+          }
+        } else {    // the im2col COLUMN (kh,kw,ci) never changes: keep (kh*d-p, kw*d-p, ci); -1 = column out of range
+          if (c + CH <= v.Cc) {
+            const unsigned cu = (unsigned)c, cell = cu / (unsigned)v.C, ci = cu - cell * (unsigned)v.C;
+            const unsigned kh = cell / (unsigned)v.KW, kw = cell - kh * (unsigned)v.KW;
+            ca[i] = (int)ci;
+            cb[i] = (int)kh * v.dil - v.pad;
+            cc_[i] = (int)kw * v.dil - v.pad;
+          } else {
+            ca[i] = -1;
+          }
+        }
+      }
     }
   }
   // r/c of chunk i for k-tile kt (t0 = first free-index of the block tile)
@@ -116,6 +142,27 @@ struct Stager {
         else if (r < v.R && c < v.Cc) reg[i] = load_chunk<T>(v, base, r, c);  // ragged last chunk
         else reg[i] = make_uint4(0u, 0u, 0u, 0u);
         off[i] += step;
+      } else if (cfast && ca[i] >= 0 && (KS ? r < v.R : c + CH <= v.Cc)) {
+        int bH, ih, iw, ci;
+        if (!KS) {
+          const unsigned cu = (unsigned)c, cell = cu / (unsigned)v.C;
+          ci = (int)(cu - cell * (unsigned)v.C);
+          const unsigned kh = cell / (unsigned)v.KW, kw = cell - kh * (unsigned)v.KW;
+          bH = ca[i];
+          ih = cb[i] + (int)kh * v.dil;
+          iw = cc_[i] + (int)kw * v.dil;
+        } else {
+          const unsigned ohw = (unsigned)(v.OH * v.OW), ru = (unsigned)r;
+          const unsigned b = ru / ohw, rem = ru - b * ohw, oh = rem / (unsigned)v.OW, ow = rem - oh * (unsigned)v.OW;
+          ci = ca[i];
+          bH = (int)b * v.H;
+          ih = (int)oh * v.stride + cb[i];
+          iw = (int)ow * v.stride + cc_[i];
+        }
+        if (ih >= 0 && ih < v.H && iw >= 0 && iw < v.W)
+          reg[i] = *reinterpret_cast<const uint4*>(base + ((long)(bH + ih) * v.W + iw) * v.C + ci);
+        else
+          reg[i] = make_uint4(0u, 0u, 0u, 0u);
       } else {
         reg[i] = load_chunk<T>(v, base, r, c);
       }
@@ -154,10 +201,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   const int wm = wid >> 1, wn = wid & 1;
   const int g = lane >> 4, l15 = lane & 15;
 
-  const int tiles_m = (p.M + BM - 1) / BM;
-  const int bt = blockIdx.x;
-  const long m0 = (long)(bt % tiles_m) * BM;
-  const long n0 = (long)(bt / tiles_m) * BN;
+  // Tile order: blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2), so give every XCD a contiguous
+  // run of tiles, and inside a run walk the n-tiles of one m-panel first: the A panel (activations, the big operand) is
+  // then re-read from that XCD's L2 instead of HBM.  Pure speed heuristic, any placement is correct.
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int ntile = gridDim.x;
+  int bt = blockIdx.x;
+  {
+    const int q = ntile / 8, rr = ntile % 8, xcd = bt % 8, loc = bt / 8;
+    bt = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+  }
+  const long m0 = (long)(bt / tiles_n) * BM;
+  const long n0 = (long)(bt % tiles_n) * BN;
   const int z = blockIdx.z;
   const int bz = z / p.splits;
   const int split = z - bz * p.splits;
@@ -377,8 +432,8 @@ int launch_dtype(GemmParams& p, void* stream) {
   } else {
     if (p.splits <= 0) p.splits = 1;
     const long sp = p.splits;
-    if (p.N > 64 && blocks(128, 128) * sp >= 256) tile = 0;
-    else if (blocks(128, 64) * sp >= 256) tile = 1;
+    if (p.N > 64 && blocks(128, 128) * sp >= 512) tile = 0;
+    else if (blocks(128, 64) * sp >= 512) tile = 1;
     else tile = 2;
   }
   if (tile == 0) return launch_tile<T, 4, 4>(p, stream);

