@@ -154,17 +154,28 @@ __global__ void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
   }
 }
 
+// block = 8 channels x 32 partial-sum lanes: every lane adds nblocks/32 partials, LDS tree over the 32 lanes
 __global__ void ln_bwd_finalize_kernel(const float* __restrict__ ws, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                        int nblocks, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  __shared__ float red[2][32][8];
+  const int cx = threadIdx.x & 7, part = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cx;
   float sg = 0.f, sb = 0.f;
-  for (int b = 0; b < nblocks; ++b) {
-    sg += ws[((long)b * 2 + 0) * C + c];
-    sb += ws[((long)b * 2 + 1) * C + c];
+  if (c < C)
+    for (int b = part; b < nblocks; b += 32) {
+      sg += ws[((long)b * 2 + 0) * C + c];
+      sb += ws[((long)b * 2 + 1) * C + c];
+    }
+  red[0][part][cx] = sg;
+  red[1][part][cx] = sb;
+  __syncthreads();
+  if (part == 0 && c < C) {
+    float a = 0.f, b2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) { a += red[0][k][cx]; b2 += red[1][k][cx]; }
+    dgamma[c] += a;
+    dbeta[c] += b2;
   }
-  dgamma[c] += sg;
-  dbeta[c] += sb;
 }
 
 }  // namespace
@@ -196,6 +207,6 @@ extern "C" int cmda_layernorm_bwd(const void* dy, const void* x, const float* ga
   const int grid = (int)std::max<long>(1, std::min<long>((rows + wpb - 1) / wpb, 512));
   CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((ln_bwd_kernel<T>), dim3(grid), dim3(64 * wpb), 0, stream, (const T*)dy,
                                          (const T*)x, gamma, mean, rstd, (const T*)dres, (T*)dx, ws, (long)rows, C));
-  CMDA_LAUNCH(ln_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)ws, dgamma, dbeta, grid, C);
+  CMDA_LAUNCH(ln_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, stream, (const float*)ws, dgamma, dbeta, grid, C);
   CMDA_CHECK_LAUNCH();
 }
