@@ -88,7 +88,7 @@ struct Stager {
   long off[NCH];       // plain fast path: element offset of the chunk for the current k-tile
   int rowcol[NCH];     // (row << 8) | chunk-in-row
   int ca[NCH], cb[NCH], cc_[NCH];  // conv fast path: per-chunk constants (see init)
-  uint4 reg[2][NCH];   // two k-tiles in flight (sets alternate; always indexed by a compile-time constant)
+  uint4 reg[NCH];
   bool fast, cfast;
   long step;
 
@@ -130,8 +130,7 @@ struct Stager {
       }
     }
   }
-  // r/c of chunk i for k-tile kt (t0 = first free-index of the block tile); S = register set
-  template <int S>
+  // r/c of chunk i for k-tile kt (t0 = first free-index of the block tile)
   __device__ __forceinline__ void load(const GemmView& v, const T* base, long t0, int kt) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
@@ -139,9 +138,9 @@ struct Stager {
       const long r = KS ? (long)kt * BK + row : t0 + row;
       const long c = KS ? t0 + cc * CH : (long)kt * BK + cc * CH;
       if (fast) {
-        if (r < v.R && c + CH <= v.Cc) reg[S][i] = *reinterpret_cast<const uint4*>(base + off[i]);
-        else if (r < v.R && c < v.Cc) reg[S][i] = load_chunk<T>(v, base, r, c);  // ragged last chunk
-        else reg[S][i] = make_uint4(0u, 0u, 0u, 0u);
+        if (r < v.R && c + CH <= v.Cc) reg[i] = *reinterpret_cast<const uint4*>(base + off[i]);
+        else if (r < v.R && c < v.Cc) reg[i] = load_chunk<T>(v, base, r, c);  // ragged last chunk
+        else reg[i] = make_uint4(0u, 0u, 0u, 0u);
         off[i] += step;
       } else if (cfast && ca[i] >= 0 && (KS ? r < v.R : c + CH <= v.Cc)) {
         int bH, ih, iw, ci;
@@ -161,20 +160,19 @@ struct Stager {
           iw = (int)ow * v.stride + cc_[i];
         }
         if (ih >= 0 && ih < v.H && iw >= 0 && iw < v.W)
-          reg[S][i] = *reinterpret_cast<const uint4*>(base + ((long)(bH + ih) * v.W + iw) * v.C + ci);
+          reg[i] = *reinterpret_cast<const uint4*>(base + ((long)(bH + ih) * v.W + iw) * v.C + ci);
         else
-          reg[S][i] = make_uint4(0u, 0u, 0u, 0u);
+          reg[i] = make_uint4(0u, 0u, 0u, 0u);
       } else {
-        reg[S][i] = load_chunk<T>(v, base, r, c);
+        reg[i] = load_chunk<T>(v, base, r, c);
       }
     }
   }
-  template <int S>
   __device__ __forceinline__ void store(T* lds) const {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int row = rowcol[i] >> 8, cc = rowcol[i] & 255;
-      *reinterpret_cast<uint4*>(&lds[row * PITCH + cc * CH]) = reg[S][i];
+      *reinterpret_cast<uint4*>(&lds[row * PITCH + cc * CH]) = reg[i];
     }
   }
 };
@@ -239,96 +237,80 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // Software pipeline, two k-tiles ahead: while tile kt is multiplied out of LDS stage kt&1, tile kt+1 sits in one
-  // register set (issued an iteration ago) and tile kt+2 is being fetched into the other; ONE barrier per k-tile.
-  auto compute = [&](const T* sA, const T* sB) {
-    if constexpr (sizeof(T) == 2) {
-#pragma unroll
-    for (int kk = 0; kk < BK / 32; ++kk) {
-      u16x8 fa[TM], fb[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int mr = wm * 16 * TM + i * 16;
-        if constexpr (!AKS) {
-          fa[i] = *reinterpret_cast<const u16x8*>(&sA[(mr + l15) * PITCH_A + kk * 32 + 8 * g]);
-        } else {
-          const int q = l15 >> 2, pp = l15 & 3;
-          const u16x4 lo = lds_read_tr16(reinterpret_cast<const bf16_t*>(&sA[(kk * 32 + 8 * g + q) * PITCH_A + mr + 4 * pp]));
-          const u16x4 hi = lds_read_tr16(reinterpret_cast<const bf16_t*>(&sA[(kk * 32 + 8 * g + 4 + q) * PITCH_A + mr + 4 * pp]));
-          fa[i] = u16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int nr = wn * 16 * TN + j * 16;
-        if constexpr (!BKS) {
-          fb[j] = *reinterpret_cast<const u16x8*>(&sB[(nr + l15) * PITCH_B + kk * 32 + 8 * g]);
-        } else {
-          const int q = l15 >> 2, pp = l15 & 3;
-          const u16x4 lo = lds_read_tr16(reinterpret_cast<const bf16_t*>(&sB[(kk * 32 + 8 * g + q) * PITCH_B + nr + 4 * pp]));
-          const u16x4 hi = lds_read_tr16(reinterpret_cast<const bf16_t*>(&sB[(kk * 32 + 8 * g + 4 + q) * PITCH_B + nr + 4 * pp]));
-          fb[j] = u16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16_16x16x32(fa[i], fb[j], acc[i][j]);
-    }
-  } else {
-#pragma unroll
-    for (int ks = 0; ks < BK / 4; ++ks) {
-      float fa[TM], fb[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int mr = wm * 16 * TM + i * 16;
-        fa[i] = AKS ? sA[(ks * 4 + g) * PITCH_A + mr + l15] : sA[(mr + l15) * PITCH_A + ks * 4 + g];
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int nr = wn * 16 * TN + j * 16;
-        fb[j] = BKS ? sB[(ks * 4 + g) * PITCH_B + nr + l15] : sB[(nr + l15) * PITCH_B + ks * 4 + g];
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_f32_16x16x4(fa[i], fb[j], acc[i][j]);
-    }
-  }
-  };
   if (kt0 < kt1) {
-    stA.template load<0>(p.A, baseA, m0, kt0);
-    stB.template load<0>(p.B, baseB, n0, kt0);
-    stA.template store<0>(sAbase);
-    stB.template store<0>(sBbase);
-    if (kt0 + 1 < kt1) {
-      stA.template load<1>(p.A, baseA, m0, kt0 + 1);
-      stB.template load<1>(p.B, baseB, n0, kt0 + 1);
-    }
+    stA.load(p.A, baseA, m0, kt0);
+    stB.load(p.B, baseB, n0, kt0);
+    stA.store(sAbase);
+    stB.store(sBbase);
   }
   __syncthreads();
-  for (int kt = kt0; kt < kt1; kt += 2) {
-    if (kt + 2 < kt1) {
-      stA.template load<0>(p.A, baseA, m0, kt + 2);
-      stB.template load<0>(p.B, baseB, n0, kt + 2);
+  int cur = 0;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const T* sA = sAbase + cur * SZ_A;
+    const T* sB = sBbase + cur * SZ_B;
+    if (kt + 1 < kt1) {  // next tile's HBM/L2 reads fly behind this tile's MFMAs
+      stA.load(p.A, baseA, m0, kt + 1);
+      stB.load(p.B, baseB, n0, kt + 1);
     }
-    compute(sAbase, sBbase);
-    if (kt + 1 < kt1) {  // stage 1 was last read one iteration ago, behind that iteration's barrier
-      stA.template store<1>(sAbase + SZ_A);
-      stB.template store<1>(sBbase + SZ_B);
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int kk = 0; kk < BK / 32; ++kk) {
+        u16x8 fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int mr = wm * 16 * TM + i * 16;
+          if constexpr (!AKS) {
+            fa[i] = *reinterpret_cast<const u16x8*>(&sA[(mr + l15) * PITCH_A + kk * 32 + 8 * g]);
+          } else {
+            const int q = l15 >> 2, pp = l15 & 3;
+            const u16x4 lo = lds_read_tr16(reinterpret_cast<const bf16_t*>(&sA[(kk * 32 + 8 * g + q) * PITCH_A + mr + 4 * pp]));
+            const u16x4 hi = lds_read_tr16(reinterpret_cast<const bf16_t*>(&sA[(kk * 32 + 8 * g + 4 + q) * PITCH_A + mr + 4 * pp]));
+            fa[i] = u16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int nr = wn * 16 * TN + j * 16;
+          if constexpr (!BKS) {
+            fb[j] = *reinterpret_cast<const u16x8*>(&sB[(nr + l15) * PITCH_B + kk * 32 + 8 * g]);
+          } else {
+            const int q = l15 >> 2, pp = l15 & 3;
+            const u16x4 lo = lds_read_tr16(reinterpret_cast<const bf16_t*>(&sB[(kk * 32 + 8 * g + q) * PITCH_B + nr + 4 * pp]));
+            const u16x4 hi = lds_read_tr16(reinterpret_cast<const bf16_t*>(&sB[(kk * 32 + 8 * g + 4 + q) * PITCH_B + nr + 4 * pp]));
+            fb[j] = u16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16_16x16x32(fa[i], fb[j], acc[i][j]);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < BK / 4; ++ks) {
+        float fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int mr = wm * 16 * TM + i * 16;
+          fa[i] = AKS ? sA[(ks * 4 + g) * PITCH_A + mr + l15] : sA[(mr + l15) * PITCH_A + ks * 4 + g];
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int nr = wn * 16 * TN + j * 16;
+          fb[j] = BKS ? sB[(ks * 4 + g) * PITCH_B + nr + l15] : sB[(nr + l15) * PITCH_B + ks * 4 + g];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = mfma_f32_16x16x4(fa[i], fb[j], acc[i][j]);
+      }
+    }
+    if (kt + 1 < kt1) {  // the other stage was last read one iteration ago, behind the barrier below
+      stA.store(sAbase + (cur ^ 1) * SZ_A);
+      stB.store(sBbase + (cur ^ 1) * SZ_B);
     }
     __syncthreads();
-    if (kt + 1 >= kt1) break;
-    if (kt + 3 < kt1) {
-      stA.template load<1>(p.A, baseA, m0, kt + 3);
-      stB.template load<1>(p.B, baseB, n0, kt + 3);
-    }
-    compute(sAbase + SZ_A, sBbase + SZ_B);
-    if (kt + 2 < kt1) {
-      stA.template store<0>(sAbase);
-      stB.template store<0>(sBbase);
-    }
-    __syncthreads();
+    cur ^= 1;
   }
 
   if (kt0 >= kt1 && p.splits > 1) return;  // empty split contributes nothing
