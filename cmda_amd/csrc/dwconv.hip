@@ -239,7 +239,7 @@ extern "C" int cmda_dwconv3x3_bwd_weight(const void* dz, const void* x, float* d
   if (C & 3) return CMDA_ERR_SHAPE;
   const int gx = (C / 4 + 63) / 64;
   int ppb = 512;
-  while (ppb > 32 && (npix + ppb - 1) / ppb * gx < 512) ppb >>= 1;
+  while (ppb > 32 && (npix + ppb - 1) / ppb * gx < 4096) ppb >>= 1;  // short per-thread pixel loops: latency-bound otherwise
   dim3 grid(gx, (unsigned)((npix + ppb - 1) / ppb));
   CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((dw_bwd_weight_kernel<T>), grid, dim3(256), 0, stream, (const T*)dz,
                                          (const T*)x, dw, dbias, B, H, W, C, dil, ppb));

@@ -51,8 +51,22 @@ class FlatAdamW:
                     p.grad = self.flat_g[off:off + n].view(p.shape)
                     off += (n + 3) // 4 * 4
                 self.segments.append((start, off, lm, dm))
+        # bf16 compute copies of every parameter, kept current by the AdamW kernel itself (no per-step cast launches)
+        self.flat_bf16 = None
+        if rt.compute_dtype() == torch.bfloat16 and self.flat_p.is_cuda:
+            self.flat_bf16 = torch.empty(total, dtype=torch.bfloat16, device=dev)
+            base = self.flat_p.data_ptr()
+            for _, p in uniq:
+                o = (p.data.data_ptr() - base) // 4
+                p._cmda_bf16 = self.flat_bf16[o:o + p.numel()].view(p.shape)
+            self.sync_bf16()
         self.step_count = 0
         rt.invalidate()
+
+    def sync_bf16(self):
+        """Refresh the bf16 copies after the masters were written by anything but step() (e.g. load_state_dict)."""
+        if self.flat_bf16 is not None:
+            ops.permute4(self.flat_p, self.flat_bf16, (self.flat_p.numel(), 1, 1, 1), (0, 1, 2, 3))
 
     def zero_grad(self):
         self.flat_g.zero_()
@@ -62,7 +76,7 @@ class FlatAdamW:
         for start, end, lm, dm in self.segments:
             ops.adamw_step(self.flat_p[start:end], self.flat_g[start:end], self.flat_m[start:end], self.flat_v[start:end],
                            self.lr * lm * lr_scale, self.betas[0], self.betas[1], self.eps, self.weight_decay * dm,
-                           self.step_count)
+                           self.step_count, p_bf16=self.flat_bf16[start:end] if self.flat_bf16 is not None else None)
         rt.invalidate()
 
 

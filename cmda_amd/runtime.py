@@ -41,6 +41,9 @@ def w(param):
     """Linear weight [N,K] in the compute dtype."""
     if _state['dtype'] == torch.float32:
         return param.data
+    live = getattr(param, '_cmda_bf16', None)  # maintained by optim.FlatAdamW's fused update
+    if live is not None:
+        return live
     key = (id(param), 'w')
     t = _cache.get(key)
     if t is None:
