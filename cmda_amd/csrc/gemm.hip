@@ -79,106 +79,119 @@ static __device__ __forceinline__ uint4 load_chunk(const GemmView& v, const T* b
   return out;
 }
 
-// Per-thread staging state of one operand: which (row, 16-byte chunk) pairs of the LDS tile this thread fills and, for
-// plain views, the running element offset of each (so the K loop only adds a constant instead of re-deriving addresses).
-template <typename T, int NCH, bool KS, int TILE, int BK>
+// Per-thread staging state of one operand.  Thread t fills chunks id = t + i*256 of the LDS tile: they all sit in the
+// same 16-byte column `cc` and in rows row0 + i*RSTEP, so one base offset + one uniform stride describe all of them
+// (plain views), and the K loop only adds a constant instead of re-deriving addresses.  PF register sets hold the
+// k-tiles in flight (always indexed by compile-time constants).
+template <typename T, int NCH, bool KS, int TILE, int BK, int PF>
 struct Stager {
   static constexpr int CH = Num<T>::kChunk;
-  static constexpr int COLS = KS ? TILE : BK, CPR = COLS / CH, PITCH = COLS + CH;
-  long off[NCH];       // plain fast path: element offset of the chunk for the current k-tile
-  int rowcol[NCH];     // (row << 8) | chunk-in-row
-  int ca[NCH], cb[NCH], cc_[NCH];  // conv fast path: per-chunk constants (see init)
-  uint4 reg[NCH];
+  static constexpr int COLS = KS ? TILE : BK, CPR = COLS / CH, PITCH = COLS + CH, RSTEP = 256 / CPR;
+  long off0;           // plain fast path: element offset of chunk 0 for the next k-tile to load
+  long istride;        // plain fast path: offset between consecutive chunks of this thread (RSTEP rows)
+  long kstep;          // plain fast path: offset between consecutive k-tiles
+  int row0, cc;
+  int ca[KS ? 1 : NCH], cbc[KS ? 1 : NCH];  // conv fast path constants (see init)
+  int cx;
+  uint4 reg[PF][NCH];
   bool fast, cfast;
-  long step;
 
   __device__ __forceinline__ void init(const GemmView& v, int tid, long t0, int kt0) {
     fast = v.vec_ok && !v.conv;
-    cfast = v.vec_ok && v.conv && v.in_dil <= 1 && !v.reflect && v.R < (1L << 31) && v.Cc < (1L << 31);
-    step = KS ? (long)BK * v.ld : (long)BK;
+    cfast = v.vec_ok && v.conv && v.in_dil <= 1 && !v.reflect && v.R < (1L << 31) && v.Cc < (1L << 31) &&
+            v.H < 32768 && v.W < 32768;
+    row0 = tid / CPR;
+    cc = tid - row0 * CPR;
+    const long r = KS ? (long)kt0 * BK + row0 : t0 + row0;
+    const long c = KS ? t0 + cc * CH : (long)kt0 * BK + cc * CH;
+    off0 = r * v.ld + c;
+    istride = (long)RSTEP * v.ld;
+    kstep = KS ? (long)BK * v.ld : (long)BK;
+    cx = 0;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int id = tid + i * 256;
-      const int row = id / CPR, cc = id - row * CPR;
-      rowcol[i] = (row << 8) | cc;
-      const long r = KS ? (long)kt0 * BK + row : t0 + row;
-      const long c = KS ? t0 + cc * CH : (long)kt0 * BK + cc * CH;
-      off[i] = r * v.ld + c;
-      ca[i] = cb[i] = cc_[i] = 0;
-      if (cfast) {
-        if (!KS) {  // the im2col ROW (b,oh,ow) of this chunk never changes: keep (b*H, oh*s-p, ow*s-p); -1 = row out of range
-          if (r < v.R) {
-            const unsigned ohw = (unsigned)(v.OH * v.OW), ru = (unsigned)r;
+    for (int i = 0; i < (KS ? 1 : NCH); ++i) ca[i] = cbc[i] = 0;
+    if (cfast) {
+      if (!KS) {  // the im2col ROW (b,oh,ow) of a chunk never changes: keep b*H and (oh*s-p, ow*s-p); -1 = out of range
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          const long ri = r + (long)i * RSTEP;
+          if (ri < v.R) {
+            const unsigned ohw = (unsigned)(v.OH * v.OW), ru = (unsigned)ri;
             const unsigned b = ru / ohw, rem = ru - b * ohw, oh = rem / (unsigned)v.OW, ow = rem - oh * (unsigned)v.OW;
             ca[i] = (int)b * v.H;
-            cb[i] = (int)oh * v.stride - v.pad;
-            cc_[i] = (int)ow * v.stride - v.pad;
-          } else {
-            ca[i] = -1;
-          }
-        } else {    // the im2col COLUMN (kh,kw,ci) never changes: keep (kh*d-p, kw*d-p, ci); -1 = column out of range
-          if (c + CH <= v.Cc) {
-            const unsigned cu = (unsigned)c, cell = cu / (unsigned)v.C, ci = cu - cell * (unsigned)v.C;
-            const unsigned kh = cell / (unsigned)v.KW, kw = cell - kh * (unsigned)v.KW;
-            ca[i] = (int)ci;
-            cb[i] = (int)kh * v.dil - v.pad;
-            cc_[i] = (int)kw * v.dil - v.pad;
+            cbc[i] = (((int)oh * v.stride - v.pad) << 16) | (((int)ow * v.stride - v.pad) & 0xffff);
           } else {
             ca[i] = -1;
           }
         }
+      } else {    // the im2col COLUMN (kh,kw,ci) is the same for all chunks of this thread; -1 = out of range
+        if (c + CH <= v.Cc) {
+          const unsigned cu = (unsigned)c, cell = cu / (unsigned)v.C, ci = cu - cell * (unsigned)v.C;
+          const unsigned kh = cell / (unsigned)v.KW, kw = cell - kh * (unsigned)v.KW;
+          ca[0] = (int)ci;
+          cbc[0] = (((int)kh * v.dil - v.pad) << 16) | (((int)kw * v.dil - v.pad) & 0xffff);
+        } else {
+          ca[0] = -1;
+        }
       }
     }
   }
-  // r/c of chunk i for k-tile kt (t0 = first free-index of the block tile)
+
+  template <int S>
   __device__ __forceinline__ void load(const GemmView& v, const T* base, long t0, int kt) {
+    const long rbase = KS ? (long)kt * BK + row0 : t0 + row0;
+    const long c = KS ? t0 + cc * CH : (long)kt * BK + cc * CH;
+    unsigned kh = 0, kw = 0;
+    int ci = 0;
+    if (cfast && !KS) {  // (kh,kw,ci) of this k-tile's column: same for all chunks of the thread
+      const unsigned cu = (unsigned)c, cell = cu / (unsigned)v.C;
+      ci = (int)(cu - cell * (unsigned)v.C);
+      kh = cell / (unsigned)v.KW;
+      kw = cell - kh * (unsigned)v.KW;
+    }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int row = rowcol[i] >> 8, cc = rowcol[i] & 255;
-      const long r = KS ? (long)kt * BK + row : t0 + row;
-      const long c = KS ? t0 + cc * CH : (long)kt * BK + cc * CH;
+      const long r = rbase + (long)i * RSTEP;
       if (fast) {
-        if (r < v.R && c + CH <= v.Cc) reg[i] = *reinterpret_cast<const uint4*>(base + off[i]);
-        else if (r < v.R && c < v.Cc) reg[i] = load_chunk<T>(v, base, r, c);  // ragged last chunk
-        else reg[i] = make_uint4(0u, 0u, 0u, 0u);
-        off[i] += step;
-      } else if (cfast && ca[i] >= 0 && (KS ? r < v.R : c + CH <= v.Cc)) {
-        int bH, ih, iw, ci;
+        if (r < v.R && c + CH <= v.Cc) reg[S][i] = *reinterpret_cast<const uint4*>(base + off0 + (long)i * istride);
+        else if (r < v.R && c < v.Cc) reg[S][i] = load_chunk<T>(v, base, r, c);  // ragged last chunk
+        else reg[S][i] = make_uint4(0u, 0u, 0u, 0u);
+      } else if (cfast && ca[KS ? 0 : i] >= 0 && (KS ? r < v.R : c + CH <= v.Cc)) {
+        int bH, ih, iw, cin;
         if (!KS) {
-          const unsigned cu = (unsigned)c, cell = cu / (unsigned)v.C;
-          ci = (int)(cu - cell * (unsigned)v.C);
-          const unsigned kh = cell / (unsigned)v.KW, kw = cell - kh * (unsigned)v.KW;
           bH = ca[i];
-          ih = cb[i] + (int)kh * v.dil;
-          iw = cc_[i] + (int)kw * v.dil;
+          ih = (cbc[i] >> 16) + (int)kh * v.dil;
+          iw = (int)(short)(cbc[i] & 0xffff) + (int)kw * v.dil;
+          cin = ci;
         } else {
           const unsigned ohw = (unsigned)(v.OH * v.OW), ru = (unsigned)r;
           const unsigned b = ru / ohw, rem = ru - b * ohw, oh = rem / (unsigned)v.OW, ow = rem - oh * (unsigned)v.OW;
-          ci = ca[i];
+          cin = ca[0];
           bH = (int)b * v.H;
-          ih = (int)oh * v.stride + cb[i];
-          iw = (int)ow * v.stride + cc_[i];
+          ih = (int)oh * v.stride + (cbc[0] >> 16);
+          iw = (int)ow * v.stride + (int)(short)(cbc[0] & 0xffff);
         }
         if (ih >= 0 && ih < v.H && iw >= 0 && iw < v.W)
-          reg[i] = *reinterpret_cast<const uint4*>(base + ((long)(bH + ih) * v.W + iw) * v.C + ci);
+          reg[S][i] = *reinterpret_cast<const uint4*>(base + ((long)(bH + ih) * v.W + iw) * v.C + cin);
         else
-          reg[i] = make_uint4(0u, 0u, 0u, 0u);
+          reg[S][i] = make_uint4(0u, 0u, 0u, 0u);
       } else {
-        reg[i] = load_chunk<T>(v, base, r, c);
+        reg[S][i] = load_chunk<T>(v, base, r, c);
       }
     }
+    off0 += kstep;
   }
+
+  template <int S>
   __device__ __forceinline__ void store(T* lds) const {
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int row = rowcol[i] >> 8, cc = rowcol[i] & 255;
-      *reinterpret_cast<uint4*>(&lds[row * PITCH + cc * CH]) = reg[i];
-    }
+    for (int i = 0; i < NCH; ++i)
+      *reinterpret_cast<uint4*>(&lds[(row0 + i * RSTEP) * PITCH + cc * CH]) = reg[S][i];
   }
 };
 
 template <typename T, int TM, int TN, bool AKS, bool BKS>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   constexpr int CH = Num<T>::kChunk;
   constexpr int BM = 32 * TM, BN = 32 * TN, BK = 8 * CH;  // BK = 64 (bf16) / 32 (f32)
   constexpr int ROWS_A = AKS ? BK : BM, COLS_A = AKS ? BM : BK, PITCH_A = COLS_A + CH;
@@ -226,8 +239,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   const T* baseA = reinterpret_cast<const T*>(p.A.ptr) + (long)batch * p.A.batch_stride + (long)batch2 * p.A.batch2_stride;
   const T* baseB = reinterpret_cast<const T*>(p.B.ptr) + (long)batch * p.B.batch_stride + (long)batch2 * p.B.batch2_stride;
 
-  Stager<T, NCH_A, AKS, BM, BK> stA;
-  Stager<T, NCH_B, BKS, BN, BK> stB;
+  constexpr int PF = (TM * TN <= 8) ? 2 : 1;  // k-tiles in flight in registers (the 128x128 tile has no room for 2)
+  Stager<T, NCH_A, AKS, BM, BK, PF> stA;
+  Stager<T, NCH_B, BKS, BN, BK, PF> stB;
   stA.init(p.A, tid, m0, kt0);
   stB.init(p.B, tid, n0, kt0);
 
@@ -237,80 +251,120 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (kt0 < kt1) {
-    stA.load(p.A, baseA, m0, kt0);
-    stB.load(p.B, baseB, n0, kt0);
-    stA.store(sAbase);
-    stB.store(sBbase);
-  }
-  __syncthreads();
-  int cur = 0;
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const T* sA = sAbase + cur * SZ_A;
-    const T* sB = sBbase + cur * SZ_B;
-    if (kt + 1 < kt1) {  // next tile's HBM/L2 reads fly behind this tile's MFMAs
-      stA.load(p.A, baseA, m0, kt + 1);
-      stB.load(p.B, baseB, n0, kt + 1);
-    }
+  // Software pipeline, two k-tiles ahead: while tile kt is multiplied out of LDS stage kt&1, tile kt+1 sits in one
+  // register set (issued an iteration ago) and tile kt+2 is being fetched into the other; ONE barrier per k-tile.
+  auto compute = [&](const T* sA, const T* sB) {
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
-      for (int kk = 0; kk < BK / 32; ++kk) {
-        u16x8 fa[TM], fb[TN];
+    for (int kk = 0; kk < BK / 32; ++kk) {
+      u16x8 fa[TM], fb[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const int mr = wm * 16 * TM + i * 16;
-          if constexpr (!AKS) {
-            fa[i] = *reinterpret_cast<const u16x8*>(&sA[(mr + l15) * PITCH_A + kk * 32 + 8 * g]);
-          } else {
-            const int q = l15 >> 2, pp = l15 & 3;
-            const u16x4 lo = lds_read_tr16(reinterpret_cast<const bf16_t*>(&sA[(kk * 32 + 8 * g + q) * PITCH_A + mr + 4 * pp]));
-            const u16x4 hi = lds_read_tr16(reinterpret_cast<const bf16_t*>(&sA[(kk * 32 + 8 * g + 4 + q) * PITCH_A + mr + 4 * pp]));
-            fa[i] = u16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          }
+      for (int i = 0; i < TM; ++i) {
+        const int mr = wm * 16 * TM + i * 16;
+        if constexpr (!AKS) {
+          fa[i] = *reinterpret_cast<const u16x8*>(&sA[(mr + l15) * PITCH_A + kk * 32 + 8 * g]);
+        } else {
+          const int q = l15 >> 2, pp = l15 & 3;
+          const u16x4 lo = lds_read_tr16(reinterpret_cast<const bf16_t*>(&sA[(kk * 32 + 8 * g + q) * PITCH_A + mr + 4 * pp]));
+          const u16x4 hi = lds_read_tr16(reinterpret_cast<const bf16_t*>(&sA[(kk * 32 + 8 * g + 4 + q) * PITCH_A + mr + 4 * pp]));
+          fa[i] = u16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int nr = wn * 16 * TN + j * 16;
-          if constexpr (!BKS) {
-            fb[j] = *reinterpret_cast<const u16x8*>(&sB[(nr + l15) * PITCH_B + kk * 32 + 8 * g]);
-          } else {
-            const int q = l15 >> 2, pp = l15 & 3;
-            const u16x4 lo = lds_read_tr16(reinterpret_cast<const bf16_t*>(&sB[(kk * 32 + 8 * g + q) * PITCH_B + nr + 4 * pp]));
-            const u16x4 hi = lds_read_tr16(reinterpret_cast<const bf16_t*>(&sB[(kk * 32 + 8 * g + 4 + q) * PITCH_B + nr + 4 * pp]));
-            fb[j] = u16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16_16x16x32(fa[i], fb[j], acc[i][j]);
       }
-    } else {
 #pragma unroll
-      for (int ks = 0; ks < BK / 4; ++ks) {
-        float fa[TM], fb[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const int mr = wm * 16 * TM + i * 16;
-          fa[i] = AKS ? sA[(ks * 4 + g) * PITCH_A + mr + l15] : sA[(mr + l15) * PITCH_A + ks * 4 + g];
+      for (int j = 0; j < TN; ++j) {
+        const int nr = wn * 16 * TN + j * 16;
+        if constexpr (!BKS) {
+          fb[j] = *reinterpret_cast<const u16x8*>(&sB[(nr + l15) * PITCH_B + kk * 32 + 8 * g]);
+        } else {
+          const int q = l15 >> 2, pp = l15 & 3;
+          const u16x4 lo = lds_read_tr16(reinterpret_cast<const bf16_t*>(&sB[(kk * 32 + 8 * g + q) * PITCH_B + nr + 4 * pp]));
+          const u16x4 hi = lds_read_tr16(reinterpret_cast<const bf16_t*>(&sB[(kk * 32 + 8 * g + 4 + q) * PITCH_B + nr + 4 * pp]));
+          fb[j] = u16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int nr = wn * 16 * TN + j * 16;
-          fb[j] = BKS ? sB[(ks * 4 + g) * PITCH_B + nr + l15] : sB[(nr + l15) * PITCH_B + ks * 4 + g];
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = mfma_f32_16x16x4(fa[i], fb[j], acc[i][j]);
       }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16_16x16x32(fa[i], fb[j], acc[i][j]);
     }
-    if (kt + 1 < kt1) {  // the other stage was last read one iteration ago, behind the barrier below
-      stA.store(sAbase + (cur ^ 1) * SZ_A);
-      stB.store(sBbase + (cur ^ 1) * SZ_B);
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < BK / 4; ++ks) {
+      float fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int mr = wm * 16 * TM + i * 16;
+        fa[i] = AKS ? sA[(ks * 4 + g) * PITCH_A + mr + l15] : sA[(mr + l15) * PITCH_A + ks * 4 + g];
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int nr = wn * 16 * TN + j * 16;
+        fb[j] = BKS ? sB[(ks * 4 + g) * PITCH_B + nr + l15] : sB[(nr + l15) * PITCH_B + ks * 4 + g];
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_f32_16x16x4(fa[i], fb[j], acc[i][j]);
+    }
+  }
+  };
+  if constexpr (PF == 2) {
+    if (kt0 < kt1) {
+      stA.template load<0>(p.A, baseA, m0, kt0);
+      stB.template load<0>(p.B, baseB, n0, kt0);
+      stA.template store<0>(sAbase);
+      stB.template store<0>(sBbase);
+      if (kt0 + 1 < kt1) {
+        stA.template load<1>(p.A, baseA, m0, kt0 + 1);
+        stB.template load<1>(p.B, baseB, n0, kt0 + 1);
+      }
     }
     __syncthreads();
-    cur ^= 1;
+    for (int kt = kt0; kt < kt1; kt += 2) {
+      if (kt + 2 < kt1) {
+        stA.template load<0>(p.A, baseA, m0, kt + 2);
+        stB.template load<0>(p.B, baseB, n0, kt + 2);
+      }
+      compute(sAbase, sBbase);
+      if (kt + 1 < kt1) {  // stage 1 was last read one iteration ago, behind that iteration's barrier
+        stA.template store<1>(sAbase + SZ_A);
+        stB.template store<1>(sBbase + SZ_B);
+      }
+      __syncthreads();
+      if (kt + 1 >= kt1) break;
+      if (kt + 3 < kt1) {
+        stA.template load<1>(p.A, baseA, m0, kt + 3);
+        stB.template load<1>(p.B, baseB, n0, kt + 3);
+      }
+      compute(sAbase + SZ_A, sBbase + SZ_B);
+      if (kt + 2 < kt1) {
+        stA.template store<0>(sAbase);
+        stB.template store<0>(sBbase);
+      }
+      __syncthreads();
+    }
+  } else {
+    if (kt0 < kt1) {
+      stA.template load<0>(p.A, baseA, m0, kt0);
+      stB.template load<0>(p.B, baseB, n0, kt0);
+      stA.template store<0>(sAbase);
+      stB.template store<0>(sBbase);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+      if (kt + 1 < kt1) {  // next tile's HBM/L2 reads fly behind this tile's MFMAs
+        stA.template load<0>(p.A, baseA, m0, kt + 1);
+        stB.template load<0>(p.B, baseB, n0, kt + 1);
+      }
+      compute(sAbase + cur * SZ_A, sBbase + cur * SZ_B);
+      if (kt + 1 < kt1) {
+        stA.template store<0>(sAbase + (cur ^ 1) * SZ_A);
+        stB.template store<0>(sBbase + (cur ^ 1) * SZ_B);
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
   }
 
   if (kt0 >= kt1 && p.splits > 1) return;  // empty split contributes nothing
