@@ -16,6 +16,7 @@
 // 16x16 accumulators; bf16 uses v_mfma_f32_16x16x32_bf16 (BK=32), f32 uses v_mfma_f32_16x16x4_f32 (BK=16, exact
 // fp32 -- the parity mode).  Global->register prefetch of tile k+1 overlaps the MFMAs of tile k.
 // Roofline: MFMA-bound for K,N >= 256; HBM-bound below (stage-1/2 Linear layers, C=64/128).
+#include <cstdlib>
 #include "common.h"
 #include "../../include/cmda_hip.h"
 
@@ -489,6 +490,10 @@ int launch_dtype(GemmParams& p, void* stream) {
     if (p.N > 64 && blocks(128, 128) * sp >= 512) tile = 0;
     else if (blocks(128, 64) * sp >= 512) tile = 1;
     else tile = 2;
+  }
+  {  // tuning aid (tools/gemm_bench.py): CMDA_GEMM_TILE=0|1|2 forces the tile
+    static const char* force = getenv("CMDA_GEMM_TILE");
+    if (force && force[0] >= '0' && force[0] <= '2') tile = force[0] - '0';
   }
   if (tile == 0) return launch_tile<T, 4, 4>(p, stream);
   if (tile == 1) return launch_tile<T, 4, 2>(p, stream);

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the GEMM kernel on the shapes the MiT-B5 + DAFormer step actually launches (per-GPU batch 8).
+Usage (GPU box): python tools/gemm_bench.py [--tile N]   -- prints us / TFLOP/s per shape; used for kernel tuning."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cmda_amd import ops  # noqa: E402
+
+
+def timeit(fn, iters=30):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--dtype', default='bf16')
+    args = ap.parse_args()
+    dt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    tag = 1 if dt == torch.bfloat16 else 0
+    dev = torch.device('cuda:0')
+    r = lambda *s: torch.randn(*s, device=dev).to(dt)
+    rows = []
+
+    def nt(name, M, N, K):
+        a, b, o = r(M, K), r(N, K), torch.empty(M, N, dtype=dt, device=dev)
+        bias = torch.randn(N, device=dev)
+        rows.append((name, 2.0 * M * N * K, timeit(lambda: ops.gemm(ops.plain_view(a, M, K), ops.plain_view(b, N, K), o, M, N, K, dtype=tag, bias=bias))))
+
+    def nn(name, M, N, K):  # dx = dy[M,K] @ W[K,N]
+        a, b, o = r(M, K), r(K, N), torch.empty(M, N, dtype=dt, device=dev)
+        rows.append((name, 2.0 * M * N * K, timeit(lambda: ops.gemm(ops.plain_view(a, M, K), ops.plain_view(b, K, N), o, M, N, K, b_kstrided=True, dtype=tag))))
+
+    def tn(name, M, N, K):  # dW[M,N] = dy[K,M]^T x[K,N]
+        a, b, o = r(K, M), r(K, N), torch.zeros(M, N, device=dev)
+        rows.append((name, 2.0 * M * N * K, timeit(lambda: ops.gemm(ops.plain_view(a, K, M), ops.plain_view(b, K, N), o, M, N, K, a_kstrided=True, b_kstrided=True, dtype=tag, atomic=True, splits=0))))
+
+    def conv(name, B, H, W, Ci, Co, k):
+        x, w = r(B * H * W, Ci), r(Co, k * k * Ci)
+        M, K = B * H * W, k * k * Ci
+        o = torch.empty(M, Co, dtype=dt, device=dev)
+        rows.append((name + ' fwd', 2.0 * M * Co * K, timeit(lambda: ops.gemm(ops.conv_view(x, B, H, W, Ci, k, k, 1, k // 2), ops.plain_view(w, Co, K), o, M, Co, K, dtype=tag), 10)))
+        dy, dw = r(M, Co), torch.zeros(Co, K, device=dev)
+        rows.append((name + ' wgrad', 2.0 * M * Co * K, timeit(lambda: ops.gemm(ops.plain_view(dy, M, Co), ops.conv_view(x, B, H, W, Ci, k, k, 1, k // 2), dw, Co, K, M, a_kstrided=True, b_kstrided=True, dtype=tag, atomic=True, splits=0), 10)))
+
+    nt('s3 fc1   NT 8192x1280x320', 8192, 1280, 320)
+    nt('s3 fc2   NT 8192x320x1280', 8192, 320, 1280)
+    nt('s3 q     NT 8192x320x320', 8192, 320, 320)
+    nn('s3 dfc2  NN 8192x1280x320', 8192, 1280, 320)
+    nn('s3 dfc1  NN 8192x320x1280', 8192, 320, 1280)
+    tn('s3 wfc1  TN 1280x320x8192', 1280, 320, 8192)
+    tn('s3 wq    TN 320x320x8192', 320, 320, 8192)
+    nt('s1 fc1   NT 131072x256x64', 131072, 256, 64)
+    nt('s1 fc2   NT 131072x64x256', 131072, 64, 256)
+    tn('s1 wfc1  TN 256x64x131072', 256, 64, 131072)
+    nt('s2 fc1   NT 32768x512x128', 32768, 512, 128)
+    nt('hd pw    NT 131072x256x1024', 131072, 256, 1024)
+    nn('hd dpw   NN 131072x1024x256', 131072, 1024, 256)
+    tn('hd wpw   TN 256x1024x131072', 256, 1024, 131072)
+    conv('hd bottleneck 3x3 1024->256', 8, 128, 128, 1024, 256, 3)
+    nt('big      NT 8192x8192x8192', 8192, 8192, 8192)
+    tot = 0
+    for name, fl, us in rows:
+        print(f'{name:38s} {us:10.1f} us  {fl / us / 1e6:8.1f} TFLOP/s')
+    print('env', {k: v for k, v in os.environ.items() if k.startswith('CMDA_')})
+
+
+if __name__ == '__main__':
+    main()
