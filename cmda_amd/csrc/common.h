@@ -156,6 +156,20 @@ static inline u16x4 lds_read_tr16(const bf16_t* p) {
 }
 #endif
 
+// Asynchronous 16-byte global -> LDS copy (global_load_lds_dwordx4): the wave writes 1 KiB at `lds_wave_base`
+// (wave-uniform), lane l landing at +16*l, from per-lane source addresses.  Completion is tracked by vmcnt; hipcc
+// drains it (vmcnt(0)) in front of __syncthreads().
+#ifndef CMDA_EMU
+static __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+#else
+static inline void glds16(const void* gsrc, void* lds_wave_base) {
+  memcpy(static_cast<char*>(lds_wave_base) + 16 * emu::my_lane(), gsrc, 16);
+}
+#endif
+
 static __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 static __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));

@@ -450,6 +450,174 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant for the most common case: bf16, both operands plain and K-contiguous ("NT": every Linear forward,
+// Q K^T, dP = dO V^T), K a multiple of 64.  Tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR staging, no
+// ds_write), two LDS stages, ONE barrier per k-tile.  LDS rows are unpadded 128-byte lines (what a 1-KiB wave write
+// needs); the 16-byte slot of logical chunk c of row r is c ^ (r & 7), applied on the SOURCE address when filling and on
+// the LDS address when reading, so the ds_read_b128 fragment reads spread over the banks.  Edge tiles clamp the row
+// index instead of zero-filling (rows >= M / N are never stored by the epilogue).
+template <int TM, int TN>
+__global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmParams p) {
+  typedef bf16_t T;
+  constexpr int BM = 32 * TM, BN = 32 * TN, BK = 64;
+  constexpr int SZ_A = BM * BK, SZ_B = BN * BK;                       // elements per stage (128 B per row)
+  constexpr int PITCH_C = BN + 4;
+  constexpr size_t STAGE_BYTES = (size_t)2 * (SZ_A + SZ_B) * sizeof(T);
+  constexpr size_t EPI_BYTES = (size_t)BM * PITCH_C * sizeof(float);
+  constexpr size_t LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
+  __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
+  T* const sAbase = reinterpret_cast<T*>(smem);
+  T* const sBbase = sAbase + 2 * SZ_A;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1, g = lane >> 4, l15 = lane & 15;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int ntile = gridDim.x;
+  int bt = blockIdx.x;
+  {
+    const int q = ntile / 8, rr = ntile % 8, xcd = bt % 8, loc = bt / 8;
+    bt = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+  }
+  const long m0 = (long)(bt / tiles_n) * BM;
+  const long n0 = (long)(bt % tiles_n) * BN;
+  const int bz = blockIdx.z;
+  const int batch = bz / p.batch2, batch2 = bz - batch * p.batch2;
+  const int nkt = p.K / BK;
+  const T* baseA = reinterpret_cast<const T*>(p.A.ptr) + (long)batch * p.A.batch_stride + (long)batch2 * p.A.batch2_stride;
+  const T* baseB = reinterpret_cast<const T*>(p.B.ptr) + (long)batch * p.B.batch_stride + (long)batch2 * p.B.batch2_stride;
+
+  // DMA assignment: wave w issues instructions j = 0..BM/32-1 for A (8 rows each): rows (w*BM/32 + j)*8 + lane/8
+  constexpr int JA = BM / 32, JB = BN / 32;
+  const int lrow = lane >> 3, slot = lane & 7;
+  const T* srcA[JA];
+  const T* srcB[JB];
+#pragma unroll
+  for (int j = 0; j < JA; ++j) {
+    const int row = (wid * JA + j) * 8 + lrow;
+    const long gr = min(m0 + row, (long)p.M - 1);
+    srcA[j] = baseA + gr * p.A.ld + ((slot ^ (row & 7)) << 3);
+  }
+#pragma unroll
+  for (int j = 0; j < JB; ++j) {
+    const int row = (wid * JB + j) * 8 + lrow;
+    const long gr = min(n0 + row, (long)p.N - 1);
+    srcB[j] = baseB + gr * p.B.ld + ((slot ^ (row & 7)) << 3);
+  }
+  auto issue = [&](int stage, int kt) {
+    T* dA = sAbase + stage * SZ_A;
+    T* dB = sBbase + stage * SZ_B;
+#pragma unroll
+    for (int j = 0; j < JA; ++j) glds16(srcA[j] + (long)kt * BK, dA + (wid * JA + j) * 8 * BK);
+#pragma unroll
+    for (int j = 0; j < JB; ++j) glds16(srcB[j] + (long)kt * BK, dB + (wid * JB + j) * 8 * BK);
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (nkt > 0) issue(0, 0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();  // tile kt has landed (vmcnt(0) in front of the barrier) and stage (kt+1)&1 is free again
+    if (kt + 1 < nkt) issue((kt + 1) & 1, kt + 1);
+    const T* sA = sAbase + (kt & 1) * SZ_A;
+    const T* sB = sBbase + (kt & 1) * SZ_B;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      u16x8 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * 16 * TM + i * 16 + l15;
+        fa[i] = *reinterpret_cast<const u16x8*>(&sA[row * BK + (((kk * 4 + g) ^ (row & 7)) << 3)]);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = wn * 16 * TN + j * 16 + l15;
+        fb[j] = *reinterpret_cast<const u16x8*>(&sB[row * BK + (((kk * 4 + g) ^ (row & 7)) << 3)]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16_16x16x32(fa[i], fb[j], acc[i][j]);
+    }
+  }
+  __syncthreads();
+
+  const long cb = (long)batch * p.c_batch_stride + (long)batch2 * p.c_batch2_stride;
+  const long rb_off = (long)batch * p.res_batch_stride + (long)batch2 * p.res_batch2_stride;
+  float* sC = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        sC[(wm * 16 * TM + i * 16 + 4 * g + r) * PITCH_C + wn * 16 * TN + j * 16 + l15] = acc[i][j][r];
+  __syncthreads();
+  const bool vec = p.c_vec_ok != 0;
+  constexpr int QPR = BN / 4;
+  for (int id = tid; id < BM * QPR; id += 256) {
+    const int row = id / QPR, q4 = (id - row * QPR) * 4;
+    const long m = m0 + row, n = n0 + q4;
+    if (m >= p.M || n >= p.N) continue;
+    const float4 t = *reinterpret_cast<const float4*>(&sC[row * PITCH_C + q4]);
+    float v[4] = {t.x, t.y, t.z, t.w};
+    const float rs = p.rowscale ? p.rowscale[m / p.rows_per_scale] : 1.f;
+    const long ci = cb + m * p.ldc + n;
+    const long ri = rb_off + m * p.ldres + n;
+    const bool full = vec && n + 4 <= p.N;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f}, rv[4] = {0.f, 0.f, 0.f, 0.f}, ov[4] = {0.f, 0.f, 0.f, 0.f};
+    if (full) {
+      if (p.bias) ld4(p.bias + n, bv);
+      if (p.res) ld4(reinterpret_cast<const T*>(p.res) + ri, rv);
+      if (p.beta != 0.f) {
+        if (p.out_f32) ld4(reinterpret_cast<const float*>(p.C) + ci, ov);
+        else ld4(reinterpret_cast<const T*>(p.C) + ci, ov);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (n + e >= p.N) continue;
+        if (p.bias) bv[e] = p.bias[n + e];
+        if (p.res) rv[e] = ldf(reinterpret_cast<const T*>(p.res) + ri + e);
+        if (p.beta != 0.f) ov[e] = p.out_f32 ? reinterpret_cast<const float*>(p.C)[ci + e] : ldf(reinterpret_cast<const T*>(p.C) + ci + e);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float x = p.alpha * v[e] + bv[e];
+      if (p.act == 1) x = fmaxf(x, 0.f);
+      else if (p.act == 2) x = gelu_erf(x);
+      else if (p.act == 3) x = tanhf(x);
+      v[e] = x * rs + rv[e] + p.beta * ov[e];
+    }
+    if (full) {
+      if (p.out_f32) st4(reinterpret_cast<float*>(p.C) + ci, v);
+      else st4(reinterpret_cast<T*>(p.C) + ci, v);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (n + e >= p.N) continue;
+        if (p.out_f32) reinterpret_cast<float*>(p.C)[ci + e] = v[e];
+        else stf(reinterpret_cast<T*>(p.C) + ci + e, v[e]);
+      }
+    }
+  }
+}
+
+template <int TM, int TN>
+int launch_glds(const GemmParams& p, void* stream) {
+  constexpr int BM = 32 * TM, BN = 32 * TN;
+  const long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  if (tiles > 0x7fffffffL || (long)p.batch * p.batch2 > 65535) return CMDA_ERR_SHAPE;
+  dim3 grid((unsigned)tiles, 1, (unsigned)(p.batch * p.batch2));
+  CMDA_LAUNCH((gemm_nt_glds_kernel<TM, TN>), grid, dim3(256), 0, stream, p);
+  CMDA_CHECK_LAUNCH();
+}
+
 template <typename T, int TM, int TN>
 int launch_tile(const GemmParams& p, void* stream) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
@@ -494,6 +662,16 @@ int launch_dtype(GemmParams& p, void* stream) {
   {  // tuning aid (tools/gemm_bench.py): CMDA_GEMM_TILE=0|1|2 forces the tile
     static const char* force = getenv("CMDA_GEMM_TILE");
     if (force && force[0] >= '0' && force[0] <= '2') tile = force[0] - '0';
+  }
+  if constexpr (sizeof(T) == 2) {
+    static const char* no_glds = getenv("CMDA_GEMM_NO_GLDS");
+    const bool nt_plain = !p.a_kstrided && !p.b_kstrided && !p.A.conv && !p.B.conv && p.A.vec_ok && p.B.vec_ok &&
+                          !p.atomic && p.splits == 1 && (p.K % 64) == 0 && p.K >= 64;
+    if (nt_plain && !no_glds) {
+      if (tile == 0) return launch_glds<4, 4>(p, stream);
+      if (tile == 1) return launch_glds<4, 2>(p, stream);
+      return launch_glds<2, 2>(p, stream);
+    }
   }
   if (tile == 0) return launch_tile<T, 4, 4>(p, stream);
   if (tile == 1) return launch_tile<T, 4, 2>(p, stream);

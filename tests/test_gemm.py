@@ -10,7 +10,8 @@ DT = [(torch.float32, 0, 2e-5), (torch.bfloat16, 1, 1.5e-2)]
 
 
 @pytest.mark.parametrize('dt,tag,tol', DT)
-@pytest.mark.parametrize('M,N,K', [(70, 50, 40), (130, 19, 147), (256, 128, 64), (33, 200, 8), (300, 260, 96)])
+@pytest.mark.parametrize('M,N,K', [(70, 50, 40), (130, 19, 147), (256, 128, 64), (33, 200, 8), (300, 260, 96),
+                                   (300, 260, 128), (130, 19, 192), (700, 64, 320)])
 def test_gemm_layouts(tgt, dt, tag, tol, M, N, K):
     torch.manual_seed(M * 7 + N)
     a, b = torch.randn(M, K).to(dt), torch.randn(N, K).to(dt)
@@ -43,7 +44,7 @@ def test_gemm_layouts(tgt, dt, tag, tol, M, N, K):
 @pytest.mark.parametrize('dt,tag,tol', DT)
 def test_gemm_batched_heads(tgt, dt, tag, tol):
     torch.manual_seed(1)
-    Bn, Nq, Nk, h, hd = 2, 40, 24, 2, 16
+    Bn, Nq, Nk, h, hd = 2, 40, 24, 2, 64  # hd = 64: the LDS-DMA NT kernel's K
     C = h * hd
     q, kv = torch.randn(Bn, Nq, C).to(dt), torch.randn(Bn, Nk, 2 * C).to(dt)
     qd, kvd = tgt.to(q), tgt.to(kv)
@@ -55,6 +56,12 @@ def test_gemm_batched_heads(tgt, dt, tag, tol):
     qr = q.float().view(Bn, Nq, h, hd).permute(0, 2, 1, 3)
     kr = kv.float()[..., :C].reshape(Bn, Nk, h, hd).permute(0, 2, 1, 3)
     assert_close(S, 0.25 * qr @ kr.transpose(-1, -2), tol, name='batched QK^T')
+    # same product in ONE launch over (batch, head) = (batch, batch2)
+    S2 = torch.empty(Bn, h, Nq, Nk, dtype=dt, device=tgt.device)
+    ops.gemm(ops.plain_view(qd, Nq, hd, ld=C, batch_stride=Nq * C, batch2_stride=hd),
+             ops.plain_view(kvd, Nk, hd, ld=2 * C, batch_stride=Nk * 2 * C, batch2_stride=hd), S2, Nq, Nk, hd, batch=Bn,
+             batch2=h, c_batch_stride=h * Nq * Nk, c_batch2_stride=Nq * Nk, dtype=tag, alpha=0.25)
+    assert_close(S2, 0.25 * qr @ kr.transpose(-1, -2), tol, name='batched QK^T (batch2)')
 
 
 CONVS = [(2, 9, 11, 8, 24, 3, 1, 1, 1), (1, 16, 16, 3, 16, 7, 4, 3, 1), (1, 12, 12, 16, 8, 3, 2, 1, 1),
