@@ -451,17 +451,100 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// LDS-DMA variant for the most common case: bf16, both operands plain and K-contiguous ("NT": every Linear forward,
-// Q K^T, dP = dO V^T), K a multiple of 64.  Tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR staging, no
-// ds_write), two LDS stages, ONE barrier per k-tile.  LDS rows are unpadded 128-byte lines (what a 1-KiB wave write
-// needs); the 16-byte slot of logical chunk c of row r is c ^ (r & 7), applied on the SOURCE address when filling and on
-// the LDS address when reading, so the ds_read_b128 fragment reads spread over the banks.  Edge tiles clamp the row
-// index instead of zero-filling (rows >= M / N are never stored by the epilogue).
-template <int TM, int TN>
-__global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmParams p) {
+// LDS-DMA variant (bf16): tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR staging, no ds_write), two LDS
+// stages, ONE barrier per k-tile.  Works for every operand mode whose 16-byte chunks are aligned (view.vec_ok):
+//   K-contiguous tile  [rows][64 k]   : 128-byte lines, fragments by ds_read_b128
+//   K-strided   tile   [64 k][cols]   : lines of `cols` bf16, fragments by ds_read_b64_tr_b16
+// LDS lines are unpadded (a wave's DMA writes 1 KiB contiguously); the 16-byte slot of logical chunk c of line r is
+// c ^ (r & 7), applied to the SOURCE address when filling and to the LDS address when reading.  Anything that must read
+// as zero (conv padding, rows/columns past the matrix, the K tail) is fetched from a 16-byte zero block, so no lane
+// ever needs a predicated LDS write.
+__device__ __attribute__((aligned(16))) unsigned g_zero16[4] = {0u, 0u, 0u, 0u};
+
+template <bool KS, int TILE>
+struct DmaSrc {
+  static constexpr int BK = 64;
+  static constexpr int J = TILE / 32;                               // DMA instructions per wave per stage
+  static constexpr int CPL = KS ? TILE / 8 : 8;                     // 16-byte chunks per LDS line
+  static constexpr int LPI = 64 / CPL;                              // lines per DMA instruction
+  const bf16_t* ptr[J];   // plain: address of (line, chunk) for k-tile 0, or nullptr when the fixed index is out of range
+  int ca[J], cbc[J];      // conv: fixed-index constants
+  int fixed[J];           // the fixed coordinate (K-contig: r, K-strided: c), -1 when out of range
+  int line[J];            // LDS line of this lane for instruction j
+  int chunk[J];           // logical chunk of this lane for instruction j
+  bool conv;
+
+  __device__ __forceinline__ void init(const GemmView& v, const bf16_t* base, int wid, int lane, long t0) {
+    conv = v.conv != 0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int ln = (wid * J + j) * LPI + lane / CPL;              // K-contig: tile row; K-strided: k row
+      const int slot = lane % CPL;
+      line[j] = ln;
+      chunk[j] = slot ^ (ln & 7);
+      ca[j] = cbc[j] = 0;
+      ptr[j] = nullptr;
+      if (!KS) {
+        const long r = t0 + ln;
+        fixed[j] = r < v.R ? (int)r : -1;
+        if (fixed[j] >= 0) {
+          if (!conv) {
+            ptr[j] = base + r * v.ld + chunk[j] * 8;
+          } else {
+            const unsigned ohw = (unsigned)(v.OH * v.OW), ru = (unsigned)r;
+            const unsigned b = ru / ohw, rem = ru - b * ohw, oh = rem / (unsigned)v.OW, ow = rem - oh * (unsigned)v.OW;
+            ca[j] = (int)b * v.H;
+            cbc[j] = (((int)oh * v.stride - v.pad) << 16) | (((int)ow * v.stride - v.pad) & 0xffff);
+          }
+        }
+      } else {
+        const long c = t0 + chunk[j] * 8;
+        fixed[j] = c + 8 <= v.Cc ? (int)c : -1;
+        if (fixed[j] >= 0) {
+          if (!conv) {
+            ptr[j] = base + (long)ln * v.ld + c;
+          } else {
+            const unsigned cu = (unsigned)c, cell = cu / (unsigned)v.C, ci = cu - cell * (unsigned)v.C;
+            const unsigned kh = cell / (unsigned)v.KW, kw = cell - kh * (unsigned)v.KW;
+            ca[j] = (int)ci;
+            cbc[j] = (((int)kh * v.dil - v.pad) << 16) | (((int)kw * v.dil - v.pad) & 0xffff);
+          }
+        }
+      }
+    }
+  }
+
+  // source address of this lane's 16 bytes for instruction j of k-tile kt
+  __device__ __forceinline__ const void* src(const GemmView& v, const bf16_t* base, int j, int kt) const {
+    const void* zero = reinterpret_cast<const void*>(g_zero16);
+    if (fixed[j] < 0) return zero;
+    if (!KS) {
+      const long c = (long)kt * BK + chunk[j] * 8;
+      if (c + 8 > v.Cc) return zero;
+      if (!conv) return ptr[j] + (long)kt * BK;
+      const unsigned cu = (unsigned)c, cell = cu / (unsigned)v.C, ci = cu - cell * (unsigned)v.C;
+      const unsigned kh = cell / (unsigned)v.KW, kw = cell - kh * (unsigned)v.KW;
+      const int ih = (cbc[j] >> 16) + (int)kh * v.dil, iw = (int)(short)(cbc[j] & 0xffff) + (int)kw * v.dil;
+      if (ih < 0 || ih >= v.H || iw < 0 || iw >= v.W) return zero;
+      return base + ((long)(ca[j] + ih) * v.W + iw) * v.C + (int)ci;
+    } else {
+      const long r = (long)kt * BK + line[j];
+      if (r >= v.R) return zero;
+      if (!conv) return ptr[j] + (long)kt * BK * v.ld;
+      const unsigned ohw = (unsigned)(v.OH * v.OW), ru = (unsigned)r;
+      const unsigned b = ru / ohw, rem = ru - b * ohw, oh = rem / (unsigned)v.OW, ow = rem - oh * (unsigned)v.OW;
+      const int ih = (int)oh * v.stride + (cbc[j] >> 16), iw = (int)ow * v.stride + (int)(short)(cbc[j] & 0xffff);
+      if (ih < 0 || ih >= v.H || iw < 0 || iw >= v.W) return zero;
+      return base + ((long)((int)b * v.H + ih) * v.W + iw) * v.C + ca[j];
+    }
+  }
+};
+
+template <int TM, int TN, bool AKS, bool BKS>
+__global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmParams p) {
   typedef bf16_t T;
   constexpr int BM = 32 * TM, BN = 32 * TN, BK = 64;
-  constexpr int SZ_A = BM * BK, SZ_B = BN * BK;                       // elements per stage (128 B per row)
+  constexpr int SZ_A = BM * BK, SZ_B = BN * BK;                       // elements per stage
   constexpr int PITCH_C = BN + 4;
   constexpr size_t STAGE_BYTES = (size_t)2 * (SZ_A + SZ_B) * sizeof(T);
   constexpr size_t EPI_BYTES = (size_t)BM * PITCH_C * sizeof(float);
@@ -481,36 +564,28 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmParams p) {
   }
   const long m0 = (long)(bt / tiles_n) * BM;
   const long n0 = (long)(bt % tiles_n) * BN;
-  const int bz = blockIdx.z;
+  const int z = blockIdx.z;
+  const int bz = z / p.splits;
+  const int split = z - bz * p.splits;
   const int batch = bz / p.batch2, batch2 = bz - batch * p.batch2;
-  const int nkt = p.K / BK;
+  const int nkt = (p.K + BK - 1) / BK;
+  const int kt_per = (nkt + p.splits - 1) / p.splits;
+  const int kt0 = split * kt_per;
+  const int kt1 = min(nkt, kt0 + kt_per);
   const T* baseA = reinterpret_cast<const T*>(p.A.ptr) + (long)batch * p.A.batch_stride + (long)batch2 * p.A.batch2_stride;
   const T* baseB = reinterpret_cast<const T*>(p.B.ptr) + (long)batch * p.B.batch_stride + (long)batch2 * p.B.batch2_stride;
 
-  // DMA assignment: wave w issues instructions j = 0..BM/32-1 for A (8 rows each): rows (w*BM/32 + j)*8 + lane/8
-  constexpr int JA = BM / 32, JB = BN / 32;
-  const int lrow = lane >> 3, slot = lane & 7;
-  const T* srcA[JA];
-  const T* srcB[JB];
-#pragma unroll
-  for (int j = 0; j < JA; ++j) {
-    const int row = (wid * JA + j) * 8 + lrow;
-    const long gr = min(m0 + row, (long)p.M - 1);
-    srcA[j] = baseA + gr * p.A.ld + ((slot ^ (row & 7)) << 3);
-  }
-#pragma unroll
-  for (int j = 0; j < JB; ++j) {
-    const int row = (wid * JB + j) * 8 + lrow;
-    const long gr = min(n0 + row, (long)p.N - 1);
-    srcB[j] = baseB + gr * p.B.ld + ((slot ^ (row & 7)) << 3);
-  }
+  DmaSrc<AKS, BM> dA;
+  DmaSrc<BKS, BN> dB;
+  dA.init(p.A, baseA, wid, lane, m0);
+  dB.init(p.B, baseB, wid, lane, n0);
   auto issue = [&](int stage, int kt) {
-    T* dA = sAbase + stage * SZ_A;
-    T* dB = sBbase + stage * SZ_B;
+    char* la = reinterpret_cast<char*>(sAbase + stage * SZ_A) + wid * dA.J * 1024;
+    char* lb = reinterpret_cast<char*>(sBbase + stage * SZ_B) + wid * dB.J * 1024;
 #pragma unroll
-    for (int j = 0; j < JA; ++j) glds16(srcA[j] + (long)kt * BK, dA + (wid * JA + j) * 8 * BK);
+    for (int j = 0; j < dA.J; ++j) glds16(dA.src(p.A, baseA, j, kt), la + j * 1024);
 #pragma unroll
-    for (int j = 0; j < JB; ++j) glds16(srcB[j] + (long)kt * BK, dB + (wid * JB + j) * 8 * BK);
+    for (int j = 0; j < dB.J; ++j) glds16(dB.src(p.B, baseB, j, kt), lb + j * 1024);
   };
 
   f32x4 acc[TM][TN];
@@ -519,24 +594,45 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (nkt > 0) issue(0, 0);
-  for (int kt = 0; kt < nkt; ++kt) {
-    __syncthreads();  // tile kt has landed (vmcnt(0) in front of the barrier) and stage (kt+1)&1 is free again
-    if (kt + 1 < nkt) issue((kt + 1) & 1, kt + 1);
-    const T* sA = sAbase + (kt & 1) * SZ_A;
-    const T* sB = sBbase + (kt & 1) * SZ_B;
+  if (kt0 < kt1) issue(0, kt0);
+  for (int kt = kt0; kt < kt1; ++kt) {
+    __syncthreads();  // tile kt has landed (vmcnt(0) in front of the barrier) and the other stage is free again
+    const int st = (kt - kt0) & 1;
+    if (kt + 1 < kt1) issue(st ^ 1, kt + 1);
+    const T* sA = sAbase + st * SZ_A;
+    const T* sB = sBbase + st * SZ_B;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       u16x8 fa[TM], fb[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const int row = wm * 16 * TM + i * 16 + l15;
-        fa[i] = *reinterpret_cast<const u16x8*>(&sA[row * BK + (((kk * 4 + g) ^ (row & 7)) << 3)]);
+        const int mr = wm * 16 * TM + i * 16;
+        if constexpr (!AKS) {
+          const int row = mr + l15;
+          fa[i] = *reinterpret_cast<const u16x8*>(&sA[row * BK + (((kk * 4 + g) ^ (row & 7)) << 3)]);
+        } else {
+          const int q = l15 >> 2, pp = l15 & 3;
+          const int k0 = kk * 32 + 8 * g + q, k1 = k0 + 4;
+          const int cidx = (mr >> 3) + (pp >> 1), half = (pp & 1) << 2;
+          const u16x4 lo = lds_read_tr16(&sA[k0 * BM + ((cidx ^ (k0 & 7)) << 3) + half]);
+          const u16x4 hi = lds_read_tr16(&sA[k1 * BM + ((cidx ^ (k1 & 7)) << 3) + half]);
+          fa[i] = u16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int row = wn * 16 * TN + j * 16 + l15;
-        fb[j] = *reinterpret_cast<const u16x8*>(&sB[row * BK + (((kk * 4 + g) ^ (row & 7)) << 3)]);
+        const int nr = wn * 16 * TN + j * 16;
+        if constexpr (!BKS) {
+          const int row = nr + l15;
+          fb[j] = *reinterpret_cast<const u16x8*>(&sB[row * BK + (((kk * 4 + g) ^ (row & 7)) << 3)]);
+        } else {
+          const int q = l15 >> 2, pp = l15 & 3;
+          const int k0 = kk * 32 + 8 * g + q, k1 = k0 + 4;
+          const int cidx = (nr >> 3) + (pp >> 1), half = (pp & 1) << 2;
+          const u16x4 lo = lds_read_tr16(&sB[k0 * BN + ((cidx ^ (k0 & 7)) << 3) + half]);
+          const u16x4 hi = lds_read_tr16(&sB[k1 * BN + ((cidx ^ (k1 & 7)) << 3) + half]);
+          fb[j] = u16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -546,8 +642,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmParams p) {
   }
   __syncthreads();
 
+  if (kt0 >= kt1 && p.splits > 1) return;
   const long cb = (long)batch * p.c_batch_stride + (long)batch2 * p.c_batch2_stride;
   const long rb_off = (long)batch * p.res_batch_stride + (long)batch2 * p.res_batch2_stride;
+  if (p.atomic) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const long n = n0 + wn * 16 * TN + j * 16 + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long m = m0 + wm * 16 * TM + i * 16 + 4 * g + r;
+          if (m < p.M && n < p.N) atomicAdd(reinterpret_cast<float*>(p.C) + cb + m * p.ldc + n, p.alpha * acc[i][j][r]);
+        }
+      }
+    return;
+  }
   float* sC = reinterpret_cast<float*>(smem);
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -612,9 +723,13 @@ template <int TM, int TN>
 int launch_glds(const GemmParams& p, void* stream) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
   const long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  if (tiles > 0x7fffffffL || (long)p.batch * p.batch2 > 65535) return CMDA_ERR_SHAPE;
-  dim3 grid((unsigned)tiles, 1, (unsigned)(p.batch * p.batch2));
-  CMDA_LAUNCH((gemm_nt_glds_kernel<TM, TN>), grid, dim3(256), 0, stream, p);
+  if (tiles > 0x7fffffffL || (long)p.batch * p.batch2 * p.splits > 65535) return CMDA_ERR_SHAPE;
+  dim3 grid((unsigned)tiles, 1, (unsigned)(p.batch * p.batch2 * p.splits));
+  const bool aks = p.a_kstrided != 0, bks = p.b_kstrided != 0;
+  if (!aks && !bks) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, false, false>), grid, dim3(256), 0, stream, p);
+  else if (!aks && bks) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, false, true>), grid, dim3(256), 0, stream, p);
+  else if (aks && bks) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, true, true>), grid, dim3(256), 0, stream, p);
+  else CMDA_LAUNCH((gemm_glds_kernel<TM, TN, true, false>), grid, dim3(256), 0, stream, p);
   CMDA_CHECK_LAUNCH();
 }
 
@@ -665,8 +780,13 @@ int launch_dtype(GemmParams& p, void* stream) {
   }
   if constexpr (sizeof(T) == 2) {
     static const char* no_glds = getenv("CMDA_GEMM_NO_GLDS");
-    const bool nt_plain = !p.a_kstrided && !p.b_kstrided && !p.A.conv && !p.B.conv && p.A.vec_ok && p.B.vec_ok &&
-                          !p.atomic && p.splits == 1 && (p.K % 64) == 0 && p.K >= 64;
+    // LDS-DMA path: every operand mode with aligned 16-byte chunks; transposed-conv / reflect views and operands
+    // too large for 32-bit tile arithmetic stay on the register-staged kernel
+    auto dma_ok = [](const GemmView& v) {
+      return v.vec_ok && v.in_dil <= 1 && !v.reflect && v.R < (1L << 31) && v.Cc < (1L << 31) &&
+             (!v.conv || (v.H < 32768 && v.W < 32768)) && (v.conv || (v.ld % 8) == 0) && (v.Cc % 8) == 0;
+    };
+    const bool nt_plain = dma_ok(p.A) && dma_ok(p.B);
     if (nt_plain && !no_glds) {
       if (tile == 0) return launch_glds<4, 4>(p, stream);
       if (tile == 1) return launch_glds<4, 2>(p, stream);
