@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 // ever needs a predicated LDS write.
 __device__ __attribute__((aligned(16))) unsigned g_zero16[4] = {0u, 0u, 0u, 0u};
 
-template <bool KS, int TILE>
+template <bool KS, int TILE, bool CONV>
 struct DmaSrc {
   static constexpr int BK = 64;
   static constexpr int J = TILE / 32;                               // DMA instructions per wave per stage
@@ -472,10 +472,9 @@ struct DmaSrc {
   int fixed[J];           // the fixed coordinate (K-contig: r, K-strided: c), -1 when out of range
   int line[J];            // LDS line of this lane for instruction j
   int chunk[J];           // logical chunk of this lane for instruction j
-  bool conv;
+  static constexpr bool conv = CONV;
 
   __device__ __forceinline__ void init(const GemmView& v, const bf16_t* base, int wid, int lane, long t0) {
-    conv = v.conv != 0;
 #pragma unroll
     for (int j = 0; j < J; ++j) {
       const int ln = (wid * J + j) * LPI + lane / CPL;              // K-contig: tile row; K-strided: k row
@@ -540,7 +539,7 @@ struct DmaSrc {
   }
 };
 
-template <int TM, int TN, bool AKS, bool BKS>
+template <int TM, int TN, bool AKS, bool BKS, bool ACONV, bool BCONV>
 __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmParams p) {
   typedef bf16_t T;
   constexpr int BM = 32 * TM, BN = 32 * TN, BK = 64;
@@ -575,8 +574,8 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmParams p) {
   const T* baseA = reinterpret_cast<const T*>(p.A.ptr) + (long)batch * p.A.batch_stride + (long)batch2 * p.A.batch2_stride;
   const T* baseB = reinterpret_cast<const T*>(p.B.ptr) + (long)batch * p.B.batch_stride + (long)batch2 * p.B.batch2_stride;
 
-  DmaSrc<AKS, BM> dA;
-  DmaSrc<BKS, BN> dB;
+  DmaSrc<AKS, BM, ACONV> dA;
+  DmaSrc<BKS, BN, BCONV> dB;
   dA.init(p.A, baseA, wid, lane, m0);
   dB.init(p.B, baseB, wid, lane, n0);
   auto issue = [&](int stage, int kt) {
@@ -725,11 +724,14 @@ int launch_glds(const GemmParams& p, void* stream) {
   const long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   if (tiles > 0x7fffffffL || (long)p.batch * p.batch2 * p.splits > 65535) return CMDA_ERR_SHAPE;
   dim3 grid((unsigned)tiles, 1, (unsigned)(p.batch * p.batch2 * p.splits));
-  const bool aks = p.a_kstrided != 0, bks = p.b_kstrided != 0;
-  if (!aks && !bks) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, false, false>), grid, dim3(256), 0, stream, p);
-  else if (!aks && bks) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, false, true>), grid, dim3(256), 0, stream, p);
-  else if (aks && bks) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, true, true>), grid, dim3(256), 0, stream, p);
-  else CMDA_LAUNCH((gemm_glds_kernel<TM, TN, true, false>), grid, dim3(256), 0, stream, p);
+  const bool aks = p.a_kstrided != 0, bks = p.b_kstrided != 0, ac = p.A.conv != 0, bc = p.B.conv != 0;
+  if (!aks && !bks && !ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, false, false, false, false>), grid, dim3(256), 0, stream, p);
+  else if (!aks && bks && !ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, false, true, false, false>), grid, dim3(256), 0, stream, p);
+  else if (aks && bks && !ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, true, true, false, false>), grid, dim3(256), 0, stream, p);
+  else if (aks && !bks && !ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, true, false, false, false>), grid, dim3(256), 0, stream, p);
+  else if (!aks && !bks && ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, false, false, true, false>), grid, dim3(256), 0, stream, p);
+  else if (aks && bks && !ac && bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, true, true, false, true>), grid, dim3(256), 0, stream, p);
+  else return CMDA_ERR_UNSUPPORTED;
   CMDA_CHECK_LAUNCH();
 }
 
@@ -764,14 +766,16 @@ int launch_dtype(GemmParams& p, void* stream) {
     const long b = tile == 0 ? blocks(128, 128) : blocks(64, 64);
     long s = (512 + b - 1) / b;
     s = std::min<long>(s, std::max(1, nkt / 8));
-    s = std::min<long>(s, 16);
+    const long out_bytes = (long)p.M * p.N * 4 * zb;
+    s = std::min<long>(s, std::max<long>(16, (16L << 20) / std::max<long>(out_bytes, 1)));  // atomic traffic bound
+    s = std::min<long>(s, 128);
     s = std::min<long>(s, std::max<long>(1, 65535 / std::max<long>(zb, 1)));
     p.splits = (int)std::max<long>(1, s);
   } else {
     if (p.splits <= 0) p.splits = 1;
     const long sp = p.splits;
-    if (p.N > 64 && blocks(128, 128) * sp >= 512) tile = 0;
-    else if (blocks(128, 64) * sp >= 512) tile = 1;
+    if (p.N > 64 && blocks(128, 128) * sp >= 1024) tile = 0;
+    else if (blocks(128, 64) * sp >= 2048) tile = 1;
     else tile = 2;
   }
   {  // tuning aid (tools/gemm_bench.py): CMDA_GEMM_TILE=0|1|2 forces the tile
@@ -786,7 +790,9 @@ int launch_dtype(GemmParams& p, void* stream) {
       return v.vec_ok && v.in_dil <= 1 && !v.reflect && v.R < (1L << 31) && v.Cc < (1L << 31) &&
              (!v.conv || (v.H < 32768 && v.W < 32768)) && (v.conv || (v.ld % 8) == 0) && (v.Cc % 8) == 0;
     };
-    const bool nt_plain = dma_ok(p.A) && dma_ok(p.B);
+    const bool ac = p.A.conv != 0, bc = p.B.conv != 0, aks = p.a_kstrided != 0, bks = p.b_kstrided != 0;
+    const bool kind_ok = (!ac && !bc) || (ac && !bc && !aks && !bks) || (!ac && bc && aks && bks);
+    const bool nt_plain = kind_ok && dma_ok(p.A) && dma_ok(p.B);
     if (nt_plain && !no_glds) {
       if (tile == 0) return launch_glds<4, 4>(p, stream);
       if (tile == 1) return launch_glds<4, 2>(p, stream);
