@@ -145,7 +145,7 @@ def main():
     gemm_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in prof)
     gemm_flops = sum(f for f, _, _ in prof)
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-    roofline = {'bound': 'mfma', 'kernel': 'gemm_kernel (bf16 MFMA 16x16x32 tile GEMM / implicit-GEMM conv family)',
+    roofline = {'bound': 'mfma', 'kernel': 'gemm_glds_kernel + gemm_kernel (bf16 MFMA 16x16x32 tile GEMM / implicit-GEMM conv family, all template instances)',
                 'achieved': round(achieved, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,
                 'launches_per_step': len(prof), 'avg_launch_us': round(gemm_ms * 1e3 / max(len(prof), 1), 2),
