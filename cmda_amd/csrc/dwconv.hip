@@ -141,8 +141,10 @@ template <typename T>
 __global__ void dw_bwd_weight_kernel(const T* __restrict__ dz, const T* __restrict__ x, float* __restrict__ dw,
                                      float* __restrict__ dbias, int B, int H, int W, int C, int dil,
                                      int pix_per_block) {
-  __shared__ float red[4][64][41];
+  __shared__ float red[64][41];  // 10.5 KiB: the 4 pixel-lane waves fold into it with LDS float atomics
   const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+  for (int k = threadIdx.x; k < 64 * 41; k += blockDim.x) (&red[0][0])[k] = 0.f;
+  __syncthreads();
   const int c = (blockIdx.x * 64 + cx) * 4;
   const long npix = (long)B * H * W;
   const long p0 = (long)blockIdx.y * pix_per_block;
@@ -181,16 +183,16 @@ __global__ void dw_bwd_weight_kernel(const T* __restrict__ dz, const T* __restri
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) red[py][cx][t * 4 + j] = acc[t][j];
+    for (int j = 0; j < 4; ++j) atomicAdd(&red[cx][t * 4 + j], acc[t][j]);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) red[py][cx][36 + j] = accb[j];
+  for (int j = 0; j < 4; ++j) atomicAdd(&red[cx][36 + j], accb[j]);
   __syncthreads();
   // 64 channel groups x 40 values, summed over the 4 pixel lanes
   for (int k = threadIdx.x; k < 64 * 40; k += blockDim.x) {
     const int gx = k / 40, v = k - gx * 40;
     const int cc = (blockIdx.x * 64 + gx) * 4;
     if (cc >= C) continue;
-    const float s = red[0][gx][v] + red[1][gx][v] + red[2][gx][v] + red[3][gx][v];
+    const float s = red[gx][v];
     if (v < 36) {
       const int t = v >> 2, j = v & 3;
       atomicAdd(dw + (cc + j) * 9 + t, s);

@@ -593,6 +593,9 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // optional fused bias gradient: blocks of the first n-tile also add up their A tile along k (A is dY^T here)
+  const bool do_colsum = AKS && p.colsum != nullptr && n0 == 0;
+  float bsum = 0.f;
   if (kt0 < kt1) issue(0, kt0);
   for (int kt = kt0; kt < kt1; ++kt) {
     __syncthreads();  // tile kt has landed (vmcnt(0) in front of the barrier) and the other stage is free again
@@ -600,6 +603,12 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmParams p) {
     if (kt + 1 < kt1) issue(st ^ 1, kt + 1);
     const T* sA = sAbase + st * SZ_A;
     const T* sB = sBbase + st * SZ_B;
+    if constexpr (AKS) {
+      if (do_colsum && tid < BM) {
+#pragma unroll 8
+        for (int k = 0; k < BK; ++k) bsum += bf2f(sA[k * BM + (((tid >> 3) ^ (k & 7)) << 3) + (tid & 7)]);
+      }
+    }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       u16x8 fa[TM], fb[TN];
@@ -642,6 +651,9 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmParams p) {
   __syncthreads();
 
   if (kt0 >= kt1 && p.splits > 1) return;
+  if constexpr (AKS) {
+    if (do_colsum && tid < BM && m0 + tid < p.M) atomicAdd(p.colsum + m0 + tid, bsum);
+  }
   const long cb = (long)batch * p.c_batch_stride + (long)batch2 * p.c_batch2_stride;
   const long rb_off = (long)batch * p.res_batch_stride + (long)batch2 * p.res_batch2_stride;
   if (p.atomic) {
@@ -793,12 +805,14 @@ int launch_dtype(GemmParams& p, void* stream) {
     const bool ac = p.A.conv != 0, bc = p.B.conv != 0, aks = p.a_kstrided != 0, bks = p.b_kstrided != 0;
     const bool kind_ok = (!ac && !bc) || (ac && !bc && !aks && !bks) || (!ac && bc && aks && bks);
     const bool nt_plain = kind_ok && dma_ok(p.A) && dma_ok(p.B);
+    if (p.colsum && !(nt_plain && !no_glds && aks)) return CMDA_ERR_UNSUPPORTED;
     if (nt_plain && !no_glds) {
       if (tile == 0) return launch_glds<4, 4>(p, stream);
       if (tile == 1) return launch_glds<4, 2>(p, stream);
       return launch_glds<2, 2>(p, stream);
     }
   }
+  if (p.colsum) return CMDA_ERR_UNSUPPORTED;  // the fused bias gradient lives in the LDS-DMA kernel only
   if (tile == 0) return launch_tile<T, 4, 4>(p, stream);
   if (tile == 1) return launch_tile<T, 4, 2>(p, stream);
   return launch_tile<T, 2, 2>(p, stream);

@@ -28,9 +28,12 @@ def linear_bwd(dy, x, weight, bias, M, K, *, need_dx=True, dx_out=None, dx_beta=
     """dW += dy^T x, db += colsum(dy), returns dx = dy @ W (optionally accumulated into dx_out)."""
     N = weight.shape[0]
     dyv_k = plain_view(dy, M, N, ld=dy_ld, offset=dy_off)  # (r = token, c = n)
-    ops.gemm(dyv_k, plain_view(x, M, K, ld=x_ld, offset=x_off), rt.grad(weight), N, K, M, a_kstrided=True,
-             b_kstrided=True, dtype=rt.tag(), atomic=True, splits=0)
-    if bias is not None:
+    xv = plain_view(x, M, K, ld=x_ld, offset=x_off)
+    fused = (bias is not None and rt.tag() == 1 and dyv_k.vec_ok and xv.vec_ok and N % 8 == 0 and K % 8 == 0
+             and (dy_ld or N) % 8 == 0 and (x_ld or K) % 8 == 0)
+    ops.gemm(dyv_k, xv, rt.grad(weight), N, K, M, a_kstrided=True, b_kstrided=True, dtype=rt.tag(), atomic=True,
+             splits=0, colsum=rt.grad(bias) if fused else None)  # bias gradient rides along in the wgrad kernel
+    if bias is not None and not fused:
         ops.colsum(dy, rt.grad(bias), M, N, ld=dy_ld, offset=dy_off)
     if not need_dx:
         return None

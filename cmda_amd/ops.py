@@ -46,7 +46,7 @@ GEMM_PROFILE = None
 
 def gemm(A, B, out, M, N, K, *, a_kstrided=False, b_kstrided=False, ldc=None, batch=1, c_batch_stride=0,
          batch2=1, c_batch2_stride=0, res_batch2_stride=0, splits=1, alpha=1.0, beta=0.0, bias=None, act=None, res=None, ldres=None, res_batch_stride=0,
-         rowscale=None, rows_per_scale=1, atomic=False, dtype=None, c_offset=0):
+         rowscale=None, rows_per_scale=1, atomic=False, dtype=None, c_offset=0, colsum=None):
     """out[m,n] = epi(alpha * sum_k A(m,k) B(n,k)); A/B are `View`s built by plain_view / conv_view."""
     check_dev(out, bias, res, rowscale)
     out_f32 = out.dtype == torch.float32
@@ -75,6 +75,7 @@ def gemm(A, B, out, M, N, K, *, a_kstrided=False, b_kstrided=False, ldc=None, ba
     if bias is not None:
         ok = ok and bias.data_ptr() % 16 == 0
     p.c_vec_ok = int(ok)
+    p.colsum = colsum.data_ptr() if colsum is not None else None
     if GEMM_PROFILE is not None and out.is_cuda:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -34,7 +34,7 @@ class FlatAdamW:
             groups.setdefault(_group_of(n, custom_keys), []).append(p)
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         dev = uniq[0][1].device
-        total = sum((p.numel() + 3) // 4 * 4 for _, p in uniq)
+        total = sum((p.numel() + 7) // 8 * 8 for _, p in uniq)  # 8-element slots: 16-byte aligned in fp32 AND in the bf16 mirror
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -49,7 +49,7 @@ class FlatAdamW:
                     self.flat_p[off:off + n].copy_(p.data.reshape(-1))
                     p.data = self.flat_p[off:off + n].view(p.shape)
                     p.grad = self.flat_g[off:off + n].view(p.shape)
-                    off += (n + 3) // 4 * 4
+                    off += (n + 7) // 8 * 8
                 self.segments.append((start, off, lm, dm))
         # bf16 compute copies of every parameter, kept current by the AdamW kernel itself (no per-step cast launches)
         self.flat_bf16 = None

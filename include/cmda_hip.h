@@ -70,6 +70,7 @@ typedef struct cmda_gemm_params_t {
   int32_t atomic;       /* C += via fp32 atomics (split-K / gradient accumulation) */
   int32_t dtype;
   int32_t c_vec_ok;     /* C, res and bias may be accessed 4 elements at a time (pitches, offsets % 4 == 0, 16-B bases) */
+  float* colsum;        /* optional, A K-strided only: colsum[m] += sum_k A(m,k) (bias gradient fused into wgrad) */
 } cmda_gemm_params_t;
 
 int cmda_gemm(const cmda_gemm_params_t* p, void* stream);
