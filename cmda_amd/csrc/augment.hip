@@ -1,0 +1,121 @@
+// augment.hip -- the "strong" augmentations DACS applies to the ClassMix-ed image (uda/dacs.py:446-456,721-723 ->
+// models/utils/dacs_transforms.py: color_jitter :64-79, gaussian_blur :82-98).  The reference delegates to
+// kornia 0.5.8 (third-party, absent here; restated from its documented 0.5.x behaviour -- parity unpinned):
+//   ColorJitter(b,c,s,h): four ops applied in a random order on the [0,1] image:
+//     brightness: clamp(x + (f_b - 1), 0, 1)      contrast: clamp(x * f_c, 0, 1)
+//     saturation: HSV, S <- clamp(S * f_s, 0, 1)  hue: HSV, H <- fmod(H + 2*pi*f_h, 2*pi)
+//   GaussianBlur2d((k,k),(sigma,sigma)), border 'reflect': separable normalised Gaussian.
+// Both are HBM-bound per-pixel kernels on the NCHW fp32 image; denorm (x*std+mean)/255 and renorm are fused in.
+#include "common.h"
+
+namespace {
+
+static __device__ __forceinline__ void rgb2hsv(float r, float g, float b, float& h, float& s, float& v) {
+  const float mx = fmaxf(r, fmaxf(g, b)), mn = fminf(r, fminf(g, b));
+  const float d = mx - mn;
+  v = mx;
+  s = d / (mx + 1e-6f);
+  const float dd = d == 0.f ? 1.f : d;
+  float hh;
+  if (mx == r) hh = (g - b) / dd;
+  else if (mx == g) hh = 2.f + (b - r) / dd;
+  else hh = 4.f + (r - g) / dd;
+  hh = hh / 6.f;
+  hh = hh - floorf(hh);
+  h = d == 0.f ? 0.f : hh * 6.283185307179586f;
+}
+
+static __device__ __forceinline__ void hsv2rgb(float h, float s, float v, float& r, float& g, float& b) {
+  const float hp = h / 6.283185307179586f * 6.f;
+  const float hi = floorf(hp);
+  const float f = hp - hi;
+  const int i = ((int)hi) % 6;
+  const float p = v * (1.f - s), q = v * (1.f - f * s), t = v * (1.f - (1.f - f) * s);
+  switch (i) {
+    case 0: r = v; g = t; b = p; break;
+    case 1: r = q; g = v; b = p; break;
+    case 2: r = p; g = v; b = t; break;
+    case 3: r = p; g = q; b = v; break;
+    case 4: r = t; g = p; b = v; break;
+    default: r = v; g = p; b = q; break;
+  }
+}
+
+// img: NCHW fp32 [B,3,H,W], normalised; in place.  prm: [order0..3, f_brightness, f_contrast, f_saturation, f_hue]
+__global__ void color_jitter_kernel(float* __restrict__ img, int B, int HW, float m0, float m1, float m2, float s0, float s1,
+                                    float s2, int o0, int o1, int o2, int o3, float fb, float fc, float fs, float fh) {
+  const long total = (long)B * HW;
+  const int order[4] = {o0, o1, o2, o3};
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / HW, p = i - b * HW;
+    float* px = img + b * 3 * HW + p;
+    float r = (px[0] * s0 + m0) / 255.f, g = (px[HW] * s1 + m1) / 255.f, bl = (px[2L * HW] * s2 + m2) / 255.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int op = order[k];
+      if (op == 0) {
+        r = fminf(fmaxf(r + (fb - 1.f), 0.f), 1.f); g = fminf(fmaxf(g + (fb - 1.f), 0.f), 1.f); bl = fminf(fmaxf(bl + (fb - 1.f), 0.f), 1.f);
+      } else if (op == 1) {
+        r = fminf(fmaxf(r * fc, 0.f), 1.f); g = fminf(fmaxf(g * fc, 0.f), 1.f); bl = fminf(fmaxf(bl * fc, 0.f), 1.f);
+      } else {
+        float h, s, v;
+        rgb2hsv(r, g, bl, h, s, v);
+        if (op == 2) s = fminf(fmaxf(s * fs, 0.f), 1.f);
+        else { h = fmodf(h + fh * 6.283185307179586f, 6.283185307179586f); if (h < 0.f) h += 6.283185307179586f; }
+        hsv2rgb(h, s, v, r, g, bl);
+      }
+    }
+    px[0] = (r * 255.f - m0) / s0;
+    px[HW] = (g * 255.f - m1) / s1;
+    px[2L * HW] = (bl * 255.f - m2) / s2;
+  }
+}
+
+static __device__ __forceinline__ int reflect101(int i, int n) {
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * (n - 1) - i;
+  return i;
+}
+
+// one separable pass along x (axis=1) or y (axis=0); planes = B*3; taps: fp32[k] normalised
+__global__ void blur_pass_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ taps,
+                                 int planes, int H, int W, int k, int axis) {
+  const long total = (long)planes * H * W;
+  const int r = k / 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W);
+    const long t = i / W;
+    const int y = (int)(t % H);
+    const float* pl = in + (t / H) * H * W;
+    float acc = 0.f;
+    for (int j = 0; j < k; ++j) {
+      const int xx = axis ? reflect101(x + j - r, W) : x;
+      const int yy = axis ? y : reflect101(y + j - r, H);
+      acc += taps[j] * pl[(long)yy * W + xx];
+    }
+    out[i] = acc;
+  }
+}
+
+static inline int grid_for(long n) { return (int)std::max<long>(1, std::min<long>((n + 255) / 256, 8192)); }
+}  // namespace
+
+// prm (HOST pointer, 8 floats): order[4] (0 brightness, 1 contrast, 2 saturation, 3 hue), factors f_b, f_c, f_s, f_h
+extern "C" int cmda_color_jitter(float* img, int B, int H, int W, const float* mean3, const float* std3, const float* prm,
+                                 void* stream) {
+  if ((long)B * H * W <= 0) return CMDA_OK;
+  CMDA_LAUNCH(color_jitter_kernel, dim3(grid_for((long)B * H * W)), dim3(256), 0, stream, img, B, H * W, mean3[0], mean3[1],
+              mean3[2], std3[0], std3[1], std3[2], (int)prm[0], (int)prm[1], (int)prm[2], (int)prm[3], prm[4], prm[5], prm[6],
+              prm[7]);
+  CMDA_CHECK_LAUNCH();
+}
+
+// img, tmp: fp32 [planes,H,W]; taps: DEVICE fp32[k] (normalised Gaussian); result ends up in img
+extern "C" int cmda_gaussian_blur(float* img, float* tmp, const float* taps, int planes, int H, int W, int k, void* stream) {
+  const long n = (long)planes * H * W;
+  if (n <= 0) return CMDA_OK;
+  if (k <= 0 || !(k & 1)) return CMDA_ERR_SHAPE;
+  CMDA_LAUNCH(blur_pass_kernel, dim3(grid_for(n)), dim3(256), 0, stream, (const float*)img, tmp, taps, planes, H, W, k, 1);
+  CMDA_LAUNCH(blur_pass_kernel, dim3(grid_for(n)), dim3(256), 0, stream, (const float*)tmp, img, taps, planes, H, W, k, 0);
+  CMDA_CHECK_LAUNCH();
+}

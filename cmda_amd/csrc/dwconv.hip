@@ -15,116 +15,59 @@
 
 namespace {
 
-template <typename T>
-static __device__ __forceinline__ void dw_accum(const T* __restrict__ x, const float* __restrict__ w, int b, int h,
-                                                int wx, int c, int H, int W, int C, int dil, float (&acc)[4]) {
+// Stencil kernels: block = 64 channel-quads x 4 pixel lanes; a thread keeps ITS 4 channels' nine taps (and bias) in
+// registers and walks `pix_per_block / 4` pixels, so the per-pixel work is 9 coalesced 8/16-byte loads + FMAs.
+// MODE 0: y = act(conv(x) + bias)          (forward)
+// MODE 1: dz = da * gelu'(conv(x) + bias)  (backward prep: recomputes the pre-activation instead of saving it)
+// MODE 2: dx (+)= conv^T(dy)               (data gradient: taps mirrored)
+template <typename T, int MODE>
+__global__ void dw_stencil_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                  const T* __restrict__ da, T* __restrict__ out, int B, int H, int W, int C, int dil, int act,
+                                  int accumulate, int pix_per_block) {
+  const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + cx) * 4;
+  if (c >= C) return;
+  float wr[9][4], bs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int kh = 0; kh < 3; ++kh) {
-    const int ih = h + (kh - 1) * dil;
-    if (ih < 0 || ih >= H) continue;
-#pragma unroll
-    for (int kw = 0; kw < 3; ++kw) {
-      const int iw = wx + (kw - 1) * dil;
-      if (iw < 0 || iw >= W) continue;
-      float xv[4], wv[4];
-      ld4(x + ((long)(b * H + ih) * W + iw) * C + c, xv);
-      ld4(w + (kh * 3 + kw) * C + c, wv);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] += xv[j] * wv[j];
-    }
-  }
-}
-
-// y = act(dwconv(x) + bias)
-template <typename T>
-__global__ void dw_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                              T* __restrict__ y, int B, int H, int W, int C, int dil, int act) {
-  const int cg = C >> 2;
-  const long total = (long)B * H * W * cg;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const unsigned iu = (unsigned)i;  // launchers guarantee total < 2^32
-    const int c = (int)(iu % (unsigned)cg) * 4;
-    unsigned pix = iu / (unsigned)cg;
-    const int wx = (int)(pix % (unsigned)W);
-    pix /= (unsigned)W;
-    const int h = (int)(pix % (unsigned)H);
-    const int b = (int)(pix / (unsigned)H);
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    if (bias) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = bias[c + j];
-    }
-    dw_accum(x, w, b, h, wx, c, H, W, C, dil, acc);
-    if (act == 2) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = gelu_erf(acc[j]);
-    }
-    st4(y + ((long)(b * H + h) * W + wx) * C + c, acc);
-  }
-}
-
-// dz = da * gelu'(dwconv(x) + bias)   (recomputes the pre-activation instead of saving it)
-template <typename T>
-__global__ void dw_gelu_bwd_prep_kernel(const T* __restrict__ x, const float* __restrict__ w,
-                                        const float* __restrict__ bias, const T* __restrict__ da, T* __restrict__ dz,
-                                        int B, int H, int W, int C, int dil) {
-  const int cg = C >> 2;
-  const long total = (long)B * H * W * cg;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const unsigned iu = (unsigned)i;  // launchers guarantee total < 2^32
-    const int c = (int)(iu % (unsigned)cg) * 4;
-    unsigned pix = iu / (unsigned)cg;
-    const int wx = (int)(pix % (unsigned)W);
-    pix /= (unsigned)W;
-    const int h = (int)(pix % (unsigned)H);
-    const int b = (int)(pix / (unsigned)H);
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    if (bias) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = bias[c + j];
-    }
-    dw_accum(x, w, b, h, wx, c, H, W, C, dil, acc);
-    const long o = ((long)(b * H + h) * W + wx) * C + c;
-    float g[4];
-    ld4(da + o, g);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) g[j] *= gelu_erf_grad(acc[j]);
-    st4(dz + o, g);
-  }
-}
-
-// dx[b,h,w,c] = sum_taps dy[b, h-(kh-1)d, w-(kw-1)d, c] * w[c,kh,kw]
-template <typename T>
-__global__ void dw_bwd_data_kernel(const T* __restrict__ dy, const float* __restrict__ w, T* __restrict__ dx, int B,
-                                   int H, int W, int C, int dil, int accumulate) {
-  const int cg = C >> 2;
-  const long total = (long)B * H * W * cg;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const unsigned iu = (unsigned)i;  // launchers guarantee total < 2^32
-    const int c = (int)(iu % (unsigned)cg) * 4;
-    unsigned pix = iu / (unsigned)cg;
-    const int wx = (int)(pix % (unsigned)W);
-    pix /= (unsigned)W;
-    const int h = (int)(pix % (unsigned)H);
-    const int b = (int)(pix / (unsigned)H);
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < 9; ++t) ld4(w + t * C + c, wr[t]);
+  if (MODE != 2 && bias) ld4(bias + c, bs);
+  const long npix = (long)B * H * W;
+  const long p0 = (long)blockIdx.y * pix_per_block;
+  const long p1 = min(npix, p0 + pix_per_block);
+  const int sgn = MODE == 2 ? -1 : 1;
+  for (long pix = p0 + py; pix < p1; pix += 4) {
+    const unsigned pu = (unsigned)pix;
+    const int wx = (int)(pu % (unsigned)W);
+    const unsigned t2 = pu / (unsigned)W;
+    const int h = (int)(t2 % (unsigned)H);
+    const int b = (int)(t2 / (unsigned)H);
+    float acc[4] = {bs[0], bs[1], bs[2], bs[3]};
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
-      const int oh = h - (kh - 1) * dil;
-      if (oh < 0 || oh >= H) continue;
+      const int ih = h + sgn * (kh - 1) * dil;
+      if (ih < 0 || ih >= H) continue;
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
-        const int ow = wx - (kw - 1) * dil;
-        if (ow < 0 || ow >= W) continue;
-        float gv[4], wv[4];
-        ld4(dy + ((long)(b * H + oh) * W + ow) * C + c, gv);
-        ld4(w + (kh * 3 + kw) * C + c, wv);
+        const int iw = wx + sgn * (kw - 1) * dil;
+        if (iw < 0 || iw >= W) continue;
+        float xv[4];
+        ld4(x + ((long)(b * H + ih) * W + iw) * C + c, xv);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] += gv[j] * wv[j];
+        for (int j = 0; j < 4; ++j) acc[j] += xv[j] * wr[kh * 3 + kw][j];
       }
     }
-    T* o = dx + ((long)(b * H + h) * W + wx) * C + c;
-    if (accumulate) {
+    T* o = out + pix * C + c;
+    if (MODE == 0) {
+      if (act == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = gelu_erf(acc[j]);
+      }
+    } else if (MODE == 1) {
+      float g[4];
+      ld4(da + pix * C + c, g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = g[j] * gelu_erf_grad(acc[j]);
+    } else if (accumulate) {
       float prev[4];
       ld4(o, prev);
 #pragma unroll
@@ -202,36 +145,37 @@ __global__ void dw_bwd_weight_kernel(const T* __restrict__ dz, const T* __restri
   }
 }
 
-static inline int grid_for(long n) { return (int)std::max<long>(1, std::min<long>((n + 255) / 256, 16384)); }
 static inline bool too_big(long n) { return n >= (1L << 32); }
 
+template <int MODE>
+static int launch_stencil(const void* x, const float* w, const float* bias, const void* da, void* out, int B, int H, int W,
+                          int C, int dil, int act, int accumulate, int dtype, void* stream) {
+  const long npix = (long)B * H * W;
+  if (npix * C <= 0) return CMDA_OK;
+  if ((C & 3) || too_big(npix)) return CMDA_ERR_SHAPE;
+  const int gx = (C / 4 + 63) / 64;
+  int ppb = 64;
+  while (ppb > 8 && (npix + ppb - 1) / ppb * gx < 4096) ppb >>= 1;
+  dim3 grid(gx, (unsigned)((npix + ppb - 1) / ppb));
+  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((dw_stencil_kernel<T, MODE>), grid, dim3(256), 0, stream, (const T*)x, w, bias,
+                                         (const T*)da, (T*)out, B, H, W, C, dil, act, accumulate, ppb));
+  CMDA_CHECK_LAUNCH();
+}
 }  // namespace
 
 extern "C" int cmda_dwconv3x3_fwd(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C,
                                   int dil, int act, int dtype, void* stream) {
-  if ((long)B * H * W * C <= 0) return CMDA_OK;
-  if ((C & 3) || too_big((long)B * H * W * (C / 4))) return CMDA_ERR_SHAPE;
-  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((dw_fwd_kernel<T>), dim3(grid_for((long)B * H * W * (C / 4))), dim3(256), 0,
-                                         stream, (const T*)x, w, bias, (T*)y, B, H, W, C, dil, act));
-  CMDA_CHECK_LAUNCH();
+  return launch_stencil<0>(x, w, bias, nullptr, y, B, H, W, C, dil, act, 0, dtype, stream);
 }
 
 extern "C" int cmda_dwconv3x3_gelu_bwd_prep(const void* x, const float* w, const float* bias, const void* da, void* dz,
                                             int B, int H, int W, int C, int dil, int dtype, void* stream) {
-  if ((long)B * H * W * C <= 0) return CMDA_OK;
-  if ((C & 3) || too_big((long)B * H * W * (C / 4))) return CMDA_ERR_SHAPE;
-  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((dw_gelu_bwd_prep_kernel<T>), dim3(grid_for((long)B * H * W * (C / 4))),
-                                         dim3(256), 0, stream, (const T*)x, w, bias, (const T*)da, (T*)dz, B, H, W, C, dil));
-  CMDA_CHECK_LAUNCH();
+  return launch_stencil<1>(x, w, bias, da, dz, B, H, W, C, dil, 2, 0, dtype, stream);
 }
 
 extern "C" int cmda_dwconv3x3_bwd_data(const void* dy, const float* w, void* dx, int B, int H, int W, int C, int dil,
                                        int accumulate, int dtype, void* stream) {
-  if ((long)B * H * W * C <= 0) return CMDA_OK;
-  if ((C & 3) || too_big((long)B * H * W * (C / 4))) return CMDA_ERR_SHAPE;
-  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((dw_bwd_data_kernel<T>), dim3(grid_for((long)B * H * W * (C / 4))), dim3(256),
-                                         0, stream, (const T*)dy, w, (T*)dx, B, H, W, C, dil, accumulate));
-  CMDA_CHECK_LAUNCH();
+  return launch_stencil<2>(dy, w, nullptr, nullptr, dx, B, H, W, C, dil, 0, accumulate, dtype, stream);
 }
 
 extern "C" int cmda_dwconv3x3_bwd_weight(const void* dz, const void* x, float* dw, float* dbias, int B, int H, int W,

@@ -355,7 +355,8 @@ def isr_from_gray(gray, val_range, threshold, clip_range, shift_pixel, shift_dir
     dirs_t = torch.tensor(dirs, dtype=torch.int32).to(gray.device)
     mm = torch.empty(B * len(dirs) * 4, dtype=torch.int32, device=gray.device)
     out = torch.empty(B, 3, H, W, dtype=torch.float32, device=gray.device)
-    call('cmda_isr_from_gray', ptr(gray), ptr(isr_lut(val_range, gray.device)), ptr(dirs_t), c_i32(len(dirs)), ptr(mm),
+    lut = isr_lut(val_range, gray.device)
+    call('cmda_isr_from_gray', ptr(gray), ptr(lut), ptr(dirs_t), c_i32(len(dirs)), ptr(mm),
          ptr(out), c_i32(B), c_i32(H), c_i32(W), c_f32(float(np.float32(span * threshold))),
          c_f32(float(np.float32(span * clip_range))), stream_of(gray))
     return out
@@ -376,3 +377,28 @@ def events_norm(events, clip_range, final_range=1.0):
     call('cmda_events_norm', ptr(events), ptr(out), ptr(ws), c_i64(events.numel()), c_f32(clip_range), c_f32(final_range),
          stream_of(events))
     return out
+
+
+def color_jitter_(img, order, fb, fc, fs, fh):
+    """In place on the normalised NCHW fp32 image: kornia-0.5 ColorJitter with the given op order and factors."""
+    check_dev(img)
+    B, _, H, W = img.shape
+    prm = (ctypes.c_float * 8)(*[float(v) for v in order], fb, fc, fs, fh)
+    call('cmda_color_jitter', ptr(img), c_i32(B), c_i32(H), c_i32(W), _IMG_MEAN, _IMG_STD, prm, stream_of(img))
+    return img
+
+
+def gaussian_taps(k, sigma, device):
+    x = torch.arange(k, dtype=torch.float32) - k // 2
+    g = torch.exp(-x * x / (2.0 * sigma * sigma))
+    return (g / g.sum()).to(device)
+
+
+def gaussian_blur_(img, k, sigma):
+    """In place separable Gaussian blur (reflect border) of an NCHW fp32 image."""
+    check_dev(img)
+    B, C, H, W = img.shape
+    tmp = torch.empty_like(img)
+    taps = gaussian_taps(k, sigma, img.device)  # keep a reference until the launch is enqueued
+    call('cmda_gaussian_blur', ptr(img), ptr(tmp), ptr(taps), c_i32(B * C), c_i32(H), c_i32(W), c_i32(k), stream_of(img))
+    return img

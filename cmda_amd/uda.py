@@ -263,7 +263,15 @@ class DACS(nn.Module):
         lab = day_label.view(B, H, W)
         classes = self._choose_classes(day_label)
         mixed_img = ops.class_mix(day_image, night_image, lab, classes)
-        # TODO(next): kornia ColorJitter / GaussianBlur of the mixed image (dacs_transforms.py:64-98), stochastic
+        # strong_transform's colour jitter / Gaussian blur of the mixed image (dacs_transforms.py:64-98; kornia semantics)
+        if strong['color_jitter'] > self.color_jitter_p:
+            s_ = self.color_jitter_s
+            order = list(np.random.permutation(4))
+            ops.color_jitter_(mixed_img, order, random.uniform(max(0.0, 1 - s_), 1 + s_), random.uniform(max(0.0, 1 - s_), 1 + s_),
+                              random.uniform(max(0.0, 1 - s_), 1 + s_), random.uniform(-s_, s_))
+        if strong['blur'] > 0.5:
+            k = int(np.floor(np.ceil(0.1 * H) - 0.5 + np.ceil(0.1 * H) % 2))
+            ops.gaussian_blur_(mixed_img, k, strong['sigma'])
         mixed_events = ops.class_mix(day_events, night_events, lab, classes) if day_events is not None else None
         gray = ops.isr_gray(mixed_img)
         if self.shift_type == 'random':

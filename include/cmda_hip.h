@@ -169,6 +169,11 @@ int cmda_events_to_voxel_grid(const float* t, const float* x, const float* y, co
 int cmda_events_norm(const float* events, float* out, void* ws, int64_t n, float clip_range, float final_range, void*
     stream);
 
+/* ---- Strong augmentation of the mixed image -- models/utils/dacs_transforms.py:64-98 (kornia 0.5.8 ColorJitter and
+ * GaussianBlur2d, restated).  mean3/std3/prm are HOST pointers; taps is a DEVICE fp32[k] normalised Gaussian. */
+int cmda_color_jitter(float* img, int B, int H, int W, const float* mean3, const float* std3, const float* prm, void* stream);
+int cmda_gaussian_blur(float* img, float* tmp, const float* taps, int planes, int H, int W, int k, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -214,3 +214,63 @@ def param_group_options(name, base_lr, base_wd, custom_keys):
             wd = base_wd * custom_keys[key].get('decay_mult', 1.0)
             break
     return lr, wd
+
+
+# ---------------------------------------------------------------- strong augmentation (kornia 0.5.8, restated; unpinned)
+def _rgb_to_hsv(img):
+    r, g, b = img[:, 0], img[:, 1], img[:, 2]
+    mx, mn = img.max(1)[0], img.min(1)[0]
+    d = mx - mn
+    s = d / (mx + 1e-6)
+    dd = torch.where(d == 0, torch.ones_like(d), d)
+    h = torch.where(mx == r, (g - b) / dd, torch.where(mx == g, 2.0 + (b - r) / dd, 4.0 + (r - g) / dd)) / 6.0
+    h = h - torch.floor(h)
+    h = torch.where(d == 0, torch.zeros_like(h), h * (2 * math.pi))
+    return h, s, mx
+
+
+def _hsv_to_rgb(h, s, v):
+    hp = h / (2 * math.pi) * 6.0
+    hi = torch.floor(hp)
+    f = hp - hi
+    i = hi.long() % 6
+    p, q, t = v * (1 - s), v * (1 - f * s), v * (1 - (1 - f) * s)
+    sel = lambda *c: torch.stack(c, 0).gather(0, i[None])[0]
+    return torch.stack([sel(v, q, p, p, t, v), sel(t, v, v, q, p, p), sel(p, p, t, v, v, q)], 1)
+
+
+def color_jitter(img, order, fb, fc, fs, fh, mean=IMG_MEAN, std=IMG_STD):
+    """img: normalised [B,3,H,W]; ops 0..3 = brightness, contrast, saturation, hue applied in `order`."""
+    m = torch.tensor(mean).view(1, 3, 1, 1)
+    sd = torch.tensor(std).view(1, 3, 1, 1)
+    x = (img * sd + m) / 255.0
+    for op in order:
+        if op == 0:
+            x = (x + (fb - 1.0)).clamp(0, 1)
+        elif op == 1:
+            x = (x * fc).clamp(0, 1)
+        else:
+            h, s, v = _rgb_to_hsv(x)
+            if op == 2:
+                s = (s * fs).clamp(0, 1)
+            else:
+                h = torch.fmod(h + fh * 2 * math.pi, 2 * math.pi)
+                h = torch.where(h < 0, h + 2 * math.pi, h)
+            x = _hsv_to_rgb(h, s, v)
+    return (x * 255.0 - m) / sd
+
+
+def gaussian_blur(img, k, sigma):
+    x = torch.arange(k, dtype=torch.float32) - k // 2
+    g = torch.exp(-x * x / (2.0 * sigma * sigma))
+    g = g / g.sum()
+    C = img.shape[1]
+    pad = k // 2
+    y = F.pad(img, (pad, pad, 0, 0), mode='reflect')
+    y = F.conv2d(y, g.view(1, 1, 1, k).repeat(C, 1, 1, 1), groups=C)
+    y = F.pad(y, (0, 0, pad, pad), mode='reflect')
+    return F.conv2d(y, g.view(1, 1, k, 1).repeat(C, 1, 1, 1), groups=C)
+
+
+def blur_kernel_size(n):
+    return int(np.floor(np.ceil(0.1 * n) - 0.5 + np.ceil(0.1 * n) % 2))

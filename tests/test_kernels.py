@@ -254,3 +254,17 @@ def test_voxel_golden(tgt):
         assert_close(vg, g[f'vg{bins}'], 2e-6, atol=1e-6, name='voxel grid')
         nrm = ops.events_norm(tgt.to(g[f'vg{bins}']), (5000 / 500000) * 1.5 * 100)
         assert_close(nrm, g[f'norm{bins}'], 1e-5, name='events_norm')
+
+
+def test_strong_augmentation(tgt):
+    from oracle import uda as ouda
+    torch.manual_seed(9)
+    img = torch.randn(2, 3, 40, 56)
+    order, fb, fc, fs, fh = [2, 0, 3, 1], 1.1, 0.9, 1.15, -0.07
+    ref = ouda.color_jitter(img, order, fb, fc, fs, fh)
+    out = ops.color_jitter_(tgt.to(img.clone()), order, fb, fc, fs, fh)
+    assert_close(out, ref, 1e-4, atol=2e-4, name='color jitter', outlier_frac=1e-3, outlier_rtol=2.0)
+    k = ouda.blur_kernel_size(56)
+    refb = ouda.gaussian_blur(img, k, 0.8)
+    outb = ops.gaussian_blur_(tgt.to(img.clone()), k, 0.8)
+    assert_close(outb, refb, 1e-5, atol=1e-6, name='gaussian blur')
