@@ -72,10 +72,12 @@ def test_softmax(tgt, dt, tol, L):
 
 
 @pytest.mark.parametrize('dt,tol', DT)
-@pytest.mark.parametrize('dil,act', [(1, 'gelu'), (1, None), (6, None)])
-def test_dwconv(tgt, dt, tol, dil, act):
+@pytest.mark.parametrize('dil,act,shape', [(1, 'gelu', (2, 13, 9, 24)), (1, None, (2, 13, 9, 24)), (6, None, (2, 13, 9, 24)),
+                                           (1, 'gelu', (1, 5, 40, 260)), (3, None, (2, 7, 43, 8)), (18, None, (1, 20, 24, 12)),
+                                           (12, None, (1, 3, 128, 4))])
+def test_dwconv(tgt, dt, tol, dil, act, shape):
     torch.manual_seed(dil)
-    B, H, W, C = 2, 13, 9, 24
+    B, H, W, C = shape
     x = torch.randn(B, H, W, C).to(dt)
     w, b = torch.randn(C, 1, 3, 3) * 0.3, torch.randn(C)
     xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)

@@ -1,0 +1,79 @@
+"""Micro-benchmark of the HBM-bound kernels at the config-2 (MiT-B5, 512x512, per-GPU batch 16) shapes.
+
+    python tools/hbm_bench.py [--batch 16]
+prints per kernel: avg microseconds, algorithmic GB/s (DESIGN.md section 5 byte counts) and the fraction of 8 TB/s.
+"""
+import argparse
+import sys
+import os
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cmda_amd import ops  # noqa: E402
+
+
+def timeit(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3  # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=16)
+    a = ap.parse_args()
+    B = a.batch
+    dev = 'cuda'
+    bf = torch.bfloat16
+    rows = []
+
+    def rec(name, us, nbytes):
+        rows.append((name, us, nbytes / us / 1e3))
+
+    # MixFFN depthwise stencils per stage (hidden = 4*dim) + sep-ASPP depthwise
+    for (H, C, dil) in ((128, 256, 1), (64, 512, 1), (32, 1280, 1), (16, 2048, 1), (128, 1024, 6), (128, 1024, 18)):
+        n = B * H * H * C
+        x = torch.randn(B, H, H, C, device=dev).to(bf)
+        dy = torch.randn_like(x)
+        w = torch.randn(9, C, device=dev) * 0.3
+        bias = torch.randn(C, device=dev)
+        dw = torch.zeros(C, 9, device=dev)
+        db = torch.zeros(C, device=dev)
+        tag = f'H{H} C{C} d{dil}'
+        rec(f'dw fwd+gelu {tag}', timeit(lambda: ops.dwconv_fwd(x, w, bias, B, H, H, C, dil, 'gelu')), 2 * n * 2)
+        rec(f'dw gelu-bwd-prep {tag}', timeit(lambda: ops.dwconv_gelu_bwd_prep(x, w, bias, dy, B, H, H, C, dil)), 3 * n * 2)
+        rec(f'dw bwd-data {tag}', timeit(lambda: ops.dwconv_bwd_data(dy, w, B, H, H, C, dil)), 2 * n * 2)
+        rec(f'dw bwd-weight {tag}', timeit(lambda: ops.dwconv_bwd_weight(dy, x, dw, db, B, H, H, C, dil)), 2 * n * 2)
+        del x, dy
+    # LayerNorm per stage
+    for (H, C) in ((128, 64), (64, 128), (32, 320), (16, 512)):
+        R = B * H * H
+        x = torch.randn(R, C, device=dev).to(bf)
+        dy = torch.randn_like(x)
+        g = torch.randn(C, device=dev)
+        b = torch.randn(C, device=dev)
+        y, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-6)
+        dg, dbeta = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        rec(f'ln fwd R{R} C{C}', timeit(lambda: ops.layernorm_fwd(x, g, b, 1e-6)), 2 * R * C * 2)
+        rec(f'ln bwd R{R} C{C}', timeit(lambda: ops.layernorm_bwd(dy, x, g, mean, rstd, dg, dbeta)), 3 * R * C * 2)
+    # attention softmax per stage: rows = B*heads*N, L = N/sr^2
+    for (N, heads, L) in ((16384, 1, 256), (4096, 2, 256), (1024, 5, 256), (256, 8, 256)):
+        R = B * heads * N
+        s = torch.randn(R, L, device=dev).to(bf)
+        dp = torch.randn_like(s)
+        rec(f'softmax fwd R{R} L{L}', timeit(lambda: ops.softmax_fwd_(s, R, L, 0.125)), 2 * R * L * 2)
+        rec(f'softmax bwd R{R} L{L}', timeit(lambda: ops.softmax_bwd_(s, dp, R, L, 0.125)), 3 * R * L * 2)
+    print(f'{"kernel":44s} {"us":>10s} {"GB/s":>9s} {"frac":>6s}')
+    for name, us, gbs in rows:
+        print(f'{name:44s} {us:10.1f} {gbs:9.0f} {gbs / 8000:6.3f}')
+
+
+if __name__ == '__main__':
+    main()
