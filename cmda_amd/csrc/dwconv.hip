@@ -5,9 +5,10 @@
 //   depthwise half of DepthwiseSeparableConvModule (3x3, dilation 6/12/18, no bias) in the sep-ASPP
 //   decode_heads/sep_aspp_head.py:18-27 (mmcv DepthwiseSeparableConvModule.depthwise_conv)
 //
-// HBM-bound stencils: a thread owns 4 adjacent channels and a RUN of 8 pixels of one image row spaced `dil` apart; it
-// slides a 3x3 register window along the run, so every output costs 3 new coalesced 8/16-byte loads (lanes run along
-// C) instead of 9.  Algorithmic bytes per pixel-channel:
+// HBM-bound stencils: a thread owns 4 adjacent channels and a RUN of 8 pixels of one image row spaced `dil` apart.  It
+// first issues ALL 3 x (RUN+2) window loads (clamped addresses, zero-selected afterwards -- no branch between them, so
+// ~15 KiB per wave is in flight), then slides a 3x3 register window along the run: 3.75 coalesced 8/16-byte loads per
+// output (lanes run along C) instead of 9.  Algorithmic bytes per pixel-channel:
 // fwd 2*sizeof(T); gelu-bwd-prep 3*sizeof(T); bwd-data 2*sizeof(T); bwd-weight 2*sizeof(T).
 // Depthwise weights/bias stay fp32.  The stencil kernels read a tap-major [9][C] copy of the reference's [C,1,3,3]
 // parameter (rt.wdw: one tiny permute per optimizer step) so that the 4 channel weights of a lane are one coalesced
@@ -16,35 +17,75 @@
 
 namespace {
 
-constexpr int kRun = 8;  // outputs per thread along a row (stride dil)
-
 // Runs: a row's columns split into `dil` residue classes; class rho holds w = rho, rho+dil, ... and is cut into runs
-// of kRun outputs.  run id -> (b, h, rho, k); first column w0 = rho + k*kRun*dil.
+// of `run` outputs.  run id -> (b, h, rho, k); first column w0 = rho + k*run*dil.
 struct RunGeom {
   int H, W, dil, rpc, rpr;  // rpc: runs per residue class, rpr = dil * rpc runs per row
   long nruns;
 };
-static inline RunGeom run_geom(int B, int H, int W, int dil) {
+static inline RunGeom run_geom(int B, int H, int W, int dil, int run) {
   RunGeom g;
   g.H = H; g.W = W; g.dil = dil;
   const int per_class = (W + dil - 1) / dil;
-  g.rpc = (per_class + kRun - 1) / kRun;
+  g.rpc = (per_class + run - 1) / run;
   g.rpr = dil * g.rpc;
   g.nruns = (long)B * H * g.rpr;
   return g;
 }
 
-// column of three taps (rows h-dil, h, h+dil) at column iw for 4 channels; zero outside the image
-template <typename T>
-static __device__ __forceinline__ void load_col(const T* __restrict__ x, long row_base, int h, int iw, int H, int W, int C,
-                                                int dil, float col[3][4]) {
+// raw (unconverted) 4-channel vectors: bf16 stays packed in 2 VGPRs while it waits in the prefetched window
+template <typename T> struct Raw;
+template <> struct Raw<float> {
+  float4 v;
+  __device__ __forceinline__ void load(const float* p, bool ok) {
+    v = *reinterpret_cast<const float4*>(p);
+    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __device__ __forceinline__ void unpack(float (&o)[4]) const { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+};
+template <> struct Raw<bf16_t> {
+  u16x4 v;
+  __device__ __forceinline__ void load(const bf16_t* p, bool ok) {
+    v = *reinterpret_cast<const u16x4*>(p);
+    if (!ok) v = (u16x4)(0);
+  }
+  __device__ __forceinline__ void unpack(float (&o)[4]) const {
+    o[0] = bf2f(v[0]); o[1] = bf2f(v[1]); o[2] = bf2f(v[2]); o[3] = bf2f(v[3]);
+  }
+};
+template <typename T> struct RunLen { static constexpr int value = 8; };
+template <> struct RunLen<float> { static constexpr int value = 4; };  // fp32 (parity mode): half the window registers
+
+struct RunPos {
+  int h, w0;
+  long row_base;  // pixel index of (b, h, 0)
+};
+static __device__ __forceinline__ bool decode_run(const RunGeom& g, long run, int runlen, RunPos& r) {
+  const unsigned ru = (unsigned)run;
+  const int rr = (int)(ru % (unsigned)g.rpr);
+  const unsigned bh = ru / (unsigned)g.rpr;  // b*H + h
+  r.h = (int)(bh % (unsigned)g.H);
+  const int rho = rr / g.rpc, k = rr - rho * g.rpc;
+  r.w0 = rho + k * runlen * g.dil;
+  r.row_base = (long)bh * g.W;
+  return r.w0 < g.W;
+}
+
+// the whole 3 x (RUN+2) window of a run: every load is unconditional (out-of-image taps read a clamped in-image address and
+// are zeroed by a select), so the compiler issues them back to back
+template <typename T, int RUN>
+static __device__ __forceinline__ void load_window(const T* __restrict__ xc, const RunGeom& g, const RunPos& r, int C,
+                                                   Raw<T> (&raw)[3][RUN + 2]) {
 #pragma unroll
   for (int kh = 0; kh < 3; ++kh) {
-    const int ih = h + (kh - 1) * dil;
-    if (iw >= 0 && iw < W && ih >= 0 && ih < H) {
-      ld4(x + (row_base + (long)(kh - 1) * dil * W + iw) * C, col[kh]);
-    } else {
-      col[kh][0] = col[kh][1] = col[kh][2] = col[kh][3] = 0.f;
+    const int ih = r.h + (kh - 1) * g.dil;
+    const bool okh = ih >= 0 && ih < g.H;
+    const T* rowp = xc + (r.row_base + (okh ? (long)(kh - 1) * g.dil * g.W : 0L)) * C;
+#pragma unroll
+    for (int ci = 0; ci < RUN + 2; ++ci) {
+      const int iw = r.w0 + (ci - 1) * g.dil;
+      const bool ok = okh && iw >= 0 && iw < g.W;
+      raw[kh][ci].load(rowp + (long)(ok ? iw : r.w0) * C, ok);
     }
   }
 }
@@ -58,31 +99,36 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(256) void dw_stencil_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, const T* __restrict__ da,
                                                          T* __restrict__ out, RunGeom g, int C, int act, int accumulate) {
+  constexpr int RUN = RunLen<T>::value;
   const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
   const int c = (blockIdx.x * 64 + cx) * 4;
   const long run = (long)blockIdx.y * 4 + py;
-  if (c >= C || run >= g.nruns) return;
+  RunPos r;
+  if (c >= C || run >= g.nruns || !decode_run(g, run, RUN, r)) return;
+  Raw<T> raw[3][RUN + 2], rda[RUN];
+  load_window<T, RUN>(x + c, g, r, C, raw);
+  if (MODE == 1) {
+#pragma unroll
+    for (int i = 0; i < RUN; ++i) {
+      const int wx = r.w0 + i * g.dil;
+      rda[i].load(da + (r.row_base + (wx < g.W ? wx : r.w0)) * C + c, true);
+    }
+  }
   float wr[9][4], bs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < 9; ++t) ld4(w + (MODE == 2 ? 8 - t : t) * C + c, wr[t]);
   if (MODE != 2 && bias) ld4(bias + c, bs);
-  const unsigned ru = (unsigned)run;
-  const int rr = (int)(ru % (unsigned)g.rpr);
-  const unsigned bh = ru / (unsigned)g.rpr;  // b*H + h
-  const int h = (int)(bh % (unsigned)g.H);
-  const int rho = rr / g.rpc, k = rr - rho * g.rpc;
-  const int w0 = rho + k * kRun * g.dil;
-  if (w0 >= g.W) return;
-  const long row_base = (long)bh * g.W;  // pixel index of (b, h, 0)
-  const T* xc = x + c;
-  float win[3][3][4];
-  load_col(xc, row_base, h, w0 - g.dil, g.H, g.W, C, g.dil, win[0]);
-  load_col(xc, row_base, h, w0, g.H, g.W, C, g.dil, win[1]);
+  float win[3][3][4];  // [column slot][kh][channel]
 #pragma unroll
-  for (int i = 0; i < kRun; ++i) {
-    const int wx = w0 + i * g.dil;
-    if (wx >= g.W) break;
-    load_col(xc, row_base, h, wx + g.dil, g.H, g.W, C, g.dil, win[(i + 2) % 3]);
+  for (int kh = 0; kh < 3; ++kh) {
+    raw[kh][0].unpack(win[0][kh]);
+    raw[kh][1].unpack(win[1][kh]);
+  }
+#pragma unroll
+  for (int i = 0; i < RUN; ++i) {
+    const int wx = r.w0 + i * g.dil;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) raw[kh][i + 2].unpack(win[(i + 2) % 3][kh]);
     float acc[4] = {bs[0], bs[1], bs[2], bs[3]};
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw)
@@ -90,39 +136,41 @@ __global__ __launch_bounds__(256) void dw_stencil_kernel(const T* __restrict__ x
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] += win[(i + kw) % 3][kh][j] * wr[kh * 3 + kw][j];
-    const long pix = row_base + wx;
-    T* o = out + pix * C + c;
-    if (MODE == 0) {
-      if (act == 2) {
+    if (wx < g.W) {
+      T* o = out + (r.row_base + wx) * C + c;
+      if (MODE == 0) {
+        if (act == 2) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = gelu_erf(acc[j]);
+          for (int j = 0; j < 4; ++j) acc[j] = gelu_erf(acc[j]);
+        }
+      } else if (MODE == 1) {
+        float gd[4];
+        rda[i].unpack(gd);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = gd[j] * gelu_erf_grad(acc[j]);
+      } else if (accumulate) {
+        float prev[4];
+        ld4(o, prev);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += prev[j];
       }
-    } else if (MODE == 1) {
-      float gd[4];
-      ld4(da + pix * C + c, gd);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = gd[j] * gelu_erf_grad(acc[j]);
-    } else if (accumulate) {
-      float prev[4];
-      ld4(o, prev);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] += prev[j];
+      st4(o, acc);
     }
-    st4(o, acc);
   }
 }
 
 // dw[c,tap] += sum_pix dz[pix,c] * x[pix+tap,c];  dbias[c] += sum_pix dz[pix,c]
-// block = 64 channel-quads x 16 run lanes (1024 threads); every thread walks runs_per_block/16 runs of its quad with
-// the same sliding window (4 loads per pixel).  The 16 run lanes fold into a 4-slot LDS array in four
+// block = 64 channel-quads x 8 run lanes (512 threads); every thread walks runs_per_block/8 runs of its quad with the
+// same prefetched sliding window (4.75 loads per pixel).  The 8 run lanes fold into a 4-slot LDS array in two
 // barrier-separated rounds (no LDS atomics), then ONE fp32 global atomic per (channel, tap) per block -- few, fat
 // blocks keep the same-address atomic traffic low.
 template <typename T>
-__global__ __launch_bounds__(1024) void dw_bwd_weight_kernel(const T* __restrict__ dz, const T* __restrict__ x,
-                                                             float* __restrict__ dw, float* __restrict__ dbias, RunGeom g,
-                                                             int C, int runs_per_block) {
+__global__ __launch_bounds__(512) void dw_bwd_weight_kernel(const T* __restrict__ dz, const T* __restrict__ x,
+                                                            float* __restrict__ dw, float* __restrict__ dbias, RunGeom g,
+                                                            int C, int runs_per_block) {
+  constexpr int RUN = RunLen<T>::value;
   __shared__ float red[4][64][41];
-  const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;  // py = 0..15
+  const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;  // py = 0..7
   const int c = (blockIdx.x * 64 + cx) * 4;
   const long r0 = (long)blockIdx.y * runs_per_block;
   const long r1 = min(g.nruns, r0 + runs_per_block);
@@ -132,26 +180,29 @@ __global__ __launch_bounds__(1024) void dw_bwd_weight_kernel(const T* __restrict
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[t][j] = 0.f;
   if (c < C) {
-    const T* xc = x + c;
-    for (long run = r0 + py; run < r1; run += 16) {
-      const unsigned ru = (unsigned)run;
-      const int rr = (int)(ru % (unsigned)g.rpr);
-      const unsigned bh = ru / (unsigned)g.rpr;
-      const int h = (int)(bh % (unsigned)g.H);
-      const int rho = rr / g.rpc, k = rr - rho * g.rpc;
-      const int w0 = rho + k * kRun * g.dil;
-      if (w0 >= g.W) continue;
-      const long row_base = (long)bh * g.W;
-      float win[3][3][4];
-      load_col(xc, row_base, h, w0 - g.dil, g.H, g.W, C, g.dil, win[0]);
-      load_col(xc, row_base, h, w0, g.H, g.W, C, g.dil, win[1]);
+    for (long run = r0 + py; run < r1; run += 8) {
+      RunPos r;
+      if (!decode_run(g, run, RUN, r)) continue;
+      Raw<T> raw[3][RUN + 2], rdz[RUN];
+      load_window<T, RUN>(x + c, g, r, C, raw);
 #pragma unroll
-      for (int i = 0; i < kRun; ++i) {
-        const int wx = w0 + i * g.dil;
-        if (wx >= g.W) break;
-        load_col(xc, row_base, h, wx + g.dil, g.H, g.W, C, g.dil, win[(i + 2) % 3]);
+      for (int i = 0; i < RUN; ++i) {
+        const int wx = r.w0 + i * g.dil;
+        const bool ok = wx < g.W;
+        rdz[i].load(dz + (r.row_base + (ok ? wx : r.w0)) * C + c, ok);
+      }
+      float win[3][3][4];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        raw[kh][0].unpack(win[0][kh]);
+        raw[kh][1].unpack(win[1][kh]);
+      }
+#pragma unroll
+      for (int i = 0; i < RUN; ++i) {
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) raw[kh][i + 2].unpack(win[(i + 2) % 3][kh]);
         float gd[4];
-        ld4(dz + (row_base + wx) * C + c, gd);
+        rdz[i].unpack(gd);  // zero beyond the row end
 #pragma unroll
         for (int j = 0; j < 4; ++j) accb[j] += gd[j];
 #pragma unroll
@@ -163,7 +214,7 @@ __global__ __launch_bounds__(1024) void dw_bwd_weight_kernel(const T* __restrict
       }
     }
   }
-  for (int round = 0; round < 4; ++round) {
+  for (int round = 0; round < 2; ++round) {
     if ((py >> 2) == round) {
       float* slot = red[py & 3][cx];
 #pragma unroll
@@ -190,6 +241,7 @@ __global__ __launch_bounds__(1024) void dw_bwd_weight_kernel(const T* __restrict
 }
 
 static inline bool too_big(long n) { return n >= (1L << 32); }
+static inline int run_len(int dtype) { return dtype == CMDA_BF16 ? RunLen<bf16_t>::value : RunLen<float>::value; }
 
 template <int MODE>
 static int launch_stencil(const void* x, const float* w, const float* bias, const void* da, void* out, int B, int H, int W,
@@ -197,7 +249,7 @@ static int launch_stencil(const void* x, const float* w, const float* bias, cons
   const long npix = (long)B * H * W;
   if (npix * C <= 0) return CMDA_OK;
   if ((C & 3) || dil < 1) return CMDA_ERR_SHAPE;
-  const RunGeom g = run_geom(B, H, W, dil);
+  const RunGeom g = run_geom(B, H, W, dil, run_len(dtype));
   if (too_big(npix) || too_big(g.nruns)) return CMDA_ERR_SHAPE;
   const int gx = (C / 4 + 63) / 64;
   dim3 grid(gx, (unsigned)((g.nruns + 3) / 4));
@@ -227,13 +279,13 @@ extern "C" int cmda_dwconv3x3_bwd_weight(const void* dz, const void* x, float* d
   const long npix = (long)B * H * W;
   if (npix * C <= 0) return CMDA_OK;
   if ((C & 3) || dil < 1) return CMDA_ERR_SHAPE;
-  const RunGeom g = run_geom(B, H, W, dil);
+  const RunGeom g = run_geom(B, H, W, dil, run_len(dtype));
   if (too_big(npix) || too_big(g.nruns)) return CMDA_ERR_SHAPE;
   const int gx = (C / 4 + 63) / 64;
-  int rpb = 128;  // runs per block (16 run lanes -> 8 runs per thread)
-  while (rpb > 16 && (g.nruns + rpb - 1) / rpb * gx < 512) rpb >>= 1;
+  int rpb = 64;  // runs per block (8 run lanes -> 8 runs per thread)
+  while (rpb > 8 && (g.nruns + rpb - 1) / rpb * gx < 1024) rpb >>= 1;
   dim3 grid(gx, (unsigned)((g.nruns + rpb - 1) / rpb));
-  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((dw_bwd_weight_kernel<T>), grid, dim3(1024), 0, stream, (const T*)dz,
+  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((dw_bwd_weight_kernel<T>), grid, dim3(512), 0, stream, (const T*)dz,
                                          (const T*)x, dw, dbias, g, C, rpb));
   CMDA_CHECK_LAUNCH();
 }

@@ -4,8 +4,9 @@
 // (Block norm1/norm2, eps 1e-6), :175 (OverlapPatchEmbed.norm, eps 1e-5), :76 (Attention.norm,
 // eps 1e-5), :270-318 (per-stage norm, eps 1e-6).
 //
-// HBM-bound: one wave per row, 16-byte (f32) / 8-byte (bf16) lane accesses, wave-shuffle
-// reductions, statistics in fp32.  Algorithmic bytes: fwd 2*rows*C*sizeof(T); bwd 3*rows*C*sizeof(T)
+// HBM-bound: a row is owned by 16, 32 or 64 lanes of a wave (so C = 64 / 128 rows of the first MiT stages still fill
+// every lane: 4 / 2 rows per wave), 16-byte (f32) / 8-byte (bf16) lane accesses, xor-shuffle reductions inside the lane
+// group, statistics in fp32.  Algorithmic bytes: fwd 2*rows*C*sizeof(T); bwd 3*rows*C*sizeof(T)
 // (+ rows*C*sizeof(T) when a residual gradient is fused in).
 #include "common.h"
 
@@ -13,33 +14,49 @@ namespace {
 
 constexpr int kMaxVec = 4;  // 4 * 64 lanes * 4 elems = C up to 1024
 
+// lanes per row: the smallest of 16/32/64 that covers C/4 vectors in one pass (64 otherwise)
+static inline int lanes_per_row(int C) {
+  const int nvec = C >> 2;
+  return nvec <= 16 ? 16 : nvec <= 32 ? 32 : 64;
+}
+static __device__ __forceinline__ float group_sum(float v, int lpr) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    if (o < lpr) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
 template <typename T>
 __global__ void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                               T* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out, long rows,
-                              int C, float eps) {
+                              int C, float eps, int lpr) {
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
   const int wpb = blockDim.x >> 6;
+  const int rpw = 64 / lpr, li = lane & (lpr - 1), grp = lane / lpr;
   const int nvec = C >> 2;
-  for (long row = (long)blockIdx.x * wpb + wid; row < rows; row += (long)gridDim.x * wpb) {
+  // the loop bound is wave-uniform (all lanes take part in the shuffles); a group past the end is only predicated off
+  for (long row0 = ((long)blockIdx.x * wpb + wid) * rpw; row0 < rows; row0 += (long)gridDim.x * wpb * rpw) {
+    const long row = row0 + grp;
+    const bool live = row < rows;
     const T* xr = x + row * C;
     float v[kMaxVec][4];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < kMaxVec; ++i) {
-      const int vi = i * 64 + lane;
-      if (vi < nvec) {
+      const int vi = i * lpr + li;
+      if (live && vi < nvec) {
         ld4(xr + vi * 4, v[i]);
         s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
       } else {
         v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
       }
     }
-    const float mean = wave_sum(s) / (float)C;
+    const float mean = group_sum(s, lpr) / (float)C;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < kMaxVec; ++i) {
-      const int vi = i * 64 + lane;
+      const int vi = i * lpr + li;
       if (vi < nvec) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -48,11 +65,12 @@ __global__ void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__
         }
       }
     }
-    const float var = wave_sum(q) / (float)C;
+    const float var = group_sum(q, lpr) / (float)C;
     const float rstd = rsqrtf(var + eps);
+    if (!live) continue;
 #pragma unroll
     for (int i = 0; i < kMaxVec; ++i) {
-      const int vi = i * 64 + lane;
+      const int vi = i * lpr + li;
       if (vi < nvec) {
         float g[4], b[4], o[4];
         ld4(gamma + vi * 4, g);
@@ -62,7 +80,7 @@ __global__ void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__
         st4(y + row * C + vi * 4, o);
       }
     }
-    if (lane == 0) {
+    if (li == 0) {
       if (mean_out) mean_out[row] = mean;
       if (rstd_out) rstd_out[row] = rstd;
     }
@@ -76,34 +94,43 @@ template <typename T>
 __global__ void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
                               const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                               const T* __restrict__ dres, T* __restrict__ dx, float* __restrict__ ws, long rows,
-                              int C) {
-  __shared__ float red[2][4][1024];  // [gamma/beta][wave][channel]  (32 KiB)
+                              int C, int lpr) {
+  __shared__ float red[2][4096];  // [gamma/beta][slot = wave*rows_per_wave + group][channel]  (32 KiB; slots*C <= 4096)
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
   const int wpb = blockDim.x >> 6;
+  const int rpw = 64 / lpr, li = lane & (lpr - 1), grp = lane / lpr;
   const int nvec = C >> 2;
-  float ag[kMaxVec][4], ab[kMaxVec][4];
+  float ag[kMaxVec][4], ab[kMaxVec][4], gm[kMaxVec][4];
 #pragma unroll
-  for (int i = 0; i < kMaxVec; ++i)
+  for (int i = 0; i < kMaxVec; ++i) {
+    const int vi = i * lpr + li;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ag[i][j] = ab[i][j] = 0.f;
+    for (int j = 0; j < 4; ++j) ag[i][j] = ab[i][j] = gm[i][j] = 0.f;
+    if (vi < nvec) ld4(gamma + vi * 4, gm[i]);
+  }
 
-  for (long row = (long)blockIdx.x * wpb + wid; row < rows; row += (long)gridDim.x * wpb) {
-    const float mean = mean_in[row], rstd = rstd_in[row];
+  for (long row0 = ((long)blockIdx.x * wpb + wid) * rpw; row0 < rows; row0 += (long)gridDim.x * wpb * rpw) {
+    const long row = row0 + grp;
+    const bool live = row < rows;
+    float mean = 0.f, rstd = 0.f;
+    if (live) {
+      mean = mean_in[row];
+      rstd = rstd_in[row];
+    }
     float xh[kMaxVec][4], g[kMaxVec][4];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < kMaxVec; ++i) {
-      const int vi = i * 64 + lane;
-      if (vi < nvec) {
-        float xv[4], dv[4], gm[4];
+      const int vi = i * lpr + li;
+      if (live && vi < nvec) {
+        float xv[4], dv[4];
         ld4(x + row * C + vi * 4, xv);
         ld4(dy + row * C + vi * 4, dv);
-        ld4(gamma + vi * 4, gm);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           xh[i][j] = (xv[j] - mean) * rstd;
-          g[i][j] = dv[j] * gm[j];
+          g[i][j] = dv[j] * gm[i][j];
           s1 += g[i][j];
           s2 += g[i][j] * xh[i][j];
           ag[i][j] += dv[j] * xh[i][j];
@@ -111,11 +138,12 @@ __global__ void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
         }
       }
     }
-    s1 = wave_sum(s1) / (float)C;
-    s2 = wave_sum(s2) / (float)C;
+    s1 = group_sum(s1, lpr) / (float)C;
+    s2 = group_sum(s2, lpr) / (float)C;
+    if (!live) continue;
 #pragma unroll
     for (int i = 0; i < kMaxVec; ++i) {
-      const int vi = i * 64 + lane;
+      const int vi = i * lpr + li;
       if (vi < nvec) {
         float o[4];
 #pragma unroll
@@ -130,24 +158,25 @@ __global__ void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
       }
     }
   }
-  // cross-wave reduce of the parameter gradients, then one atomic per channel per block
+  // cross-group / cross-wave reduce of the parameter gradients, one partial per channel per block
+  const int slot = wid * rpw + grp, nslots = wpb * rpw;
 #pragma unroll
   for (int i = 0; i < kMaxVec; ++i) {
-    const int vi = i * 64 + lane;
+    const int vi = i * lpr + li;
     if (vi < nvec) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        red[0][wid][vi * 4 + j] = ag[i][j];
-        red[1][wid][vi * 4 + j] = ab[i][j];
+        red[0][slot * C + vi * 4 + j] = ag[i][j];
+        red[1][slot * C + vi * 4 + j] = ab[i][j];
       }
     }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float sg = 0.f, sb = 0.f;
-    for (int w = 0; w < wpb; ++w) {
-      sg += red[0][w][c];
-      sb += red[1][w][c];
+    for (int w = 0; w < nslots; ++w) {
+      sg += red[0][w * C + c];
+      sb += red[1][w * C + c];
     }
     ws[((long)blockIdx.x * 2 + 0) * C + c] = sg;
     ws[((long)blockIdx.x * 2 + 1) * C + c] = sb;
@@ -184,29 +213,32 @@ extern "C" int cmda_layernorm_fwd(const void* x, const float* gamma, const float
                                   float* rstd, int64_t rows, int C, float eps, int dtype, void* stream) {
   if (rows <= 0) return CMDA_OK;
   if (C <= 0 || (C & 3) || C > kMaxVec * 256) return CMDA_ERR_SHAPE;
-  const int wpb = 4;
-  const int grid = (int)std::min<long>((rows + wpb - 1) / wpb, 4096);
+  const int wpb = 4, lpr = lanes_per_row(C);
+  const long rpb = wpb * (64 / lpr);
+  const int grid = (int)std::min<long>((rows + rpb - 1) / rpb, 8192);
   CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((ln_fwd_kernel<T>), dim3(grid), dim3(64 * wpb), 0, stream, (const T*)x, gamma,
-                                         beta, (T*)y, mean, rstd, (long)rows, C, eps));
+                                         beta, (T*)y, mean, rstd, (long)rows, C, eps, lpr));
   CMDA_CHECK_LAUNCH();
+}
+
+static inline long ln_bwd_grid(long rows, int C) {
+  const long rpb = 4 * (64 / lanes_per_row(C));
+  return std::max<long>(1, std::min<long>((rows + rpb - 1) / rpb, 2048));
 }
 
 // dgamma / dbeta are ACCUMULATED into (caller zeroes them once per optimizer step).  ws: scratch of
 // cmda_layernorm_bwd_ws_floats(rows, C) floats.
-extern "C" int64_t cmda_layernorm_bwd_ws_floats(int64_t rows, int C) {
-  const long grid = std::max<long>(1, std::min<long>((rows + 3) / 4, 512));
-  return grid * 2 * C;
-}
+extern "C" int64_t cmda_layernorm_bwd_ws_floats(int64_t rows, int C) { return ln_bwd_grid(rows, C) * 2 * C; }
 
 extern "C" int cmda_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                                   const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, float* ws,
                                   int64_t rows, int C, int dtype, void* stream) {
   if (rows <= 0) return CMDA_OK;
   if (C <= 0 || (C & 3) || C > kMaxVec * 256) return CMDA_ERR_SHAPE;
-  const int wpb = 4;
-  const int grid = (int)std::max<long>(1, std::min<long>((rows + wpb - 1) / wpb, 512));
+  const int wpb = 4, lpr = lanes_per_row(C);
+  const int grid = (int)ln_bwd_grid(rows, C);
   CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((ln_bwd_kernel<T>), dim3(grid), dim3(64 * wpb), 0, stream, (const T*)dy,
-                                         (const T*)x, gamma, mean, rstd, (const T*)dres, (T*)dx, ws, (long)rows, C));
+                                         (const T*)x, gamma, mean, rstd, (const T*)dres, (T*)dx, ws, (long)rows, C, lpr));
   CMDA_LAUNCH(ln_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, stream, (const float*)ws, dgamma, dbeta, grid, C);
   CMDA_CHECK_LAUNCH();
 }

@@ -10,7 +10,7 @@ DT = [(torch.float32, 3e-5), (torch.bfloat16, 1.6e-2)]
 
 
 @pytest.mark.parametrize('dt,tol', DT)
-@pytest.mark.parametrize('C', [64, 320, 1024])
+@pytest.mark.parametrize('C', [32, 64, 128, 160, 320, 1024])
 def test_layernorm(tgt, dt, tol, C):
     torch.manual_seed(C)
     rows = 37
