@@ -47,8 +47,8 @@ _emulated = False
 
 def _declare(lib):
     lib.cmda_abi_version.restype = ctypes.c_int
-    for name in dir(lib):
-        pass
+    lib.cmda_layernorm_bwd_ws_floats.restype = ctypes.c_int64
+    lib.cmda_layernorm_bwd_ws_floats.argtypes = [ctypes.c_int64, ctypes.c_int]
     return lib
 
 
@@ -61,7 +61,7 @@ def _load():
             f'{_LIB_PATH} not found: build the gfx950 kernel library first '
             '(python -c "import __graft_entry__ as g; g.build()" or `make hip`). '
             'cmda_amd has no CPU fallback.')
-    _lib = ctypes.CDLL(_LIB_PATH)
+    _lib = _declare(ctypes.CDLL(_LIB_PATH))
     if _lib.cmda_abi_version() != 1:
         raise CmdaError('libcmda_hip.so ABI version mismatch')
     return _lib
@@ -70,7 +70,7 @@ def _load():
 def _bind_for_tests(path):
     """TEST ONLY: route the C ABI to the CPU emulator build of the same kernel sources."""
     global _lib, _emulated
-    _lib = ctypes.CDLL(path)
+    _lib = _declare(ctypes.CDLL(path))
     _emulated = True
     return _lib
 

@@ -104,7 +104,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None):
     C = x.shape[-1]
     rows = x.numel() // C
     dx = torch.empty_like(x)
-    ws = torch.empty(max(1, min((rows + 3) // 4, 512)) * 2 * C, dtype=torch.float32, device=x.device)
+    ws = torch.empty(L.lib().cmda_layernorm_bwd_ws_floats(rows, C), dtype=torch.float32, device=x.device)
     call('cmda_layernorm_bwd', ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dgamma),
          ptr(dbeta), ptr(ws), c_i64(rows), c_i32(C), dtype_tag(x), stream_of(x))
     return dx
