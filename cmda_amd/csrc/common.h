@@ -170,6 +170,19 @@ static inline void glds16(const void* gsrc, void* lds_wave_base) {
 }
 #endif
 
+// Barrier of a multi-stage LDS-DMA pipeline: wait until at most N of this wave's DMA loads are still in flight (the older
+// ones -- the stage about to be read -- have landed), then s_barrier WITHOUT the vmcnt(0) drain __syncthreads() implies,
+// so the younger stages stay in flight across the barrier.
+#ifndef CMDA_EMU
+template <int N>
+static __device__ __forceinline__ void pipe_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+#else
+template <int N>
+static inline void pipe_barrier() { __syncthreads(); }
+#endif
+
 // erf by Abramowitz & Stegun 7.1.26 (|abs error| < 1.5e-7, i.e. fp32 round-off level): ~12 VALU ops instead of the
 // ~40 of libm's erff -- the exact-erf GELU of the reference (nn.GELU, mix_transformer.py:26) stays well inside the parity
 // bound while the MixFFN stencil kernels stop being VALU-bound.

@@ -451,8 +451,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// LDS-DMA variant (bf16): tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR staging, no ds_write), two LDS
-// stages, ONE barrier per k-tile.  Works for every operand mode whose 16-byte chunks are aligned (view.vec_ok):
+// LDS-DMA variant (bf16): tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR staging, no ds_write), 2-4 LDS
+// stages (GldsStages), ONE barrier per k-tile that leaves the younger stages' loads in flight.  Works for every operand mode whose 16-byte chunks are aligned (view.vec_ok):
 //   K-contiguous tile  [rows][64 k]   : 128-byte lines, fragments by ds_read_b128
 //   K-strided   tile   [64 k][cols]   : lines of `cols` bf16, fragments by ds_read_b64_tr_b16
 // LDS lines are unpadded (a wave's DMA writes 1 KiB contiguously); the 16-byte slot of logical chunk c of line r is
@@ -539,18 +539,23 @@ struct DmaSrc {
   }
 };
 
+// LDS stages per tile shape: the small tiles do little MFMA work per k-tile, so what bounds them is the HBM/L2 round
+// trip per stage -- they get a deeper pipeline (more DMA bytes in flight per block) within the same ~64 KiB of LDS.
+template <int TM, int TN> struct GldsStages { static constexpr int value = (TM * TN <= 4) ? 4 : (TM * TN <= 8) ? 3 : 2; };
+
 template <int TM, int TN, bool AKS, bool BKS, bool ACONV, bool BCONV>
 __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmParams p) {
   typedef bf16_t T;
   constexpr int BM = 32 * TM, BN = 32 * TN, BK = 64;
+  constexpr int NS = GldsStages<TM, TN>::value;
   constexpr int SZ_A = BM * BK, SZ_B = BN * BK;                       // elements per stage
   constexpr int PITCH_C = BN + 4;
-  constexpr size_t STAGE_BYTES = (size_t)2 * (SZ_A + SZ_B) * sizeof(T);
+  constexpr size_t STAGE_BYTES = (size_t)NS * (SZ_A + SZ_B) * sizeof(T);
   constexpr size_t EPI_BYTES = (size_t)BM * PITCH_C * sizeof(float);
   constexpr size_t LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
   __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
   T* const sAbase = reinterpret_cast<T*>(smem);
-  T* const sBbase = sAbase + 2 * SZ_A;
+  T* const sBbase = sAbase + NS * SZ_A;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1, g = lane >> 4, l15 = lane & 15;
@@ -596,11 +601,21 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmParams p) {
   // optional fused bias gradient: blocks of the first n-tile also add up their A tile along k (A is dY^T here)
   const bool do_colsum = AKS && p.colsum != nullptr && n0 == 0;
   float bsum = 0.f;
-  if (kt0 < kt1) issue(0, kt0);
+  constexpr int LPT = DmaSrc<AKS, BM, ACONV>::J + DmaSrc<BKS, BN, BCONV>::J;  // DMA instructions per wave per k-tile
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (kt0 + s < kt1) issue(s, kt0 + s);
+  int st = 0;
   for (int kt = kt0; kt < kt1; ++kt) {
-    __syncthreads();  // tile kt has landed (vmcnt(0) in front of the barrier) and the other stage is free again
-    const int st = (kt - kt0) & 1;
-    if (kt + 1 < kt1) issue(st ^ 1, kt + 1);
+    // tile kt has landed: in steady state NS-2 younger tiles may stay in flight; in the tail fewer were issued, so drain.
+    // Past the barrier every wave is done reading stage (st-1), which the next DMA overwrites.
+    if (kt + NS - 2 < kt1) pipe_barrier<(NS - 2) * LPT>();
+    else pipe_barrier<0>();
+    {
+      int sn = st + NS - 1;
+      if (sn >= NS) sn -= NS;
+      if (kt + NS - 1 < kt1) issue(sn, kt + NS - 1);
+    }
     const T* sA = sAbase + st * SZ_A;
     const T* sB = sBbase + st * SZ_B;
     if constexpr (AKS) {
@@ -647,6 +662,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16_16x16x32(fa[i], fb[j], acc[i][j]);
     }
+    if (++st == NS) st = 0;
   }
   __syncthreads();
 

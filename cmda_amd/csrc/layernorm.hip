@@ -223,7 +223,8 @@ extern "C" int cmda_layernorm_fwd(const void* x, const float* gamma, const float
 
 static inline long ln_bwd_grid(long rows, int C) {
   const long rpb = 4 * (64 / lanes_per_row(C));
-  return std::max<long>(1, std::min<long>((rows + rpb - 1) / rpb, 2048));
+  // more partial rows cost the finalize pass 2*C floats each: only the narrow (C <= 128) rows get the wide grid
+  return std::max<long>(1, std::min<long>((rows + rpb - 1) / rpb, C <= 128 ? 2048 : 512));
 }
 
 // dgamma / dbeta are ACCUMULATED into (caller zeroes them once per optimizer step).  ws: scratch of

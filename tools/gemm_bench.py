@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of the GEMM kernel on the shapes the MiT-B5 + DAFormer step actually launches (per-GPU batch 8).
+"""Micro-benchmark of the GEMM kernel on the shapes the MiT-B5 + DAFormer step actually launches (per-GPU batch --batch, default 16).
 Usage (GPU box): python tools/gemm_bench.py [--tile N]   -- prints us / TFLOP/s per shape; used for kernel tuning."""
 import argparse
 import os
@@ -27,6 +27,8 @@ def timeit(fn, iters=30):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--dtype', default='bf16')
+    ap.add_argument('--batch', type=int, default=16)
+    ap.add_argument('--splits', type=int, default=0, help='force the split-K count of the weight-gradient GEMMs')
     args = ap.parse_args()
     dt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     tag = 1 if dt == torch.bfloat16 else 0
@@ -55,21 +57,29 @@ def main():
         dy, dw = r(M, Co), torch.zeros(Co, K, device=dev)
         rows.append((name + ' wgrad', 2.0 * M * Co * K, timeit(lambda: ops.gemm(ops.plain_view(dy, M, Co), ops.conv_view(x, B, H, W, Ci, k, k, 1, k // 2), dw, Co, K, M, a_kstrided=True, b_kstrided=True, dtype=tag, atomic=True, splits=0), 10)))
 
-    nt('s3 fc1   NT 8192x1280x320', 8192, 1280, 320)
-    nt('s3 fc2   NT 8192x320x1280', 8192, 320, 1280)
-    nt('s3 q     NT 8192x320x320', 8192, 320, 320)
-    nn('s3 dfc2  NN 8192x1280x320', 8192, 1280, 320)
-    nn('s3 dfc1  NN 8192x320x1280', 8192, 320, 1280)
-    tn('s3 wfc1  TN 1280x320x8192', 1280, 320, 8192)
-    tn('s3 wq    TN 320x320x8192', 320, 320, 8192)
-    nt('s1 fc1   NT 131072x256x64', 131072, 256, 64)
-    nt('s1 fc2   NT 131072x64x256', 131072, 64, 256)
-    tn('s1 wfc1  TN 256x64x131072', 256, 64, 131072)
-    nt('s2 fc1   NT 32768x512x128', 32768, 512, 128)
-    nt('hd pw    NT 131072x256x1024', 131072, 256, 1024)
-    nn('hd dpw   NN 131072x1024x256', 131072, 1024, 256)
-    tn('hd wpw   TN 256x1024x131072', 256, 1024, 131072)
-    conv('hd bottleneck 3x3 1024->256', 8, 128, 128, 1024, 256, 3)
+    Bt = args.batch
+    T1, T2, T3, T4 = Bt * 16384, Bt * 4096, Bt * 1024, Bt * 256
+    nt(f's3 fc1   NT {T3}x1280x320', T3, 1280, 320)
+    nt(f's3 fc2   NT {T3}x320x1280', T3, 320, 1280)
+    nt(f's3 q     NT {T3}x320x320', T3, 320, 320)
+    nn(f's3 dfc2  NN {T3}x1280x320', T3, 1280, 320)
+    nn(f's3 dfc1  NN {T3}x320x1280', T3, 320, 1280)
+    nn(f's3 dq    NN {T3}x320x320', T3, 320, 320)
+    tn(f's3 wfc1  TN 1280x320x{T3}', 1280, 320, T3)
+    tn(f's3 wfc2  TN 320x1280x{T3}', 320, 1280, T3)
+    tn(f's3 wq    TN 320x320x{T3}', 320, 320, T3)
+    nt(f's1 fc1   NT {T1}x256x64', T1, 256, 64)
+    nt(f's1 fc2   NT {T1}x64x256', T1, 64, 256)
+    tn(f's1 wfc1  TN 256x64x{T1}', 256, 64, T1)
+    nt(f's2 fc1   NT {T2}x512x128', T2, 512, 128)
+    nt(f's2 fc2   NT {T2}x128x512', T2, 128, 512)
+    nt(f's4 fc1   NT {T4}x2048x512', T4, 2048, 512)
+    nt(f's4 fc2   NT {T4}x512x2048', T4, 512, 2048)
+    tn(f's4 wfc1  TN 2048x512x{T4}', 2048, 512, T4)
+    nt(f'hd pw    NT {T1}x256x1024', T1, 256, 1024)
+    nn(f'hd dpw   NN {T1}x1024x256', T1, 1024, 256)
+    tn(f'hd wpw   TN 256x1024x{T1}', 256, 1024, T1)
+    conv('hd bottleneck 3x3 1024->256', Bt, 128, 128, 1024, 256, 3)
     nt('big      NT 8192x8192x8192', 8192, 8192, 8192)
     tot = 0
     for name, fl, us in rows:
