@@ -32,6 +32,13 @@ build/emu/hip_emu.o: tests/emu/hip_emu.cpp tests/emu/hip_emu.h
 tests/emu/libcmda_emu.so: $(EMU_OBJS)
 	$(CLANGXX) -shared -fPIC -pthread -o $@ $(EMU_OBJS)
 
+# tuning build: the same library with the LDS-DMA GEMM's phase stamps compiled in (tools/gemm_phase.py)
+build/hip_timing/gemm.o: $(CSRC)/gemm.hip $(CSRC)/common.h
+	@mkdir -p build/hip_timing
+	$(HIPCC) $(HIPFLAGS) -DCMDA_GEMM_TIMING -c $< -o $@
+timing: build/hip_timing/gemm.o $(HIP_OBJS)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o build/libcmda_hip_timing.so build/hip_timing/gemm.o $(filter-out build/hip/gemm.o,$(HIP_OBJS))
+
 clean:
 	rm -rf build cmda_amd/libcmda_hip.so tests/emu/libcmda_emu.so
-.PHONY: all hip emu clean
+.PHONY: all hip emu timing clean

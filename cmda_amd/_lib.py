@@ -12,7 +12,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, 'libcmda_hip.so')
+# CMDA_HIP_LIB: tuning builds of the SAME library (e.g. `make timing`); never a different backend
+_LIB_PATH = os.environ.get('CMDA_HIP_LIB') or os.path.join(_HERE, 'libcmda_hip.so')
 
 c_i32, c_i64, c_f32, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 

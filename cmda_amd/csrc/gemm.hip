@@ -191,6 +191,92 @@ struct Stager {
   }
 };
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fused epilogue, shared by both kernels: C = act(alpha*acc + bias) * rowscale + res + beta*C, read from the fp32 tile
+// staged in LDS.  A thread keeps ONE column quad for all its rows, so bias / tail / alignment decisions are made once;
+// the row loop is specialised on the activation and has nothing but uniform scalar branches around its loads (the first,
+// generic version of this loop spent ~7 us per 128x128 tile in branchy per-element code -- more than the k-loop of the
+// short-K GEMMs).
+template <int ACT>
+static __device__ __forceinline__ float epi_act(float x) {
+  if (ACT == 1) return fmaxf(x, 0.f);
+  if (ACT == 2) return gelu_erf(x);
+  if (ACT == 3) return tanhf(x);
+  return x;
+}
+
+template <typename T, int ACT, int BM, int BN, int PITCH_C>
+static __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* __restrict__ sC, long m0, long n,
+                                                     int q4, int r0, long cb, long rb_off, bool full, const float (&bv)[4]) {
+  constexpr int QPR = BN / 4, RSTEP = 256 / QPR, NIT = BM / RSTEP;
+  const bool has_res = p.res != nullptr, has_beta = p.beta != 0.f, has_rs = p.rowscale != nullptr, f32o = p.out_f32 != 0;
+  const float alpha = p.alpha, beta = p.beta;
+#pragma unroll 4
+  for (int it = 0; it < NIT; ++it) {
+    const int row = r0 + it * RSTEP;
+    const long m = m0 + row;
+    if (m >= p.M) break;
+    const float4 t = *reinterpret_cast<const float4*>(&sC[row * PITCH_C + q4]);
+    float v[4] = {t.x, t.y, t.z, t.w};
+    const long ci = cb + m * p.ldc + n;
+    const long ri = rb_off + m * p.ldres + n;
+    float rv[4] = {0.f, 0.f, 0.f, 0.f}, ov[4] = {0.f, 0.f, 0.f, 0.f};
+    float rs = 1.f;
+    if (has_rs) rs = p.rowscale[m / p.rows_per_scale];
+    if (full) {
+      if (has_res) ld4(reinterpret_cast<const T*>(p.res) + ri, rv);
+      if (has_beta) {
+        if (f32o) ld4(reinterpret_cast<const float*>(p.C) + ci, ov);
+        else ld4(reinterpret_cast<const T*>(p.C) + ci, ov);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (n + e >= p.N) continue;
+        if (has_res) rv[e] = ldf(reinterpret_cast<const T*>(p.res) + ri + e);
+        if (has_beta) ov[e] = f32o ? reinterpret_cast<const float*>(p.C)[ci + e] : ldf(reinterpret_cast<const T*>(p.C) + ci + e);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = epi_act<ACT>(alpha * v[e] + bv[e]) * rs + rv[e] + beta * ov[e];
+    if (full) {
+      if (f32o) st4(reinterpret_cast<float*>(p.C) + ci, v);
+      else st4(reinterpret_cast<T*>(p.C) + ci, v);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (n + e >= p.N) continue;
+        if (f32o) reinterpret_cast<float*>(p.C)[ci + e] = v[e];
+        else stf(reinterpret_cast<T*>(p.C) + ci + e, v[e]);
+      }
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int PITCH_C>
+static __device__ __forceinline__ void epilogue_store(const GemmParams& p, const float* __restrict__ sC, long m0, long n0,
+                                                      long cb, long rb_off, int tid) {
+  constexpr int QPR = BN / 4;  // quads per tile row
+  static_assert(256 % QPR == 0 && BM % (256 / QPR) == 0, "tile shape");
+  const int q4 = (tid % QPR) * 4, r0 = tid / QPR;
+  const long n = n0 + q4;
+  if (n >= p.N) return;
+  const bool full = p.c_vec_ok != 0 && n + 4 <= p.N;
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) {
+    if (full) ld4(p.bias + n, bv);
+    else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n + e < p.N) bv[e] = p.bias[n + e];
+    }
+  }
+  if (p.act == 0) epilogue_rows<T, 0, BM, BN, PITCH_C>(p, sC, m0, n, q4, r0, cb, rb_off, full, bv);
+  else if (p.act == 1) epilogue_rows<T, 1, BM, BN, PITCH_C>(p, sC, m0, n, q4, r0, cb, rb_off, full, bv);
+  else if (p.act == 2) epilogue_rows<T, 2, BM, BN, PITCH_C>(p, sC, m0, n, q4, r0, cb, rb_off, full, bv);
+  else epilogue_rows<T, 3, BM, BN, PITCH_C>(p, sC, m0, n, q4, r0, cb, rb_off, full, bv);
+}
+
 template <typename T, int TM, int TN, bool AKS, bool BKS>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   constexpr int CH = Num<T>::kChunk;
@@ -398,56 +484,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
       for (int r = 0; r < 4; ++r)
         sC[(wm * 16 * TM + i * 16 + 4 * g + r) * PITCH_C + wn * 16 * TN + j * 16 + l15] = acc[i][j][r];
   __syncthreads();
-  const bool vec = p.c_vec_ok != 0;
-  constexpr int QPR = BN / 4;  // quads per tile row
-  for (int id = tid; id < BM * QPR; id += 256) {
-    const int row = id / QPR, q4 = (id - row * QPR) * 4;
-    const long m = m0 + row, n = n0 + q4;
-    if (m >= p.M || n >= p.N) continue;
-    const float4 t = *reinterpret_cast<const float4*>(&sC[row * PITCH_C + q4]);
-    float v[4] = {t.x, t.y, t.z, t.w};
-    const float rs = p.rowscale ? p.rowscale[m / p.rows_per_scale] : 1.f;
-    const long ci = cb + m * p.ldc + n;
-    const long ri = rb_off + m * p.ldres + n;
-    const bool full = vec && n + 4 <= p.N;
-    float bv[4] = {0.f, 0.f, 0.f, 0.f}, rv[4] = {0.f, 0.f, 0.f, 0.f}, ov[4] = {0.f, 0.f, 0.f, 0.f};
-    if (full) {
-      if (p.bias) ld4(p.bias + n, bv);
-      if (p.res) ld4(reinterpret_cast<const T*>(p.res) + ri, rv);
-      if (p.beta != 0.f) {
-        if (p.out_f32) ld4(reinterpret_cast<const float*>(p.C) + ci, ov);
-        else ld4(reinterpret_cast<const T*>(p.C) + ci, ov);
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (n + e >= p.N) continue;
-        if (p.bias) bv[e] = p.bias[n + e];
-        if (p.res) rv[e] = ldf(reinterpret_cast<const T*>(p.res) + ri + e);
-        if (p.beta != 0.f) ov[e] = p.out_f32 ? reinterpret_cast<const float*>(p.C)[ci + e] : ldf(reinterpret_cast<const T*>(p.C) + ci + e);
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float x = p.alpha * v[e] + bv[e];
-      if (p.act == 1) x = fmaxf(x, 0.f);
-      else if (p.act == 2) x = gelu_erf(x);
-      else if (p.act == 3) x = tanhf(x);
-      x = x * rs + rv[e] + p.beta * ov[e];
-      v[e] = x;
-    }
-    if (full) {
-      if (p.out_f32) st4(reinterpret_cast<float*>(p.C) + ci, v);
-      else st4(reinterpret_cast<T*>(p.C) + ci, v);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (n + e >= p.N) continue;
-        if (p.out_f32) reinterpret_cast<float*>(p.C)[ci + e] = v[e];
-        else stf(reinterpret_cast<T*>(p.C) + ci + e, v[e]);
-      }
-    }
-  }
+  epilogue_store<T, BM, BN, PITCH_C>(p, sC, m0, n0, cb, rb_off, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -460,6 +497,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 // as zero (conv padding, rows/columns past the matrix, the K tail) is fetched from a 16-byte zero block, so no lane
 // ever needs a predicated LDS write.
 __device__ __attribute__((aligned(16))) unsigned g_zero16[4] = {0u, 0u, 0u, 0u};
+
+// -DCMDA_GEMM_TIMING (tuning builds only): thread 0 of the first 256 blocks stamps the 100 MHz wall clock at the phases
+// of the LDS-DMA kernel; tools/gemm_phase.py reads the stamps back through cmda_debug_gemm_stamps().
+#ifdef CMDA_GEMM_TIMING
+__device__ unsigned long long g_stamps[256 * 8];
+#define CMDA_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 256 && blockIdx.z == 0) g_stamps[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define CMDA_STAMP(i) do { } while (0)
+#endif
 
 template <bool KS, int TILE, bool CONV>
 struct DmaSrc {
@@ -579,6 +625,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmParams p) {
   const T* baseA = reinterpret_cast<const T*>(p.A.ptr) + (long)batch * p.A.batch_stride + (long)batch2 * p.A.batch2_stride;
   const T* baseB = reinterpret_cast<const T*>(p.B.ptr) + (long)batch * p.B.batch_stride + (long)batch2 * p.B.batch2_stride;
 
+  CMDA_STAMP(0);
   DmaSrc<AKS, BM, ACONV> dA;
   DmaSrc<BKS, BN, BCONV> dB;
   dA.init(p.A, baseA, wid, lane, m0);
@@ -605,12 +652,14 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmParams p) {
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s)
     if (kt0 + s < kt1) issue(s, kt0 + s);
+  CMDA_STAMP(1);
   int st = 0;
   for (int kt = kt0; kt < kt1; ++kt) {
     // tile kt has landed: in steady state NS-2 younger tiles may stay in flight; in the tail fewer were issued, so drain.
     // Past the barrier every wave is done reading stage (st-1), which the next DMA overwrites.
     if (kt + NS - 2 < kt1) pipe_barrier<(NS - 2) * LPT>();
     else pipe_barrier<0>();
+    if (kt == kt0) CMDA_STAMP(2);
     {
       int sn = st + NS - 1;
       if (sn >= NS) sn -= NS;
@@ -664,6 +713,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmParams p) {
     }
     if (++st == NS) st = 0;
   }
+  CMDA_STAMP(3);
   __syncthreads();
 
   if (kt0 >= kt1 && p.splits > 1) return;
@@ -695,55 +745,9 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmParams p) {
       for (int r = 0; r < 4; ++r)
         sC[(wm * 16 * TM + i * 16 + 4 * g + r) * PITCH_C + wn * 16 * TN + j * 16 + l15] = acc[i][j][r];
   __syncthreads();
-  const bool vec = p.c_vec_ok != 0;
-  constexpr int QPR = BN / 4;
-  for (int id = tid; id < BM * QPR; id += 256) {
-    const int row = id / QPR, q4 = (id - row * QPR) * 4;
-    const long m = m0 + row, n = n0 + q4;
-    if (m >= p.M || n >= p.N) continue;
-    const float4 t = *reinterpret_cast<const float4*>(&sC[row * PITCH_C + q4]);
-    float v[4] = {t.x, t.y, t.z, t.w};
-    const float rs = p.rowscale ? p.rowscale[m / p.rows_per_scale] : 1.f;
-    const long ci = cb + m * p.ldc + n;
-    const long ri = rb_off + m * p.ldres + n;
-    const bool full = vec && n + 4 <= p.N;
-    float bv[4] = {0.f, 0.f, 0.f, 0.f}, rv[4] = {0.f, 0.f, 0.f, 0.f}, ov[4] = {0.f, 0.f, 0.f, 0.f};
-    if (full) {
-      if (p.bias) ld4(p.bias + n, bv);
-      if (p.res) ld4(reinterpret_cast<const T*>(p.res) + ri, rv);
-      if (p.beta != 0.f) {
-        if (p.out_f32) ld4(reinterpret_cast<const float*>(p.C) + ci, ov);
-        else ld4(reinterpret_cast<const T*>(p.C) + ci, ov);
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (n + e >= p.N) continue;
-        if (p.bias) bv[e] = p.bias[n + e];
-        if (p.res) rv[e] = ldf(reinterpret_cast<const T*>(p.res) + ri + e);
-        if (p.beta != 0.f) ov[e] = p.out_f32 ? reinterpret_cast<const float*>(p.C)[ci + e] : ldf(reinterpret_cast<const T*>(p.C) + ci + e);
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float x = p.alpha * v[e] + bv[e];
-      if (p.act == 1) x = fmaxf(x, 0.f);
-      else if (p.act == 2) x = gelu_erf(x);
-      else if (p.act == 3) x = tanhf(x);
-      v[e] = x * rs + rv[e] + p.beta * ov[e];
-    }
-    if (full) {
-      if (p.out_f32) st4(reinterpret_cast<float*>(p.C) + ci, v);
-      else st4(reinterpret_cast<T*>(p.C) + ci, v);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (n + e >= p.N) continue;
-        if (p.out_f32) reinterpret_cast<float*>(p.C)[ci + e] = v[e];
-        else stf(reinterpret_cast<T*>(p.C) + ci + e, v[e]);
-      }
-    }
-  }
+  CMDA_STAMP(4);
+  epilogue_store<T, BM, BN, PITCH_C>(p, sC, m0, n0, cb, rb_off, tid);
+  CMDA_STAMP(5);
 }
 
 template <int TM, int TN>
@@ -849,3 +853,9 @@ extern "C" int cmda_gemm(const cmda_gemm_params_t* pp, void* stream) {
   if (p.dtype == CMDA_BF16) return launch_dtype<bf16_t>(p, stream);
   return CMDA_ERR_DTYPE;
 }
+
+#ifdef CMDA_GEMM_TIMING
+extern "C" int cmda_debug_gemm_stamps(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 256 * 8) == hipSuccess ? 0 : -3;
+}
+#endif
