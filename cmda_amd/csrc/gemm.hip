@@ -585,9 +585,10 @@ struct DmaSrc {
   }
 };
 
-// LDS stages per tile shape: the small tiles do little MFMA work per k-tile, so what bounds them is the HBM/L2 round
-// trip per stage -- they get a deeper pipeline (more DMA bytes in flight per block) within the same ~64 KiB of LDS.
-template <int TM, int TN> struct GldsStages { static constexpr int value = (TM * TN <= 4) ? 4 : (TM * TN <= 8) ? 3 : 2; };
+// LDS stages per tile shape.  Measured (profiles/README.md, round 1 k): 4 stages on the 64x64 tile cut the k-loop of a
+// lone block from ~5 to 1.6 us, but 64 KiB of LDS halves the blocks per CU and the whole step got slower (the loop is
+// bound by the per-CU L2->LDS rate, ~65 GB/s, which wants MORE resident blocks, not deeper ones) -- so every tile keeps 2.
+template <int TM, int TN> struct GldsStages { static constexpr int value = 2; };
 
 template <int TM, int TN, bool AKS, bool BKS, bool ACONV, bool BCONV>
 __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmParams p) {
@@ -794,8 +795,12 @@ int launch_dtype(GemmParams& p, void* stream) {
     // fits the output, then split K until the grid fills the chip
     // Every split adds one fp32 atomic per output element (chip-wide ~1.3 TB/s), so splits stay small and the tile
     // only grows to 128x128 when the output alone already has enough tiles.
-    tile = (p.M > 64 && p.N > 64 && blocks(128, 128) >= 64) ? 0 : 2;
-    const long b = tile == 0 ? blocks(128, 128) : blocks(64, 64);
+    tile = 2;
+    if (p.M > 64 && p.N > 64) {
+      if (blocks(128, 128) >= 64) tile = 0;
+      else if (blocks(128, 64) >= 48) tile = 1;  // e.g. the 320x1280 MixFFN weight gradients (57 vs 72 us on 64x64 tiles)
+    }
+    const long b = tile == 0 ? blocks(128, 128) : tile == 1 ? blocks(128, 64) : blocks(64, 64);
     long s = (512 + b - 1) / b;
     s = std::min<long>(s, std::max(1, nkt / 8));
     const long out_bytes = (long)p.M * p.N * 4 * zb;
@@ -806,7 +811,8 @@ int launch_dtype(GemmParams& p, void* stream) {
   } else {
     if (p.splits <= 0) p.splits = 1;
     const long sp = p.splits;
-    if (p.N > 64 && blocks(128, 128) * sp >= 1024) tile = 0;
+    // measured with the lean epilogue (profiles/README.md, forced-tile sweep): the 128x128 tile wins from ~1 block per CU up
+    if (p.N > 64 && blocks(128, 128) * sp >= 256) tile = 0;
     else if (blocks(128, 64) * sp >= 2048) tile = 1;
     else tile = 2;
   }
