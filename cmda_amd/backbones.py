@@ -74,6 +74,11 @@ class Block(nn.Module):
     def _dp(self, B, device):
         if not self.training or self.drop_path_rate == 0. or not getattr(self, 'stochastic', True):
             return None
+        pool = getattr(self, '_dp_pool', None)
+        if pool is not None and pool[0].shape[1] == B:  # rows drawn once per backbone pass (3 launches instead of 4 per call)
+            masks, idx = pool
+            pool[1] = idx + 1
+            return masks[idx]
         keep = 1.0 - self.drop_path_rate
         return (keep + torch.rand(B, device=device)).floor_().div_(keep)
 
@@ -192,18 +197,37 @@ class MixVisionTransformer(nn.Module):
             cur += self.depths[s]
 
     # -- hand-scheduled passes ------------------------------------------------------------------------------
+    def _draw_drop_path(self, B, device):
+        """Stochastic depth (mix_transformer.py:147-152, DropPath per residual branch): all of a pass's per-sample keep
+        masks come from ONE torch.rand call; block i takes rows 2i (attention branch) and 2i+1 (MLP branch)."""
+        blocks = [blk for s in range(1, 5) for blk in getattr(self, f'block{s}')]
+        live = [blk for blk in blocks if blk.training and blk.drop_path_rate > 0. and getattr(blk, 'stochastic', True)]
+        if not live:
+            return
+        rates = tuple(blk.drop_path_rate for blk in live)
+        cached = getattr(self, '_dp_keep', None)
+        if cached is None or cached[0] != (rates, str(device)):
+            keep = torch.tensor([1.0 - r for r in rates for _ in range(2)], dtype=torch.float32).to(device).unsqueeze(1)
+            self._dp_keep = cached = ((rates, str(device)), keep)
+        keep = cached[1]
+        masks = (keep + torch.rand(2 * len(live), B, device=device)).floor_().div_(keep)
+        for i, blk in enumerate(live):
+            blk._dp_pool = [masks, 2 * i]
+
     def fwd(self, img, save=True):
         """img: NCHW fp32 [B,3,H,W] (the reference's input layout).  Returns ([(feat [B*N,C], H, W)] * 4, saved)."""
         B, Cin, H, W = img.shape
         x = torch.empty(B * H * W, Cin, dtype=rt.compute_dtype(), device=img.device)
         ops.permute4(img.contiguous(), x, (B, Cin, H, W), (0, 2, 3, 1))
         feats, saved = [], []
+        self._draw_drop_path(B, img.device)
         for s in range(1, 5):
             pe = getattr(self, f'patch_embed{s}')
             x, H, W, sv_pe = pe.fwd(x, B, H, W)
             sv_blocks = []
             for blk in getattr(self, f'block{s}'):
                 x, sv = blk.fwd(x, B, H, W, save=save)
+                blk._dp_pool = None
                 sv_blocks.append(sv)
             nrm = getattr(self, f'norm{s}')
             xin = x

@@ -14,6 +14,10 @@
 
 namespace {
 
+// All four streaming kernels share one shape: block = 64 channel-quads x 4 row lanes, a thread keeps its quad's
+// per-channel constants in registers and walks its rows four at a time (four independent 8/16-byte loads in flight).
+constexpr int kRowUnroll = 4;
+
 template <typename T>
 __global__ void bn_reduce_kernel(const T* __restrict__ x, float* __restrict__ ws, long M, int C, int rows_per_block) {
   __shared__ float red[2][4][64][4];
@@ -24,14 +28,22 @@ __global__ void bn_reduce_kernel(const T* __restrict__ x, float* __restrict__ ws
   if (c < C) {
     float sh[4];
     ld4(x + c, sh);  // shift = row 0
-    for (long r = r0 + ry; r < r1; r += 4) {
-      float v[4];
-      ld4(x + r * C + c, v);
+    for (long r = r0 + ry; r < r1; r += 4 * kRowUnroll) {
+      float v[kRowUnroll][4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float d = v[j] - sh[j];
-        s[j] += d;
-        q[j] += d * d;
+      for (int u = 0; u < kRowUnroll; ++u) {
+        const long ru = r + 4 * u;
+        ld4(x + (ru < r1 ? ru : r) * C + c, v[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < kRowUnroll; ++u) {
+        if (r + 4 * u >= r1) break;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float d = v[u][j] - sh[j];
+          s[j] += d;
+          q[j] += d * d;
+        }
       }
     }
   }
@@ -74,24 +86,34 @@ __global__ void bn_finalize_kernel(const T* __restrict__ x, const float* __restr
 template <typename T>
 __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
                                 const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y,
-                                long M, int C, int relu, int ldy, int coff) {
-  const int cg = C >> 2;
-  const long total = M * cg;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % cg) * 4;
-    const long r = i / cg;
-    float v[4], mu[4], rs[4], g[4], b[4];
-    ld4(x + r * C + c, v);
-    ld4(mean + c, mu);
-    ld4(rstd + c, rs);
-    ld4(gamma + c, g);
-    ld4(beta + c, b);
+                                long M, int C, int relu, int ldy, int coff, int rows_per_block) {
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + cx) * 4;
+  if (c >= C) return;
+  const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float mu[4], rs[4], g[4], b[4];
+  ld4(mean + c, mu);
+  ld4(rstd + c, rs);
+  ld4(gamma + c, g);
+  ld4(beta + c, b);
+  for (long r = r0 + ry; r < r1; r += 4 * kRowUnroll) {
+    float v[kRowUnroll][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      v[j] = (v[j] - mu[j]) * rs[j] * g[j] + b[j];
-      if (relu) v[j] = fmaxf(v[j], 0.f);
+    for (int u = 0; u < kRowUnroll; ++u) {
+      const long ru = r + 4 * u;
+      ld4(x + (ru < r1 ? ru : r) * C + c, v[u]);
     }
-    st4(y + r * ldy + coff + c, v);
+#pragma unroll
+    for (int u = 0; u < kRowUnroll; ++u) {
+      const long ru = r + 4 * u;
+      if (ru >= r1) break;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[u][j] = (v[u][j] - mu[j]) * rs[j] * g[j] + b[j];
+        if (relu) v[u][j] = fmaxf(v[u][j], 0.f);
+      }
+      st4(y + ru * ldy + coff + c, v[u]);
+    }
   }
 }
 
@@ -112,16 +134,25 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restri
     ld4(rstd + c, rs);
     ld4(gamma + c, g);
     ld4(beta + c, b);
-    for (long r = r0 + ry; r < r1; r += 4) {
-      float v[4], d[4];
-      ld4(x + r * C + c, v);
-      ld4(dy + r * lddy + coff + c, d);
+    for (long r = r0 + ry; r < r1; r += 4 * kRowUnroll) {
+      float v[kRowUnroll][4], d[kRowUnroll][4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float xh = (v[j] - mu[j]) * rs[j];
-        if (relu && xh * g[j] + b[j] <= 0.f) d[j] = 0.f;
-        s1[j] += d[j];
-        s2[j] += d[j] * xh;
+      for (int u = 0; u < kRowUnroll; ++u) {
+        const long ru = r + 4 * u < r1 ? r + 4 * u : r;
+        ld4(x + ru * C + c, v[u]);
+        ld4(dy + ru * lddy + coff + c, d[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < kRowUnroll; ++u) {
+        if (r + 4 * u >= r1) break;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xh = (v[u][j] - mu[j]) * rs[j];
+          float dj = d[u][j];
+          if (relu && xh * g[j] + b[j] <= 0.f) dj = 0.f;
+          s1[j] += dj;
+          s2[j] += dj * xh;
+        }
       }
     }
   }
@@ -140,48 +171,70 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restri
   }
 }
 
-// dx = gamma*rstd*(dyr - s1/M - xhat*s2/M); block 0 also folds s1/s2 into dbeta/dgamma
+// dx = gamma*rstd * (dyr - mean(dyr) - xhat * mean(dyr*xhat)); also accumulates dgamma / dbeta from ws
 template <typename T>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ mean,
                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
                                     const float* __restrict__ beta, const float* __restrict__ ws, T* __restrict__ dx,
                                     float* __restrict__ dgamma, float* __restrict__ dbeta, long M, int C, int relu,
-                                    int lddy, int coff) {
-  const int cg = C >> 2;
-  const long total = M * cg;
+                                    int lddy, int coff, int rows_per_block) {
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + cx) * 4;
+  if (c >= C) return;
+  const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
   const float invM = 1.f / (float)M;
-  if (blockIdx.x == 0) {
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-      dbeta[c] += ws[c];
-      dgamma[c] += ws[C + c];
-    }
-  }
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % cg) * 4;
-    const long r = i / cg;
-    float v[4], d[4], mu[4], rs[4], g[4], b[4], a1[4], a2[4];
-    ld4(x + r * C + c, v);
-    ld4(dy + r * lddy + coff + c, d);
-    ld4(mean + c, mu);
-    ld4(rstd + c, rs);
-    ld4(gamma + c, g);
-    ld4(beta + c, b);
-    ld4(ws + c, a1);
-    ld4(ws + C + c, a2);
+  float mu[4], rs[4], g[4], b[4], a1[4], a2[4];
+  ld4(mean + c, mu);
+  ld4(rstd + c, rs);
+  ld4(gamma + c, g);
+  ld4(beta + c, b);
+  ld4(ws + c, a1);
+  ld4(ws + C + c, a2);
+  if (blockIdx.y == 0 && ry == 0) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float xh = (v[j] - mu[j]) * rs[j];
-      if (relu && xh * g[j] + b[j] <= 0.f) d[j] = 0.f;
-      v[j] = g[j] * rs[j] * (d[j] - a1[j] * invM - xh * a2[j] * invM);
+      dbeta[c + j] += a1[j];
+      dgamma[c + j] += a2[j];
     }
-    st4(dx + r * C + c, v);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    a1[j] *= invM;
+    a2[j] *= invM;
+  }
+  for (long r = r0 + ry; r < r1; r += 4 * kRowUnroll) {
+    float v[kRowUnroll][4], d[kRowUnroll][4];
+#pragma unroll
+    for (int u = 0; u < kRowUnroll; ++u) {
+      const long ru = r + 4 * u < r1 ? r + 4 * u : r;
+      ld4(x + ru * C + c, v[u]);
+      ld4(dy + ru * lddy + coff + c, d[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < kRowUnroll; ++u) {
+      const long ru = r + 4 * u;
+      if (ru >= r1) break;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float xh = (v[u][j] - mu[j]) * rs[j];
+        float dj = d[u][j];
+        if (relu && xh * g[j] + b[j] <= 0.f) dj = 0.f;
+        v[u][j] = g[j] * rs[j] * (dj - a1[j] - xh * a2[j]);
+      }
+      st4(dx + ru * C + c, v[u]);
+    }
   }
 }
 
-static inline int grid_for(long n) { return (int)std::max<long>(1, std::min<long>((n + 255) / 256, 8192)); }
+// reductions: few fat blocks (one fp32 atomic per channel per block); streaming applies: >= ~8 blocks per CU
 static inline int rows_per_block(long M, int gx) {
   int rpb = 512;
-  while (rpb > 32 && (M + rpb - 1) / rpb * gx < 512) rpb >>= 1;
+  while (rpb > 32 && (M + rpb - 1) / rpb * gx < 1024) rpb >>= 1;
+  return rpb;
+}
+static inline int rows_per_block_apply(long M, int gx) {
+  int rpb = 256;
+  while (rpb > 16 && (M + rpb - 1) / rpb * gx < 2048) rpb >>= 1;
   return rpb;
 }
 }  // namespace
@@ -196,12 +249,14 @@ extern "C" int cmda_bn_train_fwd(const void* x, const float* gamma, const float*
   const int gx = (C / 4 + 63) / 64;
   const int rpb = rows_per_block(M, gx);
   dim3 rgrid(gx, (unsigned)((M + rpb - 1) / rpb));
+  const int arpb = rows_per_block_apply(M, gx);
+  dim3 agrid(gx, (unsigned)((M + arpb - 1) / arpb));
   CMDA_DISPATCH_DTYPE(dtype, {
     CMDA_LAUNCH((bn_reduce_kernel<T>), rgrid, dim3(256), 0, stream, (const T*)x, ws, (long)M, C, rpb);
     CMDA_LAUNCH((bn_finalize_kernel<T>), dim3((C + 255) / 256), dim3(256), 0, stream, (const T*)x, ws, mean, rstd,
                 running_mean, running_var, (long)M, C, eps, momentum);
-    CMDA_LAUNCH((bn_apply_kernel<T>), dim3(grid_for(M * (C / 4))), dim3(256), 0, stream, (const T*)x, mean, rstd, gamma,
-                beta, (T*)y, (long)M, C, relu, ldy, coff);
+    CMDA_LAUNCH((bn_apply_kernel<T>), agrid, dim3(256), 0, stream, (const T*)x, mean, rstd, gamma, beta, (T*)y, (long)M, C,
+                relu, ldy, coff, arpb);
   });
   CMDA_CHECK_LAUNCH();
 }
@@ -211,8 +266,11 @@ extern "C" int cmda_bn_apply(const void* x, const float* mean, const float* rstd
                              void* y, int64_t M, int C, int relu, int ldy, int coff, int dtype, void* stream) {
   if (M <= 0 || C <= 0) return CMDA_OK;
   if ((C & 3) || (ldy & 3) || (coff & 3)) return CMDA_ERR_SHAPE;
-  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((bn_apply_kernel<T>), dim3(grid_for(M * (C / 4))), dim3(256), 0, stream,
-                                         (const T*)x, mean, rstd, gamma, beta, (T*)y, (long)M, C, relu, ldy, coff));
+  const int gx = (C / 4 + 63) / 64;
+  const int arpb = rows_per_block_apply(M, gx);
+  dim3 agrid(gx, (unsigned)((M + arpb - 1) / arpb));
+  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((bn_apply_kernel<T>), agrid, dim3(256), 0, stream, (const T*)x, mean, rstd, gamma,
+                                         beta, (T*)y, (long)M, C, relu, ldy, coff, arpb));
   CMDA_CHECK_LAUNCH();
 }
 
@@ -226,11 +284,13 @@ extern "C" int cmda_bn_train_bwd(const void* dy, const void* x, const float* mea
   const int gx = (C / 4 + 63) / 64;
   const int rpb = rows_per_block(M, gx);
   dim3 rgrid(gx, (unsigned)((M + rpb - 1) / rpb));
+  const int arpb = rows_per_block_apply(M, gx);
+  dim3 agrid(gx, (unsigned)((M + arpb - 1) / arpb));
   CMDA_DISPATCH_DTYPE(dtype, {
     CMDA_LAUNCH((bn_bwd_reduce_kernel<T>), rgrid, dim3(256), 0, stream, (const T*)dy, (const T*)x, mean, rstd, gamma,
                 beta, ws, (long)M, C, relu, lddy, coff, rpb);
-    CMDA_LAUNCH((bn_bwd_apply_kernel<T>), dim3(grid_for(M * (C / 4))), dim3(256), 0, stream, (const T*)dy, (const T*)x,
-                mean, rstd, gamma, beta, ws, (T*)dx, dgamma, dbeta, (long)M, C, relu, lddy, coff);
+    CMDA_LAUNCH((bn_bwd_apply_kernel<T>), agrid, dim3(256), 0, stream, (const T*)dy, (const T*)x, mean, rstd, gamma, beta,
+                ws, (T*)dx, dgamma, dbeta, (long)M, C, relu, lddy, coff, arpb);
   });
   CMDA_CHECK_LAUNCH();
 }

@@ -13,6 +13,7 @@
 namespace {
 
 constexpr int kMaxVec = 4;  // 4 * 64 lanes * 4 elems = C up to 1024
+constexpr int kSlots = 64;  // partial-sum rows of the backward workspace
 
 // lanes per row: the smallest of 16/32/64 that covers C/4 vectors in one pass (64 otherwise)
 static inline int lanes_per_row(int C) {
@@ -88,8 +89,10 @@ __global__ void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__
 }
 
 // dx = [dres +] rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
-// per-block partial sums of dy*xhat / dy go to ws[block][2][C]; ln_bwd_finalize adds them into dgamma / dbeta
-// (no atomics: hundreds of blocks hammering the same 2*C addresses was the bottleneck of the first version)
+// per-block partial sums of dy*xhat / dy are added (fp32 atomics) into ws[block % 64][2][C]; ln_bwd_finalize folds the 64
+// slots into dgamma / dbeta.  (All blocks hammering the same 2*C addresses was the bottleneck of the first version, one
+// workspace row per block made the finalize pass as expensive as the main kernel -- 64 slots keeps both cheap: <= 32
+// adds per address, and the grid can be as wide as the rows want.)
 template <typename T>
 __global__ void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
                               const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
@@ -178,13 +181,13 @@ __global__ void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
       sg += red[0][w * C + c];
       sb += red[1][w * C + c];
     }
-    ws[((long)blockIdx.x * 2 + 0) * C + c] = sg;
-    ws[((long)blockIdx.x * 2 + 1) * C + c] = sb;
+    atomicAdd(&ws[((long)(blockIdx.x % kSlots) * 2 + 0) * C + c], sg);
+    atomicAdd(&ws[((long)(blockIdx.x % kSlots) * 2 + 1) * C + c], sb);
   }
 }
 
 // block = 8 channels x 32 partial-sum lanes: every lane adds nblocks/32 partials, LDS tree over the 32 lanes
-__global__ void ln_bwd_finalize_kernel(const float* __restrict__ ws, float* __restrict__ dgamma, float* __restrict__ dbeta,
+__global__ void ln_bwd_finalize_kernel(float* __restrict__ ws, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                        int nblocks, int C) {
   __shared__ float red[2][32][8];
   const int cx = threadIdx.x & 7, part = threadIdx.x >> 3;
@@ -194,6 +197,8 @@ __global__ void ln_bwd_finalize_kernel(const float* __restrict__ ws, float* __re
     for (int b = part; b < nblocks; b += 32) {
       sg += ws[((long)b * 2 + 0) * C + c];
       sb += ws[((long)b * 2 + 1) * C + c];
+      ws[((long)b * 2 + 0) * C + c] = 0.f;  // leave the workspace zeroed for the next call
+      ws[((long)b * 2 + 1) * C + c] = 0.f;
     }
   red[0][part][cx] = sg;
   red[1][part][cx] = sb;
@@ -223,13 +228,13 @@ extern "C" int cmda_layernorm_fwd(const void* x, const float* gamma, const float
 
 static inline long ln_bwd_grid(long rows, int C) {
   const long rpb = 4 * (64 / lanes_per_row(C));
-  // more partial rows cost the finalize pass 2*C floats each: only the narrow (C <= 128) rows get the wide grid
-  return std::max<long>(1, std::min<long>((rows + rpb - 1) / rpb, C <= 128 ? 2048 : 512));
+  return std::max<long>(1, std::min<long>((rows + rpb - 1) / rpb, 2048));
 }
 
 // dgamma / dbeta are ACCUMULATED into (caller zeroes them once per optimizer step).  ws: scratch of
-// cmda_layernorm_bwd_ws_floats(rows, C) floats.
-extern "C" int64_t cmda_layernorm_bwd_ws_floats(int64_t rows, int C) { return ln_bwd_grid(rows, C) * 2 * C; }
+// cmda_layernorm_bwd_ws_floats(rows, C) floats that must be ZERO on entry and is zero again when the call completes (the
+// finalize pass clears what it consumed), so one persistent buffer serves every call on a stream without a memset.
+extern "C" int64_t cmda_layernorm_bwd_ws_floats(int64_t rows, int C) { (void)rows; return (int64_t)kSlots * 2 * C; }
 
 extern "C" int cmda_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                                   const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, float* ws,
@@ -240,6 +245,7 @@ extern "C" int cmda_layernorm_bwd(const void* dy, const void* x, const float* ga
   const int grid = (int)ln_bwd_grid(rows, C);
   CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((ln_bwd_kernel<T>), dim3(grid), dim3(64 * wpb), 0, stream, (const T*)dy,
                                          (const T*)x, gamma, mean, rstd, (const T*)dres, (T*)dx, ws, (long)rows, C, lpr));
-  CMDA_LAUNCH(ln_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, stream, (const float*)ws, dgamma, dbeta, grid, C);
+  CMDA_LAUNCH(ln_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, stream, ws, dgamma, dbeta,
+              std::min(grid, kSlots), C);
   CMDA_CHECK_LAUNCH();
 }

@@ -99,12 +99,25 @@ def layernorm_fwd(x, gamma, beta, eps, save_stats=True):
     return y, mean, rstd
 
 
+_LN_WS = {}
+
+
+def _ln_ws(device, n):
+    """persistent zero-initialised LayerNorm-backward workspace (the kernel pair leaves it zeroed; calls on one stream
+    are ordered, so one buffer per device is enough)"""
+    key = (device.type, device.index)
+    ws = _LN_WS.get(key)
+    if ws is None or ws.numel() < n:
+        ws = _LN_WS[key] = torch.zeros(max(n, 64 * 2 * 1024), dtype=torch.float32, device=device)
+    return ws
+
+
 def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None):
     check_dev(dy, x, gamma, mean, rstd, dgamma, dbeta, dres)
     C = x.shape[-1]
     rows = x.numel() // C
     dx = torch.empty_like(x)
-    ws = torch.empty(L.lib().cmda_layernorm_bwd_ws_floats(rows, C), dtype=torch.float32, device=x.device)
+    ws = _ln_ws(x.device, L.lib().cmda_layernorm_bwd_ws_floats(rows, C))
     call('cmda_layernorm_bwd', ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dgamma),
          ptr(dbeta), ptr(ws), c_i64(rows), c_i32(C), dtype_tag(x), stream_of(x))
     return dx

@@ -76,7 +76,8 @@ typedef struct cmda_gemm_params_t {
 int cmda_gemm(const cmda_gemm_params_t* p, void* stream);
 
 /* ---- LayerNorm -- nn.LayerNorm at mmseg/models/backbones/mix_transformer.py:76 (sr norm, eps 1e-5), :123,:136 (Block, 1e-6),
- * :175 (patch embed, 1e-5), :270-318 (stage norms).  bwd: dx = [dres +] LN'(dy); dgamma/dbeta accumulated. */
+ * :175 (patch embed, 1e-5), :270-318 (stage norms).  bwd: dx = [dres +] LN'(dy); dgamma/dbeta accumulated.
+ * ws: cmda_layernorm_bwd_ws_floats() floats, ZERO on entry; the call leaves it zeroed again (reusable without a memset). */
 int cmda_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
     int64_t rows, int C, float eps, int dtype, void* stream);
 int64_t cmda_layernorm_bwd_ws_floats(int64_t rows, int C);
