@@ -1,0 +1,382 @@
+// attention.hip -- fused spatial-reduction attention core (bf16, head_dim 64, up to 256 keys): scores, softmax and the
+// weighted sum of values in ONE kernel each way; the [N, Nk] score / probability matrices never reach HBM.
+//
+// Reference ops replaced: Attention.forward of mmseg/models/backbones/mix_transformer.py:86-103
+//   attn = (q @ k.transpose(-2, -1)) * scale ; attn = attn.softmax(dim=-1) ; x = (attn @ v)      (attn_drop = 0)
+// and its autograd backward.  q comes from the `q` Linear ([B*N, C], head h = columns 64h..64h+63), k / v from the `kv`
+// Linear over the spatially reduced tokens ([B*Nk, 2C]: K at column 64h, V at column C + 64h).  With CMDA's 512x512
+// crops every stage has Nk = 256 keys (sr_ratios 8/4/2/1), which is what makes the whole key set fit in LDS.
+//
+// Orientation: everything is computed TRANSPOSED, S^T = K Q^T, so that the MFMA result layout (row = 4*(lane>>4)+r,
+// col = lane&15) puts the keys on (lane>>4, r) and the queries on lane&15.  Then
+//   * the softmax over keys is a per-lane reduction plus two xor-shuffles (16, 32),
+//   * P^T is already in the B-operand layout of the second GEMM O^T = V^T P^T (k = keys): no LDS round trip for P,
+//   * V^T is read from the row-major V tile with ds_read_b64_tr_b16.
+// The k index of an MFMA is a free labelling as long as A and B agree; here slot (g, j) of the u-th group of 32 keys is
+// key 32u + 4g + j (j < 4) or 32u + 16 + 4g + (j - 4), i.e. exactly the accumulator registers of score tiles 2u and 2u+1.
+//
+// MFMA-bound per block but small: per 16 queries 32 + 32 v_mfma_f32_16x16x32_bf16.  HBM traffic per (batch, head):
+// Q, O once, K, V once per 128-query block (L2 hits).  Algorithmic bytes per query: 2 * 64 * 2 (q, o) + the K/V share.
+#include "common.h"
+
+namespace {
+
+constexpr int kHD = 64;     // head dim
+constexpr int kMaxK = 256;  // keys kept in LDS
+constexpr int kNT = kMaxK / 16;
+
+struct AttnParams {
+  const bf16_t* q;   // [B*N, C]
+  const bf16_t* kv;  // [B*Nk, 2C]
+  bf16_t* o;         // [B*N, C]
+  int B, N, Nk, heads, C;
+  float scale;
+};
+
+// K or V of one (batch, head) -> LDS [kMaxK][64] bf16, 128-byte lines, 16-byte chunk c of line r stored at slot c ^ (r & 7);
+// rows >= Nk come from the zero block.  One DMA instruction moves 8 lines (1 KiB); the 4 waves take 8 instructions each.
+extern __device__ __attribute__((aligned(16))) unsigned g_attn_zero16[4];
+__device__ __attribute__((aligned(16))) unsigned g_attn_zero16[4] = {0u, 0u, 0u, 0u};
+
+static __device__ __forceinline__ void load_kv_tile(const bf16_t* __restrict__ src, int ld, int Nk, bf16_t* lds, int wid,
+                                                    int lane, int nwaves) {
+  for (int i = wid; i < kMaxK / 8; i += nwaves) {
+    const int row = 8 * i + (lane >> 3);
+    const int chunk = (lane & 7) ^ (row & 7);
+    const void* s = row < Nk ? static_cast<const void*>(src + (long)row * ld + chunk * 8)
+                             : static_cast<const void*>(g_attn_zero16);
+    glds16(s, reinterpret_cast<char*>(lds) + i * 1024);
+  }
+}
+
+// A operand (rows = 16 consecutive tile rows, k = 32 consecutive d) of a row-major swizzled [rows][64] tile
+static __device__ __forceinline__ u16x8 frag_rows(const bf16_t* tile, int row0, int kk, int g, int l15) {
+  const int row = row0 + l15;
+  return *reinterpret_cast<const u16x8*>(&tile[row * kHD + (((kk * 4 + g) ^ (row & 7)) << 3)]);
+}
+
+// A operand of the transposed tile: rows = d (16dt + l15), k slot (g, j) = tile row R0 + j (j < 4) / R1 + (j - 4)
+static __device__ __forceinline__ u16x8 frag_cols(const bf16_t* tile, int R0, int R1, int dt, int l15) {
+  const int q = l15 >> 2, pp = l15 & 3;
+  const int r0 = R0 + q, r1 = R1 + q;
+  const int cidx = 2 * dt + (pp >> 1), half = (pp & 1) << 2;
+  const u16x4 lo = lds_read_tr16(&tile[r0 * kHD + ((cidx ^ (r0 & 7)) << 3) + half]);
+  const u16x4 hi = lds_read_tr16(&tile[r1 * kHD + ((cidx ^ (r1 & 7)) << 3) + half]);
+  return u16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+static __device__ __forceinline__ float col_max(float v) {  // over the 4 lane groups holding one query column
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+static __device__ __forceinline__ float col_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+// scores^T of 16 queries against all key tiles, then the softmax over keys: p[t][r] = P^T[key 16t + 4g + r][query l15]
+static __device__ __forceinline__ void scores_softmax(const bf16_t* sK, const u16x8 (&qf)[2], int nt, int Nk, float scale,
+                                                      int g, int l15, f32x4 (&p)[kNT]) {
+#pragma unroll
+  for (int t = 0; t < kNT; ++t) {
+    p[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (t < nt) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) p[t] = mfma_bf16_16x16x32(frag_rows(sK, 16 * t, kk, g, l15), qf[kk], p[t]);
+    }
+  }
+  float m = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < kNT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool live = 16 * t + 4 * g + r < Nk;
+      p[t][r] = live ? p[t][r] * scale : -INFINITY;
+      m = fmaxf(m, p[t][r]);
+    }
+  m = col_max(m);
+  float l = 0.f;
+#pragma unroll
+  for (int t = 0; t < kNT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      p[t][r] = __expf(p[t][r] - m);  // exp(-inf) = 0 for the masked keys
+      l += p[t][r];
+    }
+  const float inv = 1.f / col_sum(l);
+#pragma unroll
+  for (int t = 0; t < kNT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[t][r] *= inv;
+}
+
+static __device__ __forceinline__ u16x8 pack_pair(const f32x4& a, const f32x4& b) {
+  return u16x8{f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3]), f2bf(b[0]), f2bf(b[1]), f2bf(b[2]), f2bf(b[3])};
+}
+
+// B operand b[k = d][col = query]: 16 bytes of row (row0 + l15) of a [rows, ld] global matrix; rows past `nrows` repeat the last
+static __device__ __forceinline__ void load_qfrag(const bf16_t* __restrict__ base, long row0, long nrows, int ld, int g,
+                                                  int l15, u16x8 (&f)[2]) {
+  long row = row0 + l15;
+  if (row >= nrows) row = nrows - 1;
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) f[kk] = *reinterpret_cast<const u16x8*>(base + row * ld + 32 * kk + 8 * g);
+}
+
+constexpr int kFwdQB = 128;  // queries per block (4 waves x 2 passes x 16)
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
+  __shared__ __attribute__((aligned(1024))) bf16_t sK[kMaxK * kHD];
+  __shared__ __attribute__((aligned(1024))) bf16_t sV[kMaxK * kHD];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const bf16_t* kbase = p.kv + (long)b * p.Nk * 2 * p.C + h * kHD;
+  load_kv_tile(kbase, 2 * p.C, p.Nk, sK, wid, lane, 4);
+  load_kv_tile(kbase + p.C, 2 * p.C, p.Nk, sV, wid, lane, 4);
+  __syncthreads();
+  const int nt = (p.Nk + 15) >> 4;
+  const bf16_t* qb = p.q + (long)b * p.N * p.C + h * kHD;
+  bf16_t* ob = p.o + (long)b * p.N * p.C + h * kHD;
+  for (int pass = 0; pass < kFwdQB / 64; ++pass) {
+    const long q0 = (long)blockIdx.x * kFwdQB + pass * 64 + wid * 16;
+    if (q0 >= p.N) break;  // wave-uniform
+    u16x8 qf[2];
+    load_qfrag(qb, q0, p.N, p.C, g, l15, qf);
+    f32x4 pr[kNT];
+    scores_softmax(sK, qf, nt, p.Nk, p.scale, g, l15, pr);
+    f32x4 oacc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < kNT / 2; ++u) {
+      if (2 * u < nt) {
+        const u16x8 pb = pack_pair(pr[2 * u], pr[2 * u + 1]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          oacc[dt] = mfma_bf16_16x16x32(frag_cols(sV, 32 * u + 4 * g, 32 * u + 16 + 4 * g, dt, l15), pb, oacc[dt]);
+      }
+    }
+    if (q0 + l15 < p.N) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const float v[4] = {oacc[dt][0], oacc[dt][1], oacc[dt][2], oacc[dt][3]};
+        st4(ob + (q0 + l15) * p.C + 16 * dt + 4 * g, v);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward.  A block owns one (batch, head) and a span of query chunks (64 queries each); K and V stay in LDS for the
+// whole span and the block's partial dK / dV (256 x 64 fp32 each) stay in registers (wave w owns keys 64w..64w+63)
+// until one round of fp32 atomics at the end.  Per chunk:
+//   phase A (wave = 16 queries):  P^T = softmax(K Q^T), dP^T = V dO^T, D = sum_k P dP, dS^T = scale * P (dP - D),
+//                                 dQ^T = K^T dS^T -> global;  P and dS go to LDS as [query][key] bf16
+//   phase B (wave = 64 keys):     dV += P^T dO,  dK += dS^T Q   (contraction over the chunk's 64 queries; A operands are
+//                                 transposed reads of the [query][key] tiles, B operands of the [query][d] tiles)
+constexpr int kChunk = 64;
+
+// [64 queries][256 keys] bf16 tile: 16-byte chunk c of row q stored at c ^ (q & 7)
+static __device__ __forceinline__ int pk_addr(int q, int key) { return q * kMaxK + ((((key >> 3) ^ (q & 7)) << 3) | (key & 7)); }
+
+// A operand a[row = key 16kt + l15][slot (g, j) = query R0 + j / R1 + (j - 4)] from a [query][key] tile
+static __device__ __forceinline__ u16x8 frag_keys(const bf16_t* tile, int R0, int R1, int kt, int l15) {
+  const int q = l15 >> 2, pp = l15 & 3;
+  const int r0 = R0 + q, r1 = R1 + q;
+  const int key = 16 * kt + 4 * pp;
+  const u16x4 lo = lds_read_tr16(&tile[pk_addr(r0, key)]);
+  const u16x4 hi = lds_read_tr16(&tile[pk_addr(r1, key)]);
+  return u16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+struct AttnBwdParams {
+  const bf16_t* q;
+  const bf16_t* kv;
+  const bf16_t* d_o;
+  bf16_t* dq;
+  float* dkv32;
+  int B, N, Nk, heads, C, chunks_per_block;
+  float scale;
+};
+
+__global__ __launch_bounds__(256, 1) void attn_bwd_kernel(AttnBwdParams p) {
+  __shared__ __attribute__((aligned(1024))) bf16_t sK[kMaxK * kHD];
+  __shared__ __attribute__((aligned(1024))) bf16_t sV[kMaxK * kHD];
+  __shared__ __attribute__((aligned(1024))) bf16_t sP[kChunk * kMaxK];
+  __shared__ __attribute__((aligned(1024))) bf16_t sDS[kChunk * kMaxK];
+  __shared__ __attribute__((aligned(1024))) bf16_t sQ[kChunk * kHD];
+  __shared__ __attribute__((aligned(1024))) bf16_t sDO[kChunk * kHD];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const bf16_t* kbase = p.kv + (long)b * p.Nk * 2 * p.C + h * kHD;
+  load_kv_tile(kbase, 2 * p.C, p.Nk, sK, wid, lane, 4);
+  load_kv_tile(kbase + p.C, 2 * p.C, p.Nk, sV, wid, lane, 4);
+  const int nt = (p.Nk + 15) >> 4;
+  const long rowb = (long)b * p.N;
+  const bf16_t* qb = p.q + rowb * p.C + h * kHD;
+  const bf16_t* dob = p.d_o + rowb * p.C + h * kHD;
+  bf16_t* dqb = p.dq + rowb * p.C + h * kHD;
+
+  f32x4 dvacc[4][4], dkacc[4][4];  // [key tile of this wave][d tile]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dvacc[i][dt] = dkacc[i][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const long c0 = (long)blockIdx.x * p.chunks_per_block;
+  for (int ci = 0; ci < p.chunks_per_block; ++ci) {
+    const long qc = (c0 + ci) * kChunk;  // first query of the chunk
+    if (qc >= p.N) break;                // block-uniform
+    // ---- stage this wave's 16 rows of Q and dO (rows past N read as zero, so they add nothing to dK / dV)
+    {
+      const int rl = 16 * wid + (lane >> 3);  // first of the two 8-row DMA instructions
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = rl + 8 * i;
+        const int chunk = (lane & 7) ^ (row & 7);
+        const bool ok = qc + row < p.N;
+        const void* zero = static_cast<const void*>(g_attn_zero16);
+        glds16(ok ? static_cast<const void*>(qb + (qc + row) * p.C + chunk * 8) : zero,
+               reinterpret_cast<char*>(sQ) + (2 * wid + i) * 1024);
+        glds16(ok ? static_cast<const void*>(dob + (qc + row) * p.C + chunk * 8) : zero,
+               reinterpret_cast<char*>(sDO) + (2 * wid + i) * 1024);
+      }
+    }
+    // ---- phase A
+    const long q0 = qc + 16 * wid;
+    u16x8 qf[2], dof[2];
+    load_qfrag(qb, q0, p.N, p.C, g, l15, qf);
+    load_qfrag(dob, q0, p.N, p.C, g, l15, dof);
+    if (ci == 0) __syncthreads();  // K / V tiles have landed
+    f32x4 pr[kNT], dp[kNT];
+    scores_softmax(sK, qf, nt, p.Nk, p.scale, g, l15, pr);
+    float dsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < kNT; ++t) {
+      dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (t < nt) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) dp[t] = mfma_bf16_16x16x32(frag_rows(sV, 16 * t, kk, g, l15), dof[kk], dp[t]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dsum += pr[t][r] * dp[t][r];
+    }
+    dsum = col_sum(dsum);
+#pragma unroll
+    for (int t = 0; t < kNT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dp[t][r] = p.scale * pr[t][r] * (dp[t][r] - dsum);  // dS^T
+    // P, dS -> LDS [query][key] (4 consecutive keys = one 8-byte store)
+    {
+      const int ql = 16 * wid + l15;
+#pragma unroll
+      for (int t = 0; t < kNT; ++t) {
+        u16x4 a, c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          a[r] = f2bf(pr[t][r]);
+          c[r] = f2bf(dp[t][r]);
+        }
+        *reinterpret_cast<u16x4*>(&sP[pk_addr(ql, 16 * t + 4 * g)]) = a;
+        *reinterpret_cast<u16x4*>(&sDS[pk_addr(ql, 16 * t + 4 * g)]) = c;
+      }
+    }
+    // dQ^T = K^T dS^T
+    {
+      f32x4 dqacc[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dqacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < kNT / 2; ++u) {
+        if (2 * u < nt) {
+          const u16x8 db = pack_pair(dp[2 * u], dp[2 * u + 1]);
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt)
+            dqacc[dt] = mfma_bf16_16x16x32(frag_cols(sK, 32 * u + 4 * g, 32 * u + 16 + 4 * g, dt, l15), db, dqacc[dt]);
+        }
+      }
+      if (q0 + l15 < p.N) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const float v[4] = {dqacc[dt][0], dqacc[dt][1], dqacc[dt][2], dqacc[dt][3]};
+          st4(dqb + (q0 + l15) * p.C + 16 * dt + 4 * g, v);
+        }
+      }
+    }
+    __syncthreads();  // sP / sDS / sQ / sDO complete (the barrier drains the DMA loads too)
+    // ---- phase B: this wave's 64 keys
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int R0 = 32 * u + 4 * g, R1 = R0 + 16;
+      u16x8 fdo[4], fq[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        fdo[dt] = frag_cols(sDO, R0, R1, dt, l15);
+        fq[dt] = frag_cols(sQ, R0, R1, dt, l15);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int kt = 4 * wid + i;
+        if (kt < nt) {  // wave-uniform
+          const u16x8 fp = frag_keys(sP, R0, R1, kt, l15);
+          const u16x8 fs = frag_keys(sDS, R0, R1, kt, l15);
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            dvacc[i][dt] = mfma_bf16_16x16x32(fp, fdo[dt], dvacc[i][dt]);
+            dkacc[i][dt] = mfma_bf16_16x16x32(fs, fq[dt], dkacc[i][dt]);
+          }
+        }
+      }
+    }
+    __syncthreads();  // tiles free for the next chunk
+  }
+  // ---- one round of atomics: dK -> columns [64h, 64h+64), dV -> C + the same
+  float* ob = p.dkv32 + (long)b * p.Nk * 2 * p.C + h * kHD;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = 16 * (4 * wid + i) + 4 * g + r;
+        if (key < p.Nk) {
+          float* o = ob + (long)key * 2 * p.C + 16 * dt + l15;
+          atomicAdd(o, dkacc[i][dt][r]);
+          atomicAdd(o + p.C, dvacc[i][dt][r]);
+        }
+      }
+}
+
+}  // namespace
+
+// q [B*N, C] bf16, kv [B*Nk, 2C] bf16 -> o [B*N, C] bf16; head_dim = C / heads must be 64, Nk <= 256, C % 8 == 0.
+extern "C" int cmda_attention_fwd(const void* q, const void* kv, void* o, int B, int N, int Nk, int heads, int C,
+                                  float scale, int dtype, void* stream) {
+  if (B <= 0 || N <= 0) return CMDA_OK;
+  if (dtype != CMDA_BF16) return CMDA_ERR_DTYPE;
+  if (heads <= 0 || C != heads * kHD || Nk <= 0 || Nk > kMaxK) return CMDA_ERR_UNSUPPORTED;
+  if (heads > 65535 || B > 65535) return CMDA_ERR_SHAPE;
+  AttnParams p{(const bf16_t*)q, (const bf16_t*)kv, (bf16_t*)o, B, N, Nk, heads, C, scale};
+  dim3 grid((unsigned)((N + kFwdQB - 1) / kFwdQB), (unsigned)heads, (unsigned)B);
+  CMDA_LAUNCH(attn_fwd_kernel, grid, dim3(256), 0, stream, p);
+  CMDA_CHECK_LAUNCH();
+}
+
+// d_o [B*N, C] bf16 -> dq [B*N, C] bf16 (written), dkv32 [B*Nk, 2C] fp32 (accumulated: dK | dV).
+extern "C" int cmda_attention_bwd(const void* q, const void* kv, const void* d_o, void* dq, float* dkv32, int B, int N,
+                                  int Nk, int heads, int C, float scale, int dtype, void* stream) {
+  if (B <= 0 || N <= 0) return CMDA_OK;
+  if (dtype != CMDA_BF16) return CMDA_ERR_DTYPE;
+  if (heads <= 0 || C != heads * kHD || Nk <= 0 || Nk > kMaxK) return CMDA_ERR_UNSUPPORTED;
+  if (heads > 65535 || B > 65535) return CMDA_ERR_SHAPE;
+  const int chunks = (N + kChunk - 1) / kChunk;
+  // ~256 blocks (one per CU; 144 KiB of LDS each); fewer, longer spans mean fewer dK/dV atomics
+  const long bh = (long)B * heads;
+  int spans = (int)std::max<long>(1, std::min<long>(chunks, (256 + bh - 1) / bh));
+  const int cpb = (chunks + spans - 1) / spans;
+  spans = (chunks + cpb - 1) / cpb;
+  AttnBwdParams p{(const bf16_t*)q, (const bf16_t*)kv, (const bf16_t*)d_o, (bf16_t*)dq, dkv32, B, N, Nk, heads, C, cpb, scale};
+  dim3 grid((unsigned)spans, (unsigned)heads, (unsigned)B);
+  CMDA_LAUNCH(attn_bwd_kernel, grid, dim3(256), 0, stream, p);
+  CMDA_CHECK_LAUNCH();
+}

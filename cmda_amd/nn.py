@@ -4,6 +4,8 @@ Activations are 2-D [tokens, channels] tensors (NLC / NHWC flattened) in the com
 its outputs plus whatever the matching `*_bwd` needs; parameter gradients are accumulated by the kernels into
 `param.grad` (fp32) through cmda_amd.runtime.grad().
 """
+import os
+
 import torch
 
 from . import ops
@@ -88,7 +90,10 @@ def conv_bwd(dy, x, weight, bias, B, H, W, stride, pad, dil=1, *, need_dx=True, 
 
 # ------------------------------------------------------------------ attention (scores materialised; v0 path)
 def attention_fwd(q, kv, B, N, Nk, heads, C, scale):
-    """q [B*N,C], kv [B*Nk,2C] -> o [B*N,C]; returns (o, P) with P [B,heads,N,Nk] saved for the backward."""
+    """q [B*N,C], kv [B*Nk,2C] -> o [B*N,C]; returns (o, P): P [B,heads,N,Nk] saved for the backward, or None when the fused
+    kernel ran (bf16, head_dim 64, Nk <= 256: the backward recomputes the probabilities in LDS)."""
+    if ops.attention_fused_ok(q, Nk, heads, C) and not os.environ.get('CMDA_NO_FUSED_ATTENTION'):
+        return ops.attention_fused_fwd(q, kv, B, N, Nk, heads, C, scale), None
     hd = C // heads
     dev = q.device
     P = torch.empty(B, heads, N, Nk, dtype=rt.compute_dtype(), device=dev)
@@ -110,6 +115,9 @@ def attention_bwd(do, q, kv, P, B, N, Nk, heads, C, scale):
     dev = do.device
     tag = rt.tag()
     dkv32 = torch.zeros(B * Nk, 2 * C, dtype=torch.float32, device=dev)
+    if P is None:  # fused forward ran
+        dq = ops.attention_fused_bwd(q, kv, do, dkv32, B, N, Nk, heads, C, scale)
+        return dq, ops.cast(dkv32, rt.compute_dtype())
     Pv = dict(batch_stride=heads * N * Nk, batch2_stride=N * Nk)
     sp = 0  # auto split-K
     # dV_h = P_h^T dO_h

@@ -199,6 +199,27 @@ def softmax_bwd_(p, dp, rows, L, alpha):
     return dp
 
 
+def attention_fused_ok(q, Nk, heads, C):
+    return q.dtype == torch.bfloat16 and C == heads * 64 and 0 < Nk <= 256
+
+
+def attention_fused_fwd(q, kv, B, N, Nk, heads, C, scale):
+    check_dev(q, kv)
+    o = torch.empty(B * N, C, dtype=q.dtype, device=q.device)
+    call('cmda_attention_fwd', ptr(q), ptr(kv), ptr(o), c_i32(B), c_i32(N), c_i32(Nk), c_i32(heads), c_i32(C),
+         c_f32(scale), dtype_tag(q), stream_of(q))
+    return o
+
+
+def attention_fused_bwd(q, kv, do, dkv32, B, N, Nk, heads, C, scale):
+    """returns dq; accumulates dK | dV into dkv32 (fp32 [B*Nk, 2C])"""
+    check_dev(q, kv, do, dkv32)
+    dq = torch.empty(B * N, C, dtype=q.dtype, device=q.device)
+    call('cmda_attention_bwd', ptr(q), ptr(kv), ptr(do), ptr(dq), ptr(dkv32), c_i32(B), c_i32(N), c_i32(Nk), c_i32(heads),
+         c_i32(C), c_f32(scale), dtype_tag(q), stream_of(q))
+    return dq
+
+
 def dwconv_fwd(x, w, bias, B, H, W, C, dil=1, act=None):
     check_dev(x, w, bias)
     y = torch.empty_like(x)

@@ -89,6 +89,16 @@ int cmda_layernorm_bwd(const void* dy, const void* x, const float* gamma, const 
 int cmda_softmax_fwd(void* s, int64_t rows, int L, float alpha, int dtype, void* stream);
 int cmda_softmax_bwd(const void* p, void* dp, int64_t rows, int L, float alpha, int dtype, void* stream);
 
+/* ---- Fused attention core (bf16, head_dim 64, Nk <= 256) -- Attention.forward mix_transformer.py:86-103:
+ * softmax(q k^T * scale) v per (batch, head) without materialising the [N, Nk] scores.  q [B*N, C] (head h = columns
+ * 64h..), kv [B*Nk, 2C] (K at column 64h, V at C + 64h), o [B*N, C].  bwd recomputes the probabilities; dq [B*N, C] is
+ * written, dkv32 [B*Nk, 2C] fp32 is ACCUMULATED into (atomics; caller zeroes).  CMDA_ERR_UNSUPPORTED outside these
+ * limits (the caller then uses the GEMM + cmda_softmax path). */
+int cmda_attention_fwd(const void* q, const void* kv, void* o, int B, int N, int Nk, int heads, int C, float scale,
+    int dtype, void* stream);
+int cmda_attention_bwd(const void* q, const void* kv, const void* d_o, void* dq, float* dkv32, int B, int N, int Nk,
+    int heads, int C, float scale, int dtype, void* stream);
+
 /* ---- Depthwise 3x3 convolution, NHWC -- DWConv(+GELU) of MixFFN mix_transformer.py:37-44,443-455 and the dilated depthwise
  * half of the sep-ASPP decode_heads/sep_aspp_head.py:18-27.  `w` is tap-major fp32 [9][C]; dw (gradient) is [C][9]. */
 int cmda_dwconv3x3_fwd(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int dil,

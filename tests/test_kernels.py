@@ -272,3 +272,31 @@ def test_strong_augmentation(tgt):
     refb = ouda.gaussian_blur(img, k, 0.8)
     outb = ops.gaussian_blur_(tgt.to(img.clone()), k, 0.8)
     assert_close(outb, refb, 1e-5, atol=1e-6, name='gaussian blur')
+
+
+def _attention_ref(q, kv, B, N, Nk, heads, C, scale):
+    hd = C // heads
+    qf = q.view(B, N, heads, hd).permute(0, 2, 1, 3)
+    k = kv[:, :C].reshape(B, Nk, heads, hd).permute(0, 2, 1, 3)
+    v = kv[:, C:].reshape(B, Nk, heads, hd).permute(0, 2, 1, 3)
+    a = (qf @ k.transpose(-1, -2) * scale).softmax(-1)  # mix_transformer.py:97-99
+    return (a @ v).permute(0, 2, 1, 3).reshape(B * N, C)
+
+
+@pytest.mark.parametrize('B,N,Nk,heads', [(1, 64, 256, 1), (2, 200, 256, 2), (1, 70, 37, 1), (1, 300, 130, 5), (2, 520, 256, 1)])
+def test_fused_attention(tgt, B, N, Nk, heads):
+    """fused softmax(q k^T) v and its backward (probabilities recomputed in LDS) against autograd on the same bf16 inputs"""
+    torch.manual_seed(N + Nk)
+    C, scale = heads * 64, 0.125
+    q, kv, do = torch.randn(B * N, C).bfloat16(), torch.randn(B * Nk, 2 * C).bfloat16(), torch.randn(B * N, C).bfloat16()
+    qr, kvr = q.float().requires_grad_(True), kv.float().requires_grad_(True)
+    ref = _attention_ref(qr, kvr, B, N, Nk, heads, C, scale)
+    ref.backward(do.float())
+    qd, kvd, dod = tgt.to(q), tgt.to(kv), tgt.to(do)
+    assert ops.attention_fused_ok(qd, Nk, heads, C)
+    o = ops.attention_fused_fwd(qd, kvd, B, N, Nk, heads, C, scale)
+    assert_close(o, ref.detach(), 1.6e-2, name='attention o')
+    dkv = torch.zeros(B * Nk, 2 * C, device=tgt.device)
+    dq = ops.attention_fused_bwd(qd, kvd, dod, dkv, B, N, Nk, heads, C, scale)
+    assert_close(dq, qr.grad, 2e-2, name='attention dq')
+    assert_close(dkv, kvr.grad, 2e-2, name='attention dkv')
