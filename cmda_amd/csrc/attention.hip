@@ -76,7 +76,7 @@ static __device__ __forceinline__ float col_sum(float v) {
 
 // scores^T of 16 queries against all key tiles, then the softmax over keys: p[t][r] = P^T[key 16t + 4g + r][query l15]
 static __device__ __forceinline__ void scores_softmax(const bf16_t* sK, const u16x8 (&qf)[2], int nt, int Nk, float scale,
-                                                      int g, int l15, f32x4 (&p)[kNT]) {
+                                                      int g, int l15, f32x4 (&p)[kNT], float* lse_out = nullptr) {
 #pragma unroll
   for (int t = 0; t < kNT; ++t) {
     p[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -103,7 +103,9 @@ static __device__ __forceinline__ void scores_softmax(const bf16_t* sK, const u1
       p[t][r] = __expf(p[t][r] - m);  // exp(-inf) = 0 for the masked keys
       l += p[t][r];
     }
-  const float inv = 1.f / col_sum(l);
+  l = col_sum(l);
+  if (lse_out) *lse_out = m + __logf(l);
+  const float inv = 1.f / l;
 #pragma unroll
   for (int t = 0; t < kNT; ++t)
 #pragma unroll
@@ -167,89 +169,52 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Backward.  A block owns one (batch, head) and a span of query chunks (64 queries each); K and V stay in LDS for the
-// whole span and the block's partial dK / dV (256 x 64 fp32 each) stay in registers (wave w owns keys 64w..64w+63)
-// until one round of fp32 atomics at the end.  Per chunk:
-//   phase A (wave = 16 queries):  P^T = softmax(K Q^T), dP^T = V dO^T, D = sum_k P dP, dS^T = scale * P (dP - D),
-//                                 dQ^T = K^T dS^T -> global;  P and dS go to LDS as [query][key] bf16
-//   phase B (wave = 64 keys):     dV += P^T dO,  dK += dS^T Q   (contraction over the chunk's 64 queries; A operands are
-//                                 transposed reads of the [query][key] tiles, B operands of the [query][d] tiles)
-constexpr int kChunk = 64;
-
-// [64 queries][256 keys] bf16 tile: 16-byte chunk c of row q stored at c ^ (q & 7)
-static __device__ __forceinline__ int pk_addr(int q, int key) { return q * kMaxK + ((((key >> 3) ^ (q & 7)) << 3) | (key & 7)); }
-
-// A operand a[row = key 16kt + l15][slot (g, j) = query R0 + j / R1 + (j - 4)] from a [query][key] tile
-static __device__ __forceinline__ u16x8 frag_keys(const bf16_t* tile, int R0, int R1, int kt, int l15) {
-  const int q = l15 >> 2, pp = l15 & 3;
-  const int r0 = R0 + q, r1 = R1 + q;
-  const int key = 16 * kt + 4 * pp;
-  const u16x4 lo = lds_read_tr16(&tile[pk_addr(r0, key)]);
-  const u16x4 hi = lds_read_tr16(&tile[pk_addr(r1, key)]);
-  return u16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-}
-
+// Backward = two kernels, both recomputing the probabilities from q / k (nothing but q, kv, o-gradient is read):
+//   attn_bwd_dq_kernel   (forward-shaped: 16 queries per wave, all keys in LDS)
+//       P^T = softmax(K Q^T), dP^T = V dO^T, D = sum_k P dP, dS^T = scale * P (dP - D), dQ^T = K^T dS^T -> dq
+//       and per query the softmax log-sum-exp and D -> stats[b, h, q, 2] for the second kernel
+//   attn_bwd_dkv_kernel  (block = one 64-key slice of one (batch, head) x a span of queries; wave = 32 queries at a time)
+//       S = Q K^T for the slice, P = exp(scale*S - lse), dP = dO V^T, dS = scale * P (dP - D)       [query][key] tiles
+//       dV^T += dO^T P,  dK^T += Q^T dS      (contraction over the 32 queries; P / dS are B operands straight from the
+//       accumulator registers, dO^T / Q^T are transposed LDS reads of the wave's staged 32 x 64 tiles)
+//       waves fold their partial dK^T / dV^T through LDS, then one fp32 atomic per element per block.
+// (The first version did all of it in one kernel with P / dS staged in LDS: 144 KiB of LDS and 512 registers meant one
+// wave per SIMD and ~21 us per 64-query chunk -- latency-bound.  Split this way the kernels run 8 / 12 waves per CU.)
 struct AttnBwdParams {
   const bf16_t* q;
   const bf16_t* kv;
   const bf16_t* d_o;
   bf16_t* dq;
   float* dkv32;
-  int B, N, Nk, heads, C, chunks_per_block;
+  float* stats;  // [B, heads, N, 2] = (lse, D)
+  int B, N, Nk, heads, C, q_per_block;
   float scale;
 };
 
-__global__ __launch_bounds__(256, 1) void attn_bwd_kernel(AttnBwdParams p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
   __shared__ __attribute__((aligned(1024))) bf16_t sK[kMaxK * kHD];
   __shared__ __attribute__((aligned(1024))) bf16_t sV[kMaxK * kHD];
-  __shared__ __attribute__((aligned(1024))) bf16_t sP[kChunk * kMaxK];
-  __shared__ __attribute__((aligned(1024))) bf16_t sDS[kChunk * kMaxK];
-  __shared__ __attribute__((aligned(1024))) bf16_t sQ[kChunk * kHD];
-  __shared__ __attribute__((aligned(1024))) bf16_t sDO[kChunk * kHD];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, l15 = lane & 15;
   const int h = blockIdx.y, b = blockIdx.z;
   const bf16_t* kbase = p.kv + (long)b * p.Nk * 2 * p.C + h * kHD;
   load_kv_tile(kbase, 2 * p.C, p.Nk, sK, wid, lane, 4);
   load_kv_tile(kbase + p.C, 2 * p.C, p.Nk, sV, wid, lane, 4);
+  __syncthreads();
   const int nt = (p.Nk + 15) >> 4;
   const long rowb = (long)b * p.N;
   const bf16_t* qb = p.q + rowb * p.C + h * kHD;
   const bf16_t* dob = p.d_o + rowb * p.C + h * kHD;
   bf16_t* dqb = p.dq + rowb * p.C + h * kHD;
-
-  f32x4 dvacc[4][4], dkacc[4][4];  // [key tile of this wave][d tile]
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) dvacc[i][dt] = dkacc[i][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const long c0 = (long)blockIdx.x * p.chunks_per_block;
-  for (int ci = 0; ci < p.chunks_per_block; ++ci) {
-    const long qc = (c0 + ci) * kChunk;  // first query of the chunk
-    if (qc >= p.N) break;                // block-uniform
-    // ---- stage this wave's 16 rows of Q and dO (rows past N read as zero, so they add nothing to dK / dV)
-    {
-      const int rl = 16 * wid + (lane >> 3);  // first of the two 8-row DMA instructions
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = rl + 8 * i;
-        const int chunk = (lane & 7) ^ (row & 7);
-        const bool ok = qc + row < p.N;
-        const void* zero = static_cast<const void*>(g_attn_zero16);
-        glds16(ok ? static_cast<const void*>(qb + (qc + row) * p.C + chunk * 8) : zero,
-               reinterpret_cast<char*>(sQ) + (2 * wid + i) * 1024);
-        glds16(ok ? static_cast<const void*>(dob + (qc + row) * p.C + chunk * 8) : zero,
-               reinterpret_cast<char*>(sDO) + (2 * wid + i) * 1024);
-      }
-    }
-    // ---- phase A
-    const long q0 = qc + 16 * wid;
+  float* st = p.stats + ((long)b * p.heads + h) * p.N * 2;
+  for (int pass = 0; pass < kFwdQB / 64; ++pass) {
+    const long q0 = (long)blockIdx.x * kFwdQB + pass * 64 + wid * 16;
+    if (q0 >= p.N) break;  // wave-uniform
     u16x8 qf[2], dof[2];
     load_qfrag(qb, q0, p.N, p.C, g, l15, qf);
     load_qfrag(dob, q0, p.N, p.C, g, l15, dof);
-    if (ci == 0) __syncthreads();  // K / V tiles have landed
     f32x4 pr[kNT], dp[kNT];
-    scores_softmax(sK, qf, nt, p.Nk, p.scale, g, l15, pr);
+    float lse;
+    scores_softmax(sK, qf, nt, p.Nk, p.scale, g, l15, pr, &lse);
     float dsum = 0.f;
 #pragma unroll
     for (int t = 0; t < kNT; ++t) {
@@ -266,85 +231,158 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(AttnBwdParams p) {
     for (int t = 0; t < kNT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) dp[t][r] = p.scale * pr[t][r] * (dp[t][r] - dsum);  // dS^T
-    // P, dS -> LDS [query][key] (4 consecutive keys = one 8-byte store)
-    {
-      const int ql = 16 * wid + l15;
+    f32x4 dqacc[4];
 #pragma unroll
-      for (int t = 0; t < kNT; ++t) {
-        u16x4 a, c;
+    for (int dt = 0; dt < 4; ++dt) dqacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          a[r] = f2bf(pr[t][r]);
-          c[r] = f2bf(dp[t][r]);
-        }
-        *reinterpret_cast<u16x4*>(&sP[pk_addr(ql, 16 * t + 4 * g)]) = a;
-        *reinterpret_cast<u16x4*>(&sDS[pk_addr(ql, 16 * t + 4 * g)]) = c;
+    for (int u = 0; u < kNT / 2; ++u) {
+      if (2 * u < nt) {
+        const u16x8 db = pack_pair(dp[2 * u], dp[2 * u + 1]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          dqacc[dt] = mfma_bf16_16x16x32(frag_cols(sK, 32 * u + 4 * g, 32 * u + 16 + 4 * g, dt, l15), db, dqacc[dt]);
       }
     }
-    // dQ^T = K^T dS^T
-    {
-      f32x4 dqacc[4];
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) dqacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int u = 0; u < kNT / 2; ++u) {
-        if (2 * u < nt) {
-          const u16x8 db = pack_pair(dp[2 * u], dp[2 * u + 1]);
-#pragma unroll
-          for (int dt = 0; dt < 4; ++dt)
-            dqacc[dt] = mfma_bf16_16x16x32(frag_cols(sK, 32 * u + 4 * g, 32 * u + 16 + 4 * g, dt, l15), db, dqacc[dt]);
-        }
-      }
-      if (q0 + l15 < p.N) {
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          const float v[4] = {dqacc[dt][0], dqacc[dt][1], dqacc[dt][2], dqacc[dt][3]};
-          st4(dqb + (q0 + l15) * p.C + 16 * dt + 4 * g, v);
-        }
-      }
-    }
-    __syncthreads();  // sP / sDS / sQ / sDO complete (the barrier drains the DMA loads too)
-    // ---- phase B: this wave's 64 keys
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int R0 = 32 * u + 4 * g, R1 = R0 + 16;
-      u16x8 fdo[4], fq[4];
+    if (q0 + l15 < p.N) {
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        fdo[dt] = frag_cols(sDO, R0, R1, dt, l15);
-        fq[dt] = frag_cols(sQ, R0, R1, dt, l15);
+        const float v[4] = {dqacc[dt][0], dqacc[dt][1], dqacc[dt][2], dqacc[dt][3]};
+        st4(dqb + (q0 + l15) * p.C + 16 * dt + 4 * g, v);
+      }
+      if (g == 0) {
+        st[(q0 + l15) * 2 + 0] = lse;
+        st[(q0 + l15) * 2 + 1] = dsum;
+      }
+    }
+  }
+}
+
+constexpr int kKS = 64;        // keys per dK/dV block
+constexpr int kRedPitch = 68;  // floats per key row of the cross-wave reduction buffer
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
+  __shared__ __attribute__((aligned(1024))) bf16_t sK[kKS * kHD];
+  __shared__ __attribute__((aligned(1024))) bf16_t sV[kKS * kHD];
+  constexpr int kStageBytes = 4 * 2 * 32 * kHD * 2;           // per wave: Q and dO tiles of 32 queries
+  constexpr int kRedBytes = 2 * kKS * kRedPitch * 4;          // dK | dV as [key][d] fp32
+  __shared__ __attribute__((aligned(1024))) char sbuf[kStageBytes > kRedBytes ? kStageBytes : kRedBytes];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const int h = blockIdx.y >> 2, ks = blockIdx.y & 3, b = blockIdx.z;
+  const int key0 = ks * kKS;
+  if (key0 >= p.Nk) return;  // block-uniform: this slice holds no key
+  const int nkeys = min(kKS, p.Nk - key0);
+  const bf16_t* kbase = p.kv + ((long)b * p.Nk + key0) * 2 * p.C + h * kHD;
+  for (int i = wid; i < kKS / 8; i += 4) {
+    const int row = 8 * i + (lane >> 3);
+    const int chunk = (lane & 7) ^ (row & 7);
+    const void* zero = static_cast<const void*>(g_attn_zero16);
+    const bf16_t* src = kbase + (long)row * 2 * p.C + chunk * 8;
+    glds16(row < nkeys ? static_cast<const void*>(src) : zero, reinterpret_cast<char*>(sK) + i * 1024);
+    glds16(row < nkeys ? static_cast<const void*>(src + p.C) : zero, reinterpret_cast<char*>(sV) + i * 1024);
+  }
+  __syncthreads();
+  const long rowb = (long)b * p.N;
+  const bf16_t* qb = p.q + rowb * p.C + h * kHD;
+  const bf16_t* dob = p.d_o + rowb * p.C + h * kHD;
+  const float* st = p.stats + ((long)b * p.heads + h) * p.N * 2;
+  bf16_t* sQw = reinterpret_cast<bf16_t*>(sbuf) + wid * 2 * 32 * kHD;
+  bf16_t* sDOw = sQw + 32 * kHD;
+
+  f32x4 dvacc[4][4], dkacc[4][4];  // [d tile][key tile]: dV^T, dK^T
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) dvacc[dt][kt] = dkacc[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const long qbeg = (long)blockIdx.x * p.q_per_block;
+  const long qend = min((long)p.N, qbeg + p.q_per_block);
+  for (long q32 = qbeg + 32 * wid; q32 < qend; q32 += 128) {
+    // stage this wave's 32 rows of Q and dO (rows past N read as zero)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 8 * i + (lane >> 3);
+      const int chunk = (lane & 7) ^ (row & 7);
+      const bool ok = q32 + row < p.N;
+      const void* zero = static_cast<const void*>(g_attn_zero16);
+      glds16(ok ? static_cast<const void*>(qb + (q32 + row) * p.C + chunk * 8) : zero, reinterpret_cast<char*>(sQw) + i * 1024);
+      glds16(ok ? static_cast<const void*>(dob + (q32 + row) * p.C + chunk * 8) : zero, reinterpret_cast<char*>(sDOw) + i * 1024);
+    }
+    float lse[2][4], dd[2][4];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long qi = q32 + 16 * qt + 4 * g + r;
+        const bool ok = qi < p.N;
+        lse[qt][r] = ok ? st[qi * 2] : INFINITY;  // exp(s - inf) = 0: a missing query contributes nothing
+        dd[qt][r] = ok ? st[qi * 2 + 1] : 0.f;
+      }
+    dma_wait<0>();
+    f32x4 pr[2][4], ds[2][4];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      u16x8 fq[2], fdo[2];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        fq[kk] = frag_rows(sQw, 16 * qt, kk, g, l15);
+        fdo[kk] = frag_rows(sDOw, 16 * qt, kk, g, l15);
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int kt = 4 * wid + i;
-        if (kt < nt) {  // wave-uniform
-          const u16x8 fp = frag_keys(sP, R0, R1, kt, l15);
-          const u16x8 fs = frag_keys(sDS, R0, R1, kt, l15);
+      for (int kt = 0; kt < 4; ++kt) {
+        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, d = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int dt = 0; dt < 4; ++dt) {
-            dvacc[i][dt] = mfma_bf16_16x16x32(fp, fdo[dt], dvacc[i][dt]);
-            dkacc[i][dt] = mfma_bf16_16x16x32(fs, fq[dt], dkacc[i][dt]);
-          }
+        for (int kk = 0; kk < 2; ++kk) {
+          s = mfma_bf16_16x16x32(fq[kk], frag_rows(sK, 16 * kt, kk, g, l15), s);
+          d = mfma_bf16_16x16x32(fdo[kk], frag_rows(sV, 16 * kt, kk, g, l15), d);
+        }
+        const bool live = 16 * kt + l15 < nkeys;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = live ? __expf(s[r] * p.scale - lse[qt][r]) : 0.f;
+          pr[qt][kt][r] = pv;
+          ds[qt][kt][r] = p.scale * pv * (d[r] - dd[qt][r]);
         }
       }
     }
-    __syncthreads();  // tiles free for the next chunk
-  }
-  // ---- one round of atomics: dK -> columns [64h, 64h+64), dV -> C + the same
-  float* ob = p.dkv32 + (long)b * p.Nk * 2 * p.C + h * kHD;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int dt = 0; dt < 4; ++dt) {
+      const u16x8 fdoT = frag_cols(sDOw, 4 * g, 16 + 4 * g, dt, l15);
+      const u16x8 fqT = frag_cols(sQw, 4 * g, 16 + 4 * g, dt, l15);
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = 16 * (4 * wid + i) + 4 * g + r;
-        if (key < p.Nk) {
-          float* o = ob + (long)key * 2 * p.C + 16 * dt + l15;
-          atomicAdd(o, dkacc[i][dt][r]);
-          atomicAdd(o + p.C, dvacc[i][dt][r]);
-        }
+      for (int kt = 0; kt < 4; ++kt) {
+        dvacc[dt][kt] = mfma_bf16_16x16x32(fdoT, pack_pair(pr[0][kt], pr[1][kt]), dvacc[dt][kt]);
+        dkacc[dt][kt] = mfma_bf16_16x16x32(fqT, pack_pair(ds[0][kt], ds[1][kt]), dkacc[dt][kt]);
       }
+    }
+  }
+  // ---- fold the four waves' partials through LDS ([key][d], pitch 68), then one atomic per element
+  __syncthreads();  // every wave is done with its staging tiles (the buffer is reused)
+  float* red = reinterpret_cast<float*>(sbuf);
+  for (int w = 0; w < 4; ++w) {
+    if (wid == w) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          float* rk = red + (16 * kt + l15) * kRedPitch + 16 * dt + 4 * g;
+          float* rv = rk + kKS * kRedPitch;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            rk[r] = (w ? rk[r] : 0.f) + dkacc[dt][kt][r];
+            rv[r] = (w ? rv[r] : 0.f) + dvacc[dt][kt][r];
+          }
+        }
+    }
+    __syncthreads();
+  }
+  float* ob = p.dkv32 + ((long)b * p.Nk + key0) * 2 * p.C + h * kHD;
+  for (int e = tid; e < kKS * kHD; e += 256) {
+    const int kl = e >> 6, d = e & 63;
+    if (kl < nkeys) {
+      atomicAdd(ob + (long)kl * 2 * p.C + d, red[kl * kRedPitch + d]);
+      atomicAdd(ob + (long)kl * 2 * p.C + p.C + d, red[(kKS + kl) * kRedPitch + d]);
+    }
+  }
 }
 
 }  // namespace
@@ -363,20 +401,25 @@ extern "C" int cmda_attention_fwd(const void* q, const void* kv, void* o, int B,
 }
 
 // d_o [B*N, C] bf16 -> dq [B*N, C] bf16 (written), dkv32 [B*Nk, 2C] fp32 (accumulated: dK | dV).
-extern "C" int cmda_attention_bwd(const void* q, const void* kv, const void* d_o, void* dq, float* dkv32, int B, int N,
-                                  int Nk, int heads, int C, float scale, int dtype, void* stream) {
+// stats: scratch of cmda_attention_bwd_ws_floats(B, N, heads) floats.
+extern "C" int64_t cmda_attention_bwd_ws_floats(int B, int N, int heads) { return (int64_t)B * N * heads * 2; }
+
+extern "C" int cmda_attention_bwd(const void* q, const void* kv, const void* d_o, void* dq, float* dkv32, float* stats,
+                                  int B, int N, int Nk, int heads, int C, float scale, int dtype, void* stream) {
   if (B <= 0 || N <= 0) return CMDA_OK;
   if (dtype != CMDA_BF16) return CMDA_ERR_DTYPE;
   if (heads <= 0 || C != heads * kHD || Nk <= 0 || Nk > kMaxK) return CMDA_ERR_UNSUPPORTED;
-  if (heads > 65535 || B > 65535) return CMDA_ERR_SHAPE;
-  const int chunks = (N + kChunk - 1) / kChunk;
-  // ~256 blocks (one per CU; 144 KiB of LDS each); fewer, longer spans mean fewer dK/dV atomics
-  const long bh = (long)B * heads;
-  int spans = (int)std::max<long>(1, std::min<long>(chunks, (256 + bh - 1) / bh));
-  const int cpb = (chunks + spans - 1) / spans;
-  spans = (chunks + cpb - 1) / cpb;
-  AttnBwdParams p{(const bf16_t*)q, (const bf16_t*)kv, (const bf16_t*)d_o, (bf16_t*)dq, dkv32, B, N, Nk, heads, C, cpb, scale};
-  dim3 grid((unsigned)spans, (unsigned)heads, (unsigned)B);
-  CMDA_LAUNCH(attn_bwd_kernel, grid, dim3(256), 0, stream, p);
+  if (heads * 4 > 65535 || B > 65535) return CMDA_ERR_SHAPE;
+  AttnBwdParams p{(const bf16_t*)q, (const bf16_t*)kv, (const bf16_t*)d_o, (bf16_t*)dq, dkv32, stats, B, N, Nk, heads, C, 0, scale};
+  dim3 g1((unsigned)((N + kFwdQB - 1) / kFwdQB), (unsigned)heads, (unsigned)B);
+  CMDA_LAUNCH(attn_bwd_dq_kernel, g1, dim3(256), 0, stream, p);
+  // dK/dV: (batch, head, key slice) x query spans; ~1024 blocks (3 per CU resident), spans a multiple of 128 queries
+  const long slices = (long)B * heads * ((Nk + kKS - 1) / kKS);
+  long spans = std::max<long>(1, (1024 + slices - 1) / slices);
+  long qpb = ((N + spans - 1) / spans + 127) / 128 * 128;
+  spans = (N + qpb - 1) / qpb;
+  p.q_per_block = (int)qpb;
+  dim3 g2((unsigned)spans, (unsigned)(heads * 4), (unsigned)B);
+  CMDA_LAUNCH(attn_bwd_dkv_kernel, g2, dim3(256), 0, stream, p);
   CMDA_CHECK_LAUNCH();
 }

@@ -183,6 +183,17 @@ template <int N>
 static inline void pipe_barrier() { __syncthreads(); }
 #endif
 
+// Wave-local wait for this wave's own LDS-DMA loads (no barrier): at most N still in flight.
+#ifndef CMDA_EMU
+template <int N>
+static __device__ __forceinline__ void dma_wait() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+#else
+template <int N>
+static inline void dma_wait() { emu::wave_barrier(); }  // emulated lanes are fibers: rendezvous so every lane's copy is done
+#endif
+
 // erf by Abramowitz & Stegun 7.1.26 (|abs error| < 1.5e-7, i.e. fp32 round-off level): ~12 VALU ops instead of the
 // ~40 of libm's erff -- the exact-erf GELU of the reference (nn.GELU, mix_transformer.py:26) stays well inside the parity
 // bound while the MixFFN stencil kernels stop being VALU-bound.

@@ -215,8 +215,9 @@ def attention_fused_bwd(q, kv, do, dkv32, B, N, Nk, heads, C, scale):
     """returns dq; accumulates dK | dV into dkv32 (fp32 [B*Nk, 2C])"""
     check_dev(q, kv, do, dkv32)
     dq = torch.empty(B * N, C, dtype=q.dtype, device=q.device)
-    call('cmda_attention_bwd', ptr(q), ptr(kv), ptr(do), ptr(dq), ptr(dkv32), c_i32(B), c_i32(N), c_i32(Nk), c_i32(heads),
-         c_i32(C), c_f32(scale), dtype_tag(q), stream_of(q))
+    stats = torch.empty(B * N * heads * 2, dtype=torch.float32, device=q.device)
+    call('cmda_attention_bwd', ptr(q), ptr(kv), ptr(do), ptr(dq), ptr(dkv32), ptr(stats), c_i32(B), c_i32(N), c_i32(Nk),
+         c_i32(heads), c_i32(C), c_f32(scale), dtype_tag(q), stream_of(q))
     return dq
 
 
