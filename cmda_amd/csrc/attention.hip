@@ -413,9 +413,11 @@ extern "C" int cmda_attention_bwd(const void* q, const void* kv, const void* d_o
   AttnBwdParams p{(const bf16_t*)q, (const bf16_t*)kv, (const bf16_t*)d_o, (bf16_t*)dq, dkv32, stats, B, N, Nk, heads, C, 0, scale};
   dim3 g1((unsigned)((N + kFwdQB - 1) / kFwdQB), (unsigned)heads, (unsigned)B);
   CMDA_LAUNCH(attn_bwd_dq_kernel, g1, dim3(256), 0, stream, p);
-  // dK/dV: (batch, head, key slice) x query spans; ~1024 blocks (3 per CU resident), spans a multiple of 128 queries
+  // dK/dV: (batch, head, key slice) x query spans, spans a multiple of 128 queries.  Every span costs one fp32 atomic per
+  // dK/dV element (~1.3 TB/s chip-wide: 1280 blocks of the stage-3 shape spent 31 of their 61 us there), so only as many
+  // spans as it takes to reach ~2 blocks per CU.
   const long slices = (long)B * heads * ((Nk + kKS - 1) / kKS);
-  long spans = std::max<long>(1, (1024 + slices - 1) / slices);
+  long spans = std::max<long>(1, 512 / slices);
   long qpb = ((N + spans - 1) / spans + 127) / 128 * 128;
   spans = (N + qpb - 1) / qpb;
   p.q_per_block = (int)qpb;
