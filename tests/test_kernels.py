@@ -149,7 +149,7 @@ def test_batchnorm(tgt, dt, tol, relu):
     assert_close(db, bn.bias.grad, 1e-4, name='bn dbeta')
 
 
-@pytest.mark.parametrize('h,w,H,W', [(8, 8, 32, 32), (6, 10, 24, 40), (7, 5, 28, 20)])
+@pytest.mark.parametrize('h,w,H,W', [(8, 8, 32, 32), (6, 10, 24, 40), (7, 5, 28, 20), (8, 8, 8, 8), (5, 7, 13, 18), (2, 3, 32, 48), (9, 17, 36, 68)])
 @pytest.mark.parametrize('use_weight', [True, False])
 def test_ce_upsample(tgt, h, w, H, W, use_weight):
     torch.manual_seed(h * 3 + w)
