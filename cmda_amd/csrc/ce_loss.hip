@@ -172,6 +172,21 @@ __global__ __launch_bounds__(256) void ce_bwd_tile_kernel(const float* __restric
   lo_hi_range(x0, w, W, isw, Xa, t1);
   lo_hi_range(x1, w, W, isw, t0, Xb);
   const int TW = Xb - Xa + 1, TH = Yb - Ya + 1;
+  // interpolation weight of every footprint row / column onto each of the tile's low-resolution rows / columns
+  float* wyt = tile + (long)TW * TH * nc;  // [kTileY][TH]
+  float* wxt = wyt + kTileY * TH;          // [kTileX][TW]
+  for (int i = threadIdx.x; i < kTileY * TH + kTileX * TW; i += blockDim.x) {
+    if (i < kTileY * TH) {
+      const int ly = i / TH, Y = Ya + i % TH;
+      const BilinTap t = bilin_tap(Y, h, H, sh);
+      wyt[i] = (t.i0 == y0 + ly ? t.l0 : 0.f) + (t.i1 == y0 + ly ? t.l1 : 0.f);
+    } else {
+      const int j = i - kTileY * TH;
+      const int lx = j / TW, X = Xa + j % TW;
+      const BilinTap t = bilin_tap(X, w, W, sw);
+      wxt[j] = (t.i0 == x0 + lx ? t.l0 : 0.f) + (t.i1 == x0 + lx ? t.l1 : 0.f);
+    }
+  }
   // ---- phase 1: weight * (p - onehot) per full-resolution pixel of the footprint
   for (int i = threadIdx.x; i < TW * TH; i += blockDim.x) {
     const int Y = Ya + i / TW, X = Xa + i % TW;
@@ -202,15 +217,16 @@ __global__ __launch_bounds__(256) void ce_bwd_tile_kernel(const float* __restric
     lo_hi_range(y, h, H, ish, Y0, Y1);
     lo_hi_range(x, w, W, isw, X0, X1);
     float g = 0.f;
+    const float* wyr = wyt + (y - y0) * TH - Ya;
+    const float* wxr = wxt + (x - x0) * TW - Xa;
     for (int Y = Y0; Y <= Y1; ++Y) {
-      const BilinTap ty = bilin_tap(Y, h, H, sh);
-      const float wy = (ty.i0 == y ? ty.l0 : 0.f) + (ty.i1 == y ? ty.l1 : 0.f);
+      const float wy = wyr[Y];
       if (wy == 0.f) continue;
+      const float* trow = tile + ((long)(Y - Ya) * TW - Xa) * nc + c;
       for (int X = X0; X <= X1; ++X) {
-        const BilinTap tx = bilin_tap(X, w, W, sw);
-        const float wx = (tx.i0 == x ? tx.l0 : 0.f) + (tx.i1 == x ? tx.l1 : 0.f);
+        const float wx = wxr[X];
         if (wx == 0.f) continue;
-        g += wy * wx * tile[((long)(Y - Ya) * TW + (X - Xa)) * nc + c];
+        g += wy * wx * trow[(long)X * nc];
       }
     }
     dlogits[(((long)b * h + y) * w + x) * nc + c] = gscale * g;
@@ -313,10 +329,11 @@ extern "C" int cmda_ce_upsample_bwd(const float* logits, const int64_t* label, c
 #ifndef CMDA_EMU
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(ce_bwd_tile_kernel),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                       kMaxTilePx * kMaxClasses * (int)sizeof(float));  // > 64 KiB needs opt-in
+                                                       (kMaxTilePx * kMaxClasses + 1024) * (int)sizeof(float));  // > 64 KiB needs opt-in
     if (attr != hipSuccess) return CMDA_ERR_HIP;
 #endif
-    CMDA_LAUNCH(ce_bwd_tile_kernel, dim3((unsigned)tiles), dim3(256), (size_t)(TW * TH * nc * sizeof(float)), stream, logits,
+    CMDA_LAUNCH(ce_bwd_tile_kernel, dim3((unsigned)tiles), dim3(256),
+                (size_t)((TW * TH * nc + kTileY * TH + kTileX * TW) * sizeof(float)), stream, logits,
                 (const long long*)label, weight, lse, gscale_ptr, gscale_mul, dlogits, B, h, w, H, W, nc, ignore_index);
     CMDA_CHECK_LAUNCH();
   }

@@ -12,14 +12,13 @@
 
 namespace {
 
-constexpr int kMaxVec = 5;  // vectors of 4 channels per lane: 5 * 16 lanes (C = 320) ... 4 * 64 lanes (C = 1024)
+constexpr int kMaxVec = 4;  // 4 * 64 lanes * 4 elems = C up to 1024
 constexpr int kSlots = 64;  // partial-sum rows of the backward workspace
 
-// lanes per row: the narrowest group whose lanes need at most 5 passes -- C = 320 (80 vectors) runs as 16 lanes x 5 with
-// every lane busy and four rows in flight per wave, instead of 64 lanes x 2 with the second pass 3/4 empty
+// lanes per row: the smallest of 16/32/64 that covers C/4 vectors in one pass (64 otherwise)
 static inline int lanes_per_row(int C) {
   const int nvec = C >> 2;
-  return nvec <= 80 ? 16 : nvec <= 160 ? 32 : 64;
+  return nvec <= 16 ? 16 : nvec <= 32 ? 32 : 64;
 }
 static __device__ __forceinline__ float group_sum(float v, int lpr) {
 #pragma unroll
@@ -99,7 +98,7 @@ __global__ void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                               const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                               const T* __restrict__ dres, T* __restrict__ dx, float* __restrict__ ws, long rows,
                               int C, int lpr) {
-  __shared__ float red[2][4096];  // [gamma/beta][wave][channel]  (32 KiB)
+  __shared__ float red[2][4096];  // [gamma/beta][slot = wave*rows_per_wave + group][channel]  (32 KiB; slots*C <= 4096)
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
   const int wpb = blockDim.x >> 6;
@@ -162,27 +161,16 @@ __global__ void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
       }
     }
   }
-  // parameter gradients: fold the wave's row groups by shuffles (lanes li, li + lpr, ... hold the same channels), then
-  // the waves through LDS, one partial per channel per block
-  const int nslots = wpb;
+  // cross-group / cross-wave reduce of the parameter gradients, one partial per channel per block
+  const int slot = wid * rpw + grp, nslots = wpb * rpw;
 #pragma unroll
   for (int i = 0; i < kMaxVec; ++i) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-      for (int o = 16; o < 64; o <<= 1) {
-        if (o >= lpr) {
-          ag[i][j] += __shfl_xor(ag[i][j], o, 64);
-          ab[i][j] += __shfl_xor(ab[i][j], o, 64);
-        }
-      }
-    }
     const int vi = i * lpr + li;
-    if (grp == 0 && vi < nvec) {
+    if (vi < nvec) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        red[0][wid * C + vi * 4 + j] = ag[i][j];
-        red[1][wid * C + vi * 4 + j] = ab[i][j];
+        red[0][slot * C + vi * 4 + j] = ag[i][j];
+        red[1][slot * C + vi * 4 + j] = ab[i][j];
       }
     }
   }
@@ -229,7 +217,7 @@ __global__ void ln_bwd_finalize_kernel(float* __restrict__ ws, float* __restrict
 extern "C" int cmda_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
                                   float* rstd, int64_t rows, int C, float eps, int dtype, void* stream) {
   if (rows <= 0) return CMDA_OK;
-  if (C <= 0 || (C & 3) || C > 1024) return CMDA_ERR_SHAPE;
+  if (C <= 0 || (C & 3) || C > kMaxVec * 256) return CMDA_ERR_SHAPE;
   const int wpb = 4, lpr = lanes_per_row(C);
   const long rpb = wpb * (64 / lpr);
   const int grid = (int)std::min<long>((rows + rpb - 1) / rpb, 8192);
@@ -240,8 +228,10 @@ extern "C" int cmda_layernorm_fwd(const void* x, const float* gamma, const float
 
 static inline long ln_bwd_grid(long rows, int C) {
   const long rpb = 4 * (64 / lanes_per_row(C));
-  static const char* force = getenv("CMDA_LN_BWD_GRID");  // tuning aid (tools/hbm_bench.py)
-  const long cap = force ? atol(force) : 1024;  // measured: 256 / 512 / 2048 are all slower (profiles/README.md)
+  // measured per shape (tools/ln_bench.py under rocprofv3): caps 256 / 512 / 2048 are all slower than 1024; so were 16-lane
+  // row groups for C = 320 with a shuffle fold of the parameter gradients (32-38 us against 21.5)
+  static const char* force = getenv("CMDA_LN_BWD_GRID");  // tuning aid
+  const long cap = force ? atol(force) : 1024;
   return std::max<long>(1, std::min<long>((rows + rpb - 1) / rpb, cap));
 }
 
@@ -254,7 +244,7 @@ extern "C" int cmda_layernorm_bwd(const void* dy, const void* x, const float* ga
                                   const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, float* ws,
                                   int64_t rows, int C, int dtype, void* stream) {
   if (rows <= 0) return CMDA_OK;
-  if (C <= 0 || (C & 3) || C > 1024) return CMDA_ERR_SHAPE;
+  if (C <= 0 || (C & 3) || C > kMaxVec * 256) return CMDA_ERR_SHAPE;
   const int wpb = 4, lpr = lanes_per_row(C);
   const int grid = (int)ln_bwd_grid(rows, C);
   CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((ln_bwd_kernel<T>), dim3(grid), dim3(64 * wpb), 0, stream, (const T*)dy,
