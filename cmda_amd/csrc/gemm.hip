@@ -205,10 +205,10 @@ static __device__ __forceinline__ float epi_act(float x) {
   return x;
 }
 
-template <typename T, int ACT, int BM, int BN, int PITCH_C>
+template <typename T, int ACT, int BM, int BN, int PITCH_C, int NT>
 static __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* __restrict__ sC, long m0, long n,
                                                      int q4, int r0, long cb, long rb_off, bool full, const float (&bv)[4]) {
-  constexpr int QPR = BN / 4, RSTEP = 256 / QPR, NIT = BM / RSTEP;
+  constexpr int QPR = BN / 4, RSTEP = NT / QPR, NIT = BM / RSTEP;
   const bool has_res = p.res != nullptr, has_beta = p.beta != 0.f, has_rs = p.rowscale != nullptr, f32o = p.out_f32 != 0;
   const float alpha = p.alpha, beta = p.beta;
 #pragma unroll 4
@@ -253,11 +253,11 @@ static __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const 
   }
 }
 
-template <typename T, int BM, int BN, int PITCH_C>
+template <typename T, int BM, int BN, int PITCH_C, int NT = 256>
 static __device__ __forceinline__ void epilogue_store(const GemmParams& p, const float* __restrict__ sC, long m0, long n0,
                                                       long cb, long rb_off, int tid) {
   constexpr int QPR = BN / 4;  // quads per tile row
-  static_assert(256 % QPR == 0 && BM % (256 / QPR) == 0, "tile shape");
+  static_assert(NT % QPR == 0 && BM % (NT / QPR) == 0, "tile shape");
   const int q4 = (tid % QPR) * 4, r0 = tid / QPR;
   const long n = n0 + q4;
   if (n >= p.N) return;
@@ -271,10 +271,10 @@ static __device__ __forceinline__ void epilogue_store(const GemmParams& p, const
         if (n + e < p.N) bv[e] = p.bias[n + e];
     }
   }
-  if (p.act == 0) epilogue_rows<T, 0, BM, BN, PITCH_C>(p, sC, m0, n, q4, r0, cb, rb_off, full, bv);
-  else if (p.act == 1) epilogue_rows<T, 1, BM, BN, PITCH_C>(p, sC, m0, n, q4, r0, cb, rb_off, full, bv);
-  else if (p.act == 2) epilogue_rows<T, 2, BM, BN, PITCH_C>(p, sC, m0, n, q4, r0, cb, rb_off, full, bv);
-  else epilogue_rows<T, 3, BM, BN, PITCH_C>(p, sC, m0, n, q4, r0, cb, rb_off, full, bv);
+  if (p.act == 0) epilogue_rows<T, 0, BM, BN, PITCH_C, NT>(p, sC, m0, n, q4, r0, cb, rb_off, full, bv);
+  else if (p.act == 1) epilogue_rows<T, 1, BM, BN, PITCH_C, NT>(p, sC, m0, n, q4, r0, cb, rb_off, full, bv);
+  else if (p.act == 2) epilogue_rows<T, 2, BM, BN, PITCH_C, NT>(p, sC, m0, n, q4, r0, cb, rb_off, full, bv);
+  else epilogue_rows<T, 3, BM, BN, PITCH_C, NT>(p, sC, m0, n, q4, r0, cb, rb_off, full, bv);
 }
 
 template <typename T, int TM, int TN, bool AKS, bool BKS>
@@ -507,10 +507,10 @@ __device__ unsigned long long g_stamps[256 * 8];
 #define CMDA_STAMP(i) do { } while (0)
 #endif
 
-template <bool KS, int TILE, bool CONV>
+template <bool KS, int TILE, bool CONV, int NW = 4>
 struct DmaSrc {
   static constexpr int BK = 64;
-  static constexpr int J = TILE / 32;                               // DMA instructions per wave per stage
+  static constexpr int J = TILE / (8 * NW);                         // DMA instructions per wave per stage
   static constexpr int CPL = KS ? TILE / 8 : 8;                     // 16-byte chunks per LDS line
   static constexpr int LPI = 64 / CPL;                              // lines per DMA instruction
   const bf16_t* ptr[J];   // plain: address of (line, chunk) for k-tile 0, or nullptr when the fixed index is out of range
@@ -590,15 +590,20 @@ struct DmaSrc {
 // bound by the per-CU L2->LDS rate, ~65 GB/s, which wants MORE resident blocks, not deeper ones) -- so every tile keeps 2.
 template <int TM, int TN> struct GldsStages { static constexpr int value = 2; };
 
-template <int TM, int TN, bool AKS, bool BKS, bool ACONV, bool BCONV>
-__global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmParams p) {
+// NW = 4 waves (2 x 2): tiles 64x64 / 128x64 / 128x128.  NW = 8 waves (4 x 2, 512 threads, one block per CU): the 256x256
+// tile for the large GEMMs -- the k-loop is bound by the per-CU L2->LDS rate, and a 256x256 tile moves half the bytes
+// per FLOP of a 128x128 one.  Its epilogue goes through LDS one wave-row (64 rows) at a time.
+template <int TM, int TN, bool AKS, bool BKS, bool ACONV, bool BCONV, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void gemm_glds_kernel(GemmParams p) {
   typedef bf16_t T;
-  constexpr int BM = 32 * TM, BN = 32 * TN, BK = 64;
+  constexpr int WM = NW / 2, NTHR = 64 * NW;
+  constexpr int BM = 16 * TM * WM, BN = 32 * TN, BK = 64;
   constexpr int NS = GldsStages<TM, TN>::value;
   constexpr int SZ_A = BM * BK, SZ_B = BN * BK;                       // elements per stage
   constexpr int PITCH_C = BN + 4;
+  constexpr int EPI_ROWS = NW == 8 ? 16 * TM : BM;                    // rows staged per epilogue pass
   constexpr size_t STAGE_BYTES = (size_t)NS * (SZ_A + SZ_B) * sizeof(T);
-  constexpr size_t EPI_BYTES = (size_t)BM * PITCH_C * sizeof(float);
+  constexpr size_t EPI_BYTES = (size_t)EPI_ROWS * PITCH_C * sizeof(float);
   constexpr size_t LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
   __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
   T* const sAbase = reinterpret_cast<T*>(smem);
@@ -627,8 +632,8 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmParams p) {
   const T* baseB = reinterpret_cast<const T*>(p.B.ptr) + (long)batch * p.B.batch_stride + (long)batch2 * p.B.batch2_stride;
 
   CMDA_STAMP(0);
-  DmaSrc<AKS, BM, ACONV> dA;
-  DmaSrc<BKS, BN, BCONV> dB;
+  DmaSrc<AKS, BM, ACONV, NW> dA;
+  DmaSrc<BKS, BN, BCONV, NW> dB;
   dA.init(p.A, baseA, wid, lane, m0);
   dB.init(p.B, baseB, wid, lane, n0);
   auto issue = [&](int stage, int kt) {
@@ -649,7 +654,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmParams p) {
   // optional fused bias gradient: blocks of the first n-tile also add up their A tile along k (A is dY^T here)
   const bool do_colsum = AKS && p.colsum != nullptr && n0 == 0;
   float bsum = 0.f;
-  constexpr int LPT = DmaSrc<AKS, BM, ACONV>::J + DmaSrc<BKS, BN, BCONV>::J;  // DMA instructions per wave per k-tile
+  constexpr int LPT = DmaSrc<AKS, BM, ACONV, NW>::J + DmaSrc<BKS, BN, BCONV, NW>::J;  // DMA instructions per wave per k-tile
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s)
     if (kt0 + s < kt1) issue(s, kt0 + s);
@@ -738,32 +743,52 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmParams p) {
     return;
   }
   float* sC = reinterpret_cast<float*>(smem);
+  if constexpr (NW == 4) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        sC[(wm * 16 * TM + i * 16 + 4 * g + r) * PITCH_C + wn * 16 * TN + j * 16 + l15] = acc[i][j][r];
-  __syncthreads();
-  CMDA_STAMP(4);
-  epilogue_store<T, BM, BN, PITCH_C>(p, sC, m0, n0, cb, rb_off, tid);
+        for (int r = 0; r < 4; ++r)
+          sC[(wm * 16 * TM + i * 16 + 4 * g + r) * PITCH_C + wn * 16 * TN + j * 16 + l15] = acc[i][j][r];
+    __syncthreads();
+    CMDA_STAMP(4);
+    epilogue_store<T, BM, BN, PITCH_C, NTHR>(p, sC, m0, n0, cb, rb_off, tid);
+  } else {
+    for (int wr = 0; wr < WM; ++wr) {  // one wave-row (16*TM rows) per pass: its two waves stage, everyone stores
+      if (wm == wr) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              sC[(i * 16 + 4 * g + r) * PITCH_C + wn * 16 * TN + j * 16 + l15] = acc[i][j][r];
+      }
+      __syncthreads();
+      if (m0 + wr * EPI_ROWS < p.M)
+        epilogue_store<T, EPI_ROWS, BN, PITCH_C, NTHR>(p, sC, m0 + wr * EPI_ROWS, n0, cb, rb_off, tid);
+      __syncthreads();
+    }
+    CMDA_STAMP(4);
+  }
   CMDA_STAMP(5);
 }
 
-template <int TM, int TN>
+template <int TM, int TN, int NW = 4>
 int launch_glds(const GemmParams& p, void* stream) {
-  constexpr int BM = 32 * TM, BN = 32 * TN;
+  constexpr int BM = 16 * TM * (NW / 2), BN = 32 * TN;
   const long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   if (tiles > 0x7fffffffL || (long)p.batch * p.batch2 * p.splits > 65535) return CMDA_ERR_SHAPE;
   dim3 grid((unsigned)tiles, 1, (unsigned)(p.batch * p.batch2 * p.splits));
+  const dim3 blk(64 * NW);
   const bool aks = p.a_kstrided != 0, bks = p.b_kstrided != 0, ac = p.A.conv != 0, bc = p.B.conv != 0;
-  if (!aks && !bks && !ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, false, false, false, false>), grid, dim3(256), 0, stream, p);
-  else if (!aks && bks && !ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, false, true, false, false>), grid, dim3(256), 0, stream, p);
-  else if (aks && bks && !ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, true, true, false, false>), grid, dim3(256), 0, stream, p);
-  else if (aks && !bks && !ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, true, false, false, false>), grid, dim3(256), 0, stream, p);
-  else if (!aks && !bks && ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, false, false, true, false>), grid, dim3(256), 0, stream, p);
-  else if (aks && bks && !ac && bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, true, true, false, true>), grid, dim3(256), 0, stream, p);
+  if (!aks && !bks && !ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, false, false, false, false, NW>), grid, blk, 0, stream, p);
+  else if (!aks && bks && !ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, false, true, false, false, NW>), grid, blk, 0, stream, p);
+  else if (aks && bks && !ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, true, true, false, false, NW>), grid, blk, 0, stream, p);
+  else if (aks && !bks && !ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, true, false, false, false, NW>), grid, blk, 0, stream, p);
+  else if (!aks && !bks && ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, false, false, true, false, NW>), grid, blk, 0, stream, p);
+  else if (aks && bks && !ac && bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, true, true, false, true, NW>), grid, blk, 0, stream, p);
   else return CMDA_ERR_UNSUPPORTED;
   CMDA_CHECK_LAUNCH();
 }
@@ -789,7 +814,7 @@ int launch_dtype(GemmParams& p, void* stream) {
   auto blocks = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * zb; };
   constexpr int BK = 8 * Num<T>::kChunk;
   const int nkt = (p.K + BK - 1) / BK;
-  int tile;  // 0: 128x128, 1: 128x64, 2: 64x64
+  int tile;  // 0: 128x128, 1: 128x64, 2: 64x64, 3: 256x256 (8 waves)
   if (p.atomic && p.splits <= 0) {
     // accumulate-by-atomics GEMMs (weight gradients): few output tiles, very long contraction -> largest tile that
     // fits the output, then split K until the grid fills the chip
@@ -797,10 +822,11 @@ int launch_dtype(GemmParams& p, void* stream) {
     // only grows to 128x128 when the output alone already has enough tiles.
     tile = 2;
     if (p.M > 64 && p.N > 64) {
-      if (blocks(128, 128) >= 64) tile = 0;
+      if (sizeof(T) == 2 && p.M >= 256 && p.N >= 256 && blocks(256, 256) >= 32) tile = 3;
+      else if (blocks(128, 128) >= 64) tile = 0;
       else if (blocks(128, 64) >= 48) tile = 1;  // e.g. the 320x1280 MixFFN weight gradients (57 vs 72 us on 64x64 tiles)
     }
-    const long b = tile == 0 ? blocks(128, 128) : tile == 1 ? blocks(128, 64) : blocks(64, 64);
+    const long b = tile == 3 ? blocks(256, 256) : tile == 0 ? blocks(128, 128) : tile == 1 ? blocks(128, 64) : blocks(64, 64);
     long s = (512 + b - 1) / b;
     s = std::min<long>(s, std::max(1, nkt / 8));
     const long out_bytes = (long)p.M * p.N * 4 * zb;
@@ -812,13 +838,16 @@ int launch_dtype(GemmParams& p, void* stream) {
     if (p.splits <= 0) p.splits = 1;
     const long sp = p.splits;
     // measured with the lean epilogue (profiles/README.md, forced-tile sweep): the 128x128 tile wins from ~1 block per CU up
-    if (p.N > 64 && blocks(128, 128) * sp >= 256) tile = 0;
+    // 256x256 (8 waves, one block per CU) from ~4 blocks per CU on deep contractions: 8192^3 1302 -> 1060 us, the head's
+    // 3x3 bottleneck conv 2134 -> 1570 us; short-K or narrow problems lose to the 128x128 tile
+    if (sizeof(T) == 2 && p.N >= 256 && p.K >= 256 && blocks(256, 256) * sp >= 1024) tile = 3;
+    else if (p.N > 64 && blocks(128, 128) * sp >= 256) tile = 0;
     else if (blocks(128, 64) * sp >= 2048) tile = 1;
     else tile = 2;
   }
-  {  // tuning aid (tools/gemm_bench.py): CMDA_GEMM_TILE=0|1|2 forces the tile
+  {  // tuning aid (tools/gemm_bench.py): CMDA_GEMM_TILE=0|1|2|3 forces the tile (3 = 256x256, LDS-DMA kernel only)
     static const char* force = getenv("CMDA_GEMM_TILE");
-    if (force && force[0] >= '0' && force[0] <= '2') tile = force[0] - '0';
+    if (force && force[0] >= '0' && force[0] <= '3') tile = force[0] - '0';
   }
   if constexpr (sizeof(T) == 2) {
     static const char* no_glds = getenv("CMDA_GEMM_NO_GLDS");
@@ -833,13 +862,14 @@ int launch_dtype(GemmParams& p, void* stream) {
     const bool nt_plain = kind_ok && dma_ok(p.A) && dma_ok(p.B);
     if (p.colsum && !(nt_plain && !no_glds && aks)) return CMDA_ERR_UNSUPPORTED;
     if (nt_plain && !no_glds) {
+      if (tile == 3) return launch_glds<4, 8, 8>(p, stream);
       if (tile == 0) return launch_glds<4, 4>(p, stream);
       if (tile == 1) return launch_glds<4, 2>(p, stream);
       return launch_glds<2, 2>(p, stream);
     }
   }
   if (p.colsum) return CMDA_ERR_UNSUPPORTED;  // the fused bias gradient lives in the LDS-DMA kernel only
-  if (tile == 0) return launch_tile<T, 4, 4>(p, stream);
+  if (tile == 0 || tile == 3) return launch_tile<T, 4, 4>(p, stream);
   if (tile == 1) return launch_tile<T, 4, 2>(p, stream);
   return launch_tile<T, 2, 2>(p, stream);
 }
