@@ -160,17 +160,17 @@ __global__ __launch_bounds__(256) void dw_stencil_kernel(const T* __restrict__ x
 }
 
 // dw[c,tap] += sum_pix dz[pix,c] * x[pix+tap,c];  dbias[c] += sum_pix dz[pix,c]
-// block = 64 channel-quads x 8 run lanes (512 threads); every thread walks runs_per_block/8 runs of its quad with the
-// same prefetched sliding window (4.75 loads per pixel).  The 8 run lanes fold into a 4-slot LDS array in two
-// barrier-separated rounds (no LDS atomics), then ONE fp32 global atomic per (channel, tap) per block -- few, fat
-// blocks keep the same-address atomic traffic low.
+// block = 64 channel-quads x 4 run lanes (256 threads: at ~166 VGPRs three such blocks share a CU, a 512-thread block
+// could only run alone); every thread walks runs_per_block/4 runs of its quad with the same prefetched sliding window
+// (4.75 loads per pixel).  The 4 run lanes meet in a 4-slot LDS array (no LDS atomics), then ONE fp32 global atomic per
+// (channel, tap) per block -- few, fat blocks keep the same-address atomic traffic low.
 template <typename T>
-__global__ __launch_bounds__(512) void dw_bwd_weight_kernel(const T* __restrict__ dz, const T* __restrict__ x,
+__global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const T* __restrict__ dz, const T* __restrict__ x,
                                                             float* __restrict__ dw, float* __restrict__ dbias, RunGeom g,
                                                             int C, int runs_per_block) {
   constexpr int RUN = RunLen<T>::value;
   __shared__ float red[4][64][41];
-  const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;  // py = 0..7
+  const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;  // py = 0..3
   const int c = (blockIdx.x * 64 + cx) * 4;
   const long r0 = (long)blockIdx.y * runs_per_block;
   const long r1 = min(g.nruns, r0 + runs_per_block);
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(512) void dw_bwd_weight_kernel(const T* __restrict_
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[t][j] = 0.f;
   if (c < C) {
-    for (long run = r0 + py; run < r1; run += 8) {
+    for (long run = r0 + py; run < r1; run += 4) {
       RunPos r;
       if (!decode_run(g, run, RUN, r)) continue;
       Raw<T> raw[3][RUN + 2], rdz[RUN];
@@ -214,18 +214,16 @@ __global__ __launch_bounds__(512) void dw_bwd_weight_kernel(const T* __restrict_
       }
     }
   }
-  for (int round = 0; round < 2; ++round) {
-    if ((py >> 2) == round) {
-      float* slot = red[py & 3][cx];
+  {
+    float* slot = red[py][cx];
 #pragma unroll
-      for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) slot[t * 4 + j] = (round ? slot[t * 4 + j] : 0.f) + acc[t][j];
+      for (int j = 0; j < 4; ++j) slot[t * 4 + j] = acc[t][j];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) slot[36 + j] = (round ? slot[36 + j] : 0.f) + accb[j];
-    }
-    __syncthreads();
+    for (int j = 0; j < 4; ++j) slot[36 + j] = accb[j];
   }
+  __syncthreads();
   for (int k = threadIdx.x; k < 64 * 40; k += blockDim.x) {
     const int gx = k / 40, v = k - gx * 40;
     const int cc = (blockIdx.x * 64 + gx) * 4;
@@ -282,10 +280,10 @@ extern "C" int cmda_dwconv3x3_bwd_weight(const void* dz, const void* x, float* d
   const RunGeom g = run_geom(B, H, W, dil, run_len(dtype));
   if (too_big(npix) || too_big(g.nruns)) return CMDA_ERR_SHAPE;
   const int gx = (C / 4 + 63) / 64;
-  int rpb = 64;  // runs per block (8 run lanes -> 8 runs per thread)
-  while (rpb > 8 && (g.nruns + rpb - 1) / rpb * gx < 1024) rpb >>= 1;
+  int rpb = 32;  // runs per block (4 run lanes -> 8 runs per thread)
+  while (rpb > 4 && (g.nruns + rpb - 1) / rpb * gx < 2048) rpb >>= 1;
   dim3 grid(gx, (unsigned)((g.nruns + rpb - 1) / rpb));
-  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((dw_bwd_weight_kernel<T>), grid, dim3(512), 0, stream, (const T*)dz,
+  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((dw_bwd_weight_kernel<T>), grid, dim3(256), 0, stream, (const T*)dz,
                                          (const T*)x, dw, dbias, g, C, rpb));
   CMDA_CHECK_LAUNCH();
 }

@@ -823,14 +823,14 @@ int launch_dtype(GemmParams& p, void* stream) {
     tile = 2;
     if (p.M > 64 && p.N > 64) {
       if (sizeof(T) == 2 && p.M >= 256 && p.N >= 256 && blocks(256, 256) >= 32) tile = 3;
-      else if (blocks(128, 128) >= 64) tile = 0;
+      else if (blocks(128, 128) >= 64 || (blocks(128, 128) >= 16 && nkt >= 1024)) tile = 0;  // very deep K: split further
       else if (blocks(128, 64) >= 48) tile = 1;  // e.g. the 320x1280 MixFFN weight gradients (57 vs 72 us on 64x64 tiles)
     }
     const long b = tile == 3 ? blocks(256, 256) : tile == 0 ? blocks(128, 128) : tile == 1 ? blocks(128, 64) : blocks(64, 64);
     long s = (512 + b - 1) / b;
     s = std::min<long>(s, std::max(1, nkt / 8));
     const long out_bytes = (long)p.M * p.N * 4 * zb;
-    s = std::min<long>(s, std::max<long>(16, (16L << 20) / std::max<long>(out_bytes, 1)));  // atomic traffic bound
+    s = std::min<long>(s, std::max<long>(16, (32L << 20) / std::max<long>(out_bytes, 1)));  // atomic traffic bound
     s = std::min<long>(s, 128);
     s = std::min<long>(s, std::max<long>(1, 65535 / std::max<long>(zb, 1)));
     p.splits = (int)std::max<long>(1, s);

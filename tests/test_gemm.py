@@ -95,3 +95,25 @@ def test_conv_implicit_gemm(tgt, dt, tag, tol, Bc, H, W, Ci, Co, KH, st, pd, dl)
         ops.gemm(ops.conv_view(dyd, Bc, OH, OW, Co, KH, KH, 1, dl * (KH - 1) - pd, dl, OH=H, OW=W),
                  ops.plain_view(wd, Ci, KH * KH * Co), dx, Bc * H * W, Ci, KH * KH * Co, dtype=tag)
         assert_close(dx, xr.grad.permute(0, 2, 3, 1), tol * 2, name='conv dgrad')
+
+
+def _run_forced_tile(marker):
+    """the tile heuristics only pick the 256x256 (8-wave) kernel for very large problems: force it (CMDA_GEMM_TILE is read
+    once per process) and run the whole GEMM suite through it in a child process"""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, CMDA_GEMM_TILE='3')
+    here = os.path.abspath(__file__)
+    r = subprocess.run([sys.executable, '-m', 'pytest', here, '-q', '-x', '-m', marker, '-k', 'not forced_tile', '-p', 'no:cacheprovider'],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_forced_tile_256_emu():
+    _run_forced_tile('not gpu')
+
+
+@pytest.mark.gpu
+def test_forced_tile_256_gpu():
+    _run_forced_tile('gpu')
