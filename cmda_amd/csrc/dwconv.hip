@@ -280,8 +280,10 @@ extern "C" int cmda_dwconv3x3_bwd_weight(const void* dz, const void* x, float* d
   const RunGeom g = run_geom(B, H, W, dil, run_len(dtype));
   if (too_big(npix) || too_big(g.nruns)) return CMDA_ERR_SHAPE;
   const int gx = (C / 4 + 63) / 64;
-  int rpb = 32;  // runs per block (4 run lanes -> 8 runs per thread)
-  while (rpb > 4 && (g.nruns + rpb - 1) / rpb * gx < 2048) rpb >>= 1;
+  // runs per block (4 run lanes): at least 4 runs per thread so the LDS fold + 2560 atomics of a block are amortised
+  // (one run per thread made the stage-3 shape 50 % slower), otherwise ~3 blocks per CU
+  int rpb = 128;
+  while (rpb > 16 && (g.nruns + rpb - 1) / rpb * gx < 768) rpb >>= 1;
   dim3 grid(gx, (unsigned)((g.nruns + rpb - 1) / rpb));
   CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((dw_bwd_weight_kernel<T>), grid, dim3(256), 0, stream, (const T*)dz,
                                          (const T*)x, dw, dbias, g, C, rpb));
