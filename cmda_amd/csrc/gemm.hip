@@ -833,7 +833,21 @@ int launch_dtype(GemmParams& p, void* stream) {
     s = std::min<long>(s, std::max<long>(16, (32L << 20) / std::max<long>(out_bytes, 1)));  // atomic traffic bound
     s = std::min<long>(s, 128);
     s = std::min<long>(s, std::max<long>(1, 65535 / std::max<long>(zb, 1)));
-    p.splits = (int)std::max<long>(1, s);
+    s = std::max<long>(1, s);
+    // wave quantisation: the grid runs in waves of `slots` resident blocks (256 CUs x blocks per CU for this tile's LDS),
+    // and a block's time is ~ K / splits -- 36 tiles x 15 splits on the one-block-per-CU 256x256 kernel is three waves
+    // (256 + 256 + 28) where 36 x 7 is one.  Take the fewest splits within 5 % of the best waves/splits ratio.
+    {
+      const long slots = 256L * (tile == 3 ? 1 : tile == 0 ? 2 : tile == 1 ? 3 : 4);
+      double best = 1e30;
+      for (long c = 1; c <= s; ++c) best = std::min(best, (double)((b * c + slots - 1) / slots) / (double)c);
+      for (long c = 1; c <= s; ++c)
+        if ((double)((b * c + slots - 1) / slots) / (double)c <= best * 1.05) {
+          s = c;
+          break;
+        }
+    }
+    p.splits = (int)s;
   } else {
     if (p.splits <= 0) p.splits = 1;
     const long sp = p.splits;
