@@ -50,6 +50,9 @@ def _declare(lib):
     lib.cmda_abi_version.restype = ctypes.c_int
     lib.cmda_layernorm_bwd_ws_floats.restype = ctypes.c_int64
     lib.cmda_layernorm_bwd_ws_floats.argtypes = [ctypes.c_int64, ctypes.c_int]
+    lib.cmda_bn_ws_floats.restype = ctypes.c_int64
+    lib.cmda_bn_ws_floats.argtypes = [ctypes.c_int]
+    lib.cmda_attention_bwd_ws_floats.restype = ctypes.c_int64
     return lib
 
 

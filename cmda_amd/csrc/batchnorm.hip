@@ -17,6 +17,9 @@ namespace {
 // All four streaming kernels share one shape: block = 64 channel-quads x 4 row lanes, a thread keeps its quad's
 // per-channel constants in registers and walks its rows four at a time (four independent 8/16-byte loads in flight).
 constexpr int kRowUnroll = 4;
+// Partial sums go to 32 workspace slots (block y % 32), not one: 1024 blocks adding into the same 2*C addresses
+// serialised in the atomic unit (~100 us of a 133 us reduction); a fold kernel / the finalize kernel sums the slots.
+constexpr int kBnSlots = 32;
 
 template <typename T>
 __global__ void bn_reduce_kernel(const T* __restrict__ x, float* __restrict__ ws, long M, int C, int rows_per_block) {
@@ -56,8 +59,9 @@ __global__ void bn_reduce_kernel(const T* __restrict__ x, float* __restrict__ ws
   if (ry == 0 && c < C) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      atomicAdd(ws + c + j, red[0][0][cx][j] + red[0][1][cx][j] + red[0][2][cx][j] + red[0][3][cx][j]);
-      atomicAdd(ws + C + c + j, red[1][0][cx][j] + red[1][1][cx][j] + red[1][2][cx][j] + red[1][3][cx][j]);
+      float* wsl = ws + (long)(blockIdx.y % kBnSlots) * 2 * C;
+      atomicAdd(wsl + c + j, red[0][0][cx][j] + red[0][1][cx][j] + red[0][2][cx][j] + red[0][3][cx][j]);
+      atomicAdd(wsl + C + c + j, red[1][0][cx][j] + red[1][1][cx][j] + red[1][2][cx][j] + red[1][3][cx][j]);
     }
   }
 }
@@ -69,7 +73,11 @@ __global__ void bn_finalize_kernel(const T* __restrict__ x, const float* __restr
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const float shift = ldf(x + c);
-  const float s = ws[c], q = ws[C + c];
+  float s = 0.f, q = 0.f;
+  for (int k = 0; k < kBnSlots; ++k) {
+    s += ws[(long)k * 2 * C + c];
+    q += ws[(long)k * 2 * C + C + c];
+  }
   const float md = s / (float)M;
   const float mu = shift + md;
   float var = q / (float)M - md * md;
@@ -165,10 +173,20 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restri
   if (ry == 0 && c < C) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      atomicAdd(ws + c + j, red[0][0][cx][j] + red[0][1][cx][j] + red[0][2][cx][j] + red[0][3][cx][j]);
-      atomicAdd(ws + C + c + j, red[1][0][cx][j] + red[1][1][cx][j] + red[1][2][cx][j] + red[1][3][cx][j]);
+      float* wsl = ws + (long)(blockIdx.y % kBnSlots) * 2 * C;
+      atomicAdd(wsl + c + j, red[0][0][cx][j] + red[0][1][cx][j] + red[0][2][cx][j] + red[0][3][cx][j]);
+      atomicAdd(wsl + C + c + j, red[1][0][cx][j] + red[1][1][cx][j] + red[1][2][cx][j] + red[1][3][cx][j]);
     }
   }
+}
+
+// ws[slots][2C] -> ws[kBnSlots][2C] (the folded sums the apply pass reads)
+__global__ void bn_fold_kernel(float* __restrict__ ws, int C2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C2) return;
+  float a = 0.f;
+  for (int k = 0; k < kBnSlots; ++k) a += ws[(long)k * C2 + i];
+  ws[(long)kBnSlots * C2 + i] = a;
 }
 
 // dx = gamma*rstd * (dyr - mean(dyr) - xhat * mean(dyr*xhat)); also accumulates dgamma / dbeta from ws
@@ -239,13 +257,15 @@ static inline int rows_per_block_apply(long M, int gx) {
 }
 }  // namespace
 
-// ws: 2*C floats of scratch (zeroed here).  Saves mean/rstd [C] for the backward, updates running stats in place.
+// ws: cmda_bn_ws_floats(C) = 66*C floats of scratch (zeroed here).  Saves mean/rstd [C] for the backward, updates running stats in place.
+extern "C" int64_t cmda_bn_ws_floats(int C) { return (int64_t)(kBnSlots + 1) * 2 * C; }
+
 extern "C" int cmda_bn_train_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                                  float* running_mean, float* running_var, float* ws, int64_t M, int C, float eps,
                                  float momentum, int relu, int ldy, int coff, int dtype, void* stream) {
   if (M <= 0 || C <= 0) return CMDA_OK;
   if ((C & 3) || (ldy & 3) || (coff & 3)) return CMDA_ERR_SHAPE;
-  (void)hipMemsetAsync(ws, 0, sizeof(float) * 2 * C, (hipStream_t)stream);
+  (void)hipMemsetAsync(ws, 0, sizeof(float) * 2 * C * kBnSlots, (hipStream_t)stream);
   const int gx = (C / 4 + 63) / 64;
   const int rpb = rows_per_block(M, gx);
   dim3 rgrid(gx, (unsigned)((M + rpb - 1) / rpb));
@@ -280,7 +300,7 @@ extern "C" int cmda_bn_train_bwd(const void* dy, const void* x, const float* mea
                                  int relu, int lddy, int coff, int dtype, void* stream) {
   if (M <= 0 || C <= 0) return CMDA_OK;
   if ((C & 3) || (lddy & 3) || (coff & 3)) return CMDA_ERR_SHAPE;
-  (void)hipMemsetAsync(ws, 0, sizeof(float) * 2 * C, (hipStream_t)stream);
+  (void)hipMemsetAsync(ws, 0, sizeof(float) * 2 * C * kBnSlots, (hipStream_t)stream);
   const int gx = (C / 4 + 63) / 64;
   const int rpb = rows_per_block(M, gx);
   dim3 rgrid(gx, (unsigned)((M + rpb - 1) / rpb));
@@ -289,8 +309,9 @@ extern "C" int cmda_bn_train_bwd(const void* dy, const void* x, const float* mea
   CMDA_DISPATCH_DTYPE(dtype, {
     CMDA_LAUNCH((bn_bwd_reduce_kernel<T>), rgrid, dim3(256), 0, stream, (const T*)dy, (const T*)x, mean, rstd, gamma,
                 beta, ws, (long)M, C, relu, lddy, coff, rpb);
+    CMDA_LAUNCH(bn_fold_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, stream, ws, 2 * C);
     CMDA_LAUNCH((bn_bwd_apply_kernel<T>), agrid, dim3(256), 0, stream, (const T*)dy, (const T*)x, mean, rstd, gamma, beta,
-                ws, (T*)dx, dgamma, dbeta, (long)M, C, relu, lddy, coff, arpb);
+                ws + (long)kBnSlots * 2 * C, (T*)dx, dgamma, dbeta, (long)M, C, relu, lddy, coff, arpb);
   });
   CMDA_CHECK_LAUNCH();
 }

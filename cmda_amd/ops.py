@@ -269,7 +269,7 @@ def bn_train_fwd(x, gamma, beta, y, running_mean, running_var, M, C, eps, moment
     check_dev(x, gamma, beta, y, running_mean, running_var)
     mean = torch.empty(C, dtype=torch.float32, device=x.device)
     rstd = torch.empty(C, dtype=torch.float32, device=x.device)
-    ws = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+    ws = torch.empty(L.lib().cmda_bn_ws_floats(C), dtype=torch.float32, device=x.device)
     call('cmda_bn_train_fwd', ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), ptr(running_mean),
          ptr(running_var), ptr(ws), c_i64(M), c_i32(C), c_f32(eps), c_f32(momentum), c_i32(int(relu)),
          c_i32(C if ldy is None else ldy), c_i32(coff), dtype_tag(x), stream_of(x))
@@ -285,7 +285,7 @@ def bn_apply(x, mean, rstd, gamma, beta, y, M, C, relu, ldy=None, coff=0):
 def bn_train_bwd(dy, x, mean, rstd, gamma, beta, dgamma, dbeta, M, C, relu, lddy=None, coff=0):
     check_dev(dy, x, mean, rstd, gamma, beta, dgamma, dbeta)
     dx = torch.empty_like(x)
-    ws = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+    ws = torch.empty(L.lib().cmda_bn_ws_floats(C), dtype=torch.float32, device=x.device)
     call('cmda_bn_train_bwd', ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(dx), ptr(dgamma),
          ptr(dbeta), ptr(ws), c_i64(M), c_i32(C), c_i32(int(relu)), c_i32(C if lddy is None else lddy), c_i32(coff),
          dtype_tag(x), stream_of(x))

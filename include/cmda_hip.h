@@ -120,7 +120,8 @@ int cmda_bilinear_bwd(const void* dy, void* dx, int B, int IH, int IW, int OH, i
 
 /* ---- Train-mode BatchNorm2d (+ReLU) -- mmcv ConvModule's norm/activate in decode_heads/daformer_head.py:46-62,
  * aspp_head.py:33-43, sep_aspp_head.py:18-27 (batch statistics, running-stat update, eps 1e-5, momentum 0.1).
- * Also used per sample as InstanceNorm2d for cyclegan/cyclegan_model.py:339-374.  ws: 2*C floats of scratch. */
+ * Also used per sample as InstanceNorm2d for cyclegan/cyclegan_model.py:339-374.  ws: cmda_bn_ws_floats(C) floats of scratch. */
+int64_t cmda_bn_ws_floats(int C);
 int cmda_bn_train_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, float*
     running_mean, float* running_var, float* ws, int64_t M, int C, float eps, float momentum, int relu, int ldy, int
     coff, int dtype, void* stream);
