@@ -117,6 +117,17 @@ def main():
                           custom_keys=dict(head=dict(lr_mult=10.0), pos_block=dict(decay_mult=0.0), norm=dict(decay_mult=0.0)))
     from cmda_amd.parallel import GradAllReducer
     reducer = GradAllReducer(opt.flat_g, wire_dtype=torch.bfloat16)  # no-op at world size 1
+    if world > 1:
+        # overlap: a stage's weight gradients (one contiguous slice of the flat buffer) start their all-reduce on the
+        # side stream as soon as that stage's backward is done; the step's reducer.all_reduce_mean() does the rest
+        stage_ranges = {f'backbone.stage{s}': opt.ranges_of(model, [f'backbone.patch_embed{s}.', f'backbone.block{s}.',
+                                                                     f'backbone.norm{s}.']) for s in range(1, 5)}
+        stage_ranges['decode_head'] = opt.ranges_of(model, ['decode_head.'])
+
+        def _ready(tag):
+            for lo, hi in stage_ranges.get(tag, ()):
+                reducer.start_range(lo, hi)
+        rt.grad_ready_hook = _ready
     torch.manual_seed(1000 + rank)  # per-rank DropPath / Dropout streams
     img, gt = synthetic_batch(args.batch, args.size, rank, dev)
     it = [0]

@@ -6,10 +6,20 @@ All trainable parameters of a model are re-homed into ONE fp32 buffer (grouped b
 gradients into a second one, so that zero_grad is one memset, the data-parallel gradient exchange is a handful of
 large RCCL calls over contiguous memory, and the AdamW update is one kernel launch per group (cmda_adamw_step).
 """
+import re
+
 import torch
 
 from . import ops
 from . import runtime as rt
+
+
+def _backward_rank(name):
+    """0 = gradients final first.  Stable for everything else (python's sort keeps the original order inside a rank)."""
+    m = re.search(r'(?:patch_embed|block|norm)([1-4])\.', name)
+    if 'decode_head' in name or 'fusion' in name:
+        return 0
+    return 5 - int(m.group(1)) if m else 5
 
 
 def _group_of(name, custom_keys):
@@ -29,9 +39,13 @@ class FlatAdamW:
             if id(p) not in seen:
                 seen.add(id(p))
                 uniq.append((n, p))
+        # inside a group, parameters sit in the order their gradients become final in the backward pass (decode head, then
+        # backbone stage 4 ... 1), so each stage's weights are ONE contiguous slice the all-reduce can start on early
+        uniq.sort(key=lambda np_: _backward_rank(np_[0]))
         groups = {}
         for n, p in uniq:
             groups.setdefault(_group_of(n, custom_keys), []).append(p)
+        self._names = {id(p): n for n, p in uniq}
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         dev = uniq[0][1].device
         total = sum((p.numel() + 7) // 8 * 8 for _, p in uniq)  # 8-element slots: 16-byte aligned in fp32 AND in the bf16 mirror
@@ -67,6 +81,24 @@ class FlatAdamW:
         """Refresh the bf16 copies after the masters were written by anything but step() (e.g. load_state_dict)."""
         if self.flat_bf16 is not None:
             ops.permute4(self.flat_p, self.flat_bf16, (self.flat_p.numel(), 1, 1, 1), (0, 1, 2, 3))
+
+    def ranges_of(self, model, prefixes, min_elems=1 << 20):
+        """Contiguous [lo, hi) slices of the flat buffers covering the parameters whose name starts with one of
+        `prefixes` (adjacent parameters merged; slices shorter than `min_elems` are dropped -- the caller's final
+        `finish()` picks those up)."""
+        base = self.flat_p.data_ptr()
+        spans = []
+        for n, p in model.named_parameters():
+            if p.requires_grad and any(n.startswith(pre) for pre in prefixes):
+                lo = (p.data.data_ptr() - base) // 4
+                spans.append((lo, lo + (p.numel() + 7) // 8 * 8))
+        out = []
+        for lo, hi in sorted(set(spans)):
+            if out and lo <= out[-1][1]:
+                out[-1][1] = max(out[-1][1], hi)
+            else:
+                out.append([lo, hi])
+        return [(lo, hi) for lo, hi in out if hi - lo >= min_elems]
 
     def zero_grad(self):
         self.flat_g.zero_()

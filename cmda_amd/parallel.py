@@ -40,41 +40,77 @@ def shard_range(total, rank, world):
 
 
 class GradAllReducer:
-    """Mean all-reduce of a flat gradient buffer in large buckets."""
+    """Mean all-reduce of a flat gradient buffer in large buckets.
+
+    Two ways to drive it per step:
+      * `all_reduce_mean()` after the backward pass (everything at once), or
+      * `start_range(lo, hi)` as soon as a contiguous slice of the buffer is final (the backward pass reports finished
+        stages through `runtime.grad_ready_hook`), then `finish()`: the collectives of the early slices run on the side
+        stream underneath the rest of the backward pass; `finish()` reduces whatever was not started and joins.
+    Every rank must issue the same ranges in the same order (it does: the schedule is a function of the model only)."""
 
     def __init__(self, flat_grad, bucket_elems=32 * 1024 * 1024, wire_dtype=torch.float32, group=None):
         self.flat = flat_grad
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.wire_dtype = wire_dtype
+        self.bucket_elems = bucket_elems
         n = flat_grad.numel()
         self.buckets = [(s, min(n, s + bucket_elems)) for s in range(0, n, bucket_elems)]
         self.stream = torch.cuda.Stream() if flat_grad.is_cuda else None
         self._wire = None
         if wire_dtype != flat_grad.dtype:
             self._wire = torch.empty(min(n, bucket_elems), dtype=wire_dtype, device=flat_grad.device)
+        self._started = []  # [lo, hi) slices already issued this step
 
-    def all_reduce_mean(self):
+    def _reduce(self, lo, hi):
+        inv = 1.0 / self.world
+        for s in range(lo, hi, self.bucket_elems):
+            e = min(hi, s + self.bucket_elems)
+            seg = self.flat[s:e]
+            if self._wire is not None:
+                w = self._wire[:e - s]
+                w.copy_(seg)
+                dist.all_reduce(w, group=self.group)
+                seg.copy_(w)
+                seg.mul_(inv)
+            else:
+                dist.all_reduce(seg, group=self.group)
+                seg.mul_(inv)
+
+    def start_range(self, lo, hi):
+        """Issue the mean all-reduce of flat[lo:hi] now (its gradients are final); returns immediately."""
+        if self.world == 1 or hi <= lo:
+            return
+        self._started.append((lo, hi))
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream())  # everything enqueued so far produced these gradients
+            with torch.cuda.stream(self.stream):
+                self._reduce(lo, hi)
+        else:
+            self._reduce(lo, hi)
+
+    def finish(self):
+        """Reduce every slice not yet started, then make the current stream wait for all of it."""
         if self.world == 1:
             return
-        inv = 1.0 / self.world
+        todo, pos = [], 0
+        for lo, hi in sorted(self._started):
+            if lo > pos:
+                todo.append((pos, lo))
+            pos = max(pos, hi)
+        if pos < self.flat.numel():
+            todo.append((pos, self.flat.numel()))
+        self._started = []
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())
-            ctx = torch.cuda.stream(self.stream)
-        else:
-            import contextlib
-            ctx = contextlib.nullcontext()
-        with ctx:
-            for lo, hi in self.buckets:
-                seg = self.flat[lo:hi]
-                if self._wire is not None:
-                    w = self._wire[:hi - lo]
-                    w.copy_(seg)
-                    dist.all_reduce(w, group=self.group)
-                    seg.copy_(w)
-                    seg.mul_(inv)
-                else:
-                    dist.all_reduce(seg, group=self.group)
-                    seg.mul_(inv)
-        if self.stream is not None:
+            with torch.cuda.stream(self.stream):
+                for lo, hi in todo:
+                    self._reduce(lo, hi)
             torch.cuda.current_stream().wait_stream(self.stream)
+        else:
+            for lo, hi in todo:
+                self._reduce(lo, hi)
+
+    def all_reduce_mean(self):
+        self.finish()

@@ -101,3 +101,14 @@ def anchor(device):
         a = torch.zeros(1, device=device, requires_grad=True)
         _anchors[device] = a
     return a
+
+
+# Optional callback fired by the hand-scheduled backward passes when a group of parameter gradients is final:
+# grad_ready_hook(tag) with tag 'decode_head' or 'backbone.stage{1..4}'.  Only meaningful when a step runs ONE backward
+# pass over those parameters (bench.py's supervised step); DACS accumulates two passes and leaves it None.
+grad_ready_hook = None
+
+
+def notify_grads_ready(tag):
+    if grad_ready_hook is not None:
+        grad_ready_hook(tag)

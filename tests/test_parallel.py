@@ -41,6 +41,18 @@ def _worker(rank, world, port, wire, out):
     w2 = torch.ones(5, requires_grad=True)
     (data * w2).pow(2).mean().backward()
     ok = ok and torch.allclose(g, w2.grad, atol=1e-6)
+    # staged exchange: two slices issued early (as the backward pass reports finished stages), the rest in finish()
+    torch.manual_seed(100 + rank)
+    flat2 = torch.randn(100003)
+    mine2 = flat2.clone()
+    red2 = GradAllReducer(flat2, bucket_elems=30000, wire_dtype=wire)
+    red2.start_range(70000, 100003)
+    red2.start_range(10, 45000)
+    red2.finish()
+    g2 = [torch.empty_like(mine2) for _ in range(world)]
+    dist.all_gather(g2, mine2)
+    ok = ok and torch.allclose(flat2, sum(g2) / world, rtol=tol, atol=tol)
+    ok = ok and red2._started == []
     out[rank] = bool(ok)
     dist.destroy_process_group()
 
@@ -56,3 +68,78 @@ def test_grad_allreduce_world2(wire):
 
 def test_shard_range():
     assert [shard_range(16, r, 8) for r in range(8)] == [(2 * r, 2 * r + 2) for r in range(8)]
+
+
+def test_flat_buffer_is_ordered_by_backward_stage():
+    """FlatAdamW lays parameters out so that a backbone stage's weights are one contiguous slice (what the overlapped
+    all-reduce starts on) and the slices of different stages are disjoint."""
+    import cmda_amd  # noqa: F401
+    from cmda_amd import optim
+    from cmda_amd.registry import build_backbone
+    import torch.nn as nn
+
+    class M(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.backbone = build_backbone(dict(type='mit_b0', style='pytorch'))
+            self.decode_head = nn.Linear(8, 8)
+    m = M()
+    opt = optim.FlatAdamW(m, custom_keys=dict(head=dict(lr_mult=10.0), pos_block=dict(decay_mult=0.0), norm=dict(decay_mult=0.0)))
+    spans = {}
+    for s in range(1, 5):
+        r = opt.ranges_of(m, [f'backbone.patch_embed{s}.', f'backbone.block{s}.', f'backbone.norm{s}.'], min_elems=0)
+        assert 1 <= len(r) <= 2, r  # the weights slice (+ the no-decay norm/bias slice of the other parameter group)
+        spans[s] = r
+        want = sum((p.numel() + 7) // 8 * 8 for n, p in m.named_parameters()
+                   if n.startswith((f'backbone.patch_embed{s}.', f'backbone.block{s}.', f'backbone.norm{s}.')))
+        assert sum(hi - lo for lo, hi in r) == want
+    flat = sorted(x for r in spans.values() for x in r)
+    assert all(a[1] <= b[0] for a, b in zip(flat, flat[1:]))
+    # stage 4 first: its weights slice starts before stage 1's in the (lr 1, decay 1) group
+    big = {s: max(r, key=lambda t: t[1] - t[0]) for s, r in spans.items()}
+    assert big[4][0] < big[3][0] < big[2][0] < big[1][0]
+
+
+@pytest.mark.gpu
+def test_backward_reports_stages_in_order_and_staged_grads_match():
+    """the hand-scheduled backward fires runtime.grad_ready_hook once per group, head first then stage 4..1, and at the
+    moment a stage is reported its slice of the flat gradient buffer is final (equal to the value after the pass)"""
+    import cmda_amd.runtime as rt
+    from cmda_amd import optim, segmentors, backbones, decode_heads  # noqa: F401
+    from cmda_amd.registry import build_segmentor
+    torch.manual_seed(0)
+    dev = torch.device('cuda:0')
+    cfg = dict(type='EncoderDecoder',
+               backbone=dict(type='MixVisionTransformer', embed_dims=[64, 128, 320, 512], num_heads=[1, 2, 5, 8],
+                             qkv_bias=True, depths=[1, 1, 1, 1], sr_ratios=[8, 4, 2, 1], drop_path_rate=0.0),
+               decode_head=dict(type='DAFormerHead', in_channels=[64, 128, 320, 512], in_index=[0, 1, 2, 3], channels=256,
+                                dropout_ratio=0.0, num_classes=19, norm_cfg=dict(type='BN'), align_corners=False,
+                                decoder_params=dict(embed_dims=256, embed_cfg=dict(type='mlp'), embed_neck_cfg=dict(type='mlp'),
+                                                    fusion_cfg=dict(type='aspp', sep=True, dilations=(1, 6, 12, 18), pool=False))))
+    model = build_segmentor(cfg).to(dev).train()
+    rt.set_compute_dtype(torch.bfloat16)
+    try:
+        opt = optim.FlatAdamW(model, custom_keys=dict(head=dict(lr_mult=10.0), norm=dict(decay_mult=0.0)))
+        ranges = {f'backbone.stage{s}': opt.ranges_of(model, [f'backbone.patch_embed{s}.', f'backbone.block{s}.', f'backbone.norm{s}.'],
+                                                     min_elems=0) for s in range(1, 5)}
+        ranges['decode_head'] = opt.ranges_of(model, ['decode_head.'], min_elems=0)
+        seen, snaps = [], {}
+
+        def hook(tag):
+            seen.append(tag)
+            snaps[tag] = [opt.flat_g[lo:hi].clone() for lo, hi in ranges[tag]]
+        rt.grad_ready_hook = hook
+        img = torch.randn(2, 3, 64, 64, device=dev)
+        gt = torch.randint(0, 19, (2, 1, 64, 64), device=dev)
+        opt.zero_grad()
+        losses, _ = model.forward_train(img, None, gt)
+        losses['decode.loss_seg'].backward()
+        torch.cuda.synchronize()
+        assert seen == ['decode_head', 'backbone.stage4', 'backbone.stage3', 'backbone.stage2', 'backbone.stage1']
+        for tag, parts in snaps.items():
+            for (lo, hi), snap in zip(ranges[tag], parts):
+                assert torch.equal(snap, opt.flat_g[lo:hi]), f'{tag}: gradients changed after the stage was reported'
+            assert sum(p.abs().sum().item() for p in parts) > 0
+    finally:
+        rt.grad_ready_hook = None
+        rt.set_compute_dtype(torch.float32)
