@@ -94,6 +94,8 @@ def main():
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--force-reducer', action='store_true',
+                    help='testing: run the gradient all-reduce path (RCCL, side stream, staged ranges) even with one rank')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -104,8 +106,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_reducer:
         import torch.distributed as dist
+        if 'MASTER_ADDR' not in os.environ:
+            os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1')
         dist.init_process_group('nccl', device_id=dev)
 
     import cmda_amd.runtime as rt
@@ -116,8 +120,8 @@ def main():
     opt = optim.FlatAdamW(model, lr=6e-5, weight_decay=0.01,
                           custom_keys=dict(head=dict(lr_mult=10.0), pos_block=dict(decay_mult=0.0), norm=dict(decay_mult=0.0)))
     from cmda_amd.parallel import GradAllReducer
-    reducer = GradAllReducer(opt.flat_g, wire_dtype=torch.bfloat16)  # no-op at world size 1
-    if world > 1:
+    reducer = GradAllReducer(opt.flat_g, wire_dtype=torch.bfloat16, force=args.force_reducer)  # no-op at world size 1
+    if reducer.active:
         # overlap: a stage's weight gradients (one contiguous slice of the flat buffer) start their all-reduce on the
         # side stream as soon as that stage's backward is done; the step's reducer.all_reduce_mean() does the rest
         stage_ranges = {f'backbone.stage{s}': opt.ranges_of(model, [f'backbone.patch_embed{s}.', f'backbone.block{s}.',
@@ -192,7 +196,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.size)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

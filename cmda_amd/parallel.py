@@ -49,10 +49,11 @@ class GradAllReducer:
         stream underneath the rest of the backward pass; `finish()` reduces whatever was not started and joins.
     Every rank must issue the same ranges in the same order (it does: the schedule is a function of the model only)."""
 
-    def __init__(self, flat_grad, bucket_elems=32 * 1024 * 1024, wire_dtype=torch.float32, group=None):
+    def __init__(self, flat_grad, bucket_elems=32 * 1024 * 1024, wire_dtype=torch.float32, group=None, force=False):
         self.flat = flat_grad
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())  # force: run the collectives even alone (testing)
         self.wire_dtype = wire_dtype
         self.bucket_elems = bucket_elems
         n = flat_grad.numel()
@@ -80,7 +81,7 @@ class GradAllReducer:
 
     def start_range(self, lo, hi):
         """Issue the mean all-reduce of flat[lo:hi] now (its gradients are final); returns immediately."""
-        if self.world == 1 or hi <= lo:
+        if not self.active or hi <= lo:
             return
         self._started.append((lo, hi))
         if self.stream is not None:
@@ -92,7 +93,7 @@ class GradAllReducer:
 
     def finish(self):
         """Reduce every slice not yet started, then make the current stream wait for all of it."""
-        if self.world == 1:
+        if not self.active:
             return
         todo, pos = [], 0
         for lo, hi in sorted(self._started):
