@@ -85,6 +85,102 @@ def cpu_baseline(size):
                       f'threads after 1 warm-up, {dt:.2f} s per image'}
 
 
+def build_dacs(dev):
+    """configs/fusion/cs2dsec_image+events_together_b5.py restated inline (the reference tree is not on the GPU box): two
+    MiT-B5 encoders, AttentionAvgFusion, shared DAFormerHeadFusion, DACS with ClassMix + ISR of the mixed image."""
+    import functools
+    import cmda_amd  # noqa: F401
+    from cmda_amd.registry import build_train_model
+    dims = [64, 128, 320, 512]
+    bb = dict(type='mit_b5', style='pytorch', drop_path_rate=0.1)
+    head = dict(type='DAFormerHeadFusion', in_channels=dims, in_index=[0, 1, 2, 3], channels=256, dropout_ratio=0.1,
+                num_classes=19, norm_cfg=dict(type='BN', requires_grad=True), align_corners=False,
+                decoder_params=dict(embed_dims=256, embed_cfg=dict(type='mlp', act_cfg=None, norm_cfg=None),
+                                    embed_neck_cfg=dict(type='mlp', act_cfg=None, norm_cfg=None),
+                                    fusion_cfg=dict(type='aspp', sep=True, dilations=(1, 6, 12, 18), pool=False,
+                                                    act_cfg=dict(type='ReLU'), norm_cfg=dict(type='BN', requires_grad=True)),
+                                    train_type='cs2dsec_image+events_together', share_decoder=True),
+                loss_decode=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0))
+    model = dict(type='FusionEncoderDecoder', backbone_image=dict(bb), backbone_events=dict(bb),
+                 fusion_module=dict(type='AttentionAvgFusion', in_channels=dims, drop_path_rate=0.1), decode_head=head,
+                 train_type='cs2dsec_image+events_together', train_cfg=dict(), test_cfg=dict(mode='whole'))
+    fcfg = dict(loss_weight={'image': 0.5, 'events': 0.5, 'fusion': 0.5, 'img_self_res': 0.25}, gradual_rate=0.0)
+    uda = dict(type='DACS', alpha=0.999, pseudo_threshold=0.968, pseudo_weight_ignore_top=15, pseudo_weight_ignore_bottom=120,
+               imnet_feature_dist_lambda=0, imnet_feature_dist_classes=None, imnet_feature_dist_scale_min_ratio=None,
+               mix='class', blur=True, color_jitter_strength=0.2, color_jitter_probability=0.2, debug_img_interval=1000,
+               print_grad_magnitude=False, train_type='cs2dsec_image+events_together', forward_cfg=fcfg,
+               cyclegan_itrd2en_path='', img_self_res_reg='no', mixed_image_to_mixed_isr=True, random_choice_thres='0.5',
+               shift_type='rightdown', isr_parms=dict(val_range=[0.01, 1.01], _threshold=0.005, _clip_range=0.1, shift_pixel=1),
+               sky_mask=None)
+    dacs = build_train_model(dict(model=model, uda=uda, runner=dict(type='IterBasedRunner', max_iters=40000)))
+    del functools
+    return dacs.to(dev).train()
+
+
+def run_dacs(args, rank, world, dev, dist):
+    import cmda_amd.runtime as rt
+    from cmda_amd import optim
+    from cmda_amd.parallel import GradAllReducer
+    B = args.batch if '--batch' in sys.argv else 2   # reference recipe: 2 source + 2 target samples per GPU
+    torch.manual_seed(1234)
+    dacs = build_dacs(dev)
+    opt = optim.FlatAdamW(dacs.model, lr=6e-5, weight_decay=0.01,
+                          custom_keys=dict(head=dict(lr_mult=10.0), pos_block=dict(decay_mult=0.0), norm=dict(decay_mult=0.0)))
+    dacs.attach_flat_store(opt)
+    reducer = GradAllReducer(opt.flat_g, wire_dtype=torch.bfloat16, force=args.force_reducer)
+    g = torch.Generator().manual_seed(100 + rank)
+    S = args.size
+    lab = torch.randint(0, 19, (B, 1, S // 32, S // 32), generator=g).repeat_interleave(32, 2).repeat_interleave(32, 3)
+    r = lambda: torch.randn(B, 3, S, S, generator=g)  # noqa: E731
+    batch = dict(source=dict(image=r().to(dev), img_time_res=r().clamp(-1, 1).to(dev), img_self_res=r().clamp(-1, 1).to(dev),
+                             label=lab.to(dev)),
+                 target=dict(warp_image=r().to(dev), events_vg=r().clamp(-1, 1).to(dev), warp_img_self_res=r().clamp(-1, 1).to(dev)))
+    torch.manual_seed(1000 + rank)
+    it = [0]
+
+    def step():
+        opt.zero_grad()
+        log_vars = dacs(**batch)
+        reducer.all_reduce_mean()
+        opt.step(optim.poly_warm_scale(it[0]))
+        it[0] += 1
+        return log_vars
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lv = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    if rank == 0:
+        nparam = sum(p.numel() for p in dacs.model.parameters())
+        out = {'metric': 'training images/sec (512x512 image+event, full CMDA UDA step)', 'value': round(2 * B * world * args.steps / dt, 3),
+               'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+               'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+               'dtype': 'bf16' if args.dtype == 'bf16' else 'f32', 'data': 'synthetic',
+               'config': {'workload': 'BASELINE.json configs[3]: full CMDA UDA step (source CE + EMA-teacher pseudo-labels, ClassMix, '
+                                      'ISR of the mixed image, colour jitter / blur, two student passes, AdamW), image+events fusion '
+                                      'student with two MiT-B5 encoders',
+                          'per_gpu_batch': f'{B} source + {B} target', 'images_counted': 'source + target samples',
+                          'image_size': S, 'parallelism': f'dp{world}', 'student_parameters_M': round(nparam / 1e6, 1)},
+               'losses': {k: round(float(v), 5) for k, v in lv.items() if 'loss' in k}}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+    del rt
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -94,6 +190,9 @@ def main():
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--workload', default='supervised', choices=['supervised', 'dacs'],
+                    help="supervised = BASELINE.json configs[1] (the bench line the driver reads); dacs = configs[3]/[4], one "
+                         "full CMDA UDA iteration (EMA teacher, pseudo-labels, ClassMix, ISR, two student passes) per step")
     ap.add_argument('--force-reducer', action='store_true',
                     help='testing: run the gradient all-reduce path (RCCL, side stream, staged ranges) even with one rank')
     args = ap.parse_args()
@@ -115,6 +214,8 @@ def main():
     import cmda_amd.runtime as rt
     from cmda_amd import ops, optim
     rt.set_compute_dtype(torch.bfloat16 if args.dtype == 'bf16' else torch.float32)
+    if args.workload == 'dacs':
+        return run_dacs(args, rank, world, dev, dist)
     torch.manual_seed(1234)  # identical initial weights on every rank
     model = build_model(dev)
     opt = optim.FlatAdamW(model, lr=6e-5, weight_decay=0.01,

@@ -103,6 +103,11 @@ class EncoderDecoder(nn.Module):
             logits, _ = self.decode_head.fwd(feats, B)
             return ops.upsample_logits_nchw(logits, H, W)
 
+    def simple_test(self, img, img_meta=None, rescale=True):
+        """encoder_decoder.py:274-285 with test_cfg mode 'whole': per-image label maps (numpy), argmax over the up-sampled
+        logits (softmax is monotone, the reference's inference() softmax does not change the argmax)."""
+        return list(self.encode_decode(img, img_meta).argmax(dim=1).cpu().numpy())
+
 
 class _Capture:
     """Adapter so that _TrainFn can hand the auxiliary outputs (logits, accuracy) back to forward_train."""

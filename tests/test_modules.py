@@ -237,3 +237,45 @@ def test_generator_golden(tgt, mode):
     seeded_fill(G, 81).eval().to(tgt.device)
     y = G(tgt.to(seeded_randn((2, 1, 32, 48), 81, 'x')))
     assert_close(y, g['y'], 1e-4 if mode == torch.float32 else 0.1, name='generator')  # bf16: 23 conv+InstanceNorm layers, random weights
+
+
+@pytest.mark.gpu
+def test_eval_path_440x640_matches_oracle():
+    """SURVEY 8f (next row): whole-image inference at the DSEC evaluation size 440x640 -- token grids that are not powers
+    of two and Nk = 260 keys (beyond the fused-attention limit, so the GEMM + softmax path runs) -- against the oracle,
+    then the mIoU bookkeeping over the two label maps."""
+    from cmda_amd import metrics
+    from cmda_amd.registry import build_segmentor
+    from oracle import head as ohd, mit as omit, segmentor as oseg
+    torch.manual_seed(0)
+    dev = torch.device('cuda:0')
+    depths = [1, 1, 1, 1]
+    cfg = dict(type='EncoderDecoder',
+               backbone=dict(type='MixVisionTransformer', embed_dims=[64, 128, 320, 512], num_heads=[1, 2, 5, 8],
+                             qkv_bias=True, depths=depths, sr_ratios=[8, 4, 2, 1], drop_path_rate=0.0),
+               decode_head=dict(type='DAFormerHead', in_channels=[64, 128, 320, 512], in_index=[0, 1, 2, 3], channels=256,
+                                dropout_ratio=0.0, num_classes=19, norm_cfg=dict(type='BN'), align_corners=False,
+                                decoder_params=dict(embed_dims=256, embed_cfg=dict(type='mlp'), embed_neck_cfg=dict(type='mlp'),
+                                                    fusion_cfg=dict(type='aspp', sep=True, dilations=(1, 6, 12, 18), pool=False))))
+    model = build_segmentor(cfg)
+    ref = oseg.EncoderDecoder(omit.MixVisionTransformer(depths=depths, drop_path_rate=0.0, eps=1e-5), ohd.DAFormerHead(dropout_ratio=0.0))
+    ref.load_state_dict(model.state_dict())
+    model.to(dev).eval()
+    ref.eval()
+    img = torch.randn(1, 3, 440, 640)
+    with torch.no_grad():
+        want = ref.encode_decode(img)
+    for dt, tol, agree_min in ((torch.float32, 1e-3, 0.9995), (torch.bfloat16, 6e-2, 0.97)):
+        rt.set_compute_dtype(dt)
+        try:
+            got = model.encode_decode(img.to(dev)).float().cpu()
+            pred = model.simple_test(img.to(dev))[0]
+        finally:
+            rt.set_compute_dtype(torch.float32)
+        assert got.shape == want.shape == (1, 19, 440, 640)
+        err = (got - want).abs().max().item() / want.abs().max().item()
+        assert err < tol, f'{dt}: logits relative error {err}'
+        agree = float((torch.from_numpy(pred) == want.argmax(1)[0]).float().mean())
+        assert agree >= agree_min, f'{dt}: argmax agreement {agree}'
+        r = metrics.mean_iou([torch.from_numpy(pred).to(dev)], [want.argmax(1)[0].to(dev)], 19, 255)
+        assert r['aAcc'].item() >= agree_min and r['IoU'].device.type == 'cuda'
