@@ -14,14 +14,15 @@ all: hip emu
 hip: cmda_amd/libcmda_hip.so
 emu: tests/emu/libcmda_emu.so
 
-build/hip/%.o: $(CSRC)/%.hip $(CSRC)/common.h
+HDRS      := $(wildcard $(CSRC)/*.h) include/cmda_hip.h
+build/hip/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p build/hip
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 cmda_amd/libcmda_hip.so: $(HIP_OBJS)
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(HIP_OBJS)
 
-build/emu/%.o: $(CSRC)/%.hip $(CSRC)/common.h tests/emu/hip_emu.h
+build/emu/%.o: $(CSRC)/%.hip $(HDRS) tests/emu/hip_emu.h
 	@mkdir -p build/emu
 	$(CLANGXX) $(EMUFLAGS) -c $< -o $@
 
@@ -33,11 +34,11 @@ tests/emu/libcmda_emu.so: $(EMU_OBJS)
 	$(CLANGXX) -shared -fPIC -pthread -o $@ $(EMU_OBJS)
 
 # tuning build: the same library with the LDS-DMA GEMM's phase stamps compiled in (tools/gemm_phase.py)
-build/hip_timing/gemm.o: $(CSRC)/gemm.hip $(CSRC)/common.h
+build/hip_timing/gemm.o: $(CSRC)/gemm.hip $(wildcard $(CSRC)/gemm_*.hip) $(HDRS)
 	@mkdir -p build/hip_timing
 	$(HIPCC) $(HIPFLAGS) -DCMDA_GEMM_TIMING -c $< -o $@
 timing: build/hip_timing/gemm.o $(HIP_OBJS)
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o build/libcmda_hip_timing.so build/hip_timing/gemm.o $(filter-out build/hip/gemm.o,$(HIP_OBJS))
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o build/libcmda_hip_timing.so build/hip_timing/gemm.o $(filter-out build/hip/gemm.o build/hip/gemm_t%.o build/hip/gemm_reg%.o,$(HIP_OBJS))
 
 clean:
 	rm -rf build cmda_amd/libcmda_hip.so tests/emu/libcmda_emu.so

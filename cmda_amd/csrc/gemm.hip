@@ -1,811 +1,8 @@
-// gemm.hip -- MFMA tile GEMM with implicit-im2col operand views and fused epilogues.
-//
-// One kernel family serves every dense contraction of the CMDA hot path (SURVEY.md K1,K3,K5,K6,K8,K10,K11,K16):
-//   nn.Linear q/kv/proj/fc1/fc2 fwd/dgrad/wgrad   mmseg/models/backbones/mix_transformer.py:31-44,62-66,80-102
-//   sr / patch-embed / ASPP / bottleneck convs     mix_transformer.py:73-76,169-173; decode_heads/daformer_head.py:63-79
-//   attention QK^T, PV and their gradients (batched, strided heads)   mix_transformer.py:97-101
-//   CycleGAN generator convs                       mmseg/models/cyclegan/cyclegan_model.py:339-374
-//
-// C[m,n] = epilogue( alpha * sum_k A(m,k) * B(n,k) ).  Each operand is a *view* V(r,c) that is either a plain
-// row-major matrix or an im2col view of an NHWC tensor (r = (b,oh,ow), c = (kh,kw,ci)); no im2col buffer is ever
-// materialised.  An operand is used either "K-contiguous" (r = free index, c = k) or "K-strided" (r = k, c = free
-// index): the LDS tile always keeps the view's natural orientation so HBM reads stay 16-byte coalesced, and the
-// K-strided bf16 fragments come out of LDS through ds_read_b64_tr_b16.
-//
-// gfx950 tiling: 256 threads = 4 waves (2x2); each wave owns (16*TM)x(16*TN) of the block tile as TMxTN MFMA
-// 16x16 accumulators; bf16 uses v_mfma_f32_16x16x32_bf16 (BK=32), f32 uses v_mfma_f32_16x16x4_f32 (BK=16, exact
-// fp32 -- the parity mode).  Global->register prefetch of tile k+1 overlaps the MFMAs of tile k.
-// Roofline: MFMA-bound for K,N >= 256; HBM-bound below (stage-1/2 Linear layers, C=64/128).
-#include <cstdlib>
-#include "common.h"
-#include "../../include/cmda_hip.h"
+// gemm.hip -- tile / split-K heuristics and dispatch of the GEMM family.  Kernel templates and their documentation:
+// gemm_kernels.h; the instantiations live in gemm_t0..t3.hip (LDS-DMA tiles) and gemm_reg.hip (register-staged).
+#include "gemm_kernels.h"
 
 namespace {
-
-typedef cmda_view_t GemmView;
-typedef cmda_gemm_params_t GemmParams;
-
-static __device__ __forceinline__ int reflect_idx(int i, int n) {
-  if (i < 0) i = -i;
-  if (i >= n) i = 2 * (n - 1) - i;
-  return i;
-}
-
-// Returns the element offset of V(r, c) or -1 when the element is structural zero (padding / out of range).
-static __device__ __forceinline__ long view_offset(const GemmView& v, long r, long c) {
-  if (r >= v.R || c >= v.Cc) return -1;
-  if (!v.conv) return r * v.ld + c;
-  const int ohw = v.OH * v.OW;
-  const int b = (int)(r / ohw);
-  const int rem = (int)(r - (long)b * ohw);
-  const int oh = rem / v.OW;
-  const int ow = rem - oh * v.OW;
-  const int cell = (int)(c / v.C);
-  const int ci = (int)(c - (long)cell * v.C);
-  const int kh = cell / v.KW;
-  const int kw = cell - kh * v.KW;
-  int ih = oh * v.stride - v.pad + kh * v.dil;
-  int iw = ow * v.stride - v.pad + kw * v.dil;
-  if (v.in_dil > 1) {  // transposed conv: input is zero-inserted by in_dil
-    if (ih < 0 || iw < 0 || (ih % v.in_dil) || (iw % v.in_dil)) return -1;
-    ih /= v.in_dil;
-    iw /= v.in_dil;
-  }
-  if (v.reflect) {
-    ih = reflect_idx(ih, v.H);
-    iw = reflect_idx(iw, v.W);
-  } else if (ih < 0 || ih >= v.H || iw < 0 || iw >= v.W) {
-    return -1;
-  }
-  return ((long)(b * v.H + ih) * v.W + iw) * v.C + ci;
-}
-
-template <typename T>
-static __device__ __forceinline__ uint4 load_chunk(const GemmView& v, const T* base, long r, long c) {
-  constexpr int CH = Num<T>::kChunk;
-  uint4 out = make_uint4(0u, 0u, 0u, 0u);
-  if (r >= v.R || c >= v.Cc) return out;
-  if (v.vec_ok && c + CH <= v.Cc) {
-    const long off = view_offset(v, r, c);
-    if (off >= 0) out = *reinterpret_cast<const uint4*>(base + off);
-    return out;
-  }
-  T tmp[CH];
-#pragma unroll
-  for (int j = 0; j < CH; ++j) {
-    const long off = view_offset(v, r, c + j);
-    tmp[j] = off >= 0 ? base[off] : (T)0;
-  }
-  __builtin_memcpy(&out, tmp, 16);
-  return out;
-}
-
-// Per-thread staging state of one operand.  Thread t fills chunks id = t + i*256 of the LDS tile: they all sit in the
-// same 16-byte column `cc` and in rows row0 + i*RSTEP, so one base offset + one uniform stride describe all of them
-// (plain views), and the K loop only adds a constant instead of re-deriving addresses.  PF register sets hold the
-// k-tiles in flight (always indexed by compile-time constants).
-template <typename T, int NCH, bool KS, int TILE, int BK, int PF>
-struct Stager {
-  static constexpr int CH = Num<T>::kChunk;
-  static constexpr int COLS = KS ? TILE : BK, CPR = COLS / CH, PITCH = COLS + CH, RSTEP = 256 / CPR;
-  long off0;           // plain fast path: element offset of chunk 0 for the next k-tile to load
-  long istride;        // plain fast path: offset between consecutive chunks of this thread (RSTEP rows)
-  long kstep;          // plain fast path: offset between consecutive k-tiles
-  int row0, cc;
-  int ca[KS ? 1 : NCH], cbc[KS ? 1 : NCH];  // conv fast path constants (see init)
-  int cx;
-  uint4 reg[PF][NCH];
-  bool fast, cfast;
-
-  __device__ __forceinline__ void init(const GemmView& v, int tid, long t0, int kt0) {
-    fast = v.vec_ok && !v.conv;
-    cfast = v.vec_ok && v.conv && v.in_dil <= 1 && !v.reflect && v.R < (1L << 31) && v.Cc < (1L << 31) &&
-            v.H < 32768 && v.W < 32768;
-    row0 = tid / CPR;
-    cc = tid - row0 * CPR;
-    const long r = KS ? (long)kt0 * BK + row0 : t0 + row0;
-    const long c = KS ? t0 + cc * CH : (long)kt0 * BK + cc * CH;
-    off0 = r * v.ld + c;
-    istride = (long)RSTEP * v.ld;
-    kstep = KS ? (long)BK * v.ld : (long)BK;
-    cx = 0;
-#pragma unroll
-    for (int i = 0; i < (KS ? 1 : NCH); ++i) ca[i] = cbc[i] = 0;
-    if (cfast) {
-      if (!KS) {  // the im2col ROW (b,oh,ow) of a chunk never changes: keep b*H and (oh*s-p, ow*s-p); -1 = out of range
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-          const long ri = r + (long)i * RSTEP;
-          if (ri < v.R) {
-            const unsigned ohw = (unsigned)(v.OH * v.OW), ru = (unsigned)ri;
-            const unsigned b = ru / ohw, rem = ru - b * ohw, oh = rem / (unsigned)v.OW, ow = rem - oh * (unsigned)v.OW;
-            ca[i] = (int)b * v.H;
-            cbc[i] = (((int)oh * v.stride - v.pad) << 16) | (((int)ow * v.stride - v.pad) & 0xffff);
-          } else {
-            ca[i] = -1;
-          }
-        }
-      } else {    // the im2col COLUMN (kh,kw,ci) is the same for all chunks of this thread; -1 = out of range
-        if (c + CH <= v.Cc) {
-          const unsigned cu = (unsigned)c, cell = cu / (unsigned)v.C, ci = cu - cell * (unsigned)v.C;
-          const unsigned kh = cell / (unsigned)v.KW, kw = cell - kh * (unsigned)v.KW;
-          ca[0] = (int)ci;
-          cbc[0] = (((int)kh * v.dil - v.pad) << 16) | (((int)kw * v.dil - v.pad) & 0xffff);
-        } else {
-          ca[0] = -1;
-        }
-      }
-    }
-  }
-
-  template <int S>
-  __device__ __forceinline__ void load(const GemmView& v, const T* base, long t0, int kt) {
-    const long rbase = KS ? (long)kt * BK + row0 : t0 + row0;
-    const long c = KS ? t0 + cc * CH : (long)kt * BK + cc * CH;
-    unsigned kh = 0, kw = 0;
-    int ci = 0;
-    if (cfast && !KS) {  // (kh,kw,ci) of this k-tile's column: same for all chunks of the thread
-      const unsigned cu = (unsigned)c, cell = cu / (unsigned)v.C;
-      ci = (int)(cu - cell * (unsigned)v.C);
-      kh = cell / (unsigned)v.KW;
-      kw = cell - kh * (unsigned)v.KW;
-    }
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const long r = rbase + (long)i * RSTEP;
-      if (fast) {
-        if (r < v.R && c + CH <= v.Cc) reg[S][i] = *reinterpret_cast<const uint4*>(base + off0 + (long)i * istride);
-        else if (r < v.R && c < v.Cc) reg[S][i] = load_chunk<T>(v, base, r, c);  // ragged last chunk
-        else reg[S][i] = make_uint4(0u, 0u, 0u, 0u);
-      } else if (cfast && ca[KS ? 0 : i] >= 0 && (KS ? r < v.R : c + CH <= v.Cc)) {
-        int bH, ih, iw, cin;
-        if (!KS) {
-          bH = ca[i];
-          ih = (cbc[i] >> 16) + (int)kh * v.dil;
-          iw = (int)(short)(cbc[i] & 0xffff) + (int)kw * v.dil;
-          cin = ci;
-        } else {
-          const unsigned ohw = (unsigned)(v.OH * v.OW), ru = (unsigned)r;
-          const unsigned b = ru / ohw, rem = ru - b * ohw, oh = rem / (unsigned)v.OW, ow = rem - oh * (unsigned)v.OW;
-          cin = ca[0];
-          bH = (int)b * v.H;
-          ih = (int)oh * v.stride + (cbc[0] >> 16);
-          iw = (int)ow * v.stride + (int)(short)(cbc[0] & 0xffff);
-        }
-        if (ih >= 0 && ih < v.H && iw >= 0 && iw < v.W)
-          reg[S][i] = *reinterpret_cast<const uint4*>(base + ((long)(bH + ih) * v.W + iw) * v.C + cin);
-        else
-          reg[S][i] = make_uint4(0u, 0u, 0u, 0u);
-      } else {
-        reg[S][i] = load_chunk<T>(v, base, r, c);
-      }
-    }
-    off0 += kstep;
-  }
-
-  template <int S>
-  __device__ __forceinline__ void store(T* lds) const {
-#pragma unroll
-    for (int i = 0; i < NCH; ++i)
-      *reinterpret_cast<uint4*>(&lds[(row0 + i * RSTEP) * PITCH + cc * CH]) = reg[S][i];
-  }
-};
-
-// ---------------------------------------------------------------------------------------------------------------
-// Fused epilogue, shared by both kernels: C = act(alpha*acc + bias) * rowscale + res + beta*C, read from the fp32 tile
-// staged in LDS.  A thread keeps ONE column quad for all its rows, so bias / tail / alignment decisions are made once;
-// the row loop is specialised on the activation and has nothing but uniform scalar branches around its loads (the first,
-// generic version of this loop spent ~7 us per 128x128 tile in branchy per-element code -- more than the k-loop of the
-// short-K GEMMs).
-template <int ACT>
-static __device__ __forceinline__ float epi_act(float x) {
-  if (ACT == 1) return fmaxf(x, 0.f);
-  if (ACT == 2) return gelu_erf(x);
-  if (ACT == 3) return tanhf(x);
-  return x;
-}
-
-template <typename T, int ACT, int BM, int BN, int PITCH_C, int NT>
-static __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* __restrict__ sC, long m0, long n,
-                                                     int q4, int r0, long cb, long rb_off, bool full, const float (&bv)[4]) {
-  constexpr int QPR = BN / 4, RSTEP = NT / QPR, NIT = BM / RSTEP;
-  const bool has_res = p.res != nullptr, has_beta = p.beta != 0.f, has_rs = p.rowscale != nullptr, f32o = p.out_f32 != 0;
-  const float alpha = p.alpha, beta = p.beta;
-#pragma unroll 4
-  for (int it = 0; it < NIT; ++it) {
-    const int row = r0 + it * RSTEP;
-    const long m = m0 + row;
-    if (m >= p.M) break;
-    const float4 t = *reinterpret_cast<const float4*>(&sC[row * PITCH_C + q4]);
-    float v[4] = {t.x, t.y, t.z, t.w};
-    const long ci = cb + m * p.ldc + n;
-    const long ri = rb_off + m * p.ldres + n;
-    float rv[4] = {0.f, 0.f, 0.f, 0.f}, ov[4] = {0.f, 0.f, 0.f, 0.f};
-    float rs = 1.f;
-    if (has_rs) rs = p.rowscale[m / p.rows_per_scale];
-    if (full) {
-      if (has_res) ld4(reinterpret_cast<const T*>(p.res) + ri, rv);
-      if (has_beta) {
-        if (f32o) ld4(reinterpret_cast<const float*>(p.C) + ci, ov);
-        else ld4(reinterpret_cast<const T*>(p.C) + ci, ov);
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (n + e >= p.N) continue;
-        if (has_res) rv[e] = ldf(reinterpret_cast<const T*>(p.res) + ri + e);
-        if (has_beta) ov[e] = f32o ? reinterpret_cast<const float*>(p.C)[ci + e] : ldf(reinterpret_cast<const T*>(p.C) + ci + e);
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = epi_act<ACT>(alpha * v[e] + bv[e]) * rs + rv[e] + beta * ov[e];
-    if (full) {
-      if (f32o) st4(reinterpret_cast<float*>(p.C) + ci, v);
-      else st4(reinterpret_cast<T*>(p.C) + ci, v);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (n + e >= p.N) continue;
-        if (f32o) reinterpret_cast<float*>(p.C)[ci + e] = v[e];
-        else stf(reinterpret_cast<T*>(p.C) + ci + e, v[e]);
-      }
-    }
-  }
-}
-
-template <typename T, int BM, int BN, int PITCH_C, int NT = 256>
-static __device__ __forceinline__ void epilogue_store(const GemmParams& p, const float* __restrict__ sC, long m0, long n0,
-                                                      long cb, long rb_off, int tid) {
-  constexpr int QPR = BN / 4;  // quads per tile row
-  static_assert(NT % QPR == 0 && BM % (NT / QPR) == 0, "tile shape");
-  const int q4 = (tid % QPR) * 4, r0 = tid / QPR;
-  const long n = n0 + q4;
-  if (n >= p.N) return;
-  const bool full = p.c_vec_ok != 0 && n + 4 <= p.N;
-  float bv[4] = {0.f, 0.f, 0.f, 0.f};
-  if (p.bias) {
-    if (full) ld4(p.bias + n, bv);
-    else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (n + e < p.N) bv[e] = p.bias[n + e];
-    }
-  }
-  if (p.act == 0) epilogue_rows<T, 0, BM, BN, PITCH_C, NT>(p, sC, m0, n, q4, r0, cb, rb_off, full, bv);
-  else if (p.act == 1) epilogue_rows<T, 1, BM, BN, PITCH_C, NT>(p, sC, m0, n, q4, r0, cb, rb_off, full, bv);
-  else if (p.act == 2) epilogue_rows<T, 2, BM, BN, PITCH_C, NT>(p, sC, m0, n, q4, r0, cb, rb_off, full, bv);
-  else epilogue_rows<T, 3, BM, BN, PITCH_C, NT>(p, sC, m0, n, q4, r0, cb, rb_off, full, bv);
-}
-
-template <typename T, int TM, int TN, bool AKS, bool BKS>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
-  constexpr int CH = Num<T>::kChunk;
-  constexpr int BM = 32 * TM, BN = 32 * TN, BK = 8 * CH;  // BK = 64 (bf16) / 32 (f32)
-  constexpr int ROWS_A = AKS ? BK : BM, COLS_A = AKS ? BM : BK, PITCH_A = COLS_A + CH;
-  constexpr int ROWS_B = BKS ? BK : BN, COLS_B = BKS ? BN : BK, PITCH_B = COLS_B + CH;
-  constexpr int NCH_A = ROWS_A * (COLS_A / CH) / 256, NCH_B = ROWS_B * (COLS_B / CH) / 256;
-  static_assert(NCH_A >= 1 && NCH_B >= 1, "tile too small for 256 threads");
-  constexpr int SZ_A = ROWS_A * PITCH_A, SZ_B = ROWS_B * PITCH_B;     // elements per stage
-  constexpr int PITCH_C = BN + 4;                                       // fp32 epilogue tile
-  constexpr size_t STAGE_BYTES = (size_t)2 * (SZ_A + SZ_B) * sizeof(T);
-  constexpr size_t EPI_BYTES = (size_t)BM * PITCH_C * sizeof(float);
-  constexpr size_t LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
-
-  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];  // ONE LDS object: 2 stages of A|B, reused by the epilogue
-  T* const sAbase = reinterpret_cast<T*>(smem);
-  T* const sBbase = sAbase + 2 * SZ_A;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
-  const int g = lane >> 4, l15 = lane & 15;
-
-  // Tile order: blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2), so give every XCD a contiguous
-  // run of tiles, and inside a run walk the n-tiles of one m-panel first: the A panel (activations, the big operand) is
-  // then re-read from that XCD's L2 instead of HBM.  Pure speed heuristic, any placement is correct.
-  const int tiles_n = (p.N + BN - 1) / BN;
-  const int ntile = gridDim.x;
-  int bt = blockIdx.x;
-  {
-    const int q = ntile / 8, rr = ntile % 8, xcd = bt % 8, loc = bt / 8;
-    bt = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
-  }
-  const long m0 = (long)(bt / tiles_n) * BM;
-  const long n0 = (long)(bt % tiles_n) * BN;
-  const int z = blockIdx.z;
-  const int bz = z / p.splits;
-  const int split = z - bz * p.splits;
-  const int batch = bz / p.batch2;
-  const int batch2 = bz - batch * p.batch2;
-  const int nkt = (p.K + BK - 1) / BK;
-  const int kt_per = (nkt + p.splits - 1) / p.splits;
-  const int kt0 = split * kt_per;
-  const int kt1 = min(nkt, kt0 + kt_per);
-
-  const T* baseA = reinterpret_cast<const T*>(p.A.ptr) + (long)batch * p.A.batch_stride + (long)batch2 * p.A.batch2_stride;
-  const T* baseB = reinterpret_cast<const T*>(p.B.ptr) + (long)batch * p.B.batch_stride + (long)batch2 * p.B.batch2_stride;
-
-  constexpr int PF = (TM * TN <= 8) ? 2 : 1;  // k-tiles in flight in registers (the 128x128 tile has no room for 2)
-  Stager<T, NCH_A, AKS, BM, BK, PF> stA;
-  Stager<T, NCH_B, BKS, BN, BK, PF> stB;
-  stA.init(p.A, tid, m0, kt0);
-  stB.init(p.B, tid, n0, kt0);
-
-  f32x4 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // Software pipeline, two k-tiles ahead: while tile kt is multiplied out of LDS stage kt&1, tile kt+1 sits in one
-  // register set (issued an iteration ago) and tile kt+2 is being fetched into the other; ONE barrier per k-tile.
-  auto compute = [&](const T* sA, const T* sB) {
-    if constexpr (sizeof(T) == 2) {
-#pragma unroll
-    for (int kk = 0; kk < BK / 32; ++kk) {
-      u16x8 fa[TM], fb[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int mr = wm * 16 * TM + i * 16;
-        if constexpr (!AKS) {
-          fa[i] = *reinterpret_cast<const u16x8*>(&sA[(mr + l15) * PITCH_A + kk * 32 + 8 * g]);
-        } else {
-          const int q = l15 >> 2, pp = l15 & 3;
-          const u16x4 lo = lds_read_tr16(reinterpret_cast<const bf16_t*>(&sA[(kk * 32 + 8 * g + q) * PITCH_A + mr + 4 * pp]));
-          const u16x4 hi = lds_read_tr16(reinterpret_cast<const bf16_t*>(&sA[(kk * 32 + 8 * g + 4 + q) * PITCH_A + mr + 4 * pp]));
-          fa[i] = u16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int nr = wn * 16 * TN + j * 16;
-        if constexpr (!BKS) {
-          fb[j] = *reinterpret_cast<const u16x8*>(&sB[(nr + l15) * PITCH_B + kk * 32 + 8 * g]);
-        } else {
-          const int q = l15 >> 2, pp = l15 & 3;
-          const u16x4 lo = lds_read_tr16(reinterpret_cast<const bf16_t*>(&sB[(kk * 32 + 8 * g + q) * PITCH_B + nr + 4 * pp]));
-          const u16x4 hi = lds_read_tr16(reinterpret_cast<const bf16_t*>(&sB[(kk * 32 + 8 * g + 4 + q) * PITCH_B + nr + 4 * pp]));
-          fb[j] = u16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16_16x16x32(fa[i], fb[j], acc[i][j]);
-    }
-  } else {
-#pragma unroll
-    for (int ks = 0; ks < BK / 4; ++ks) {
-      float fa[TM], fb[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int mr = wm * 16 * TM + i * 16;
-        fa[i] = AKS ? sA[(ks * 4 + g) * PITCH_A + mr + l15] : sA[(mr + l15) * PITCH_A + ks * 4 + g];
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int nr = wn * 16 * TN + j * 16;
-        fb[j] = BKS ? sB[(ks * 4 + g) * PITCH_B + nr + l15] : sB[(nr + l15) * PITCH_B + ks * 4 + g];
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_f32_16x16x4(fa[i], fb[j], acc[i][j]);
-    }
-  }
-  };
-  if constexpr (PF == 2) {
-    if (kt0 < kt1) {
-      stA.template load<0>(p.A, baseA, m0, kt0);
-      stB.template load<0>(p.B, baseB, n0, kt0);
-      stA.template store<0>(sAbase);
-      stB.template store<0>(sBbase);
-      if (kt0 + 1 < kt1) {
-        stA.template load<1>(p.A, baseA, m0, kt0 + 1);
-        stB.template load<1>(p.B, baseB, n0, kt0 + 1);
-      }
-    }
-    __syncthreads();
-    for (int kt = kt0; kt < kt1; kt += 2) {
-      if (kt + 2 < kt1) {
-        stA.template load<0>(p.A, baseA, m0, kt + 2);
-        stB.template load<0>(p.B, baseB, n0, kt + 2);
-      }
-      compute(sAbase, sBbase);
-      if (kt + 1 < kt1) {  // stage 1 was last read one iteration ago, behind that iteration's barrier
-        stA.template store<1>(sAbase + SZ_A);
-        stB.template store<1>(sBbase + SZ_B);
-      }
-      __syncthreads();
-      if (kt + 1 >= kt1) break;
-      if (kt + 3 < kt1) {
-        stA.template load<1>(p.A, baseA, m0, kt + 3);
-        stB.template load<1>(p.B, baseB, n0, kt + 3);
-      }
-      compute(sAbase + SZ_A, sBbase + SZ_B);
-      if (kt + 2 < kt1) {
-        stA.template store<0>(sAbase);
-        stB.template store<0>(sBbase);
-      }
-      __syncthreads();
-    }
-  } else {
-    if (kt0 < kt1) {
-      stA.template load<0>(p.A, baseA, m0, kt0);
-      stB.template load<0>(p.B, baseB, n0, kt0);
-      stA.template store<0>(sAbase);
-      stB.template store<0>(sBbase);
-    }
-    __syncthreads();
-    int cur = 0;
-    for (int kt = kt0; kt < kt1; ++kt) {
-      if (kt + 1 < kt1) {  // next tile's HBM/L2 reads fly behind this tile's MFMAs
-        stA.template load<0>(p.A, baseA, m0, kt + 1);
-        stB.template load<0>(p.B, baseB, n0, kt + 1);
-      }
-      compute(sAbase + cur * SZ_A, sBbase + cur * SZ_B);
-      if (kt + 1 < kt1) {
-        stA.template store<0>(sAbase + (cur ^ 1) * SZ_A);
-        stB.template store<0>(sBbase + (cur ^ 1) * SZ_B);
-      }
-      __syncthreads();
-      cur ^= 1;
-    }
-  }
-
-  if (kt0 >= kt1 && p.splits > 1) return;  // empty split contributes nothing
-  const long cb = (long)batch * p.c_batch_stride + (long)batch2 * p.c_batch2_stride;
-  const long rb_off = (long)batch * p.res_batch_stride + (long)batch2 * p.res_batch2_stride;
-
-  if (p.atomic) {  // split-K / gradient accumulation: fp32 atomics straight from the accumulators
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const long n = n0 + wn * 16 * TN + j * 16 + l15;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const long m = m0 + wm * 16 * TM + i * 16 + 4 * g + r;
-          if (m < p.M && n < p.N) atomicAdd(reinterpret_cast<float*>(p.C) + cb + m * p.ldc + n, p.alpha * acc[i][j][r]);
-        }
-      }
-    return;
-  }
-
-  // ---- epilogue through LDS: accumulators (C/D map col = lane&15, row = 4*(lane>>4)+r) -> fp32 tile -> every thread
-  //      finishes 4 adjacent columns of one row with vector loads/stores (bias, act, drop-path scale, residual, beta) ----
-  float* sC = reinterpret_cast<float*>(smem);
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        sC[(wm * 16 * TM + i * 16 + 4 * g + r) * PITCH_C + wn * 16 * TN + j * 16 + l15] = acc[i][j][r];
-  __syncthreads();
-  epilogue_store<T, BM, BN, PITCH_C>(p, sC, m0, n0, cb, rb_off, tid);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// LDS-DMA variant (bf16): tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR staging, no ds_write), 2-4 LDS
-// stages (GldsStages), ONE barrier per k-tile that leaves the younger stages' loads in flight.  Works for every operand mode whose 16-byte chunks are aligned (view.vec_ok):
-//   K-contiguous tile  [rows][64 k]   : 128-byte lines, fragments by ds_read_b128
-//   K-strided   tile   [64 k][cols]   : lines of `cols` bf16, fragments by ds_read_b64_tr_b16
-// LDS lines are unpadded (a wave's DMA writes 1 KiB contiguously); the 16-byte slot of logical chunk c of line r is
-// c ^ (r & 7), applied to the SOURCE address when filling and to the LDS address when reading.  Anything that must read
-// as zero (conv padding, rows/columns past the matrix, the K tail) is fetched from a 16-byte zero block, so no lane
-// ever needs a predicated LDS write.
-__device__ __attribute__((aligned(16))) unsigned g_zero16[4] = {0u, 0u, 0u, 0u};
-
-// -DCMDA_GEMM_TIMING (tuning builds only): thread 0 of the first 256 blocks stamps the 100 MHz wall clock at the phases
-// of the LDS-DMA kernel; tools/gemm_phase.py reads the stamps back through cmda_debug_gemm_stamps().
-#ifdef CMDA_GEMM_TIMING
-__device__ unsigned long long g_stamps[256 * 8];
-#define CMDA_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 256 && blockIdx.z == 0) g_stamps[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
-#else
-#define CMDA_STAMP(i) do { } while (0)
-#endif
-
-template <bool KS, int TILE, bool CONV, int NW = 4>
-struct DmaSrc {
-  static constexpr int BK = 64;
-  static constexpr int J = TILE / (8 * NW);                         // DMA instructions per wave per stage
-  static constexpr int CPL = KS ? TILE / 8 : 8;                     // 16-byte chunks per LDS line
-  static constexpr int LPI = 64 / CPL;                              // lines per DMA instruction
-  const bf16_t* ptr[J];   // plain: address of (line, chunk) for k-tile 0, or nullptr when the fixed index is out of range
-  int ca[J], cbc[J];      // conv: fixed-index constants
-  int fixed[J];           // the fixed coordinate (K-contig: r, K-strided: c), -1 when out of range
-  int line[J];            // LDS line of this lane for instruction j
-  int chunk[J];           // logical chunk of this lane for instruction j
-  static constexpr bool conv = CONV;
-
-  __device__ __forceinline__ void init(const GemmView& v, const bf16_t* base, int wid, int lane, long t0) {
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      const int ln = (wid * J + j) * LPI + lane / CPL;              // K-contig: tile row; K-strided: k row
-      const int slot = lane % CPL;
-      line[j] = ln;
-      chunk[j] = slot ^ (ln & 7);
-      ca[j] = cbc[j] = 0;
-      ptr[j] = nullptr;
-      if (!KS) {
-        const long r = t0 + ln;
-        fixed[j] = r < v.R ? (int)r : -1;
-        if (fixed[j] >= 0) {
-          if (!conv) {
-            ptr[j] = base + r * v.ld + chunk[j] * 8;
-          } else {
-            const unsigned ohw = (unsigned)(v.OH * v.OW), ru = (unsigned)r;
-            const unsigned b = ru / ohw, rem = ru - b * ohw, oh = rem / (unsigned)v.OW, ow = rem - oh * (unsigned)v.OW;
-            ca[j] = (int)b * v.H;
-            cbc[j] = (((int)oh * v.stride - v.pad) << 16) | (((int)ow * v.stride - v.pad) & 0xffff);
-          }
-        }
-      } else {
-        const long c = t0 + chunk[j] * 8;
-        fixed[j] = c + 8 <= v.Cc ? (int)c : -1;
-        if (fixed[j] >= 0) {
-          if (!conv) {
-            ptr[j] = base + (long)ln * v.ld + c;
-          } else {
-            const unsigned cu = (unsigned)c, cell = cu / (unsigned)v.C, ci = cu - cell * (unsigned)v.C;
-            const unsigned kh = cell / (unsigned)v.KW, kw = cell - kh * (unsigned)v.KW;
-            ca[j] = (int)ci;
-            cbc[j] = (((int)kh * v.dil - v.pad) << 16) | (((int)kw * v.dil - v.pad) & 0xffff);
-          }
-        }
-      }
-    }
-  }
-
-  // source address of this lane's 16 bytes for instruction j of k-tile kt
-  __device__ __forceinline__ const void* src(const GemmView& v, const bf16_t* base, int j, int kt) const {
-    const void* zero = reinterpret_cast<const void*>(g_zero16);
-    if (fixed[j] < 0) return zero;
-    if (!KS) {
-      const long c = (long)kt * BK + chunk[j] * 8;
-      if (c + 8 > v.Cc) return zero;
-      if (!conv) return ptr[j] + (long)kt * BK;
-      const unsigned cu = (unsigned)c, cell = cu / (unsigned)v.C, ci = cu - cell * (unsigned)v.C;
-      const unsigned kh = cell / (unsigned)v.KW, kw = cell - kh * (unsigned)v.KW;
-      const int ih = (cbc[j] >> 16) + (int)kh * v.dil, iw = (int)(short)(cbc[j] & 0xffff) + (int)kw * v.dil;
-      if (ih < 0 || ih >= v.H || iw < 0 || iw >= v.W) return zero;
-      return base + ((long)(ca[j] + ih) * v.W + iw) * v.C + (int)ci;
-    } else {
-      const long r = (long)kt * BK + line[j];
-      if (r >= v.R) return zero;
-      if (!conv) return ptr[j] + (long)kt * BK * v.ld;
-      const unsigned ohw = (unsigned)(v.OH * v.OW), ru = (unsigned)r;
-      const unsigned b = ru / ohw, rem = ru - b * ohw, oh = rem / (unsigned)v.OW, ow = rem - oh * (unsigned)v.OW;
-      const int ih = (int)oh * v.stride + (cbc[j] >> 16), iw = (int)ow * v.stride + (int)(short)(cbc[j] & 0xffff);
-      if (ih < 0 || ih >= v.H || iw < 0 || iw >= v.W) return zero;
-      return base + ((long)((int)b * v.H + ih) * v.W + iw) * v.C + ca[j];
-    }
-  }
-};
-
-// LDS stages per tile shape.  Measured (profiles/README.md, round 1 k): 4 stages on the 64x64 tile cut the k-loop of a
-// lone block from ~5 to 1.6 us, but 64 KiB of LDS halves the blocks per CU and the whole step got slower (the loop is
-// bound by the per-CU L2->LDS rate, ~65 GB/s, which wants MORE resident blocks, not deeper ones) -- so every tile keeps 2.
-template <int TM, int TN> struct GldsStages { static constexpr int value = 2; };
-
-// NW = 4 waves (2 x 2): tiles 64x64 / 128x64 / 128x128.  NW = 8 waves (4 x 2, 512 threads, one block per CU): the 256x256
-// tile for the large GEMMs -- the k-loop is bound by the per-CU L2->LDS rate, and a 256x256 tile moves half the bytes
-// per FLOP of a 128x128 one.  Its epilogue goes through LDS one wave-row (64 rows) at a time.
-template <int TM, int TN, bool AKS, bool BKS, bool ACONV, bool BCONV, int NW = 4>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void gemm_glds_kernel(GemmParams p) {
-  typedef bf16_t T;
-  constexpr int WM = NW / 2, NTHR = 64 * NW;
-  constexpr int BM = 16 * TM * WM, BN = 32 * TN, BK = 64;
-  constexpr int NS = GldsStages<TM, TN>::value;
-  constexpr int SZ_A = BM * BK, SZ_B = BN * BK;                       // elements per stage
-  constexpr int PITCH_C = BN + 4;
-  constexpr int EPI_ROWS = NW == 8 ? 16 * TM : BM;                    // rows staged per epilogue pass
-  constexpr size_t STAGE_BYTES = (size_t)NS * (SZ_A + SZ_B) * sizeof(T);
-  constexpr size_t EPI_BYTES = (size_t)EPI_ROWS * PITCH_C * sizeof(float);
-  constexpr size_t LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
-  __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
-  T* const sAbase = reinterpret_cast<T*>(smem);
-  T* const sBbase = sAbase + NS * SZ_A;
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1, g = lane >> 4, l15 = lane & 15;
-  const int tiles_n = (p.N + BN - 1) / BN;
-  const int ntile = gridDim.x;
-  int bt = blockIdx.x;
-  {
-    const int q = ntile / 8, rr = ntile % 8, xcd = bt % 8, loc = bt / 8;
-    bt = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
-  }
-  const long m0 = (long)(bt / tiles_n) * BM;
-  const long n0 = (long)(bt % tiles_n) * BN;
-  const int z = blockIdx.z;
-  const int bz = z / p.splits;
-  const int split = z - bz * p.splits;
-  const int batch = bz / p.batch2, batch2 = bz - batch * p.batch2;
-  const int nkt = (p.K + BK - 1) / BK;
-  const int kt_per = (nkt + p.splits - 1) / p.splits;
-  const int kt0 = split * kt_per;
-  const int kt1 = min(nkt, kt0 + kt_per);
-  const T* baseA = reinterpret_cast<const T*>(p.A.ptr) + (long)batch * p.A.batch_stride + (long)batch2 * p.A.batch2_stride;
-  const T* baseB = reinterpret_cast<const T*>(p.B.ptr) + (long)batch * p.B.batch_stride + (long)batch2 * p.B.batch2_stride;
-
-  CMDA_STAMP(0);
-  DmaSrc<AKS, BM, ACONV, NW> dA;
-  DmaSrc<BKS, BN, BCONV, NW> dB;
-  dA.init(p.A, baseA, wid, lane, m0);
-  dB.init(p.B, baseB, wid, lane, n0);
-  auto issue = [&](int stage, int kt) {
-    char* la = reinterpret_cast<char*>(sAbase + stage * SZ_A) + wid * dA.J * 1024;
-    char* lb = reinterpret_cast<char*>(sBbase + stage * SZ_B) + wid * dB.J * 1024;
-#pragma unroll
-    for (int j = 0; j < dA.J; ++j) glds16(dA.src(p.A, baseA, j, kt), la + j * 1024);
-#pragma unroll
-    for (int j = 0; j < dB.J; ++j) glds16(dB.src(p.B, baseB, j, kt), lb + j * 1024);
-  };
-
-  f32x4 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // optional fused bias gradient: blocks of the first n-tile also add up their A tile along k (A is dY^T here)
-  const bool do_colsum = AKS && p.colsum != nullptr && n0 == 0;
-  float bsum = 0.f;
-  constexpr int LPT = DmaSrc<AKS, BM, ACONV, NW>::J + DmaSrc<BKS, BN, BCONV, NW>::J;  // DMA instructions per wave per k-tile
-#pragma unroll
-  for (int s = 0; s < NS - 1; ++s)
-    if (kt0 + s < kt1) issue(s, kt0 + s);
-  CMDA_STAMP(1);
-  int st = 0;
-  for (int kt = kt0; kt < kt1; ++kt) {
-    // tile kt has landed: in steady state NS-2 younger tiles may stay in flight; in the tail fewer were issued, so drain.
-    // Past the barrier every wave is done reading stage (st-1), which the next DMA overwrites.
-    if (kt + NS - 2 < kt1) pipe_barrier<(NS - 2) * LPT>();
-    else pipe_barrier<0>();
-    if (kt == kt0) CMDA_STAMP(2);
-    {
-      int sn = st + NS - 1;
-      if (sn >= NS) sn -= NS;
-      if (kt + NS - 1 < kt1) issue(sn, kt + NS - 1);
-    }
-    const T* sA = sAbase + st * SZ_A;
-    const T* sB = sBbase + st * SZ_B;
-    if constexpr (AKS) {
-      if (do_colsum && tid < BM) {
-#pragma unroll 8
-        for (int k = 0; k < BK; ++k) bsum += bf2f(sA[k * BM + (((tid >> 3) ^ (k & 7)) << 3) + (tid & 7)]);
-      }
-    }
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      u16x8 fa[TM], fb[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int mr = wm * 16 * TM + i * 16;
-        if constexpr (!AKS) {
-          const int row = mr + l15;
-          fa[i] = *reinterpret_cast<const u16x8*>(&sA[row * BK + (((kk * 4 + g) ^ (row & 7)) << 3)]);
-        } else {
-          const int q = l15 >> 2, pp = l15 & 3;
-          const int k0 = kk * 32 + 8 * g + q, k1 = k0 + 4;
-          const int cidx = (mr >> 3) + (pp >> 1), half = (pp & 1) << 2;
-          const u16x4 lo = lds_read_tr16(&sA[k0 * BM + ((cidx ^ (k0 & 7)) << 3) + half]);
-          const u16x4 hi = lds_read_tr16(&sA[k1 * BM + ((cidx ^ (k1 & 7)) << 3) + half]);
-          fa[i] = u16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int nr = wn * 16 * TN + j * 16;
-        if constexpr (!BKS) {
-          const int row = nr + l15;
-          fb[j] = *reinterpret_cast<const u16x8*>(&sB[row * BK + (((kk * 4 + g) ^ (row & 7)) << 3)]);
-        } else {
-          const int q = l15 >> 2, pp = l15 & 3;
-          const int k0 = kk * 32 + 8 * g + q, k1 = k0 + 4;
-          const int cidx = (nr >> 3) + (pp >> 1), half = (pp & 1) << 2;
-          const u16x4 lo = lds_read_tr16(&sB[k0 * BN + ((cidx ^ (k0 & 7)) << 3) + half]);
-          const u16x4 hi = lds_read_tr16(&sB[k1 * BN + ((cidx ^ (k1 & 7)) << 3) + half]);
-          fb[j] = u16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16_16x16x32(fa[i], fb[j], acc[i][j]);
-    }
-    if (++st == NS) st = 0;
-  }
-  CMDA_STAMP(3);
-  __syncthreads();
-
-  if (kt0 >= kt1 && p.splits > 1) return;
-  if constexpr (AKS) {
-    if (do_colsum && tid < BM && m0 + tid < p.M) atomicAdd(p.colsum + m0 + tid, bsum);
-  }
-  const long cb = (long)batch * p.c_batch_stride + (long)batch2 * p.c_batch2_stride;
-  const long rb_off = (long)batch * p.res_batch_stride + (long)batch2 * p.res_batch2_stride;
-  if (p.atomic) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const long n = n0 + wn * 16 * TN + j * 16 + l15;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const long m = m0 + wm * 16 * TM + i * 16 + 4 * g + r;
-          if (m < p.M && n < p.N) atomicAdd(reinterpret_cast<float*>(p.C) + cb + m * p.ldc + n, p.alpha * acc[i][j][r]);
-        }
-      }
-    return;
-  }
-  float* sC = reinterpret_cast<float*>(smem);
-  if constexpr (NW == 4) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          sC[(wm * 16 * TM + i * 16 + 4 * g + r) * PITCH_C + wn * 16 * TN + j * 16 + l15] = acc[i][j][r];
-    __syncthreads();
-    CMDA_STAMP(4);
-    epilogue_store<T, BM, BN, PITCH_C, NTHR>(p, sC, m0, n0, cb, rb_off, tid);
-  } else {
-    for (int wr = 0; wr < WM; ++wr) {  // one wave-row (16*TM rows) per pass: its two waves stage, everyone stores
-      if (wm == wr) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              sC[(i * 16 + 4 * g + r) * PITCH_C + wn * 16 * TN + j * 16 + l15] = acc[i][j][r];
-      }
-      __syncthreads();
-      if (m0 + wr * EPI_ROWS < p.M)
-        epilogue_store<T, EPI_ROWS, BN, PITCH_C, NTHR>(p, sC, m0 + wr * EPI_ROWS, n0, cb, rb_off, tid);
-      __syncthreads();
-    }
-    CMDA_STAMP(4);
-  }
-  CMDA_STAMP(5);
-}
-
-template <int TM, int TN, int NW = 4>
-int launch_glds(const GemmParams& p, void* stream) {
-  constexpr int BM = 16 * TM * (NW / 2), BN = 32 * TN;
-  const long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  if (tiles > 0x7fffffffL || (long)p.batch * p.batch2 * p.splits > 65535) return CMDA_ERR_SHAPE;
-  dim3 grid((unsigned)tiles, 1, (unsigned)(p.batch * p.batch2 * p.splits));
-  const dim3 blk(64 * NW);
-  const bool aks = p.a_kstrided != 0, bks = p.b_kstrided != 0, ac = p.A.conv != 0, bc = p.B.conv != 0;
-  if (!aks && !bks && !ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, false, false, false, false, NW>), grid, blk, 0, stream, p);
-  else if (!aks && bks && !ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, false, true, false, false, NW>), grid, blk, 0, stream, p);
-  else if (aks && bks && !ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, true, true, false, false, NW>), grid, blk, 0, stream, p);
-  else if (aks && !bks && !ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, true, false, false, false, NW>), grid, blk, 0, stream, p);
-  else if (!aks && !bks && ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, false, false, true, false, NW>), grid, blk, 0, stream, p);
-  else if (aks && bks && !ac && bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, true, true, false, true, NW>), grid, blk, 0, stream, p);
-  else return CMDA_ERR_UNSUPPORTED;
-  CMDA_CHECK_LAUNCH();
-}
-
-template <typename T, int TM, int TN>
-int launch_tile(const GemmParams& p, void* stream) {
-  constexpr int BM = 32 * TM, BN = 32 * TN;
-  const long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  if (tiles > 0x7fffffffL || (long)p.batch * p.batch2 * p.splits > 65535) return CMDA_ERR_SHAPE;
-  dim3 grid((unsigned)tiles, 1, (unsigned)(p.batch * p.batch2 * p.splits));
-  const bool aks = p.a_kstrided != 0, bks = p.b_kstrided != 0;
-  if (!aks && !bks) CMDA_LAUNCH((gemm_kernel<T, TM, TN, false, false>), grid, dim3(256), 0, stream, p);
-  else if (!aks && bks) CMDA_LAUNCH((gemm_kernel<T, TM, TN, false, true>), grid, dim3(256), 0, stream, p);
-  else if (aks && bks) CMDA_LAUNCH((gemm_kernel<T, TM, TN, true, true>), grid, dim3(256), 0, stream, p);
-  else CMDA_LAUNCH((gemm_kernel<T, TM, TN, true, false>), grid, dim3(256), 0, stream, p);
-  CMDA_CHECK_LAUNCH();
-}
 
 template <typename T>
 int launch_dtype(GemmParams& p, void* stream) {
@@ -876,16 +73,14 @@ int launch_dtype(GemmParams& p, void* stream) {
     const bool nt_plain = kind_ok && dma_ok(p.A) && dma_ok(p.B);
     if (p.colsum && !(nt_plain && !no_glds && aks)) return CMDA_ERR_UNSUPPORTED;
     if (nt_plain && !no_glds) {
-      if (tile == 3) return launch_glds<4, 8, 8>(p, stream);
-      if (tile == 0) return launch_glds<4, 4>(p, stream);
-      if (tile == 1) return launch_glds<4, 2>(p, stream);
-      return launch_glds<2, 2>(p, stream);
+      if (tile == 3) return cmda_gemm_glds_t3_(p, stream);
+      if (tile == 0) return cmda_gemm_glds_t0_(p, stream);
+      if (tile == 1) return cmda_gemm_glds_t1_(p, stream);
+      return cmda_gemm_glds_t2_(p, stream);
     }
   }
   if (p.colsum) return CMDA_ERR_UNSUPPORTED;  // the fused bias gradient lives in the LDS-DMA kernel only
-  if (tile == 0 || tile == 3) return launch_tile<T, 4, 4>(p, stream);
-  if (tile == 1) return launch_tile<T, 4, 2>(p, stream);
-  return launch_tile<T, 2, 2>(p, stream);
+  return cmda_gemm_reg_(p, tile, stream);
 }
 
 }  // namespace
@@ -905,6 +100,18 @@ extern "C" int cmda_gemm(const cmda_gemm_params_t* pp, void* stream) {
 }
 
 #ifdef CMDA_GEMM_TIMING
+// the tuning build is ONE translation unit, so that every kernel stamps the same g_stamps array
+#include "gemm_t0.hip"
+#include "gemm_t1.hip"
+#include "gemm_t2.hip"
+#include "gemm_t3.hip"
+#include "gemm_reg.hip"
+#include "gemm_reg_f32_t0.hip"
+#include "gemm_reg_f32_t1.hip"
+#include "gemm_reg_f32_t2.hip"
+#include "gemm_reg_bf16_t0.hip"
+#include "gemm_reg_bf16_t1.hip"
+#include "gemm_reg_bf16_t2.hip"
 extern "C" int cmda_debug_gemm_stamps(unsigned long long* host_out) {
   return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 256 * 8) == hipSuccess ? 0 : -3;
 }
