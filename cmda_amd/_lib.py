@@ -33,7 +33,8 @@ class GemmParams(ctypes.Structure):
                 ('K', c_i32), ('batch', c_i32), ('batch2', c_i32), ('splits', c_i32), ('alpha', c_f32), ('beta', c_f32), ('bias', c_vp),
                 ('act', c_i32), ('res', c_vp), ('ldres', c_i64), ('res_batch_stride', c_i64), ('res_batch2_stride', c_i64),
                 ('rowscale', c_vp), ('rows_per_scale', c_i32), ('out_f32', c_i32), ('atomic', c_i32),
-                ('dtype', c_i32), ('c_vec_ok', c_i32), ('colsum', c_vp)]
+                ('dtype', c_i32), ('c_vec_ok', c_i32), ('colsum', c_vp),
+                ('c_patch_ow', c_i32), ('c_patch_kh', c_i32), ('c_patch_kwci', c_i32)]
 
 
 class CmdaError(RuntimeError):

@@ -214,6 +214,8 @@ static __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const 
   constexpr int QPR = BN / 4, RSTEP = NT / QPR, NIT = BM / RSTEP;
   const bool has_res = p.res != nullptr, has_beta = p.beta != 0.f, has_rs = p.rowscale != nullptr, f32o = p.out_f32 != 0;
   const float alpha = p.alpha, beta = p.beta;
+  const int patch_ow = p.c_patch_ow;
+  const long patch_kh = patch_ow > 0 ? n / p.c_patch_kwci : 0, patch_rest = patch_ow > 0 ? n - patch_kh * p.c_patch_kwci : 0;
 #pragma unroll 4
   for (int it = 0; it < NIT; ++it) {
     const int row = r0 + it * RSTEP;
@@ -221,7 +223,12 @@ static __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const 
     if (m >= p.M) break;
     const float4 t = *reinterpret_cast<const float4*>(&sC[row * PITCH_C + q4]);
     float v[4] = {t.x, t.y, t.z, t.w};
-    const long ci = cb + m * p.ldc + n;
+    long ci = cb + m * p.ldc + n;
+    if (patch_ow > 0) {  // un-patchify: ((boh*KH + kh) * OW + ow) * KW*Ci + (kw*Ci + ci)
+      const long boh = m / patch_ow;
+      const long ow = m - boh * patch_ow;
+      ci = ((boh * p.c_patch_kh + patch_kh) * patch_ow + ow) * p.c_patch_kwci + patch_rest;
+    }
     const long ri = rb_off + m * p.ldres + n;
     float rv[4] = {0.f, 0.f, 0.f, 0.f}, ov[4] = {0.f, 0.f, 0.f, 0.f};
     float rs = 1.f;

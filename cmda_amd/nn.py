@@ -75,12 +75,9 @@ def conv_bwd(dy, x, weight, bias, B, H, W, stride, pad, dil=1, *, need_dx=True, 
     dx = dx_out if dx_out is not None else torch.empty(B * H * W, Ci, dtype=rt.compute_dtype(), device=dy.device)
     if KH == stride and pad == 0 and dil == 1 and H % stride == 0 and W % stride == 0:
         # non-overlapping patches (spatial-reduction conv): dcol = dy @ W, then un-patchify (pure permutation)
-        dcol = torch.empty(M, K, dtype=rt.compute_dtype(), device=dy.device)
-        ops.gemm(plain_view(dy, M, Co), plain_view(rt.wconv(weight), Co, K), dcol, M, K, Co, b_kstrided=True, dtype=rt.tag())
-        if dx_beta == 0.0:
-            ops.permute4(dcol, dx, (B * OH, OW, KH, KW * Ci), (0, 2, 1, 3))
-        else:
-            ops.permute4(dcol, dx, (B * OH, OW, KH, KW * Ci), (0, 2, 1, 3), accumulate=True)
+        # the GEMM stores each row (b,oh,ow) x column (kh,kw,ci) straight at its NHWC position (c_patch): no column buffer
+        ops.gemm(plain_view(dy, M, Co), plain_view(rt.wconv(weight), Co, K), dx, M, K, Co, b_kstrided=True, dtype=rt.tag(),
+                 beta=dx_beta, c_patch=(OW, KH, KW * Ci))
         return dx
     ops.gemm(conv_view(dy, B, OH, OW, Co, KH, KW, 1, dil * (KH - 1) - pad, dil, OH=H, OW=W, in_dil=stride),
              plain_view(rt.wconv(weight, 'dgrad'), Ci, KH * KW * Co), dx, B * H * W, Ci, KH * KW * Co, dtype=rt.tag(),

@@ -46,7 +46,7 @@ GEMM_PROFILE = None
 
 def gemm(A, B, out, M, N, K, *, a_kstrided=False, b_kstrided=False, ldc=None, batch=1, c_batch_stride=0,
          batch2=1, c_batch2_stride=0, res_batch2_stride=0, splits=1, alpha=1.0, beta=0.0, bias=None, act=None, res=None, ldres=None, res_batch_stride=0,
-         rowscale=None, rows_per_scale=1, atomic=False, dtype=None, c_offset=0, colsum=None):
+         rowscale=None, rows_per_scale=1, atomic=False, dtype=None, c_offset=0, colsum=None, c_patch=None):
     """out[m,n] = epi(alpha * sum_k A(m,k) B(n,k)); A/B are `View`s built by plain_view / conv_view."""
     check_dev(out, bias, res, rowscale)
     out_f32 = out.dtype == torch.float32
@@ -76,6 +76,10 @@ def gemm(A, B, out, M, N, K, *, a_kstrided=False, b_kstrided=False, ldc=None, ba
         ok = ok and bias.data_ptr() % 16 == 0
     p.c_vec_ok = int(ok)
     p.colsum = colsum.data_ptr() if colsum is not None else None
+    if c_patch is not None:  # (OW, KH, KW*Ci): store rows (b,oh,ow) x cols (kh,kw,ci) un-patchified into NHWC
+        assert res is None and batch == 1 and batch2 == 1 and not atomic
+        p.c_patch_ow, p.c_patch_kh, p.c_patch_kwci = c_patch
+        p.c_vec_ok = int(p.C % 16 == 0 and c_patch[2] % 4 == 0 and (bias is None or bias.data_ptr() % 16 == 0))
     if GEMM_PROFILE is not None and out.is_cuda:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

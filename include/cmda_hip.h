@@ -71,6 +71,11 @@ typedef struct cmda_gemm_params_t {
   int32_t dtype;
   int32_t c_vec_ok;     /* C, res and bias may be accessed 4 elements at a time (pitches, offsets % 4 == 0, 16-B bases) */
   float* colsum;        /* optional, A K-strided only: colsum[m] += sum_k A(m,k) (bias gradient fused into wgrad) */
+  /* optional output re-layout "un-patchify" (data gradient of a kernel == stride convolution, the spatial-reduction conv
+   * of mix_transformer.py:70-75): row m = (b*OH + oh)*OW + ow, column n = (kh*KW + kw)*Ci + ci is stored at
+   * (((b*OH + oh)*KH + kh) * OW*KW + ow*KW + kw) * Ci + ci of C, i.e. straight into the NHWC input gradient instead of a
+   * column buffer.  Off when c_patch_ow == 0; ldc / batch strides / residual are ignored in this mode. */
+  int32_t c_patch_ow, c_patch_kh, c_patch_kwci;
 } cmda_gemm_params_t;
 
 int cmda_gemm(const cmda_gemm_params_t* p, void* stream);

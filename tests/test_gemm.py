@@ -117,3 +117,25 @@ def test_forced_tile_256_emu():
 @pytest.mark.gpu
 def test_forced_tile_256_gpu():
     _run_forced_tile('gpu')
+
+
+def test_gemm_unpatchify_store(tgt):
+    """c_patch: the data gradient of a kernel == stride convolution is stored straight in NHWC (mix_transformer.py:70-75's sr
+    conv backward), compared with conv_transpose2d; also with beta accumulation."""
+    import torch.nn.functional as F
+    from cmda_amd import ops
+    torch.manual_seed(5)
+    B, OH, OW, Co, Ci, k = 2, 3, 5, 24, 8, 2
+    dy = torch.randn(B, Co, OH, OW)
+    w = torch.randn(Co, Ci, k, k)
+    want = F.conv_transpose2d(dy, w, stride=k)                       # [B, Ci, OH*k, OW*k]
+    prev = torch.randn(B * OH * k * OW * k, Ci)
+    dy_rows = tgt.to(dy.permute(0, 2, 3, 1).reshape(-1, Co).contiguous())
+    w_khwc = tgt.to(w.permute(0, 2, 3, 1).reshape(Co, k * k * Ci).contiguous())
+    for beta in (0.0, 1.0):
+        dx = tgt.to(prev.clone())
+        M, K = B * OH * OW, k * k * Ci
+        ops.gemm(ops.plain_view(dy_rows, M, Co), ops.plain_view(w_khwc, Co, K), dx, M, K, Co, b_kstrided=True, dtype=0,
+                 beta=beta, c_patch=(OW, k, k * Ci))
+        ref = want.permute(0, 2, 3, 1).reshape(-1, Ci) + beta * prev
+        assert_close(dx, ref, 2e-5, name=f'unpatchify beta={beta}')
