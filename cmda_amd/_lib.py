@@ -94,9 +94,16 @@ def lib():
     return _load()
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def stream_of(t):
+    """the current HIP stream of t's device as a void* (raw handle: building a torch.cuda.Stream object per launch cost
+    ~5 us of the ~14 us a launch spends in Python)"""
     if _emulated:
         return None
+    if _raw_stream is not None:
+        return c_vp(_raw_stream(t.device.index if t.device.index is not None else torch.cuda.current_device()))
     return c_vp(torch.cuda.current_stream(t.device).cuda_stream)
 
 
