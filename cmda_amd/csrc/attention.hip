@@ -31,6 +31,7 @@ struct AttnParams {
   bf16_t* o;         // [B*N, C]
   int B, N, Nk, heads, C;
   float scale;
+  int q_per_block;
 };
 
 // K or V of one (batch, head) -> LDS [kMaxK][64] bf16, 128-byte lines, 16-byte chunk c of line r stored at slot c ^ (r & 7);
@@ -125,7 +126,11 @@ static __device__ __forceinline__ void load_qfrag(const bf16_t* __restrict__ bas
   for (int kk = 0; kk < 2; ++kk) f[kk] = *reinterpret_cast<const u16x8*>(base + row * ld + 32 * kk + 8 * g);
 }
 
-constexpr int kFwdQB = 128;  // queries per block (4 waves x 2 passes x 16)
+// queries per block of the forward-shaped kernels: 64 (one pass of 4 waves x 16) or 128 (two passes, K/V loaded once for
+// both) -- the launcher takes 64 while that still leaves the grid under ~4 blocks per CU (stage 3: 27.4 -> 22.9 us)
+static inline int fwd_queries_per_block(int B, int N, int heads) {
+  return (long)((N + 127) / 128) * heads * B < 1024 ? 64 : 128;
+}
 
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(1024))) bf16_t sK[kMaxK * kHD];
@@ -139,8 +144,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   const int nt = (p.Nk + 15) >> 4;
   const bf16_t* qb = p.q + (long)b * p.N * p.C + h * kHD;
   bf16_t* ob = p.o + (long)b * p.N * p.C + h * kHD;
-  for (int pass = 0; pass < kFwdQB / 64; ++pass) {
-    const long q0 = (long)blockIdx.x * kFwdQB + pass * 64 + wid * 16;
+  for (int pass = 0; pass < p.q_per_block / 64; ++pass) {
+    const long q0 = (long)blockIdx.x * p.q_per_block + pass * 64 + wid * 16;
     if (q0 >= p.N) break;  // wave-uniform
     u16x8 qf[2];
     load_qfrag(qb, q0, p.N, p.C, g, l15, qf);
@@ -189,6 +194,7 @@ struct AttnBwdParams {
   float* stats;  // [B, heads, N, 2] = (lse, D)
   int B, N, Nk, heads, C, q_per_block;
   float scale;
+  int fwd_q_per_block;  // of the dQ kernel
 };
 
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
@@ -206,8 +212,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
   const bf16_t* dob = p.d_o + rowb * p.C + h * kHD;
   bf16_t* dqb = p.dq + rowb * p.C + h * kHD;
   float* st = p.stats + ((long)b * p.heads + h) * p.N * 2;
-  for (int pass = 0; pass < kFwdQB / 64; ++pass) {
-    const long q0 = (long)blockIdx.x * kFwdQB + pass * 64 + wid * 16;
+  for (int pass = 0; pass < p.fwd_q_per_block / 64; ++pass) {
+    const long q0 = (long)blockIdx.x * p.fwd_q_per_block + pass * 64 + wid * 16;
     if (q0 >= p.N) break;  // wave-uniform
     u16x8 qf[2], dof[2];
     load_qfrag(qb, q0, p.N, p.C, g, l15, qf);
@@ -394,8 +400,9 @@ extern "C" int cmda_attention_fwd(const void* q, const void* kv, void* o, int B,
   if (dtype != CMDA_BF16) return CMDA_ERR_DTYPE;
   if (heads <= 0 || C != heads * kHD || Nk <= 0 || Nk > kMaxK) return CMDA_ERR_UNSUPPORTED;
   if (heads > 65535 || B > 65535) return CMDA_ERR_SHAPE;
-  AttnParams p{(const bf16_t*)q, (const bf16_t*)kv, (bf16_t*)o, B, N, Nk, heads, C, scale};
-  dim3 grid((unsigned)((N + kFwdQB - 1) / kFwdQB), (unsigned)heads, (unsigned)B);
+  const int qpb = fwd_queries_per_block(B, N, heads);
+  AttnParams p{(const bf16_t*)q, (const bf16_t*)kv, (bf16_t*)o, B, N, Nk, heads, C, scale, qpb};
+  dim3 grid((unsigned)((N + qpb - 1) / qpb), (unsigned)heads, (unsigned)B);
   CMDA_LAUNCH(attn_fwd_kernel, grid, dim3(256), 0, stream, p);
   CMDA_CHECK_LAUNCH();
 }
@@ -410,8 +417,9 @@ extern "C" int cmda_attention_bwd(const void* q, const void* kv, const void* d_o
   if (dtype != CMDA_BF16) return CMDA_ERR_DTYPE;
   if (heads <= 0 || C != heads * kHD || Nk <= 0 || Nk > kMaxK) return CMDA_ERR_UNSUPPORTED;
   if (heads * 4 > 65535 || B > 65535) return CMDA_ERR_SHAPE;
-  AttnBwdParams p{(const bf16_t*)q, (const bf16_t*)kv, (const bf16_t*)d_o, (bf16_t*)dq, dkv32, stats, B, N, Nk, heads, C, 0, scale};
-  dim3 g1((unsigned)((N + kFwdQB - 1) / kFwdQB), (unsigned)heads, (unsigned)B);
+  const int fqpb = fwd_queries_per_block(B, N, heads);
+  AttnBwdParams p{(const bf16_t*)q, (const bf16_t*)kv, (const bf16_t*)d_o, (bf16_t*)dq, dkv32, stats, B, N, Nk, heads, C, 0, scale, fqpb};
+  dim3 g1((unsigned)((N + fqpb - 1) / fqpb), (unsigned)heads, (unsigned)B);
   CMDA_LAUNCH(attn_bwd_dq_kernel, g1, dim3(256), 0, stream, p);
   // dK/dV: (batch, head, key slice) x query spans, spans a multiple of 128 queries.  Every span costs one fp32 atomic per
   // dK/dV element (~1.3 TB/s chip-wide: 1280 blocks of the stage-3 shape spent 31 of their 61 us there), so only as many

@@ -283,8 +283,11 @@ def _attention_ref(q, kv, B, N, Nk, heads, C, scale):
     return (a @ v).permute(0, 2, 1, 3).reshape(B * N, C)
 
 
-@pytest.mark.parametrize('B,N,Nk,heads', [(1, 64, 256, 1), (2, 200, 256, 2), (1, 70, 37, 1), (1, 300, 130, 5), (2, 520, 256, 1)])
+@pytest.mark.parametrize('B,N,Nk,heads', [(1, 64, 256, 1), (2, 200, 256, 2), (1, 70, 37, 1), (1, 300, 130, 5), (2, 520, 256, 1),
+                                          (16, 4100, 256, 2)])
 def test_fused_attention(tgt, B, N, Nk, heads):
+    if B * N > 20000 and tgt.device.type != 'cuda':
+        pytest.skip('the 128-queries-per-block launch shape only occurs on grids far too large for the emulator')
     """fused softmax(q k^T) v and its backward (probabilities recomputed in LDS) against autograd on the same bf16 inputs"""
     torch.manual_seed(N + Nk)
     C, scale = heads * 64, 0.125
