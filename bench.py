@@ -270,14 +270,17 @@ def main():
     step()
     torch.cuda.synchronize()
     prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
-    gemm_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in prof)
-    gemm_flops = sum(f for f, _, _ in prof)
+    gemm_ms = sum(e0.elapsed_time(e1) for _, e0, e1, _ in prof)
+    gemm_flops = sum(f for f, _, _, _ in prof)
+    gemm_bytes = sum(b for _, _, _, b in prof)
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     roofline = {'bound': 'mfma', 'kernel': 'gemm_glds_kernel + gemm_kernel (bf16 MFMA 16x16x32 tile GEMM / implicit-GEMM conv family, all template instances)',
                 'achieved': round(achieved, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,
                 'launches_per_step': len(prof), 'avg_launch_us': round(gemm_ms * 1e3 / max(len(prof), 1), 2),
-                'gemm_ms_per_step': round(gemm_ms, 3), 'algorithmic_gflop_per_step': round(gemm_flops / 1e9, 1)}
+                'gemm_ms_per_step': round(gemm_ms, 3), 'algorithmic_gflop_per_step': round(gemm_flops / 1e9, 1),
+                'algorithmic_mb_per_launch': round(gemm_bytes / max(len(prof), 1) / 1e6, 2),
+                'traffic_note': 'PMC FETCH_SIZE/WRITE_SIZE of the same command are in profiles/README.md (separate rocprofv3 passes)'}
 
     if rank == 0:
         ms = dt / args.steps * 1e3
