@@ -183,9 +183,8 @@ class MixVisionTransformer(nn.Module):
             for m in self.modules():
                 self._init_weights(m)
         elif isinstance(self.pretrained, str):
-            ckpt = torch.load(self.pretrained, map_location='cpu')
-            sd = ckpt.get('state_dict', ckpt.get('model', ckpt))
-            self.load_state_dict(sd, False)
+            from .checkpoint import load_checkpoint  # mix_transformer.py:343-357: _load_checkpoint + non-strict load
+            load_checkpoint(self, self.pretrained, map_location='cpu', strict=False)
         rt.invalidate()
 
     def reset_drop_path(self, drop_path_rate):

@@ -1,0 +1,89 @@
+"""Checkpoint I/O for the path's modules ("next" row).
+
+The reference goes through mmcv (third-party, absent from /root/reference): `mmcv.runner.load_checkpoint(model, filename,
+map_location, strict, revise_keys=[(r'^module\\.', '')])` in mmseg/apis/inference.py:42-45 and mmseg/apis/train.py:130,
+`_load_checkpoint` + `load_state_dict(strict=False)` in mix_transformer.py:343-357 (ImageNet weights: the file holds either
+the bare state dict or {'state_dict': ...} / {'model': ...}), and `save_checkpoint` from the runner's checkpoint hook
+({'meta': ..., 'state_dict': ..., 'optimizer': ...}, weights moved to the CPU).  Restated from that documented behaviour:
+same file layout, same key handling, so checkpoints written by either side load in the other (the state-dict keys of every
+module here equal the reference's: tests/golden/*_keys.json).
+
+After loading, the kernels' cached compute copies of the parameters are invalidated (runtime.invalidate) and, when the
+model's parameters live in a FlatAdamW store, `optimizer.sync_bf16()` must be called by the owner of the optimizer.
+"""
+import re
+import time
+from collections import OrderedDict
+
+import torch
+
+from . import runtime as rt
+
+
+def _state_dict_of(ckpt):
+    if not isinstance(ckpt, dict):
+        raise RuntimeError(f'no state dict found in checkpoint of type {type(ckpt)}')
+    for key in ('state_dict', 'model'):
+        if key in ckpt and isinstance(ckpt[key], dict):
+            return ckpt[key]
+    return ckpt
+
+
+def load_state_dict(module, state_dict, strict=False, logger=None):
+    """mmcv.runner.load_state_dict: never raises on shape/key mismatch unless strict; returns (missing, unexpected)."""
+    own = module.state_dict()
+    missing = [k for k in own if k not in state_dict and 'num_batches_tracked' not in k]
+    unexpected = [k for k in state_dict if k not in own]
+    mismatch = [k for k in state_dict if k in own and tuple(state_dict[k].shape) != tuple(own[k].shape)]
+    usable = {k: v for k, v in state_dict.items() if k in own and k not in mismatch}
+    with torch.no_grad():
+        for k, v in usable.items():
+            own[k].copy_(v)   # in place: parameters re-homed into flat optimizer buffers keep their storage
+    rt.invalidate()
+    msg = []
+    if unexpected:
+        msg.append('unexpected key in source state_dict: ' + ', '.join(unexpected))
+    if missing:
+        msg.append('missing keys in source state_dict: ' + ', '.join(missing))
+    if mismatch:
+        msg.append('size mismatch for: ' + ', '.join(mismatch))
+    if msg:
+        text = 'The model and loaded state dict do not match exactly\n' + '\n'.join(msg)
+        if strict:
+            raise RuntimeError(text)
+        if logger is not None:
+            logger.warning(text)
+    return missing, unexpected + mismatch
+
+
+def load_checkpoint(model, filename, map_location='cpu', strict=False, logger=None, revise_keys=((r'^module\.', ''),)):
+    """Load `filename` into `model` (a bare module or one wrapped as `.module`); returns the checkpoint dict."""
+    ckpt = torch.load(filename, map_location=map_location, weights_only=False)
+    sd = _state_dict_of(ckpt)
+    meta = getattr(sd, '_metadata', None)
+    for pat, rep in revise_keys:
+        sd = OrderedDict((re.sub(pat, rep, k), v) for k, v in sd.items())
+    if meta is not None:
+        sd._metadata = meta
+    load_state_dict(getattr(model, 'module', model), sd, strict, logger)
+    return ckpt
+
+
+def weights_to_cpu(state_dict):
+    out = OrderedDict((k, v.detach().cpu()) for k, v in state_dict.items())
+    out._metadata = getattr(state_dict, '_metadata', OrderedDict())
+    return out
+
+
+def save_checkpoint(model, filename, optimizer=None, meta=None):
+    """{'meta', 'state_dict'[, 'optimizer']} with CPU weights, as the runner's CheckpointHook writes it."""
+    meta = dict(meta or {})
+    meta.setdefault('time', time.asctime())
+    module = getattr(model, 'module', model)
+    if hasattr(module, 'CLASSES') and module.CLASSES is not None:
+        meta.setdefault('CLASSES', module.CLASSES)
+    ckpt = {'meta': meta, 'state_dict': weights_to_cpu(module.state_dict())}
+    if optimizer is not None:
+        ckpt['optimizer'] = optimizer.state_dict() if hasattr(optimizer, 'state_dict') else optimizer
+    torch.save(ckpt, filename)
+    return ckpt
