@@ -186,7 +186,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=int(os.environ.get('CMDA_BENCH_BATCH', 16)), help='images per GPU')
+    ap.add_argument('--batch', type=int, default=int(os.environ.get('CMDA_BENCH_BATCH', 64)), help='images per GPU')
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
