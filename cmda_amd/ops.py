@@ -115,9 +115,7 @@ _LN_WS = {}
 def _ln_ws(device, n):
     """persistent zero-initialised LayerNorm-backward workspace (the kernel pair leaves it zeroed; calls on one stream
     are ordered, so one buffer per device is enough)"""
-    # one buffer per (device, stream): calls on one stream are ordered, calls on different streams (the two encoders of the
-    # fusion student run concurrently) must not share it
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0)
+    key = (device.type, device.index)
     ws = _LN_WS.get(key)
     if ws is None or ws.numel() < n:
         ws = _LN_WS[key] = torch.zeros(max(n, 64 * 2 * 1024), dtype=torch.float32, device=device)

@@ -8,8 +8,6 @@ backward pass and accumulates parameter gradients in place.
 """
 from collections import OrderedDict
 
-import os
-
 import torch
 import torch.nn as nn
 
@@ -126,38 +124,6 @@ class _Capture:
         return self.model.train_bwd(saved, gscale)
 
 
-_SIDE_STREAMS = {}
-
-
-class _fork:
-    """`with _fork(tensor, enabled) as side: with side: <work A>; <work B>` -- work A runs on a side HIP stream that first
-    waits for everything enqueued so far, work B on the current stream, and leaving the block joins them (the current stream
-    waits for the side stream).  Every tensor that crosses between the two stays referenced until the join, so the caching
-    allocator never hands its memory to the other stream early.  Disabled (both run in order on the current stream) for CPU
-    tensors (emulator tests), when there is only one branch, or with CMDA_TWO_STREAMS=0."""
-
-    def __init__(self, like, enabled):
-        self.on = bool(enabled) and like is not None and like.is_cuda and os.environ.get('CMDA_TWO_STREAMS', '1') != '0'
-        self.dev = like.device if like is not None else None
-
-    def __enter__(self):
-        import contextlib
-        if not self.on:
-            return contextlib.nullcontext()
-        key = (self.dev.index, torch.cuda.current_stream(self.dev).cuda_stream)
-        side = _SIDE_STREAMS.get(key)
-        if side is None:
-            side = _SIDE_STREAMS[key] = torch.cuda.Stream(self.dev)
-        self.side = side
-        side.wait_stream(torch.cuda.current_stream(self.dev))
-        return torch.cuda.stream(side)
-
-    def __exit__(self, *exc):
-        if self.on:
-            torch.cuda.current_stream(self.dev).wait_stream(self.side)
-        return False
-
-
 def _sum_grads(a, b):
     """element-wise sum of two per-level gradient lists/dicts (entries may be None)."""
     out = []
@@ -215,17 +181,12 @@ class FusionEncoderDecoder(nn.Module):
         B = (image if image is not None else events).shape[0]
         sv = {}
         f_image = f_events = f_isr = None
-        # The image encoder and the event encoder are independent until the fusion module: run them on two HIP streams
-        # (at the reference's 2 samples per GPU a single pass leaves most of the 256 CUs idle).  events and img_self_res
-        # share backbone_events, so they stay in order on ONE stream (their gradient accumulations are not all atomic).
-        with _fork(image if image is not None else events, image is not None and (events is not None or img_self_res is not None)) as side:
-            with side:
-                if events is not None:
-                    f_events, sv['events'] = self.backbone_events.fwd(events, save=save)
-                if img_self_res is not None:
-                    f_isr, sv['isr'] = self.backbone_events.fwd(img_self_res, save=save)
-            if image is not None:
-                f_image, sv['image'] = self.backbone_image.fwd(image, save=save)
+        if image is not None:
+            f_image, sv['image'] = self.backbone_image.fwd(image, save=save)
+        if events is not None:
+            f_events, sv['events'] = self.backbone_events.fwd(events, save=save)
+        if img_self_res is not None:
+            f_isr, sv['isr'] = self.backbone_events.fwd(img_self_res, save=save)
         f_fusion = None
         if cfg.get('no_fusion'):
             pass
@@ -264,17 +225,12 @@ class FusionEncoderDecoder(nn.Module):
                 else:
                     d_evt = _sum_grads(d_evt, de)
         as_list = lambda d: [d.get(i) for i in range(4)] if isinstance(d, dict) else d
-        do_img = 'image' in sv and d_img is not None
-        do_evt = ('isr' in sv and d_isr is not None) or ('events' in sv and d_evt is not None)
-        some = next((t for t in (as_list(d_img) or []) + (as_list(d_evt) or []) + (as_list(d_isr) or []) if t is not None), None)
-        with _fork(some, do_img and do_evt) as side:  # same two-stream split as the forward pass
-            with side:
-                if 'isr' in sv and d_isr is not None:
-                    self.backbone_events.bwd(sv['isr'], as_list(d_isr))
-                if 'events' in sv and d_evt is not None:
-                    self.backbone_events.bwd(sv['events'], as_list(d_evt))
-            if do_img:
-                self.backbone_image.bwd(sv['image'], as_list(d_img))
+        if 'image' in sv and d_img is not None:
+            self.backbone_image.bwd(sv['image'], as_list(d_img))
+        if 'isr' in sv and d_isr is not None:
+            self.backbone_events.bwd(sv['isr'], as_list(d_isr))
+        if 'events' in sv and d_evt is not None:
+            self.backbone_events.bwd(sv['events'], as_list(d_evt))
 
     # -- hand-scheduled training pass ---------------------------------------------------------------------------------
     def train_fwd(self, inputs, gt, seg_weight, cfg):
