@@ -93,20 +93,22 @@ __global__ void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__
 // slots into dgamma / dbeta.  (All blocks hammering the same 2*C addresses was the bottleneck of the first version, one
 // workspace row per block made the finalize pass as expensive as the main kernel -- 64 slots keeps both cheap: <= 32
 // adds per address, and the grid can be as wide as the rows want.)
-template <typename T>
+// NV = vector passes per lane (ceil(C/4 / lanes per row)): a compile-time bound, so that C = 320 (2 passes) does not carry
+// the registers of the C = 1024 case (4 passes) -- 128 VGPRs / 4 waves per SIMD before, and the kernel is latency-bound
+template <typename T, int NV>
 __global__ void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
                               const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                               const T* __restrict__ dres, T* __restrict__ dx, float* __restrict__ ws, long rows,
                               int C, int lpr) {
-  __shared__ float red[2][4096];  // [gamma/beta][slot = wave*rows_per_wave + group][channel]  (32 KiB; slots*C <= 4096)
+  __shared__ float red[2][1024 * NV];  // [gamma/beta][slot = wave*rows_per_wave + group][channel]  (slots*C <= 1024*NV)
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
   const int wpb = blockDim.x >> 6;
   const int rpw = 64 / lpr, li = lane & (lpr - 1), grp = lane / lpr;
   const int nvec = C >> 2;
-  float ag[kMaxVec][4], ab[kMaxVec][4], gm[kMaxVec][4];
+  float ag[NV][4], ab[NV][4], gm[NV][4];
 #pragma unroll
-  for (int i = 0; i < kMaxVec; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int vi = i * lpr + li;
 #pragma unroll
     for (int j = 0; j < 4; ++j) ag[i][j] = ab[i][j] = gm[i][j] = 0.f;
@@ -121,10 +123,10 @@ __global__ void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
       mean = mean_in[row];
       rstd = rstd_in[row];
     }
-    float xh[kMaxVec][4], g[kMaxVec][4];
+    float xh[NV][4], g[NV][4];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < kMaxVec; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int vi = i * lpr + li;
       if (live && vi < nvec) {
         float xv[4], dv[4];
@@ -145,7 +147,7 @@ __global__ void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
     s2 = group_sum(s2, lpr) / (float)C;
     if (!live) continue;
 #pragma unroll
-    for (int i = 0; i < kMaxVec; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int vi = i * lpr + li;
       if (vi < nvec) {
         float o[4];
@@ -164,7 +166,7 @@ __global__ void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
   // cross-group / cross-wave reduce of the parameter gradients, one partial per channel per block
   const int slot = wid * rpw + grp, nslots = wpb * rpw;
 #pragma unroll
-  for (int i = 0; i < kMaxVec; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int vi = i * lpr + li;
     if (vi < nvec) {
 #pragma unroll
@@ -247,8 +249,14 @@ extern "C" int cmda_layernorm_bwd(const void* dy, const void* x, const float* ga
   if (C <= 0 || (C & 3) || C > kMaxVec * 256) return CMDA_ERR_SHAPE;
   const int wpb = 4, lpr = lanes_per_row(C);
   const int grid = (int)ln_bwd_grid(rows, C);
-  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((ln_bwd_kernel<T>), dim3(grid), dim3(64 * wpb), 0, stream, (const T*)dy,
-                                         (const T*)x, gamma, mean, rstd, (const T*)dres, (T*)dx, ws, (long)rows, C, lpr));
+  const int nv = ((C >> 2) + lpr - 1) / lpr;
+#define CMDA_LN_BWD(NVV)                                                                                                 \
+  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((ln_bwd_kernel<T, NVV>), dim3(grid), dim3(64 * wpb), 0, stream, (const T*)dy, \
+                                         (const T*)x, gamma, mean, rstd, (const T*)dres, (T*)dx, ws, (long)rows, C, lpr))
+  if (nv <= 1) { CMDA_LN_BWD(1); }
+  else if (nv == 2) { CMDA_LN_BWD(2); }
+  else { CMDA_LN_BWD(4); }
+#undef CMDA_LN_BWD
   CMDA_LAUNCH(ln_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, stream, ws, dgamma, dbeta,
               std::min(grid, kSlots), C);
   CMDA_CHECK_LAUNCH();
