@@ -528,9 +528,13 @@ struct DmaSrc {
   int fixed[J];           // the fixed coordinate (K-contig: r, K-strided: c), -1 when out of range
   int line[J];            // LDS line of this lane for instruction j
   int chunk[J];           // logical chunk of this lane for instruction j
+  // conv views: the moving coordinate of the NEXT k-tile, advanced incrementally by src() (one k-tile = +64 along K; two
+  // 32-bit divisions per DMA instruction per k-tile cost about as many VALU cycles as the tile's MFMAs)
+  //   K-contiguous (fwd / dgrad):  (ci, kh, kw) of the chunk's first channel      K-strided (wgrad):  (b, oh, ow) of the row
+  int s0[J], s1[J], s2[J];
   static constexpr bool conv = CONV;
 
-  __device__ __forceinline__ void init(const GemmView& v, const bf16_t* base, int wid, int lane, long t0) {
+  __device__ __forceinline__ void init(const GemmView& v, const bf16_t* base, int wid, int lane, long t0, int kt0) {
 #pragma unroll
     for (int j = 0; j < J; ++j) {
       const int ln = (wid * J + j) * LPI + lane / CPL;              // K-contig: tile row; K-strided: k row
@@ -538,6 +542,7 @@ struct DmaSrc {
       line[j] = ln;
       chunk[j] = slot ^ (ln & 7);
       ca[j] = cbc[j] = 0;
+      s0[j] = s1[j] = s2[j] = 0;
       ptr[j] = nullptr;
       if (!KS) {
         const long r = t0 + ln;
@@ -550,6 +555,10 @@ struct DmaSrc {
             const unsigned b = ru / ohw, rem = ru - b * ohw, oh = rem / (unsigned)v.OW, ow = rem - oh * (unsigned)v.OW;
             ca[j] = (int)b * v.H;
             cbc[j] = (((int)oh * v.stride - v.pad) << 16) | (((int)ow * v.stride - v.pad) & 0xffff);
+            const unsigned cu = (unsigned)((long)kt0 * BK + chunk[j] * 8), cell = cu / (unsigned)v.C;
+            s0[j] = (int)(cu - cell * (unsigned)v.C);
+            s1[j] = (int)(cell / (unsigned)v.KW);
+            s2[j] = (int)(cell - (unsigned)s1[j] * (unsigned)v.KW);
           }
         }
       } else {
@@ -563,34 +572,54 @@ struct DmaSrc {
             const unsigned kh = cell / (unsigned)v.KW, kw = cell - kh * (unsigned)v.KW;
             ca[j] = (int)ci;
             cbc[j] = (((int)kh * v.dil - v.pad) << 16) | (((int)kw * v.dil - v.pad) & 0xffff);
+            const unsigned ohw = (unsigned)(v.OH * v.OW), ru = (unsigned)((long)kt0 * BK + ln);
+            const unsigned b = ru / ohw, rem = ru - b * ohw;
+            s0[j] = (int)b;
+            s1[j] = (int)(rem / (unsigned)v.OW);
+            s2[j] = (int)(rem - (unsigned)s1[j] * (unsigned)v.OW);
           }
         }
       }
     }
   }
 
-  // source address of this lane's 16 bytes for instruction j of k-tile kt
-  __device__ __forceinline__ const void* src(const GemmView& v, const bf16_t* base, int j, int kt) const {
+  // source address of this lane's 16 bytes for instruction j of k-tile kt.  Conv views: must be called once per (j, kt)
+  // with kt = kt0, kt0 + 1, ... (the pipeline issues k-tiles in order) -- the call advances the moving coordinate.
+  __device__ __forceinline__ const void* src(const GemmView& v, const bf16_t* base, int j, int kt) {
     const void* zero = reinterpret_cast<const void*>(g_zero16);
     if (fixed[j] < 0) return zero;
     if (!KS) {
       const long c = (long)kt * BK + chunk[j] * 8;
+      if (!conv) return c + 8 > v.Cc ? zero : static_cast<const void*>(ptr[j] + (long)kt * BK);
+      const int ci = s0[j], kh = s1[j], kw = s2[j];
+      {  // advance to the next k-tile: +64 channels, carrying into (kw, kh)
+        int nci = ci + BK, nkw = kw, nkh = kh;
+        while (nci >= v.C) {
+          nci -= v.C;
+          if (++nkw == v.KW) { nkw = 0; ++nkh; }
+        }
+        s0[j] = nci; s1[j] = nkh; s2[j] = nkw;
+      }
       if (c + 8 > v.Cc) return zero;
-      if (!conv) return ptr[j] + (long)kt * BK;
-      const unsigned cu = (unsigned)c, cell = cu / (unsigned)v.C, ci = cu - cell * (unsigned)v.C;
-      const unsigned kh = cell / (unsigned)v.KW, kw = cell - kh * (unsigned)v.KW;
-      const int ih = (cbc[j] >> 16) + (int)kh * v.dil, iw = (int)(short)(cbc[j] & 0xffff) + (int)kw * v.dil;
+      const int ih = (cbc[j] >> 16) + kh * v.dil, iw = (int)(short)(cbc[j] & 0xffff) + kw * v.dil;
       if (ih < 0 || ih >= v.H || iw < 0 || iw >= v.W) return zero;
-      return base + ((long)(ca[j] + ih) * v.W + iw) * v.C + (int)ci;
+      return base + ((long)(ca[j] + ih) * v.W + iw) * v.C + ci;
     } else {
       const long r = (long)kt * BK + line[j];
+      if (!conv) return r >= v.R ? zero : static_cast<const void*>(ptr[j] + (long)kt * BK * v.ld);
+      const int b = s0[j], oh = s1[j], ow = s2[j];
+      {  // advance to the next k-tile: +64 output pixels, carrying into (oh, b)
+        int now = ow + BK, noh = oh, nb = b;
+        while (now >= v.OW) {
+          now -= v.OW;
+          if (++noh == v.OH) { noh = 0; ++nb; }
+        }
+        s0[j] = nb; s1[j] = noh; s2[j] = now;
+      }
       if (r >= v.R) return zero;
-      if (!conv) return ptr[j] + (long)kt * BK * v.ld;
-      const unsigned ohw = (unsigned)(v.OH * v.OW), ru = (unsigned)r;
-      const unsigned b = ru / ohw, rem = ru - b * ohw, oh = rem / (unsigned)v.OW, ow = rem - oh * (unsigned)v.OW;
-      const int ih = (int)oh * v.stride + (cbc[j] >> 16), iw = (int)ow * v.stride + (int)(short)(cbc[j] & 0xffff);
+      const int ih = oh * v.stride + (cbc[j] >> 16), iw = ow * v.stride + (int)(short)(cbc[j] & 0xffff);
       if (ih < 0 || ih >= v.H || iw < 0 || iw >= v.W) return zero;
-      return base + ((long)((int)b * v.H + ih) * v.W + iw) * v.C + ca[j];
+      return base + ((long)(b * v.H + ih) * v.W + iw) * v.C + ca[j];
     }
   }
 };
@@ -644,8 +673,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void gemm_glds_kernel(Gem
   CMDA_STAMP(0);
   DmaSrc<AKS, BM, ACONV, NW> dA;
   DmaSrc<BKS, BN, BCONV, NW> dB;
-  dA.init(p.A, baseA, wid, lane, m0);
-  dB.init(p.B, baseB, wid, lane, n0);
+  dA.init(p.A, baseA, wid, lane, m0, kt0);
+  dB.init(p.B, baseB, wid, lane, n0, kt0);
   auto issue = [&](int stage, int kt) {
     char* la = reinterpret_cast<char*>(sAbase + stage * SZ_A) + wid * dA.J * 1024;
     char* lb = reinterpret_cast<char*>(sBbase + stage * SZ_B) + wid * dB.J * 1024;
