@@ -25,7 +25,9 @@ int launch_dtype(GemmParams& p, void* stream) {
       else if (blocks(128, 64) >= 48) tile = 1;  // e.g. the 320x1280 MixFFN weight gradients (57 vs 72 us on 64x64 tiles)
     }
     const long b = tile == 3 ? blocks(256, 256) : tile == 0 ? blocks(128, 128) : tile == 1 ? blocks(128, 64) : blocks(64, 64);
-    long s = (512 + b - 1) / b;
+    // im2col weight gradients (very deep K, output of a few MB): let the wave-quantisation search below look as far as two
+    // full waves of the 128x128 tile (144 tiles x 7 splits: 9.6 ms against 11.2 ms at 3 splits, batch 64)
+    long s = ((p.B.conv ? 1024 : 512) + b - 1) / b;
     s = std::min<long>(s, std::max(1, nkt / 8));
     const long out_bytes = (long)p.M * p.N * 4 * zb;
     s = std::min<long>(s, std::max<long>(16, (32L << 20) / std::max<long>(out_bytes, 1)));  // atomic traffic bound
