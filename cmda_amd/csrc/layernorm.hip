@@ -27,7 +27,7 @@ static __device__ __forceinline__ float group_sum(float v, int lpr) {
   return v;
 }
 
-template <typename T>
+template <typename T, int NV>
 __global__ void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                               T* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out, long rows,
                               int C, float eps, int lpr) {
@@ -41,10 +41,10 @@ __global__ void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__
     const long row = row0 + grp;
     const bool live = row < rows;
     const T* xr = x + row * C;
-    float v[kMaxVec][4];
+    float v[NV][4];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < kMaxVec; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int vi = i * lpr + li;
       if (live && vi < nvec) {
         ld4(xr + vi * 4, v[i]);
@@ -56,7 +56,7 @@ __global__ void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__
     const float mean = group_sum(s, lpr) / (float)C;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < kMaxVec; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int vi = i * lpr + li;
       if (vi < nvec) {
 #pragma unroll
@@ -70,7 +70,7 @@ __global__ void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__
     const float rstd = rsqrtf(var + eps);
     if (!live) continue;
 #pragma unroll
-    for (int i = 0; i < kMaxVec; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int vi = i * lpr + li;
       if (vi < nvec) {
         float g[4], b[4], o[4];
@@ -223,8 +223,14 @@ extern "C" int cmda_layernorm_fwd(const void* x, const float* gamma, const float
   const int wpb = 4, lpr = lanes_per_row(C);
   const long rpb = wpb * (64 / lpr);
   const int grid = (int)std::min<long>((rows + rpb - 1) / rpb, 8192);
-  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((ln_fwd_kernel<T>), dim3(grid), dim3(64 * wpb), 0, stream, (const T*)x, gamma,
-                                         beta, (T*)y, mean, rstd, (long)rows, C, eps, lpr));
+  const int nv = ((C >> 2) + lpr - 1) / lpr;
+#define CMDA_LN_FWD(NVV)                                                                                                      \
+  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((ln_fwd_kernel<T, NVV>), dim3(grid), dim3(64 * wpb), 0, stream, (const T*)x, gamma, \
+                                         beta, (T*)y, mean, rstd, (long)rows, C, eps, lpr))
+  if (nv <= 1) { CMDA_LN_FWD(1); }
+  else if (nv == 2) { CMDA_LN_FWD(2); }
+  else { CMDA_LN_FWD(4); }
+#undef CMDA_LN_FWD
   CMDA_CHECK_LAUNCH();
 }
 
