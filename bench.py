@@ -128,6 +128,19 @@ def run_dacs(args, rank, world, dev, dist):
                           custom_keys=dict(head=dict(lr_mult=10.0), pos_block=dict(decay_mult=0.0), norm=dict(decay_mult=0.0)))
     dacs.attach_flat_store(opt)
     reducer = GradAllReducer(opt.flat_g, wire_dtype=torch.bfloat16, force=args.force_reducer)
+    if reducer.active:
+        # overlap inside the LAST backward pass of the iteration: the decode head and the image encoder (back-propagated once
+        # per pass) start their slices as they finish; the event encoder (twice per pass) and the rest go in finish()
+        student = dacs.model
+        ranges = {('decode_head', id(student.decode_head)): opt.ranges_of(student, ['decode_head.'])}
+        for s in range(1, 5):
+            ranges[(f'backbone.stage{s}', id(student.backbone_image))] = opt.ranges_of(
+                student, [f'backbone_image.patch_embed{s}.', f'backbone_image.block{s}.', f'backbone_image.norm{s}.'])
+
+        def _ready(tag, module=None):
+            for lo, hi in ranges.get((tag, id(module)), ()):
+                reducer.start_range(lo, hi)
+        dacs.final_pass_grad_hook = _ready
     g = torch.Generator().manual_seed(100 + rank)
     S = args.size
     lab = torch.randint(0, 19, (B, 1, S // 32, S // 32), generator=g).repeat_interleave(32, 2).repeat_interleave(32, 3)
@@ -229,7 +242,7 @@ def main():
                                                                      f'backbone.norm{s}.']) for s in range(1, 5)}
         stage_ranges['decode_head'] = opt.ranges_of(model, ['decode_head.'])
 
-        def _ready(tag):
+        def _ready(tag, module=None):
             for lo, hi in stage_ranges.get(tag, ()):
                 reducer.start_range(lo, hi)
         rt.grad_ready_hook = _ready

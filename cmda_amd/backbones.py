@@ -255,7 +255,7 @@ class MixVisionTransformer(nn.Module):
             for blk, sv in zip(reversed(blocks), reversed(sv_blocks)):
                 dx = blk.bwd(sv, dx, B, H, W)
             dnext = getattr(self, f'patch_embed{s}').bwd(sv_pe, dx, B, need_dx=(s > 1))
-            rt.notify_grads_ready(f'backbone.stage{s}')
+            rt.notify_grads_ready(f'backbone.stage{s}', self)
         return None
 
     def forward(self, x):

@@ -103,12 +103,14 @@ def anchor(device):
     return a
 
 
-# Optional callback fired by the hand-scheduled backward passes when a group of parameter gradients is final:
-# grad_ready_hook(tag) with tag 'decode_head' or 'backbone.stage{1..4}'.  Only meaningful when a step runs ONE backward
-# pass over those parameters (bench.py's supervised step); DACS accumulates two passes and leaves it None.
+# Optional callback fired by the hand-scheduled backward passes when a group of parameter gradients is final FOR THIS PASS:
+# grad_ready_hook(tag, module) with tag 'decode_head' or 'backbone.stage{1..4}' and the module whose gradients they are (the
+# fusion student has two encoders).  Whoever sets it decides whether "final for this pass" means final for the step: bench.py's
+# supervised step runs one backward pass; DACS arms it only around the LAST of its two passes (uda.DACS.final_pass_grad_hook)
+# and only for the encoder that is back-propagated once per pass.
 grad_ready_hook = None
 
 
-def notify_grads_ready(tag):
+def notify_grads_ready(tag, module=None):
     if grad_ready_hook is not None:
-        grad_ready_hook(tag)
+        grad_ready_hook(tag, module)

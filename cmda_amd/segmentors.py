@@ -86,7 +86,7 @@ class EncoderDecoder(nn.Module):
     def train_bwd(self, saved, gscale):
         sv_b, sv_h, B = saved
         dfs = self.decode_head.bwd_train(sv_h, B, gscale)
-        rt.notify_grads_ready('decode_head')
+        rt.notify_grads_ready('decode_head', self.decode_head)
         self.backbone.bwd(sv_b, [dfs.get(i) for i in range(4)])
 
     def forward_train(self, img, img_metas=None, gt_semantic_seg=None, seg_weight=None, return_feat=False):
@@ -241,6 +241,7 @@ class FusionEncoderDecoder(nn.Module):
     def train_bwd(self, saved, gscale):
         sv, sv_h, B = saved
         dfeats = self.decode_head.bwd_train(sv_h, B, gscale)
+        rt.notify_grads_ready('decode_head', self.decode_head)
         self._extract_bwd(sv, dfeats, B)
 
     def forward_train(self, inputs, gt_semantic_seg, seg_weight=None, return_feat=False, cfg=None):

@@ -311,7 +311,15 @@ class DACS(nn.Module):
         mix_losses.pop('features')
         mix_loss, mix_log = parse_losses(add_prefix(mix_losses, 'mix'))
         log_vars.update(mix_log)
-        mix_loss.backward()
+        # the second (last) backward pass of the iteration: gradients reported final by this pass are final for the step, so a
+        # data-parallel driver may start their all-reduce underneath the rest of the pass (runtime.grad_ready_hook)
+        prev_hook = rt.grad_ready_hook
+        if getattr(self, 'final_pass_grad_hook', None) is not None:
+            rt.grad_ready_hook = self.final_pass_grad_hook
+        try:
+            mix_loss.backward()
+        finally:
+            rt.grad_ready_hook = prev_hook
         self.local_iter += 1
         self.last_mix = dict(mixed_img=mixed_img, mixed_lbl=mixed_lbl, mixed_isr=mixed_isr, pseudo_weight=mixed_weight,
                              pseudo_label=pseudo_label, classes=classes)

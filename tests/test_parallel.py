@@ -125,7 +125,7 @@ def test_backward_reports_stages_in_order_and_staged_grads_match():
         ranges['decode_head'] = opt.ranges_of(model, ['decode_head.'], min_elems=0)
         seen, snaps = [], {}
 
-        def hook(tag):
+        def hook(tag, module=None):
             seen.append(tag)
             snaps[tag] = [opt.flat_g[lo:hi].clone() for lo, hi in ranges[tag]]
         rt.grad_ready_hook = hook
@@ -143,3 +143,56 @@ def test_backward_reports_stages_in_order_and_staged_grads_match():
     finally:
         rt.grad_ready_hook = None
         rt.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.gpu
+def test_dacs_final_pass_hook_reports_final_gradients():
+    """DACS arms runtime.grad_ready_hook only around its LAST backward pass; what it reports for the decode head and the
+    image encoder (one backward per pass) equals the gradient at the end of the iteration."""
+    import random
+    import numpy as np
+    import cmda_amd.runtime as rt
+    from cmda_amd import optim
+    from cmda_amd.registry import build_train_model
+    from test_dacs import make_cfg
+    from weights import seeded_fill, seeded_randn
+    dev = torch.device('cuda:0')
+    rt.set_compute_dtype(torch.float32)
+    B, H, W = 2, 64, 64
+    dacs = build_train_model(make_cfg())
+    seeded_fill(dacs.model, 7)
+    seeded_fill(dacs.ema_model, 8)
+    dacs.to(dev).train()
+    opt = optim.FlatAdamW(dacs.model, custom_keys=dict(head=dict(lr_mult=10.0), norm=dict(decay_mult=0.0)))
+    dacs.attach_flat_store(opt)
+    student = dacs.model
+    ranges = {('decode_head', id(student.decode_head)): opt.ranges_of(student, ['decode_head.'], min_elems=0)}
+    for s in range(1, 5):
+        ranges[(f'backbone.stage{s}', id(student.backbone_image))] = opt.ranges_of(
+            student, [f'backbone_image.patch_embed{s}.', f'backbone_image.block{s}.', f'backbone_image.norm{s}.'], min_elems=0)
+    seen, snaps = [], {}
+
+    def hook(tag, module=None):
+        key = (tag, id(module))
+        seen.append((tag, module is student.backbone_image, module is student.backbone_events))
+        if key in ranges:
+            snaps[key] = [opt.flat_g[lo:hi].clone() for lo, hi in ranges[key]]
+    dacs.final_pass_grad_hook = hook
+    g = torch.Generator().manual_seed(3)
+    lab = torch.randint(0, 6, (B, 1, H // 8, W // 8), generator=g).repeat_interleave(8, 2).repeat_interleave(8, 3)
+    src = dict(image=seeded_randn((B, 3, H, W), 7, 'img'), img_time_res=seeded_randn((B, 3, H, W), 7, 'itr'),
+               img_self_res=seeded_randn((B, 3, H, W), 7, 'isr').clamp(-1, 1), label=lab)
+    tg = dict(warp_image=seeded_randn((B, 3, H, W), 7, 'nimg'), events_vg=seeded_randn((B, 3, H, W), 7, 'nev').clamp(-1, 1),
+              warp_img_self_res=seeded_randn((B, 3, H, W), 7, 'nisr').clamp(-1, 1))
+    batch = dict(source={k: v.to(dev) for k, v in src.items()}, target={k: v.to(dev) for k, v in tg.items()})
+    torch.manual_seed(11), random.seed(11), np.random.seed(11)
+    opt.zero_grad()
+    dacs(**batch)
+    torch.cuda.synchronize()
+    assert rt.grad_ready_hook is None                       # disarmed again after the pass
+    assert seen[0][0] == 'decode_head' and len(snaps) == 5  # head + four image-encoder stages, reported once each
+    assert [t for t, img, _ in seen if img] == [f'backbone.stage{s}' for s in (4, 3, 2, 1)]
+    assert sum(1 for _, _, evt in seen if evt) == 8         # the event encoder runs twice per pass (isr + events)
+    for key, parts in snaps.items():
+        for (lo, hi), snap in zip(ranges[key], parts):
+            assert torch.equal(snap, opt.flat_g[lo:hi]), f'{key[0]}: changed after being reported'
