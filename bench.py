@@ -1,12 +1,19 @@
 #!/usr/bin/env python3
 """Headline benchmark: training images/s of the CMDA hot path on MI355X (BASELINE.json metric).
 
-Workload at N=1 = BASELINE.json configs[1]: MiT-B5 + DAFormer (sep-ASPP) head forward/backward (+ fused AdamW step),
-synthetic 512x512 inputs, bf16 activations / fp32 accumulate, random-init weights of the real architecture.
-N>1: one process per GPU (torchrun), weak scaling (per-GPU batch fixed), gradients all-reduced (mean) with RCCL.
+Default workload = BASELINE.json configs[3], the configuration the metric is quoted on ("512x512 image+event"): one
+FULL CMDA UDA iteration per step -- Motion-Extractor generator on the source time residual, EMA-teacher update, source
+forward/backward of the image+events fusion student (two MiT-B5 encoders, AttentionAvgFusion, shared DAFormer head, four
+CE terms), teacher forward + pseudo-labels, ClassMix + colour jitter + blur + ISR of the mixed image, mixed
+forward/backward, fused AdamW -- at the reference recipe's 2 source + 2 target samples per GPU, bf16 activations / fp32
+accumulate, random-init weights of the real architecture, synthetic inputs shaped as SURVEY.md section 8d prescribes
+(events through the voxel-grid kernel, ISR through the Content-Extractor kernels, sparse time residual).
+`value` counts (source, target) PAIRS per second (one "image" = one 512x512 image + its event / ISR
+companions).  N>1: one process per GPU (torchrun), weak scaling (2+2 per GPU), gradients averaged with RCCL.
+`--workload supervised` = configs[1] (MiT-B5 + DAFormer head fwd/bwd), kept as a secondary line.
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel family = the MFMA GEMM, HIP-event timed on the launch
-stream) and, at N=1, `cpu_baseline` (the oracle restatement timed on the host cores, bounded sample).
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel family = the MFMA GEMM / implicit-GEMM, HIP-event timed
+on the launch stream) and, at N=1, `cpu_baseline` (the oracle restatement timed on the host cores, bounded sample).
 """
 import argparse
 import json
@@ -21,44 +28,73 @@ sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 GFLOP_PER_IMAGE_FWD = 252.6     # MiT-B5 138.8 + DAFormer head 113.8
+GFLOP_PER_PAIR_UDA = 6430.0     # full UDA step per (source, target) pair
+
+HEAD_CFG = dict(in_channels=[64, 128, 320, 512], in_index=[0, 1, 2, 3], channels=256, num_classes=19,
+                norm_cfg=dict(type='BN', requires_grad=True), align_corners=False,
+                loss_decode=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0))
+DECODER = dict(embed_dims=256, embed_cfg=dict(type='mlp', act_cfg=None, norm_cfg=None),
+               embed_neck_cfg=dict(type='mlp', act_cfg=None, norm_cfg=None),
+               fusion_cfg=dict(type='aspp', sep=True, dilations=(1, 6, 12, 18), pool=False, act_cfg=dict(type='ReLU'),
+                               norm_cfg=dict(type='BN', requires_grad=True)))
+ISR_PARMS = dict(val_range=[0.01, 1.01], _threshold=0.005, _clip_range=0.1, shift_pixel=1)
+FORWARD_CFG = dict(loss_weight={'image': 0.5, 'events': 0.5, 'fusion': 0.5, 'img_self_res': 0.25}, gradual_rate=0.0)
+CUSTOM_KEYS = dict(head=dict(lr_mult=10.0), pos_block=dict(decay_mult=0.0), norm=dict(decay_mult=0.0))
 
 
+def host_cores():
+    """(logical CPUs visible to this process, physical cores of the host) -- the latter from /proc/cpuinfo."""
+    logical = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    phys = set()
+    try:
+        pid = cid = None
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('physical id'):
+                pid = line.split(':')[1].strip()
+            elif line.startswith('core id'):
+                cid = line.split(':')[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    return logical, (len(phys) or logical)
+
+
+# ------------------------------------------------------------------------------------------------ configs[1] (secondary)
 def build_model(dev, drop_path_rate=0.1, dropout_ratio=0.1):
     import cmda_amd  # noqa: F401
     from cmda_amd.registry import build_segmentor
-    cfg = dict(type='EncoderDecoder',
-               backbone=dict(type='mit_b5', style='pytorch', drop_path_rate=drop_path_rate),
-               decode_head=dict(type='DAFormerHead', in_channels=[64, 128, 320, 512], in_index=[0, 1, 2, 3], channels=256,
-                                dropout_ratio=dropout_ratio, num_classes=19, norm_cfg=dict(type='BN', requires_grad=True),
-                                align_corners=False,
-                                decoder_params=dict(embed_dims=256, embed_cfg=dict(type='mlp', act_cfg=None, norm_cfg=None),
-                                                    embed_neck_cfg=dict(type='mlp', act_cfg=None, norm_cfg=None),
-                                                    fusion_cfg=dict(type='aspp', sep=True, dilations=(1, 6, 12, 18),
-                                                                    pool=False, act_cfg=dict(type='ReLU'),
-                                                                    norm_cfg=dict(type='BN', requires_grad=True))),
-                                loss_decode=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0)),
+    cfg = dict(type='EncoderDecoder', backbone=dict(type='mit_b5', style='pytorch', drop_path_rate=drop_path_rate),
+               decode_head=dict(type='DAFormerHead', dropout_ratio=dropout_ratio, decoder_params=dict(DECODER), **HEAD_CFG),
                train_cfg=dict(), test_cfg=dict(mode='whole'))
     model = build_segmentor(cfg)
     model.init_weights()
     return model.to(dev).train()
 
 
-def synthetic_batch(B, size, seed, dev):
-    g = torch.Generator().manual_seed(seed)
-    img = torch.randn(B, 3, size, size, generator=g)
+def synthetic_labels(B, size, g):
     lab = torch.randint(0, 19, (B, 1, size // 32, size // 32), generator=g)
     lab = lab.repeat_interleave(32, 2).repeat_interleave(32, 3)
     lab[torch.rand(B, 1, size, size, generator=g) < 0.05] = 255
-    return img.to(dev), lab.to(dev)
+    return lab
 
 
-def cpu_baseline(size):
+def synthetic_batch(B, size, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randn(B, 3, size, size, generator=g)
+    return img.to(dev), synthetic_labels(B, size, g).to(dev)
+
+
+def cpu_baseline_supervised(size):
     """Oracle (port of the reference algorithm, oracle/) timed on the host cores: one fwd+bwd of MiT-B5 + DAFormer
     head on ONE image (bounded sample of the same workload)."""
     from oracle import head as ohd, mit as omit, segmentor as oseg
+    logical, physical = host_cores()
     # 16 threads: torch's CPU kernels at these sizes stop scaling there (256 threads took 737 s for this sample on the
     # GPU box's host, 8 threads take 11 s) -- `cores` reports the threads actually used
-    cores = min(os.cpu_count() or 1, 16)
+    cores = min(logical, 16)
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     ref = oseg.EncoderDecoder(omit.mit_b5(drop_path_rate=0.1), ohd.DAFormerHead(dropout_ratio=0.1)).train()
@@ -80,52 +116,160 @@ def cpu_baseline(size):
     for _ in range(n):
         one()
     dt = (time.time() - t0) / n
-    return {'value': round(1.0 / dt, 4), 'unit': 'img/s', 'cores': cores, 'kind': 'port',
+    return {'value': round(1.0 / dt, 4), 'unit': 'img/s', 'cores': cores, 'host_physical_cores': physical,
+            'host_logical_cpus': logical, 'kind': 'port',
             'sample': f'{n} x (1 image {size}x{size}, fwd+bwd of MiT-B5+DAFormerHead, fp32 oracle) on {cores} host '
                       f'threads after 1 warm-up, {dt:.2f} s per image'}
 
 
-def build_dacs(dev):
-    """configs/fusion/cs2dsec_image+events_together_b5.py restated inline (the reference tree is not on the GPU box): two
-    MiT-B5 encoders, AttentionAvgFusion, shared DAFormerHeadFusion, DACS with ClassMix + ISR of the mixed image."""
-    import functools
-    import cmda_amd  # noqa: F401
-    from cmda_amd.registry import build_train_model
+# ------------------------------------------------------------------------------------------------ configs[3] (headline)
+def dacs_cfg():
+    """configs/fusion/cs2dsec_image+events_together_b5.py + the launcher defaults of SURVEY.md appendix A, restated inline
+    (the reference tree is not on the GPU box).  cyclegan_itrd2en_path='random': the Motion-Extractor generator with seeded
+    random weights (no checkpoint exists offline) -- the generator RUNS in every step, as in dacs.py:400-404."""
     dims = [64, 128, 320, 512]
     bb = dict(type='mit_b5', style='pytorch', drop_path_rate=0.1)
-    head = dict(type='DAFormerHeadFusion', in_channels=dims, in_index=[0, 1, 2, 3], channels=256, dropout_ratio=0.1,
-                num_classes=19, norm_cfg=dict(type='BN', requires_grad=True), align_corners=False,
-                decoder_params=dict(embed_dims=256, embed_cfg=dict(type='mlp', act_cfg=None, norm_cfg=None),
-                                    embed_neck_cfg=dict(type='mlp', act_cfg=None, norm_cfg=None),
-                                    fusion_cfg=dict(type='aspp', sep=True, dilations=(1, 6, 12, 18), pool=False,
-                                                    act_cfg=dict(type='ReLU'), norm_cfg=dict(type='BN', requires_grad=True)),
-                                    train_type='cs2dsec_image+events_together', share_decoder=True),
-                loss_decode=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0))
+    head = dict(type='DAFormerHeadFusion', dropout_ratio=0.1,
+                decoder_params=dict(DECODER, train_type='cs2dsec_image+events_together', share_decoder=True), **HEAD_CFG)
     model = dict(type='FusionEncoderDecoder', backbone_image=dict(bb), backbone_events=dict(bb),
                  fusion_module=dict(type='AttentionAvgFusion', in_channels=dims, drop_path_rate=0.1), decode_head=head,
                  train_type='cs2dsec_image+events_together', train_cfg=dict(), test_cfg=dict(mode='whole'))
-    fcfg = dict(loss_weight={'image': 0.5, 'events': 0.5, 'fusion': 0.5, 'img_self_res': 0.25}, gradual_rate=0.0)
-    uda = dict(type='DACS', alpha=0.999, pseudo_threshold=0.968, pseudo_weight_ignore_top=15, pseudo_weight_ignore_bottom=120,
+    uda = dict(type='DACS', alpha=0.999, pseudo_threshold=0.968, pseudo_weight_ignore_top=0, pseudo_weight_ignore_bottom=0,
                imnet_feature_dist_lambda=0, imnet_feature_dist_classes=None, imnet_feature_dist_scale_min_ratio=None,
                mix='class', blur=True, color_jitter_strength=0.2, color_jitter_probability=0.2, debug_img_interval=1000,
-               print_grad_magnitude=False, train_type='cs2dsec_image+events_together', forward_cfg=fcfg,
-               cyclegan_itrd2en_path='', img_self_res_reg='no', mixed_image_to_mixed_isr=True, random_choice_thres='0.5',
-               shift_type='rightdown', isr_parms=dict(val_range=[0.01, 1.01], _threshold=0.005, _clip_range=0.1, shift_pixel=1),
-               sky_mask=None)
-    dacs = build_train_model(dict(model=model, uda=uda, runner=dict(type='IterBasedRunner', max_iters=40000)))
-    del functools
+               print_grad_magnitude=False, train_type='cs2dsec_image+events_together', forward_cfg=dict(FORWARD_CFG),
+               cyclegan_itrd2en_path='random', img_self_res_reg='no', mixed_image_to_mixed_isr=True,
+               random_choice_thres='0.5', shift_type='random', isr_parms=dict(ISR_PARMS), sky_mask=None)
+    return dict(model=model, uda=uda, runner=dict(type='IterBasedRunner', max_iters=40000))
+
+
+def build_dacs(dev):
+    import cmda_amd  # noqa: F401
+    from cmda_amd.registry import build_train_model
+    dacs = build_train_model(dacs_cfg())
+    dacs.init_weights()
     return dacs.to(dev).train()
 
 
+def synthetic_pairs(B, S, seed, dev, n_events=500000):
+    """SURVEY.md section 8d synthetic stream, one batch, resident in HBM.  Source: image N(0,1), block-structured labels with
+    5 % ignore, sparse time residual U(-1,1)*Bernoulli(0.1) (3 identical channels), ISR from the Content-Extractor kernels.
+    Target: image N(0,1), its ISR from the same kernels, events: `n_events` synthetic events per sample (fractional rectified
+    x in [0,640), y in [0,480), sorted t, polarity 0/1) -> voxel-grid kernel (1 bin) -> events_norm -> crop 400x400 -> bilinear
+    512x512 -> 3 channels (dsec.py:189-366)."""
+    from cmda_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    image = torch.randn(B, 3, S, S, generator=g).to(dev)
+    label = synthetic_labels(B, S, g).to(dev)
+    itr = (torch.rand(B, 1, S, S, generator=g) * 2 - 1) * (torch.rand(B, 1, S, S, generator=g) < 0.1)
+    itr = itr.repeat(1, 3, 1, 1).to(dev)
+    warp = torch.randn(B, 3, S, S, generator=g).to(dev)
+
+    def isr(img):
+        return ops.isr_from_gray(ops.isr_gray(img), ISR_PARMS['val_range'], ISR_PARMS['_threshold'], ISR_PARMS['_clip_range'],
+                                 ISR_PARMS['shift_pixel'], 'rightdown')
+    ev = torch.empty(B, 3, S, S, dtype=torch.float32, device=dev)
+    crop = 400
+    for b in range(B):
+        t = torch.rand(n_events, generator=g).sort().values
+        x = torch.rand(n_events, generator=g) * 640
+        y = torch.rand(n_events, generator=g) * 480
+        p = (torch.rand(n_events, generator=g) < 0.5).float()
+        grid = ops.events_to_voxel_grid(t.to(dev), x.to(dev), y.to(dev), p.to(dev), 1, 480, 640)
+        grid = ops.events_norm(grid, (n_events - 1) / 500000 * 1.5)
+        win = grid[:, 40:40 + crop, 120:120 + crop].contiguous()             # [1,400,400] == NHWC [1,400,400,1]
+        ev[b] = ops.upsample_logits_nchw(win.view(1, crop, crop, 1), S, S)[0]   # bilinear, align_corners=False (dsec.py:318-319)
+    return dict(source=dict(image=image, img_time_res=itr, img_self_res=isr(image), label=label),
+                target=dict(warp_image=warp, events_vg=ev, warp_img_self_res=isr(warp)))
+
+
+def cpu_baseline_dacs(size):
+    """The oracle's DACS iteration (oracle/dacs_iter.py: generator, EMA, source fwd/bwd, teacher, ClassMix + jitter + blur +
+    ISR, mixed fwd/bwd) on ONE (source, target) pair, fp32, timed once on the host cores -- a bounded sample of the same
+    workload (the bench's step does this for 2 pairs per GPU); the AdamW update (<1 % of the step) is not in the sample."""
+    from oracle import cyclegan as ocg, dacs_iter, fusion as ofu, head as ohd, mit as omit, segmentor as oseg
+    logical, physical = host_cores()
+    cores = min(logical, 16)   # torch's CPU kernels at these sizes stop scaling there (see cpu_baseline_supervised)
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+
+    def net(dp, do):
+        m = oseg.FusionEncoderDecoder(backbone_image=omit.mit_b5(drop_path_rate=dp), backbone_events=omit.mit_b5(drop_path_rate=dp),
+                                      fusion_module=ofu.AttentionAvgFusion(drop_path_rate=dp),
+                                      decode_head=ohd.DAFormerHeadFusion(dropout_ratio=do, share_decoder=True))
+        m.backbone_image.init_weights()
+        m.backbone_events.init_weights()
+        return m.train()
+    student, teacher, G = net(0.1, 0.1), net(0.0, 0.0), ocg.ResnetGenerator().eval()
+    g = torch.Generator().manual_seed(1)
+    r = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
+    src = dict(image=r(1, 3, size, size), img_time_res=r(1, 3, size, size).clamp(-1, 1), img_self_res=r(1, 3, size, size).clamp(-1, 1),
+               label=synthetic_labels(1, size, g))
+    tgt = dict(warp_image=r(1, 3, size, size), events_vg=r(1, 3, size, size).clamp(-1, 1),
+               warp_img_self_res=r(1, 3, size, size).clamp(-1, 1))
+    # thread-pool / allocator warm-up on a tiny problem (a full warm-up iteration would double the bench's CPU time)
+    tiny = lambda d: {k: v[..., :64, :64].contiguous() for k, v in d.items()}  # noqa: E731
+    dacs_iter.dacs_iteration(student, teacher, G, tiny(src), tiny(tgt), local_iter=0, forward_cfg=FORWARD_CFG, isr_parms=ISR_PARMS)
+    for p in student.parameters():
+        p.grad = None
+    t0 = time.time()
+    dacs_iter.dacs_iteration(student, teacher, G, src, tgt, local_iter=1, forward_cfg=FORWARD_CFG, isr_parms=ISR_PARMS,
+                             shift_type='random')
+    dt = time.time() - t0
+    return {'value': round(1.0 / dt, 5), 'unit': 'img/s', 'cores': cores, 'host_physical_cores': physical,
+            'host_logical_cpus': logical, 'kind': 'port',
+            'sample': f'1 x (full DACS iteration on 1 source + 1 target pair at {size}x{size}: generator, EMA, source fwd/bwd, '
+                      f'teacher, ClassMix/jitter/blur/ISR, mixed fwd/bwd; fp32 oracle/dacs_iter.py) on {cores} host threads '
+                      f'after a 64x64 warm-up, {dt:.1f} s per pair'}
+
+
+def profile_json(name):
+    """A committed measurement under profiles/ (None if absent): `pmc_traffic_<workload>.json` = HBM bytes per GEMM-family
+    launch from the PMC passes of this command (separate rocprofv3 --pmc runs, as MI355X_MICROARCH.md prescribes);
+    `micro_peaks.json` = the box's measured MFMA / HBM-stream rates (tools/micro)."""
+    path = os.path.join(ROOT, 'profiles', f'{name}.json')
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+def gemm_roofline(step, workload):
+    """One more (eager) step with every GEMM launch bracketed by HIP events on the launch stream."""
+    from cmda_amd import ops
+    ops.GEMM_PROFILE = []
+    step()
+    torch.cuda.synchronize()
+    prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+    gemm_ms = sum(e0.elapsed_time(e1) for _, e0, e1, _ in prof)
+    gemm_flops = sum(f for f, _, _, _ in prof)
+    gemm_bytes = sum(b for _, _, _, b in prof)
+    achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    pmc = profile_json(f'pmc_traffic_{workload}')
+    roof = {'bound': 'mfma', 'kernel': 'gemm_glds_kernel + gemm_kernel (bf16 MFMA tile GEMM / implicit-GEMM conv family, all '
+                                       'template instances)',
+            'achieved': round(achieved, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
+            'traffic': pmc['hbm_mb_per_launch'] * 1e6 if pmc else None,
+            'launches_per_step': len(prof), 'avg_launch_us': round(gemm_ms * 1e3 / max(len(prof), 1), 2),
+            'gemm_ms_per_step': round(gemm_ms, 3), 'algorithmic_gflop_per_step': round(gemm_flops / 1e9, 1),
+            'algorithmic_mb_per_launch': round(gemm_bytes / max(len(prof), 1) / 1e6, 2)}
+    if pmc:
+        roof['traffic_source'] = pmc.get('source')
+    micro = profile_json('micro_peaks')
+    if micro:
+        roof['peak_measured'] = micro
+    return roof
+
+
 def run_dacs(args, rank, world, dev, dist):
-    import cmda_amd.runtime as rt
     from cmda_amd import optim
     from cmda_amd.parallel import GradAllReducer
-    B = args.batch if '--batch' in sys.argv else 2   # reference recipe: 2 source + 2 target samples per GPU
-    torch.manual_seed(1234)
+    B = args.batch if args.batch > 0 else 2   # reference recipe: 2 source + 2 target samples per GPU
+    torch.manual_seed(1234)                   # identical initial weights on every rank
     dacs = build_dacs(dev)
-    opt = optim.FlatAdamW(dacs.model, lr=6e-5, weight_decay=0.01,
-                          custom_keys=dict(head=dict(lr_mult=10.0), pos_block=dict(decay_mult=0.0), norm=dict(decay_mult=0.0)))
+    opt = optim.FlatAdamW(dacs.model, lr=6e-5, weight_decay=0.01, custom_keys=CUSTOM_KEYS)
     dacs.attach_flat_store(opt)
     reducer = GradAllReducer(opt.flat_g, wire_dtype=torch.bfloat16, force=args.force_reducer)
     if reducer.active:
@@ -141,15 +285,11 @@ def run_dacs(args, rank, world, dev, dist):
             for lo, hi in ranges.get((tag, id(module)), ()):
                 reducer.start_range(lo, hi)
         dacs.final_pass_grad_hook = _ready
-    g = torch.Generator().manual_seed(100 + rank)
-    S = args.size
-    lab = torch.randint(0, 19, (B, 1, S // 32, S // 32), generator=g).repeat_interleave(32, 2).repeat_interleave(32, 3)
-    r = lambda: torch.randn(B, 3, S, S, generator=g)  # noqa: E731
-    batch = dict(source=dict(image=r().to(dev), img_time_res=r().clamp(-1, 1).to(dev), img_self_res=r().clamp(-1, 1).to(dev),
-                             label=lab.to(dev)),
-                 target=dict(warp_image=r().to(dev), events_vg=r().clamp(-1, 1).to(dev), warp_img_self_res=r().clamp(-1, 1).to(dev)))
-    torch.manual_seed(1000 + rank)
+    batch = synthetic_pairs(B, args.size, 100 + rank, dev)
+    torch.manual_seed(1000 + rank)            # per-rank DropPath / Dropout / ClassMix streams
     it = [0]
+    if not args.no_graph:
+        dacs.enable_graph(warmup_iters=2)     # iterations 0-1 eager, iteration 2 captures the hipGraph, then replays
 
     def step():
         opt.zero_grad()
@@ -164,6 +304,9 @@ def run_dacs(args, rank, world, dev, dist):
             dist.barrier()
         torch.cuda.synchronize()
 
+    if not args.no_graph:
+        for _ in range(3):                    # set-up, not warm-up: two eager iterations + the capturing one
+            step()
     for _ in range(args.warmup):
         step()
     fence()
@@ -176,64 +319,47 @@ def run_dacs(args, rank, world, dev, dist):
         t = torch.tensor([dt], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
+    losses = {k: round(float(v), 5) for k, v in lv.items() if 'loss' in k}
+    graph_mode = 'one hipGraph per iteration (EMA update, control-block copy, AdamW outside)' if dacs._graph is not None else 'eager'
+    dacs.disable_graph()                      # the roofline leg brackets every GEMM launch with events: eager
+    roofline = gemm_roofline(step, 'dacs') if rank == 0 else None
     if rank == 0:
         nparam = sum(p.numel() for p in dacs.model.parameters())
-        out = {'metric': 'training images/sec (512x512 image+event, full CMDA UDA step)', 'value': round(2 * B * world * args.steps / dt, 3),
+        value = B * world * args.steps / dt
+        out = {'metric': 'training images/sec (512x512 image+event, MiT-B5)', 'value': round(value, 3),
                'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                'dtype': 'bf16' if args.dtype == 'bf16' else 'f32', 'data': 'synthetic',
-               'config': {'workload': 'BASELINE.json configs[3]: full CMDA UDA step (source CE + EMA-teacher pseudo-labels, ClassMix, '
-                                      'ISR of the mixed image, colour jitter / blur, two student passes, AdamW), image+events fusion '
-                                      'student with two MiT-B5 encoders',
-                          'per_gpu_batch': f'{B} source + {B} target', 'images_counted': 'source + target samples',
-                          'image_size': S, 'parallelism': f'dp{world}', 'student_parameters_M': round(nparam / 1e6, 1)},
-               'losses': {k: round(float(v), 5) for k, v in lv.items() if 'loss' in k}}
+               'config': {'workload': 'BASELINE.json configs[3]: full CMDA UDA step (Motion-Extractor generator, EMA teacher, '
+                                      'source CE fwd/bwd, teacher pseudo-labels, ClassMix + colour jitter + blur + ISR of the '
+                                      'mixed image, mixed fwd/bwd, AdamW) on the image+events fusion student (two MiT-B5 '
+                                      'encoders, AttentionAvgFusion, shared DAFormer head)',
+                          'per_gpu_batch': f'{B} source + {B} target', 'global_batch': f'{B * world} + {B * world}',
+                          'images_counted': 'one image = one (source, target) pair with its event / ISR companions '
+                                            '(SURVEY.md 8d)', 'image_size': args.size, 'parallelism': f'dp{world}',
+                          'rccl_ranks': dist.get_world_size() if dist is not None else 1,
+                          'student_parameters_M': round(nparam / 1e6, 1), 'launch': graph_mode, 'generator': 'ResnetGenerator 9 blocks, in the step',
+                          'synthetic_inputs': 'SURVEY.md 8d: 500k events/sample through the voxel kernel, ISR through the ISR '
+                                              'kernels, sparse time residual, block labels with 5 % ignore'},
+               'losses': losses,
+               'model_gflop_per_pair': GFLOP_PER_PAIR_UDA,
+               'model_tflops_achieved': round(GFLOP_PER_PAIR_UDA * value / 1e3 / world, 2),
+               'roofline': roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline_dacs(args.size)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
-    del rt
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=int(os.environ.get('CMDA_BENCH_BATCH', 64)), help='images per GPU')
-    ap.add_argument('--size', type=int, default=512)
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--workload', default='supervised', choices=['supervised', 'dacs'],
-                    help="supervised = BASELINE.json configs[1] (the bench line the driver reads); dacs = configs[3]/[4], one "
-                         "full CMDA UDA iteration (EMA teacher, pseudo-labels, ClassMix, ISR, two student passes) per step")
-    ap.add_argument('--force-reducer', action='store_true',
-                    help='testing: run the gradient all-reduce path (RCCL, side stream, staged ranges) even with one rank')
-    args = ap.parse_args()
-
-    rank = int(os.environ.get('RANK', 0))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
-    assert torch.cuda.is_available(), 'bench.py needs an MI355X (the HIP path has no CPU fallback)'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    dist = None
-    if world > 1 or args.force_reducer:
-        import torch.distributed as dist
-        if 'MASTER_ADDR' not in os.environ:
-            os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1')
-        dist.init_process_group('nccl', device_id=dev)
-
+def run_supervised(args, rank, world, dev, dist):
     import cmda_amd.runtime as rt
-    from cmda_amd import ops, optim
-    rt.set_compute_dtype(torch.bfloat16 if args.dtype == 'bf16' else torch.float32)
-    if args.workload == 'dacs':
-        return run_dacs(args, rank, world, dev, dist)
+    from cmda_amd import optim
+    from cmda_amd.parallel import GradAllReducer
+    B = args.batch if args.batch > 0 else 64
     torch.manual_seed(1234)  # identical initial weights on every rank
     model = build_model(dev)
-    opt = optim.FlatAdamW(model, lr=6e-5, weight_decay=0.01,
-                          custom_keys=dict(head=dict(lr_mult=10.0), pos_block=dict(decay_mult=0.0), norm=dict(decay_mult=0.0)))
-    from cmda_amd.parallel import GradAllReducer
+    opt = optim.FlatAdamW(model, lr=6e-5, weight_decay=0.01, custom_keys=CUSTOM_KEYS)
     reducer = GradAllReducer(opt.flat_g, wire_dtype=torch.bfloat16, force=args.force_reducer)  # no-op at world size 1
     if reducer.active:
         # overlap: a stage's weight gradients (one contiguous slice of the flat buffer) start their all-reduce on the
@@ -247,7 +373,7 @@ def main():
                 reducer.start_range(lo, hi)
         rt.grad_ready_hook = _ready
     torch.manual_seed(1000 + rank)  # per-rank DropPath / Dropout streams
-    img, gt = synthetic_batch(args.batch, args.size, rank, dev)
+    img, gt = synthetic_batch(B, args.size, rank, dev)
     it = [0]
 
     def step():
@@ -277,44 +403,71 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     loss_val = float(loss.item())
-
-    # roofline leg: one more step with every GEMM launch bracketed by events on the launch stream
-    ops.GEMM_PROFILE = []
-    step()
-    torch.cuda.synchronize()
-    prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
-    gemm_ms = sum(e0.elapsed_time(e1) for _, e0, e1, _ in prof)
-    gemm_flops = sum(f for f, _, _, _ in prof)
-    gemm_bytes = sum(b for _, _, _, b in prof)
-    achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-    roofline = {'bound': 'mfma', 'kernel': 'gemm_glds_kernel + gemm_kernel (bf16 MFMA 16x16x32 tile GEMM / implicit-GEMM conv family, all template instances)',
-                'achieved': round(achieved, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,
-                'launches_per_step': len(prof), 'avg_launch_us': round(gemm_ms * 1e3 / max(len(prof), 1), 2),
-                'gemm_ms_per_step': round(gemm_ms, 3), 'algorithmic_gflop_per_step': round(gemm_flops / 1e9, 1),
-                'algorithmic_mb_per_launch': round(gemm_bytes / max(len(prof), 1) / 1e6, 2),
-                'traffic_note': 'PMC FETCH_SIZE/WRITE_SIZE of the same command are in profiles/README.md (separate rocprofv3 passes)'}
-
+    roofline = gemm_roofline(step, 'supervised') if rank == 0 else None
     if rank == 0:
         ms = dt / args.steps * 1e3
-        value = args.batch * world * args.steps / dt
+        value = B * world * args.steps / dt
         out = {'metric': 'training images/sec (512x512, MiT-B5 + DAFormer head fwd/bwd + AdamW step)', 'value': round(value, 3),
                'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                'dtype': 'bf16' if args.dtype == 'bf16' else 'f32', 'data': 'synthetic',
                'config': {'workload': 'BASELINE.json configs[1]: MiT-B5 + DAFormer(sep-ASPP) head fwd/bwd, random '
-                                      f'{args.size}x{args.size}, HIP kernels', 'global_batch': args.batch * world,
-                          'per_gpu_batch': args.batch, 'image_size': args.size, 'parallelism': f'dp{world}',
+                                      f'{args.size}x{args.size}, HIP kernels', 'global_batch': B * world,
+                          'per_gpu_batch': B, 'image_size': args.size, 'parallelism': f'dp{world}',
                           'drop_path_rate': 0.1, 'dropout_ratio': 0.1, 'optimizer': 'AdamW (fused, flat buffers)'},
                'final_loss': round(loss_val, 5),
                'model_gflop_per_image_fwd_bwd': round(3 * GFLOP_PER_IMAGE_FWD, 1),
                'model_tflops_achieved': round(3 * GFLOP_PER_IMAGE_FWD * value / 1e3 / world, 2),
                'roofline': roofline}
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(args.size)
+            out['cpu_baseline'] = cpu_baseline_supervised(args.size)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=int(os.environ.get('CMDA_BENCH_BATCH', 0)),
+                    help='per-GPU batch (default: 2 source + 2 target for dacs, 64 images for supervised)')
+    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--workload', default='dacs', choices=['dacs', 'supervised'],
+                    help="dacs = BASELINE.json configs[3]/[4] (the bench line the driver reads): one full CMDA UDA iteration per "
+                         "step; supervised = configs[1] (MiT-B5 + DAFormer head fwd/bwd)")
+    ap.add_argument('--no-graph', action='store_true', help='dacs: launch every kernel from Python instead of replaying the hipGraph')
+    ap.add_argument('--force-reducer', action='store_true',
+                    help='testing: run the gradient all-reduce path (RCCL, side stream, staged ranges) even with one rank')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if args.gpus > 1 and world != args.gpus:
+        sys.exit(f'bench.py --gpus {args.gpus} must be started with one process per GPU:\n  python -m torch.distributed.run '
+                 f'--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus '
+                 f'{args.gpus} --steps {args.steps} --warmup {args.warmup}   (WORLD_SIZE is {world})')
+    if args.gpus == 1 and world != 1:
+        sys.exit(f'--gpus 1 but WORLD_SIZE={world}')
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X (the HIP path has no CPU fallback)'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1 or args.force_reducer:
+        import torch.distributed as dist
+        if 'MASTER_ADDR' not in os.environ:
+            os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    import cmda_amd.runtime as rt
+    rt.set_compute_dtype(torch.bfloat16 if args.dtype == 'bf16' else torch.float32)
+    if args.workload == 'dacs':
+        return run_dacs(args, rank, world, dev, dist)
+    return run_supervised(args, rank, world, dev, dist)
 
 
 if __name__ == '__main__':

@@ -34,7 +34,7 @@ class GemmParams(ctypes.Structure):
                 ('act', c_i32), ('res', c_vp), ('ldres', c_i64), ('res_batch_stride', c_i64), ('res_batch2_stride', c_i64),
                 ('rowscale', c_vp), ('rows_per_scale', c_i32), ('out_f32', c_i32), ('atomic', c_i32),
                 ('dtype', c_i32), ('c_vec_ok', c_i32), ('colsum', c_vp),
-                ('c_patch_ow', c_i32), ('c_patch_kh', c_i32), ('c_patch_kwci', c_i32)]
+                ('c_patch_ow', c_i32), ('c_patch_kh', c_i32), ('c_patch_kwci', c_i32), ('tile_hint', c_i32)]
 
 
 class CmdaError(RuntimeError):

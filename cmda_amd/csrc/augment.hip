@@ -41,13 +41,19 @@ static __device__ __forceinline__ void hsv2rgb(float h, float s, float v, float&
   }
 }
 
-// img: NCHW fp32 [B,3,H,W], normalised; in place.  prm: [order0..3, f_brightness, f_contrast, f_saturation, f_hue]
+// img: NCHW fp32 [B,3,H,W], normalised; in place.  prm (DEVICE): per sample [order0..3, f_brightness, f_contrast,
+// f_saturation, f_hue] -- strong_transform runs once per sample (uda/dacs.py:721-724), so kornia draws fresh factors and a
+// fresh op order for every sample.  enable (DEVICE, may be null): *enable == 0 leaves the image untouched (the colour-jitter
+// gate of dacs_transforms.py:68 lives on the device so that a captured hipGraph can replay either outcome).
 __global__ void color_jitter_kernel(float* __restrict__ img, int B, int HW, float m0, float m1, float m2, float s0, float s1,
-                                    float s2, int o0, int o1, int o2, int o3, float fb, float fc, float fs, float fh) {
+                                    float s2, const float* __restrict__ prm, const int* __restrict__ enable) {
+  if (enable != nullptr && *enable == 0) return;
   const long total = (long)B * HW;
-  const int order[4] = {o0, o1, o2, o3};
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long b = i / HW, p = i - b * HW;
+    const float* q = prm + b * 8;
+    const int order[4] = {(int)q[0], (int)q[1], (int)q[2], (int)q[3]};
+    const float fb = q[4], fc = q[5], fs = q[6], fh = q[7];
     float* px = img + b * 3 * HW + p;
     float r = (px[0] * s0 + m0) / 255.f, g = (px[HW] * s1 + m1) / 255.f, bl = (px[2L * HW] * s2 + m2) / 255.f;
 #pragma unroll
@@ -79,10 +85,12 @@ static __device__ __forceinline__ int reflect101(int i, int n) {
 
 // one separable pass along x (axis=1) or y (axis=0); planes = B*3; taps: fp32[k] normalised
 __global__ void blur_pass_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ taps,
-                                 int planes, int H, int W, int k, int axis) {
+                                 int planes, int H, int W, int k, int axis, const int* __restrict__ enable) {
   const long total = (long)planes * H * W;
   const int r = k / 2;
+  const bool on = enable == nullptr || *enable != 0;  // off: copy through (the result still ends up in `img` after two passes)
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    if (!on) { out[i] = in[i]; continue; }
     const int x = (int)(i % W);
     const long t = i / W;
     const int y = (int)(t % H);
@@ -100,22 +108,24 @@ __global__ void blur_pass_kernel(const float* __restrict__ in, float* __restrict
 static inline int grid_for(long n) { return (int)std::max<long>(1, std::min<long>((n + 255) / 256, 8192)); }
 }  // namespace
 
-// prm (HOST pointer, 8 floats): order[4] (0 brightness, 1 contrast, 2 saturation, 3 hue), factors f_b, f_c, f_s, f_h
+// prm: DEVICE fp32 [B][8] = per sample order[4] (0 brightness, 1 contrast, 2 saturation, 3 hue), factors f_b, f_c, f_s, f_h;
+// enable: DEVICE int (null = on).  mean3 / std3 are HOST pointers.
 extern "C" int cmda_color_jitter(float* img, int B, int H, int W, const float* mean3, const float* std3, const float* prm,
-                                 void* stream) {
+                                 const int* enable, void* stream) {
   if ((long)B * H * W <= 0) return CMDA_OK;
   CMDA_LAUNCH(color_jitter_kernel, dim3(grid_for((long)B * H * W)), dim3(256), 0, stream, img, B, H * W, mean3[0], mean3[1],
-              mean3[2], std3[0], std3[1], std3[2], (int)prm[0], (int)prm[1], (int)prm[2], (int)prm[3], prm[4], prm[5], prm[6],
-              prm[7]);
+              mean3[2], std3[0], std3[1], std3[2], prm, enable);
   CMDA_CHECK_LAUNCH();
 }
 
-// img, tmp: fp32 [planes,H,W]; taps: DEVICE fp32[k] (normalised Gaussian); result ends up in img
-extern "C" int cmda_gaussian_blur(float* img, float* tmp, const float* taps, int planes, int H, int W, int k, void* stream) {
+// img, tmp: fp32 [planes,H,W]; taps_x / taps_y: DEVICE fp32[kx] / [ky] (normalised Gaussians; kornia's kernel_size is
+// (ky from H, kx from W), dacs_transforms.py:86-94); enable: DEVICE int (null = on); result ends up in img
+extern "C" int cmda_gaussian_blur(float* img, float* tmp, const float* taps_x, const float* taps_y, int planes, int H, int W,
+                                  int kx, int ky, const int* enable, void* stream) {
   const long n = (long)planes * H * W;
   if (n <= 0) return CMDA_OK;
-  if (k <= 0 || !(k & 1)) return CMDA_ERR_SHAPE;
-  CMDA_LAUNCH(blur_pass_kernel, dim3(grid_for(n)), dim3(256), 0, stream, (const float*)img, tmp, taps, planes, H, W, k, 1);
-  CMDA_LAUNCH(blur_pass_kernel, dim3(grid_for(n)), dim3(256), 0, stream, (const float*)tmp, img, taps, planes, H, W, k, 0);
+  if (kx <= 0 || !(kx & 1) || ky <= 0 || !(ky & 1)) return CMDA_ERR_SHAPE;
+  CMDA_LAUNCH(blur_pass_kernel, dim3(grid_for(n)), dim3(256), 0, stream, (const float*)img, tmp, taps_x, planes, H, W, kx, 1, enable);
+  CMDA_LAUNCH(blur_pass_kernel, dim3(grid_for(n)), dim3(256), 0, stream, (const float*)tmp, img, taps_y, planes, H, W, ky, 0, enable);
   CMDA_CHECK_LAUNCH();
 }

@@ -62,12 +62,9 @@ int launch_dtype(GemmParams& p, void* stream) {
     else if (blocks(128, 64) * sp >= 2048) tile = 1;
     else tile = 2;
   }
-  {  // tuning aid (tools/gemm_bench.py): CMDA_GEMM_TILE=0|1|2|3 forces the tile (3 = 256x256, LDS-DMA kernel only)
-    static const char* force = getenv("CMDA_GEMM_TILE");
-    if (force && force[0] >= '0' && force[0] <= '3') tile = force[0] - '0';
-  }
+  if (p.tile_hint >= 1 && p.tile_hint <= 4) tile = p.tile_hint - 1;  // caller's explicit tile choice (tuning sweeps, tests)
   if constexpr (sizeof(T) == 2) {
-    static const char* no_glds = getenv("CMDA_GEMM_NO_GLDS");
+    const bool no_glds = p.tile_hint < 0;  // caller asks for the register-staged kernel (tuning sweeps)
     // LDS-DMA path: every operand mode with aligned 16-byte chunks; transposed-conv / reflect views and operands
     // too large for 32-bit tile arithmetic stay on the register-staged kernel
     auto dma_ok = [](const GemmView& v) {

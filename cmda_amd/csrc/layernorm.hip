@@ -238,8 +238,7 @@ static inline long ln_bwd_grid(long rows, int C) {
   const long rpb = 4 * (64 / lanes_per_row(C));
   // measured per shape (tools/ln_bench.py under rocprofv3): caps 256 / 512 / 2048 are all slower than 1024; so were 16-lane
   // row groups for C = 320 with a shuffle fold of the parameter gradients (32-38 us against 21.5)
-  static const char* force = getenv("CMDA_LN_BWD_GRID");  // tuning aid
-  const long cap = force ? atol(force) : 1024;
+  const long cap = 1024;
   return std::max<long>(1, std::min<long>((rows + rpb - 1) / rpb, cap));
 }
 

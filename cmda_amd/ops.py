@@ -42,6 +42,8 @@ ACT = {None: 0, 'none': 0, 'relu': 1, 'gelu': 2, 'tanh': 3}
 
 # bench.py's roofline leg: when a list is installed here every GEMM launch is bracketed by events on the launch stream
 GEMM_PROFILE = None
+# cmda_gemm_params_t.tile_hint for every GEMM issued from here (0 = the library's heuristics); set by tuning sweeps / tests
+GEMM_TILE_HINT = 0
 
 
 def gemm(A, B, out, M, N, K, *, a_kstrided=False, b_kstrided=False, ldc=None, batch=1, c_batch_stride=0,
@@ -76,6 +78,7 @@ def gemm(A, B, out, M, N, K, *, a_kstrided=False, b_kstrided=False, ldc=None, ba
         ok = ok and bias.data_ptr() % 16 == 0
     p.c_vec_ok = int(ok)
     p.colsum = colsum.data_ptr() if colsum is not None else None
+    p.tile_hint = GEMM_TILE_HINT
     if c_patch is not None:  # (OW, KH, KW*Ci): store rows (b,oh,ow) x cols (kh,kw,ci) un-patchified into NHWC
         assert res is None and batch == 1 and batch2 == 1 and not atomic
         p.c_patch_ow, p.c_patch_kh, p.c_patch_kwci = c_patch
@@ -374,11 +377,25 @@ _ISR_DIRS = {'rightdown': ((0, -1), (-1, 0)), 'rightup': ((0, -1), (1, 0)), 'lef
              'leftup': ((0, 1), (1, 0)), 'all': ((1, 0), (0, 1), (-1, 0), (0, -1))}
 
 
+_ISR_LUT = {}
+
+
 def isr_lut(val_range, device):
-    """float32 log-intensity of the 256 gray levels, computed exactly as datasets/utils.py:get_ic does (numpy fp32)."""
+    """float32 log-intensity of the 256 gray levels, computed exactly as datasets/utils.py:get_ic does (numpy fp32); cached per
+    (value range, device) -- the table is a constant of the configuration."""
     import numpy as np
-    g = np.arange(256, dtype=np.float32)
-    return torch.from_numpy(np.log(g / 255 * (val_range[1] - val_range[0]) + val_range[0]).astype(np.float32)).to(device)
+    key = (float(val_range[0]), float(val_range[1]), str(device))
+    lut = _ISR_LUT.get(key)
+    if lut is None:
+        g = np.arange(256, dtype=np.float32)
+        lut = torch.from_numpy(np.log(g / 255 * (val_range[1] - val_range[0]) + val_range[0]).astype(np.float32)).to(device)
+        _ISR_LUT[key] = lut
+    return lut
+
+
+def isr_dirs(shift_direction, shift_pixel):
+    """host list of (dy, dx) shifts of get_image_change_from_pil (datasets/utils.py:108-152) for a direction name"""
+    return [(dy * shift_pixel, dx * shift_pixel) for dy, dx in _ISR_DIRS[shift_direction]]
 
 
 def isr_gray(img):
@@ -390,14 +407,16 @@ def isr_gray(img):
     return gray
 
 
-def isr_from_gray(gray, val_range, threshold, clip_range, shift_pixel, shift_direction):
-    """get_image_change_from_pil after the gray conversion -> fp32 NCHW [B,3,H,W] in [-1,1]."""
+def isr_from_gray(gray, val_range, threshold, clip_range, shift_pixel, shift_direction, dirs_dev=None):
+    """get_image_change_from_pil after the gray conversion -> fp32 NCHW [B,3,H,W] in [-1,1].  `dirs_dev`: optional DEVICE
+    int32 [ndir,2] holding the (dy,dx) shifts (then `shift_direction` only gives ndir); lets a captured launch sequence pick
+    the direction per replay."""
     import numpy as np
-    check_dev(gray)
+    check_dev(gray, dirs_dev)
     B, H, W = gray.shape
     span = np.log(val_range[1]) - np.log(val_range[0])
-    dirs = [(dy * shift_pixel, dx * shift_pixel) for dy, dx in _ISR_DIRS[shift_direction]]
-    dirs_t = torch.tensor(dirs, dtype=torch.int32).to(gray.device)
+    dirs = isr_dirs(shift_direction, shift_pixel)
+    dirs_t = dirs_dev if dirs_dev is not None else torch.tensor(dirs, dtype=torch.int32).to(gray.device)
     mm = torch.empty(B * len(dirs) * 4, dtype=torch.int32, device=gray.device)
     out = torch.empty(B, 3, H, W, dtype=torch.float32, device=gray.device)
     lut = isr_lut(val_range, gray.device)
@@ -424,26 +443,41 @@ def events_norm(events, clip_range, final_range=1.0):
     return out
 
 
-def color_jitter_(img, order, fb, fc, fs, fh):
-    """In place on the normalised NCHW fp32 image: kornia-0.5 ColorJitter with the given op order and factors."""
-    check_dev(img)
+def jitter_params(per_sample):
+    """host list of B tuples (order[4], f_b, f_c, f_s, f_h) -> CPU fp32 [B,8] (the layout cmda_color_jitter reads)"""
+    return torch.tensor([[float(v) for v in order] + [fb, fc, fs, fh] for order, fb, fc, fs, fh in per_sample],
+                        dtype=torch.float32)
+
+
+def color_jitter_(img, prm, enable=None):
+    """In place on the normalised NCHW fp32 image: kornia-0.5 ColorJitter, one (op order, factors) row of the DEVICE fp32
+    tensor `prm` [B,8] per sample; `enable`: optional DEVICE int32 gate (0 = leave the image untouched)."""
+    check_dev(img, prm, enable)
     B, _, H, W = img.shape
-    prm = (ctypes.c_float * 8)(*[float(v) for v in order], fb, fc, fs, fh)
-    call('cmda_color_jitter', ptr(img), c_i32(B), c_i32(H), c_i32(W), _IMG_MEAN, _IMG_STD, prm, stream_of(img))
+    assert prm.shape == (B, 8) and prm.dtype == torch.float32
+    call('cmda_color_jitter', ptr(img), c_i32(B), c_i32(H), c_i32(W), _IMG_MEAN, _IMG_STD, ptr(prm), ptr(enable), stream_of(img))
     return img
 
 
-def gaussian_taps(k, sigma, device):
+def gaussian_taps(k, sigma, device=None):
     x = torch.arange(k, dtype=torch.float32) - k // 2
     g = torch.exp(-x * x / (2.0 * sigma * sigma))
-    return (g / g.sum()).to(device)
+    g = g / g.sum()
+    return g if device is None else g.to(device)
 
 
-def gaussian_blur_(img, k, sigma):
-    """In place separable Gaussian blur (reflect border) of an NCHW fp32 image."""
-    check_dev(img)
+def blur_kernel_size(n):
+    """dacs_transforms.py:86-93: kernel size from the image extent n"""
+    import numpy as np
+    return int(np.floor(np.ceil(0.1 * n) - 0.5 + np.ceil(0.1 * n) % 2))
+
+
+def gaussian_blur_(img, taps_x, taps_y, enable=None):
+    """In place separable Gaussian blur (reflect border) of an NCHW fp32 image; taps_x / taps_y: DEVICE fp32 normalised
+    Gaussians (lengths kx from W, ky from H); `enable`: optional DEVICE int32 gate."""
+    check_dev(img, taps_x, taps_y, enable)
     B, C, H, W = img.shape
     tmp = torch.empty_like(img)
-    taps = gaussian_taps(k, sigma, img.device)  # keep a reference until the launch is enqueued
-    call('cmda_gaussian_blur', ptr(img), ptr(tmp), ptr(taps), c_i32(B * C), c_i32(H), c_i32(W), c_i32(k), stream_of(img))
+    call('cmda_gaussian_blur', ptr(img), ptr(tmp), ptr(taps_x), ptr(taps_y), c_i32(B * C), c_i32(H), c_i32(W),
+         c_i32(taps_x.numel()), c_i32(taps_y.numel()), ptr(enable), stream_of(img))
     return img

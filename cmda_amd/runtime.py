@@ -17,11 +17,13 @@ from . import ops
 
 _state = {'dtype': torch.float32}
 _cache = {}
+_frozen = {}   # compute copies of parameters marked `_cmda_frozen` (the Motion-Extractor generator): never invalidated
 
 
 def set_compute_dtype(dtype):
     assert dtype in (torch.float32, torch.bfloat16)
     _state['dtype'] = dtype
+    _frozen.clear()
     invalidate()
 
 
@@ -55,7 +57,10 @@ def w(param):
 def wconv(param, kind='khwc'):
     """Conv weight [Co,Ci,KH,KW] repacked for the implicit GEMM (see module docstring)."""
     key = (id(param), kind)
-    t = _cache.get(key)
+    store = _frozen if getattr(param, '_cmda_frozen', False) else _cache
+    t = store.get(key)
+    if t is not None and t.device != param.device:
+        t = None
     if t is None:
         Co, Ci, KH, KW = param.shape
         if kind == 'khwc':
@@ -64,7 +69,7 @@ def wconv(param, kind='khwc'):
         else:
             t = torch.empty(Ci, KH * KW * Co, dtype=_state['dtype'], device=param.device)
             ops.permute4(param.data, t, (Co, Ci, KH, KW), (1, 2, 3, 0), flipmask=0b1100)
-        _cache[key] = t
+        store[key] = t
     return t
 
 
@@ -88,6 +93,17 @@ def grad(param):
 
 def act_empty(*shape, device):
     return torch.empty(*shape, dtype=_state['dtype'], device=device)
+
+
+_ones = {}
+
+
+def ones1(device):
+    """fp32 [1] holding 1.0: the d(loss) seed of a hand-scheduled backward pass"""
+    t = _ones.get(device)
+    if t is None:
+        t = _ones[device] = torch.ones(1, dtype=torch.float32, device=device)
+    return t
 
 
 _anchors = {}

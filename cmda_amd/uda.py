@@ -79,6 +79,7 @@ class DACS(nn.Module):
             self.cyclegan_itrd2en.eval()
             for p in self.cyclegan_itrd2en.parameters():
                 p.requires_grad_(False)
+                p._cmda_frozen = True   # runtime: its re-laid-out compute copies survive optimizer steps
         assert cfg.get('sky_mask') is None, 'sky-mask augmentation is off in configs/fusion/* and not implemented'
         self.mixed_image_to_mixed_isr = bool(cfg.get('mixed_image_to_mixed_isr'))
         self.isr_parms = {'val_range': (1, 10 ** 2), '_threshold': 0.04, '_clip_range': 0.2, 'shift_pixel': 3}
@@ -97,6 +98,8 @@ class DACS(nn.Module):
         lfc = cfg.get('lambda_feature_consistency', -1)
         self.forward_cfg['lambda_feature_consistency'] = lfc if lfc != -1 else 0.25
         self._flat = None
+        self._graph = None
+        self._graph_warmup = None
         for p in self.ema_model.parameters():
             p.requires_grad_(False)
 
@@ -185,142 +188,284 @@ class DACS(nn.Module):
 
     def _choose_classes(self, labels):
         """get_class_masks (dacs_transforms.py:101-112): classes = unique over the WHOLE batch, ceil(n/2) drawn per
-        sample with np.random.choice.  One small device->host read (<= 20 class ids), as in the reference."""
-        classes = torch.unique(labels).cpu()
+        sample with np.random.choice.  One small device->host read (<= 20 class ids), as in the reference.  Returns a CPU
+        int64 [B, Kmax] tensor padded with -1 (Kmax fixed by num_classes, so the launch shapes never change)."""
+        if labels.is_cuda and getattr(self, '_graph_warmup', None) is not None:
+            # graph mode: the host runs far ahead of the GPU, so the read goes through a side stream instead of draining the
+            # main one (the label tensor is an input of the step: complete before train_step is called)
+            side = getattr(self, '_side_stream', None) or torch.cuda.Stream(labels.device)
+            self._side_stream = side
+            with torch.cuda.stream(side):
+                classes = torch.unique(labels).cpu()
+        else:
+            classes = torch.unique(labels).cpu()
         n = classes.shape[0]
         k = int((n + n % 2) / 2)
-        out = torch.full((labels.shape[0], max(k, 1)), -1, dtype=torch.int64)
+        out = torch.full((labels.shape[0], self._kmax()), -1, dtype=torch.int64)
         for i in range(labels.shape[0]):
             pick = np.random.choice(n, k, replace=False)
             out[i, :k] = classes[torch.as_tensor(pick).long()]
-        return out.to(labels.device)
+        return out
 
-    def forward_train(self, **kwargs):
-        src, tgt = kwargs['source'], kwargs['target']
+    def _kmax(self):
+        return (self.num_classes + 2) // 2   # labels 0..num_classes-1 plus the ignore index -> at most ceil((nc+1)/2) classes
+
+    # -- host decisions of one iteration (everything random that the reference draws on the host) -------------------------------
+    def _draw(self, day_label, H, W):
+        """dacs.py:417 (events / ISR choice), :446-456 (strong_parameters), dacs_transforms.py:101-112 (class draw), and the
+        per-sample kornia ColorJitter draws of strong_transform (one call per sample, dacs.py:721-724)."""
+        B = day_label.shape[0]
+        d = {}
+        if self.train_type == 'cs2dz_image+raw-isr':
+            d['choice'] = 0.0
+        elif self.without_events:
+            d['choice'] = -1.0
+        elif self.without_isd:
+            d['choice'] = 2.0
+        else:
+            d['choice'] = float(torch.rand(1))   # CPU generator: no device sync
+        d['color_jitter'] = random.uniform(0, 1)
+        d['blur'] = random.uniform(0, 1) if self.blur else 0
+        d['sigma'] = random.uniform(0.15, 1.15)
+        d['classes'] = self._choose_classes(day_label)
+        d['jitter'] = None
+        if d['color_jitter'] > self.color_jitter_p:
+            s_ = self.color_jitter_s
+            lo = max(0.0, 1 - s_)
+            d['jitter'] = [([int(v) for v in np.random.permutation(4)], random.uniform(lo, 1 + s_), random.uniform(lo, 1 + s_),
+                            random.uniform(lo, 1 + s_), random.uniform(-s_, s_)) for _ in range(B)]
+        if self.shift_type == 'random':
+            cj = d['color_jitter']
+            d['direction'] = _DIRECT[int(cj * 10) % 2][int(cj * 100) % 2]
+        else:
+            d['direction'] = self.shift_type
+        return d
+
+    # -- device-resident control block: what the host decided, in buffers whose addresses never change ----------------------
+    def _control_block(self, dev, B, H, W):
+        key = (str(dev), B, H, W)
+        cb = getattr(self, '_ctl', None)
+        if cb is not None and cb['key'] == key:
+            return cb
+        kx, ky = ops.blur_kernel_size(W), ops.blur_kernel_size(H)
+        ndir = 4 if self.shift_type == 'all' else 2
+        al = lambda n: (n + 3) // 4 * 4  # noqa: E731  (16-byte aligned sections)
+        sizes = [('classes', 2 * B * self._kmax()), ('jitter', 8 * B), ('taps_x', kx), ('taps_y', ky), ('dirs', 2 * ndir), ('flags', 4)]
+        off, o = {}, 0
+        for name, n in sizes:
+            off[name] = (o, n)
+            o += al(n)
+        # ring of pinned staging buffers: the host may run several iterations ahead of the GPU (graph replay), so a buffer is
+        # rewritten only after the copy that read it has executed (event per slot)
+        nring = 4 if dev.type == 'cuda' else 1
+        hosts = [torch.zeros(o, dtype=torch.int32).pin_memory() if dev.type == 'cuda' else torch.zeros(o, dtype=torch.int32)
+                 for _ in range(nring)]
+        devbuf = torch.zeros(o, dtype=torch.int32, device=dev)
+
+        def views(buf):
+            v = {n: buf[a:a + ln] for n, (a, ln) in off.items()}
+            return dict(classes=v['classes'].view(torch.int64).view(B, self._kmax()), jitter=v['jitter'].view(torch.float32).view(B, 8),
+                        taps_x=v['taps_x'].view(torch.float32), taps_y=v['taps_y'].view(torch.float32),
+                        dirs=v['dirs'].view(ndir, 2), jitter_on=v['flags'][0:1], blur_on=v['flags'][1:2])
+        self._ctl = dict(key=key, hosts=hosts, hviews=[views(h) for h in hosts], events=[None] * nring, slot=0, dev=devbuf,
+                         d=views(devbuf), kx=kx, ky=ky)
+        return self._ctl
+
+    def _stage(self, cb, draws):
+        """host decisions -> the device control block: ONE asynchronous copy per iteration"""
+        slot = cb['slot']
+        cb['slot'] = (slot + 1) % len(cb['hosts'])
+        if cb['events'][slot] is not None:
+            cb['events'][slot].synchronize()
+        h = cb['hviews'][slot]
+        h['classes'].copy_(draws['classes'])
+        on = draws['jitter'] is not None
+        h['jitter_on'][0] = int(on)
+        if on:
+            h['jitter'].copy_(ops.jitter_params(draws['jitter']))
+        blur_on = draws['blur'] > 0.5
+        h['blur_on'][0] = int(blur_on)
+        if blur_on:
+            h['taps_x'].copy_(ops.gaussian_taps(cb['kx'], draws['sigma']))
+            h['taps_y'].copy_(ops.gaussian_taps(cb['ky'], draws['sigma']))
+        h['dirs'].copy_(torch.tensor(ops.isr_dirs(draws['direction'], self.isr_parms['shift_pixel']), dtype=torch.int32))
+        cb['dev'].copy_(cb['hosts'][slot], non_blocking=True)
+        if cb['dev'].is_cuda:
+            ev = cb['events'][slot] or torch.cuda.Event()
+            ev.record()
+            cb['events'][slot] = ev
+
+    def _cfg_student(self, use_events):
         tt = self.train_type
+        if tt == 'cs2dsec_image+events_together':
+            if self.fuse_both_ice_and_e:
+                return dict(self.forward_cfg, fusion_all=True)
+            if self.isr_another_fusion and not use_events:
+                return dict(self.forward_cfg, fusion_isr=True)
+        elif tt == 'cs2dsec_image+events':
+            if self.isr_no_fusion and not use_events:
+                return dict(self.forward_cfg, no_fusion=True)
+            if self.isr_another_fusion and not use_events:
+                return dict(self.forward_cfg, fusion_isr=True)
+        return self.forward_cfg
+
+    # -- the device work of one iteration: no host reads, no host-dependent launch shapes (capturable as ONE hipGraph) ----------
+    def _iteration(self, src, tgt, ctl, use_events, teacher_second, direction):
+        """dacs.py:397-860 minus the host decisions (`_draw`), the EMA update and the optimizer step.  `ctl` = device views of
+        the control block; `teacher_second` = the teacher's second input (events or ISR, already chosen); `use_events` /
+        `direction` only select code paths that are fixed per configuration (student inputs of 'cs2dsec_image+events')."""
+        tt = self.train_type
+        day_image, day_isr, day_label = src['image'], src['img_self_res'], src['label']
         day_events = night_events = None
         if tt == 'cs2dz_image+raw-isr':
-            day_image, day_isr, day_label = src['image'], src['img_self_res'], src['label']
-            if 'warp_image' in tgt:
-                night_image, night_isr = tgt['warp_image'], tgt['warp_img_self_res']
-            else:
-                night_image, night_isr = tgt['image'], tgt['night_isr']
+            night_image = tgt['warp_image'] if 'warp_image' in tgt else tgt['image']
         else:
-            day_image, day_isr, day_label = src['image'], src['img_self_res'], src['label']
-            if self.cyclegan_itrd2en is not None:
-                itr = src['img_time_res'].mean(dim=1, keepdim=True)
-                day_events = self.cyclegan_itrd2en(itr).repeat(1, 3, 1, 1)
+            if self.cyclegan_itrd2en is not None:   # Image Motion-Extractor (dacs.py:400-404), frozen, no grad
+                day_events = self.cyclegan_itrd2en.forward_mean3(src['img_time_res'])
             else:
                 day_events = src['img_time_res']
-            night_image, night_events, night_isr = tgt['warp_image'], tgt['events_vg'], tgt['warp_img_self_res']
-            if self.without_events:
-                self.forward_cfg['isr_events_fusion_choice'] = -1
-            elif self.without_isd:
-                self.forward_cfg['isr_events_fusion_choice'] = 2
-            else:
-                self.forward_cfg['isr_events_fusion_choice'] = torch.rand(1).detach()  # CPU tensor: no device sync
-        use_events = tt != 'cs2dz_image+raw-isr' and bool(self.forward_cfg['isr_events_fusion_choice'] > self.random_choice_thres)
+            night_image, night_events = tgt['warp_image'], tgt['events_vg']
         B, _, H, W = day_image.shape
+        dev = day_image.device
         log_vars = {}
+        if not self.ema_model.training or not getattr(self, '_teacher_mode_set', False):
+            self.ema_model.train()          # BatchNorm keeps batch statistics (and updates its running stats) ...
+            set_stochastic(self.ema_model, False)  # ... but DropPath / Dropout2d are off in the teacher (dacs.py:458-462)
+            self._teacher_mode_set = True
+        student, teacher = self.get_model(), self.get_ema_model()
+        cfg_s = self._cfg_student(use_events)
+        one = rt.ones1(dev)
 
-        if self.local_iter == 0:
-            self._init_ema_weights()
-        if self.local_iter > 0:
-            self._update_ema(self.local_iter)
-        strong = {'color_jitter': random.uniform(0, 1), 'blur': random.uniform(0, 1) if self.blur else 0,
-                  'sigma': random.uniform(0.15, 1.15)}
-        self.ema_model.train()          # BatchNorm keeps batch statistics (and updates its running stats) ...
-        set_stochastic(self.ema_model, False)  # ... but DropPath / Dropout2d are off in the teacher
-
-        # ---- source ------------------------------------------------------------------------------------------------
-        student = self.get_model()
+        # ---- source (dacs.py:489-523) ------------------------------------------------------------------------------------------
         if tt == 'cs2dz_image+raw-isr':
-            inputs, cfg_s = {'image': day_image, 'events': day_isr}, self.forward_cfg
+            inputs = {'image': day_image, 'events': day_isr}
         elif tt == 'cs2dsec_image+events_together':
             inputs = {'image': day_image, 'events': day_events, 'img_self_res': day_isr}
-            if self.fuse_both_ice_and_e:
-                cfg_s = dict(self.forward_cfg, fusion_all=True)
-            elif self.isr_another_fusion and not use_events:
-                cfg_s = dict(self.forward_cfg, fusion_isr=True)
-            else:
-                cfg_s = self.forward_cfg
         else:
             inputs = {'image': day_image, 'events': day_events if use_events else day_isr}
-            if self.isr_no_fusion and not use_events:
-                cfg_s = dict(self.forward_cfg, no_fusion=True)
-            elif self.isr_another_fusion and not use_events:
-                cfg_s = dict(self.forward_cfg, fusion_isr=True)
-            else:
-                cfg_s = self.forward_cfg
-        source_losses, _ = student.forward_train(inputs, day_label, return_feat=True, cfg=cfg_s)
-        source_losses.pop('features')
-        source_loss, clean_log = parse_losses(source_losses)
-        log_vars.update(clean_log)
-        source_loss.backward()
+        loss, (losses, _, _), saved = student.train_fwd(inputs, day_label, None, cfg_s)
+        log_vars['decode.loss_seg'], log_vars['decode.acc_seg'], log_vars['loss'] = loss, losses['acc_seg'], loss
+        student.train_bwd(saved, one)
+        del saved
 
-        # ---- teacher pseudo-labels -------------------------------------------------------------------------------------
-        teacher = self.get_ema_model()
-        if tt == 'cs2dz_image+raw-isr':
-            ema = teacher.encode_decode_lowres(night_image, night_isr, test_cfg=self.forward_cfg)
+        # ---- teacher pseudo-labels (dacs.py:653-711) -----------------------------------------------------------------------------
+        if tt != 'cs2dz_image+raw-isr' and self.fuse_both_ice_and_e:
+            ema = teacher.encode_decode_lowres(night_image, night_events, tgt['warp_img_self_res'], dict(self.forward_cfg, fusion_all=True))
+        elif tt != 'cs2dz_image+raw-isr' and self.isr_another_fusion and not use_events:
+            ema = teacher.encode_decode_lowres(night_image, teacher_second, test_cfg=dict(self.forward_cfg, fusion_isr=True))
         else:
-            if self.fuse_both_ice_and_e:
-                ema = teacher.encode_decode_lowres(night_image, night_events, night_isr, dict(self.forward_cfg, fusion_all=True))
-            elif self.isr_another_fusion and not use_events:
-                ema = teacher.encode_decode_lowres(night_image, night_isr, test_cfg=dict(self.forward_cfg, fusion_isr=True))
-            elif self.isr_no_fusion:
-                ema = teacher.encode_decode_lowres(night_image, night_events, test_cfg=self.forward_cfg)
-            else:
-                ema = teacher.encode_decode_lowres(night_image, night_events if use_events else night_isr, test_cfg=self.forward_cfg)
+            ema = teacher.encode_decode_lowres(night_image, teacher_second, test_cfg=self.forward_cfg)
         pseudo_label, _, count = ops.pseudo_label(ema['fusion_output'], H, W, self.pseudo_threshold, want_prob=False)
         pseudo_weight = ops.pseudo_weight(count, B, H, W, self.psweight_ignore_top, self.psweight_ignore_bottom)
-        gt_pixel_weight = torch.ones(B, H, W, dtype=torch.float32, device=day_image.device)
+        gt_pixel_weight = torch.ones(B, H, W, dtype=torch.float32, device=dev)
 
-        # ---- ClassMix (+ ISR of the mixed image) ---------------------------------------------------------------------------
+        # ---- ClassMix + strong augmentation + ISR of the mixed image (dacs.py:716-771) --------------------------------------------
         lab = day_label.view(B, H, W)
-        classes = self._choose_classes(day_label)
+        classes = ctl['classes']
         mixed_img = ops.class_mix(day_image, night_image, lab, classes)
-        # strong_transform's colour jitter / Gaussian blur of the mixed image (dacs_transforms.py:64-98; kornia semantics)
-        if strong['color_jitter'] > self.color_jitter_p:
-            s_ = self.color_jitter_s
-            order = list(np.random.permutation(4))
-            ops.color_jitter_(mixed_img, order, random.uniform(max(0.0, 1 - s_), 1 + s_), random.uniform(max(0.0, 1 - s_), 1 + s_),
-                              random.uniform(max(0.0, 1 - s_), 1 + s_), random.uniform(-s_, s_))
-        if strong['blur'] > 0.5:
-            k = int(np.floor(np.ceil(0.1 * H) - 0.5 + np.ceil(0.1 * H) % 2))
-            ops.gaussian_blur_(mixed_img, k, strong['sigma'])
+        # strong_transform's colour jitter / Gaussian blur of the mixed image (dacs_transforms.py:64-98; kornia semantics): the
+        # on/off gates and the per-sample parameters are read from the control block by the kernels
+        if self.color_jitter_p < 1.0:
+            ops.color_jitter_(mixed_img, ctl['jitter'], ctl['jitter_on'])
+        if self.blur:
+            ops.gaussian_blur_(mixed_img, ctl['taps_x'], ctl['taps_y'], ctl['blur_on'])
         mixed_events = ops.class_mix(day_events, night_events, lab, classes) if day_events is not None else None
         gray = ops.isr_gray(mixed_img)
-        if self.shift_type == 'random':
-            cj = strong['color_jitter']
-            direction = _DIRECT[int(cj * 10) % 2][int(cj * 100) % 2]
-        else:
-            direction = self.shift_type
         mixed_isr = ops.isr_from_gray(gray, self.isr_parms['val_range'], self.isr_parms['_threshold'],
-                                      self.isr_parms['_clip_range'], self.isr_parms['shift_pixel'], direction)
+                                      self.isr_parms['_clip_range'], self.isr_parms['shift_pixel'], direction, dirs_dev=ctl['dirs'])
         mixed_lbl = ops.class_mix_label(lab, pseudo_label, lab, classes).view(B, 1, H, W)
         mixed_weight = ops.class_mix(gt_pixel_weight.view(B, 1, H, W), pseudo_weight.view(B, 1, H, W), lab, classes).view(B, H, W)
 
-        # ---- mixed ---------------------------------------------------------------------------------------------------------
+        # ---- mixed (dacs.py:820-860) ---------------------------------------------------------------------------------------------
         if tt == 'cs2dz_image+raw-isr':
             inputs = {'image': mixed_img, 'events': mixed_isr}
         elif tt == 'cs2dsec_image+events_together':
             inputs = {'image': mixed_img, 'events': mixed_events, 'img_self_res': mixed_isr}
         else:
             inputs = {'image': mixed_img, 'events': mixed_events if use_events else mixed_isr}
-        mix_losses, _ = student.forward_train(inputs, mixed_lbl, seg_weight=mixed_weight, return_feat=True, cfg=cfg_s)
-        mix_losses.pop('features')
-        mix_loss, mix_log = parse_losses(add_prefix(mix_losses, 'mix'))
-        log_vars.update(mix_log)
+        loss, (losses, _, _), saved = student.train_fwd(inputs, mixed_lbl, mixed_weight, cfg_s)
+        log_vars['mix.decode.loss_seg'], log_vars['mix.decode.acc_seg'] = loss, losses['acc_seg']
+        log_vars['loss'] = loss   # _parse_losses of the mixed step overwrites 'loss' (dacs.py:851-857)
         # the second (last) backward pass of the iteration: gradients reported final by this pass are final for the step, so a
         # data-parallel driver may start their all-reduce underneath the rest of the pass (runtime.grad_ready_hook)
         prev_hook = rt.grad_ready_hook
-        if getattr(self, 'final_pass_grad_hook', None) is not None:
+        if getattr(self, 'final_pass_grad_hook', None) is not None and not (dev.type == 'cuda' and torch.cuda.is_current_stream_capturing()):
             rt.grad_ready_hook = self.final_pass_grad_hook
         try:
-            mix_loss.backward()
+            student.train_bwd(saved, one)
         finally:
             rt.grad_ready_hook = prev_hook
+        extras = dict(mixed_img=mixed_img, mixed_lbl=mixed_lbl, mixed_isr=mixed_isr, pseudo_weight=mixed_weight,
+                      pseudo_label=pseudo_label, classes=classes, mixed_events=mixed_events, day_events=day_events,
+                      teacher_logits=ema, pseudo_count=count)
+        return log_vars, extras
+
+    # -- hipGraph replay of the iteration ------------------------------------------------------------------------------------------
+    def enable_graph(self, warmup_iters=2):
+        """Capture `_iteration` into ONE hipGraph after `warmup_iters` eager iterations and replay it from then on: at the
+        reference's 2+2 samples per GPU the eager step is bound by the host's launch rate (~17 k launches), not by the GPU.
+        Only the EMA update, the control-block copy and the optimizer step stay outside the graph."""
+        self._graph_warmup = warmup_iters
+        self._graph = None
+
+    def disable_graph(self):
+        self._graph_warmup = None
+        self._graph = None
+
+    def _capture(self, src, tgt, cb, use_events_struct, direction):
+        dev = src['image'].device
+        st_src = {k: v.clone() for k, v in src.items() if isinstance(v, torch.Tensor)}
+        st_tgt = {k: v.clone() for k, v in tgt.items() if isinstance(v, torch.Tensor)}
+        second = torch.empty_like(st_src['image'])
+        torch.cuda.synchronize(dev)
+        rt.invalidate()    # every weight re-layout must be recorded INSIDE the graph (it is re-run by each replay)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = self._iteration(st_src, st_tgt, cb['d'], use_events_struct, second, direction)
+        rt.invalidate()    # the cached re-layouts now live in the graph's pool and hold data only after a replay
+        self._graph = dict(graph=g, src=st_src, tgt=st_tgt, second=second, out=out, key=(use_events_struct, direction))
+
+    def forward_train(self, **kwargs):
+        src, tgt = kwargs['source'], kwargs['target']
+        tt = self.train_type
+        day_label = src['label']
+        B, _, H, W = src['image'].shape
+        dev = src['image'].device
+        draws = getattr(self, 'inject_draws', None) or self._draw(day_label, H, W)
+        self.last_draws = draws
+        self.forward_cfg['isr_events_fusion_choice'] = draws['choice']
+        use_events = tt != 'cs2dz_image+raw-isr' and draws['choice'] > self.random_choice_thres
+        cb = self._control_block(dev, B, H, W)
+        self._stage(cb, draws)
+        if self.local_iter == 0:
+            self._init_ema_weights()
+        if self.local_iter > 0:
+            self._update_ema(self.local_iter)
+        if tt == 'cs2dz_image+raw-isr':
+            second = tgt['warp_img_self_res'] if 'warp_image' in tgt else tgt['night_isr']
+        else:
+            second = tgt['events_vg'] if (use_events or self.isr_no_fusion) else tgt['warp_img_self_res']
+        # launch-shape-relevant part of the draws: only 'cs2dsec_image+events' / isr_another_fusion route differently by choice,
+        # and only shift_type 'all' changes the number of ISR directions (the direction itself lives in the control block)
+        struct_events = use_events if (tt == 'cs2dsec_image+events' or self.isr_another_fusion) else True
+        ndir_key = 'all' if self.shift_type == 'all' else 'rightdown'
+        graph_on = (getattr(self, '_graph_warmup', None) is not None and dev.type == 'cuda'
+                    and self.local_iter >= self._graph_warmup)
+        if graph_on:
+            if self._graph is None or self._graph['key'] != (struct_events, ndir_key):
+                self._capture(src, tgt, cb, struct_events, ndir_key)
+            G = self._graph
+            for k, v in G['src'].items():
+                if v.data_ptr() != src[k].data_ptr():
+                    v.copy_(src[k])
+            for k, v in G['tgt'].items():
+                if v.data_ptr() != tgt[k].data_ptr():
+                    v.copy_(tgt[k])
+            G['second'].copy_(second)
+            G['graph'].replay()
+            log_vars, extras = G['out']
+        else:
+            log_vars, extras = self._iteration(src, tgt, cb['d'], struct_events, second, ndir_key)
         self.local_iter += 1
-        self.last_mix = dict(mixed_img=mixed_img, mixed_lbl=mixed_lbl, mixed_isr=mixed_isr, pseudo_weight=mixed_weight,
-                             pseudo_label=pseudo_label, classes=classes)
-        return log_vars
+        self.last_mix = extras
+        return dict(log_vars)

@@ -76,6 +76,9 @@ typedef struct cmda_gemm_params_t {
    * (((b*OH + oh)*KH + kh) * OW*KW + ow*KW + kw) * Ci + ci of C, i.e. straight into the NHWC input gradient instead of a
    * column buffer.  Off when c_patch_ow == 0; ldc / batch strides / residual are ignored in this mode. */
   int32_t c_patch_ow, c_patch_kh, c_patch_kwci;
+  /* 0: the library's tile heuristics; 1..4: force tile 64x64 / 128x64 / 128x128 / 256x256 (tuning sweeps, tests of the
+   * rarely chosen tiles); -1: register-staged kernel instead of the LDS-DMA one. */
+  int32_t tile_hint;
 } cmda_gemm_params_t;
 
 int cmda_gemm(const cmda_gemm_params_t* p, void* stream);
@@ -188,9 +191,14 @@ int cmda_events_norm(const float* events, float* out, void* ws, int64_t n, float
     stream);
 
 /* ---- Strong augmentation of the mixed image -- models/utils/dacs_transforms.py:64-98 (kornia 0.5.8 ColorJitter and
- * GaussianBlur2d, restated).  mean3/std3/prm are HOST pointers; taps is a DEVICE fp32[k] normalised Gaussian. */
-int cmda_color_jitter(float* img, int B, int H, int W, const float* mean3, const float* std3, const float* prm, void* stream);
-int cmda_gaussian_blur(float* img, float* tmp, const float* taps, int planes, int H, int W, int k, void* stream);
+ * GaussianBlur2d, restated), applied per sample by uda/dacs.py:721-724.  mean3/std3 are HOST pointers; prm is DEVICE
+ * fp32 [B][8] (per sample: op order[4], f_brightness, f_contrast, f_saturation, f_hue); taps_x / taps_y are DEVICE fp32
+ * normalised Gaussians (kernel size ky from H, kx from W); enable is a DEVICE int gate (NULL = on; 0 = leave the image
+ * untouched) so that the random on/off decisions of dacs.py:446-456 do not change the launch sequence. */
+int cmda_color_jitter(float* img, int B, int H, int W, const float* mean3, const float* std3, const float* prm,
+    const int* enable, void* stream);
+int cmda_gaussian_blur(float* img, float* tmp, const float* taps_x, const float* taps_y, int planes, int H, int W, int kx,
+    int ky, const int* enable, void* stream);
 
 #ifdef __cplusplus
 }

@@ -78,6 +78,18 @@ def pseudo_labels(fusion_logits_lowres, size, threshold, ignore_top=0, ignore_bo
     return label, prob, weight, count
 
 
+def pseudo_labels_fullres(fusion_logits, threshold, ignore_top=0, ignore_bottom=0):
+    """dacs.py:680-682,701-711 on the already up-sampled teacher logits [B,nc,H,W] (what encode_decode returns)."""
+    prob, label = torch.softmax(fusion_logits, dim=1).max(dim=1)
+    count = int((prob >= threshold).sum())
+    weight = (count / label.numel()) * torch.ones(prob.shape)
+    if ignore_top > 0:
+        weight[:, :ignore_top, :] = 0
+    if ignore_bottom > 0:
+        weight[:, -ignore_bottom:, :] = 0
+    return label, prob, weight, count
+
+
 # ---------------------------------------------------------------- ClassMix
 def choose_classes(labels, rng):
     """get_class_masks' class draw: unique over the WHOLE batch tensor, ceil(n/2) classes per sample."""
@@ -270,6 +282,21 @@ def gaussian_blur(img, k, sigma):
     y = F.conv2d(y, g.view(1, 1, 1, k).repeat(C, 1, 1, 1), groups=C)
     y = F.pad(y, (0, 0, pad, pad), mode='reflect')
     return F.conv2d(y, g.view(1, 1, k, 1).repeat(C, 1, 1, 1), groups=C)
+
+
+def gaussian_blur_hw(img, ky, kx, sigma):
+    """GaussianBlur2d(kernel_size=(ky, kx), sigma=(sigma, sigma)), border 'reflect' (dacs_transforms.py:82-98: ky from the
+    image height, kx from its width)."""
+    def taps(k):
+        x = torch.arange(k, dtype=torch.float32) - k // 2
+        g = torch.exp(-x * x / (2.0 * sigma * sigma))
+        return g / g.sum()
+    C = img.shape[1]
+    gx, gy = taps(kx), taps(ky)
+    y = F.pad(img, (kx // 2, kx // 2, 0, 0), mode='reflect')
+    y = F.conv2d(y, gx.view(1, 1, 1, kx).repeat(C, 1, 1, 1), groups=C)
+    y = F.pad(y, (0, 0, ky // 2, ky // 2), mode='reflect')
+    return F.conv2d(y, gy.view(1, 1, ky, 1).repeat(C, 1, 1, 1), groups=C)
 
 
 def blur_kernel_size(n):

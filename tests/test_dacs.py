@@ -1,5 +1,13 @@
-"""One full DACS iteration (source step, EMA teacher pseudo-labels, ClassMix + on-device ISR, mixed step) on the HIP
-kernels against the same iteration composed from the oracle's pieces (reduced-depth MiT so it runs in the emulator)."""
+"""One full DACS iteration (Motion-Extractor generator, EMA teacher, source step, pseudo-labels, ClassMix + colour jitter +
+blur + on-device ISR, mixed step) on the HIP kernels against the same iteration of oracle/dacs_iter.py (which follows
+mmseg/models/uda/dacs.py:357-860).  The host decisions (events/ISR choice, jitter / blur gates and parameters, class draw)
+are taken from the HIP run (`DACS.last_draws`) and injected into the oracle, so both sides compute the same iteration.
+
+  * reduced width / depth, fp32: runs in the CPU emulator and on the GPU;
+  * MiT-B5 widths (head dim 64 -> the fused attention kernel in bf16), depth 1 per stage, fp32 and bf16: GPU only;
+  * the same iteration replayed as ONE hipGraph must reproduce the eager result: GPU only.
+"""
+import functools
 import os
 import random
 import sys
@@ -16,115 +24,162 @@ import cmda_amd  # noqa: E402,F401
 import cmda_amd.runtime as rt  # noqa: E402
 from cmda_amd.registry import build_train_model  # noqa: E402
 from conftest import assert_close  # noqa: E402
-from oracle import fusion as ofu, head as ohd, mit as omit, segmentor as oseg, uda as ouda  # noqa: E402
+from oracle import cyclegan as ocg, dacs_iter, fusion as ofu, head as ohd, mit as omit, segmentor as oseg  # noqa: E402
 
 DEPTHS = [1, 1, 1, 1]
-DIMS = [32, 64, 160, 256]   # reduced widths (head dim 32) keep the emulator run short; the full MiT-B5 runs in test_modules
-CH = 64
+SMALL = dict(dims=[32, 64, 160, 256], ch=64)   # reduced widths (head dim 32) keep the emulator run short
+FULLW = dict(dims=[64, 128, 320, 512], ch=256)  # MiT-B5 widths: head dim 64, the bench's kernel selection
 ISR = dict(val_range=[0.01, 1.01], _threshold=0.005, _clip_range=0.1, shift_pixel=1)
 FCFG = dict(loss_weight={'image': 0.5, 'events': 0.5, 'fusion': 0.5, 'img_self_res': 0.25}, gradual_rate=0.0)
 
 
-def make_cfg():
-    bb = dict(type='MixVisionTransformer', embed_dims=DIMS, num_heads=[1, 2, 5, 8], qkv_bias=True,
+def make_cfg(dims, ch, generator=True, blur=True, jitter_p=0.2, shift_type='random'):
+    bb = dict(type='MixVisionTransformer', embed_dims=dims, num_heads=[1, 2, 5, 8], qkv_bias=True,
               depths=DEPTHS, sr_ratios=[8, 4, 2, 1], drop_path_rate=0.0,
-              norm_layer=__import__('functools').partial(torch.nn.LayerNorm, eps=1e-6))
-    head = dict(type='DAFormerHeadFusion', in_channels=DIMS, in_index=[0, 1, 2, 3], channels=CH,
+              norm_layer=functools.partial(torch.nn.LayerNorm, eps=1e-6))
+    head = dict(type='DAFormerHeadFusion', in_channels=dims, in_index=[0, 1, 2, 3], channels=ch,
                 dropout_ratio=0.0, num_classes=19, norm_cfg=dict(type='BN', requires_grad=True), align_corners=False,
-                decoder_params=dict(embed_dims=CH, embed_cfg=dict(type='mlp', act_cfg=None, norm_cfg=None),
+                decoder_params=dict(embed_dims=ch, embed_cfg=dict(type='mlp', act_cfg=None, norm_cfg=None),
                                     embed_neck_cfg=dict(type='mlp', act_cfg=None, norm_cfg=None),
                                     fusion_cfg=dict(type='aspp', sep=True, dilations=(1, 6, 12, 18), pool=False,
                                                     act_cfg=dict(type='ReLU'), norm_cfg=dict(type='BN', requires_grad=True)),
                                     train_type='cs2dsec_image+events_together', share_decoder=True),
                 loss_decode=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0))
     model = dict(type='FusionEncoderDecoder', backbone_image=dict(bb), backbone_events=dict(bb),
-                 fusion_module=dict(type='AttentionAvgFusion', in_channels=DIMS, drop_path_rate=0.0), decode_head=head,
+                 fusion_module=dict(type='AttentionAvgFusion', in_channels=dims, drop_path_rate=0.0), decode_head=head,
                  train_type='cs2dsec_image+events_together', train_cfg=dict(), test_cfg=dict(mode='whole'))
     uda = dict(type='DACS', alpha=0.999, pseudo_threshold=0.968, pseudo_weight_ignore_top=0, pseudo_weight_ignore_bottom=0,
                imnet_feature_dist_lambda=0, imnet_feature_dist_classes=None, imnet_feature_dist_scale_min_ratio=None,
-               mix='class', blur=False, color_jitter_strength=0.2, color_jitter_probability=2.0, debug_img_interval=1000,
-               print_grad_magnitude=False, train_type='cs2dsec_image+events_together', forward_cfg=FCFG,
-               cyclegan_itrd2en_path='', img_self_res_reg='no', mixed_image_to_mixed_isr=True, random_choice_thres='0.5',
-               shift_type='rightdown', isr_parms=ISR, sky_mask=None)
+               mix='class', blur=blur, color_jitter_strength=0.2, color_jitter_probability=jitter_p, debug_img_interval=1000,
+               print_grad_magnitude=False, train_type='cs2dsec_image+events_together', forward_cfg=dict(FCFG),
+               cyclegan_itrd2en_path='random' if generator else '', img_self_res_reg='no', mixed_image_to_mixed_isr=True,
+               random_choice_thres='0.5', shift_type=shift_type, isr_parms=dict(ISR), sky_mask=None)
     return dict(model=model, uda=uda, runner=dict(type='IterBasedRunner', max_iters=40000))
 
 
-def oracle_student():
-    return oseg.FusionEncoderDecoder(backbone_image=omit.MixVisionTransformer(embed_dims=DIMS, depths=DEPTHS, drop_path_rate=0.0),
-                                     backbone_events=omit.MixVisionTransformer(embed_dims=DIMS, depths=DEPTHS, drop_path_rate=0.0),
-                                     fusion_module=ofu.AttentionAvgFusion(in_channels=DIMS, drop_path_rate=0.0),
-                                     decode_head=ohd.DAFormerHeadFusion(in_channels=DIMS, channels=CH, embed_dims=CH,
+def oracle_student(dims, ch):
+    return oseg.FusionEncoderDecoder(backbone_image=omit.MixVisionTransformer(embed_dims=dims, depths=DEPTHS, drop_path_rate=0.0),
+                                     backbone_events=omit.MixVisionTransformer(embed_dims=dims, depths=DEPTHS, drop_path_rate=0.0),
+                                     fusion_module=ofu.AttentionAvgFusion(in_channels=dims, drop_path_rate=0.0),
+                                     decode_head=ohd.DAFormerHeadFusion(in_channels=dims, channels=ch, embed_dims=ch,
                                                                         dropout_ratio=0.0, share_decoder=True))
 
 
-def test_dacs_iteration_matches_oracle(tgt):
-    rt.set_compute_dtype(torch.float32)
-    B, H, W = 2, 64, 64
-    dacs = build_train_model(make_cfg())
-    seeded_fill(dacs.model, 7)
-    seeded_fill(dacs.ema_model, 8)  # different from the student: iteration 0 must overwrite it
-    dacs.to(tgt.device).train()
+def make_batch(B, H, W):
     g = torch.Generator().manual_seed(3)
     lab = torch.randint(0, 6, (B, 1, H // 8, W // 8), generator=g).repeat_interleave(8, 2).repeat_interleave(8, 3)
     lab[0, 0, :4] = 255
-    src = dict(image=seeded_randn((B, 3, H, W), 7, 'img'), img_time_res=seeded_randn((B, 3, H, W), 7, 'itr'),
+    itr = seeded_randn((B, 1, H, W), 7, 'itr').clamp(-1, 1).repeat(1, 3, 1, 1)
+    src = dict(image=seeded_randn((B, 3, H, W), 7, 'img'), img_time_res=itr,
                img_self_res=seeded_randn((B, 3, H, W), 7, 'isr').clamp(-1, 1), label=lab)
     tg = dict(warp_image=seeded_randn((B, 3, H, W), 7, 'nimg'), events_vg=seeded_randn((B, 3, H, W), 7, 'nev').clamp(-1, 1),
               warp_img_self_res=seeded_randn((B, 3, H, W), 7, 'nisr').clamp(-1, 1))
+    return src, tg
+
+
+def oracle_draws(d):
+    """DACS.last_draws -> the `draws` argument of oracle.dacs_iter.dacs_iteration (class rows without the -1 padding)"""
+    out = {k: d[k] for k in ('choice', 'color_jitter', 'blur', 'sigma', 'jitter')}
+    out['classes'] = [row[row >= 0] for row in d['classes']]
+    return out
+
+
+def run_case(tgt, dims, ch, dtype, B=2, H=64, W=64, iters=1, graph=False, shift_type='random'):
+    rt.set_compute_dtype(dtype)
+    dacs = build_train_model(make_cfg(dims, ch, shift_type=shift_type))
+    seeded_fill(dacs.model, 7)
+    seeded_fill(dacs.ema_model, 8)  # different from the student: iteration 0 must overwrite it
+    seeded_fill(dacs.cyclegan_itrd2en, 9)
+    dacs.to(tgt.device).train()
+    src, tg = make_batch(B, H, W)
     batch = dict(source={k: tgt.to(v) for k, v in src.items()}, target={k: tgt.to(v) for k, v in tg.items()})
-
-    # ---- oracle iteration --------------------------------------------------------------------------------------------
-    ref = oracle_student()
+    ref, ema, G = oracle_student(dims, ch), oracle_student(dims, ch), ocg.ResnetGenerator().eval()
     seeded_fill(ref, 7).train()
-    ema = oracle_student()
     seeded_fill(ema, 8).train()
+    seeded_fill(G, 9)
     torch.manual_seed(11), random.seed(11), np.random.seed(11)
-    choice = torch.rand(1)
-    ouda.update_ema(list(ema.parameters()), list(ref.parameters()), 0, 0.999)
-    _cj = random.uniform(0, 1)
-    use_events = bool(choice > 0.5)
-    inputs = {'image': src['image'], 'events': src['img_time_res'], 'img_self_res': src['img_self_res']}
-    l_s, _ = ref.forward_train(inputs, lab, return_feat=False, cfg=FCFG)
-    l_s['decode.loss_seg'].backward()
-    with torch.no_grad():
-        out = ema.encode_decode(tg['warp_image'], tg['events_vg'] if use_events else tg['warp_img_self_res'],
-                                output_features=True, test_cfg=FCFG)
-        prob, plabel = torch.softmax(out['fusion_output'], dim=1).max(dim=1)
-        pw = (prob.ge(0.968).sum().item() / plabel.numel()) * torch.ones(prob.shape)
-    chosen = ouda.choose_classes(lab, np.random)
-    mixed_img, mixed_ev, mixed_lbl, mixed_w, mixed_isr = [], [], [], [], []
-    for i in range(B):
-        m = ouda.class_mask(lab[i], chosen[i])
-        mixed_img.append(ouda.one_mix(m, src['image'][i], tg['warp_image'][i])[None])
-        mixed_ev.append(ouda.one_mix(m, src['img_time_res'][i], tg['events_vg'][i])[None])
-        mixed_lbl.append(ouda.one_mix(m, lab[i][0], plabel[i])[None])
-        mixed_w.append(ouda.one_mix(m, torch.ones(H, W), pw[i]))
-        mixed_isr.append(ouda.mixed_image_to_isr(mixed_img[-1], 1, [0.01, 1.01], 0.005, 0.1, 'rightdown'))
-    mixed_img, mixed_ev, mixed_lbl = torch.cat(mixed_img), torch.cat(mixed_ev), torch.cat(mixed_lbl)
-    mixed_w, mixed_isr = torch.cat(mixed_w), torch.cat(mixed_isr)
-    l_m, _ = ref.forward_train({'image': mixed_img, 'events': mixed_ev, 'img_self_res': mixed_isr}, mixed_lbl,
-                               seg_weight=mixed_w, cfg=FCFG)
-    l_m['decode.loss_seg'].backward()
+    if graph:
+        dacs.enable_graph(warmup_iters=1)
+    outs = []
+    for it in range(iters):
+        for p in dacs.model.parameters():
+            if p.grad is not None:
+                p.grad.zero_()
+        log_vars = dacs(**batch)
+        mix = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in dacs.last_mix.items()}
+        grads = {n: p.grad.detach().cpu().clone() for n, p in dacs.model.named_parameters()}
+        for p in ref.parameters():
+            p.grad = None
+        o = dacs_iter.dacs_iteration(ref, ema, G, src, tg, local_iter=it, forward_cfg=FCFG, isr_parms=ISR, shift_type=shift_type,
+                                     draws=oracle_draws(dacs.last_draws))
+        outs.append((dict(log_vars), mix, grads, o, {n: q.grad.clone() for n, q in ref.named_parameters()}))
+    return dacs, ema, outs
 
-    # ---- HIP iteration (same RNG streams) --------------------------------------------------------------------------------
-    torch.manual_seed(11), random.seed(11), np.random.seed(11)
-    log_vars = dacs(**batch)
-    mix = dacs.last_mix
-    assert torch.equal(mix['classes'].cpu()[0][mix['classes'].cpu()[0] >= 0], chosen[0])
-    agree = (mix['pseudo_label'].cpu() == plabel).float().mean().item()
-    assert agree > 0.999, f'pseudo-label agreement {agree}'
-    assert_close(mix['mixed_img'], mixed_img, 0, name='mixed image')
-    same = (mix['mixed_lbl'].cpu() == mixed_lbl).float().mean().item()
-    assert same > 0.999
-    assert_close(mix['mixed_isr'], mixed_isr, 1e-5, atol=1e-6, name='mixed ISR')
-    assert_close(mix['pseudo_weight'], mixed_w, 1e-4, name='mixed weight')
-    assert_close(log_vars['decode.loss_seg'], l_s['decode.loss_seg'], 1e-4, name='source loss')
-    assert_close(log_vars['mix.decode.loss_seg'], l_m['decode.loss_seg'], 2e-3, name='mix loss')
+
+def check_iteration(out, exact, tol_loss, tol_grad, label_agree=0.999):
+    log_vars, mix, grads, o, ref_grads = out
+    assert_close(mix['day_events'], o['day_events'], 2e-4 if exact else 6e-2, name='generator output (day events)')
+    agree = (mix['pseudo_label'].cpu() == o['pseudo_label']).float().mean().item()
+    assert agree > label_agree, f'pseudo-label agreement {agree}'
+    if exact:
+        assert_close(mix['mixed_img'], o['mixed_img'], 1e-4, atol=2e-4, name='mixed image', outlier_frac=1e-3, outlier_rtol=2.0)
+        same = (mix['mixed_lbl'].cpu() == o['mixed_lbl']).float().mean().item()
+        assert same > label_agree
+        # uint8 truncation of the jittered image can move one gray level where the two colour-jitter implementations differ
+        # in the last bit: the ISR is compared on the bulk
+        assert_close(mix['mixed_isr'], o['mixed_isr'], 1e-5, atol=1e-6, name='mixed ISR', outlier_frac=5e-3, outlier_rtol=2.0)
+        assert_close(mix['pseudo_weight'], o['mixed_weight'], 1e-3, name='mixed weight')
+    assert_close(log_vars['decode.loss_seg'], o['decode.loss_seg'], tol_loss, name='source loss')
+    assert_close(log_vars['mix.decode.loss_seg'], o['mix.decode.loss_seg'], tol_loss * 20, name='mix loss')
+    worst = 0.0
+    for n, q in ref_grads.items():
+        e = (grads[n] - q).abs().max().item() / (q.abs().max().item() + 1e-12)
+        worst = max(worst, e)
+    assert worst < tol_grad, f'worst accumulated-gradient relative error {worst}'
+
+
+def test_dacs_iteration_matches_oracle(tgt):
+    """reduced widths, fp32, generator + jitter + blur + random ISR direction ON"""
+    dacs, ema, outs = run_case(tgt, SMALL['dims'], SMALL['ch'], torch.float32)
+    d = dacs.last_draws
+    assert d['jitter'] is not None and len(d['jitter']) == 2 and d['jitter'][0] != d['jitter'][1], 'per-sample jitter draws'
+    check_iteration(outs[0], True, 1e-4, 5e-2)
     for (n1, p), (n2, q) in zip(dacs.ema_model.named_parameters(), ema.named_parameters()):
         assert_close(p.data, q.data, 0, name='ema ' + n1)
-    worst = 0.0
-    for (n1, p), (n2, q) in zip(dacs.model.named_parameters(), ref.named_parameters()):
-        assert n1 == n2
-        e = (p.grad.cpu() - q.grad).abs().max().item() / (q.grad.abs().max().item() + 1e-12)
-        worst = max(worst, e)
-    assert worst < 5e-2, f'worst accumulated-gradient relative error {worst}'
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+def test_dacs_iteration_full_width_gpu(mode):
+    """MiT-B5 widths (head dim 64): in bf16 this is the bench's kernel selection (fused attention, bf16 MFMA GEMMs)"""
+    from conftest import Target
+    from cmda_amd import _lib
+    _lib._unbind_for_tests()
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU on this machine')
+    tgt = Target('gpu')
+    dt = torch.float32 if mode == 'f32' else torch.bfloat16
+    dacs, ema, outs = run_case(tgt, FULLW['dims'], FULLW['ch'], dt, H=128, W=128)
+    if mode == 'f32':
+        check_iteration(outs[0], True, 1e-4, 5e-2)
+    else:
+        check_iteration(outs[0], False, 2e-2, 0.35, label_agree=0.97)
+    rt.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.gpu
+def test_dacs_graph_replay_matches_oracle():
+    """iteration 0 eager (warm-up), iterations 1-2 captured / replayed as one hipGraph: each must still match the oracle's
+    iteration with the same draws (different draws per iteration: the gates and parameters travel through the control block)"""
+    from conftest import Target
+    from cmda_amd import _lib
+    _lib._unbind_for_tests()
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU on this machine')
+    tgt = Target('gpu')
+    dacs, ema, outs = run_case(tgt, SMALL['dims'], SMALL['ch'], torch.float32, iters=3, graph=True)
+    assert dacs._graph is not None, 'the iteration was not captured'
+    for out in outs:
+        check_iteration(out, True, 1e-4, 5e-2)
+    for (n1, p), (n2, q) in zip(dacs.ema_model.named_parameters(), ema.named_parameters()):
+        assert_close(p.data, q.data, 1e-6, name='ema ' + n1)

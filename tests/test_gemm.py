@@ -99,12 +99,13 @@ def test_conv_implicit_gemm(tgt, dt, tag, tol, Bc, H, W, Ci, Co, KH, st, pd, dl)
 
 
 def _run_forced_tile(marker):
-    """the tile heuristics only pick the 256x256 (8-wave) kernel for very large problems: force it (CMDA_GEMM_TILE is read
-    once per process) and run the whole GEMM suite through it in a child process"""
+    """the tile heuristics only pick the 256x256 (8-wave) kernel for very large problems: force it through
+    cmda_gemm_params_t.tile_hint (tests/conftest.py sets ops.GEMM_TILE_HINT from CMDA_TEST_GEMM_TILE) and run the whole GEMM
+    suite through it in a child process"""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, CMDA_GEMM_TILE='3')
+    env = dict(os.environ, CMDA_TEST_GEMM_TILE='4')
     here = os.path.abspath(__file__)
     r = subprocess.run([sys.executable, '-m', 'pytest', here, '-q', '-x', '-m', marker, '-k', 'not forced_tile', '-p', 'no:cacheprovider'],
                        env=env, capture_output=True, text=True, timeout=1500)

@@ -261,17 +261,25 @@ def test_voxel_golden(tgt):
 
 
 def test_strong_augmentation(tgt):
+    """per-sample colour-jitter parameters and the (ky from H, kx from W) blur of dacs_transforms.py:64-98, plus the device-side
+    on/off gates a captured launch sequence relies on"""
     from oracle import uda as ouda
     torch.manual_seed(9)
     img = torch.randn(2, 3, 40, 56)
-    order, fb, fc, fs, fh = [2, 0, 3, 1], 1.1, 0.9, 1.15, -0.07
-    ref = ouda.color_jitter(img, order, fb, fc, fs, fh)
-    out = ops.color_jitter_(tgt.to(img.clone()), order, fb, fc, fs, fh)
+    per_sample = [([2, 0, 3, 1], 1.1, 0.9, 1.15, -0.07), ([1, 3, 0, 2], 0.85, 1.2, 0.8, 0.11)]
+    ref = torch.cat([ouda.color_jitter(img[i:i + 1], *per_sample[i]) for i in range(2)])
+    prm = tgt.to(ops.jitter_params(per_sample))
+    on, off = tgt.to(torch.ones(1, dtype=torch.int32)), tgt.to(torch.zeros(1, dtype=torch.int32))
+    out = ops.color_jitter_(tgt.to(img.clone()), prm, on)
     assert_close(out, ref, 1e-4, atol=2e-4, name='color jitter', outlier_frac=1e-3, outlier_rtol=2.0)
-    k = ouda.blur_kernel_size(56)
-    refb = ouda.gaussian_blur(img, k, 0.8)
-    outb = ops.gaussian_blur_(tgt.to(img.clone()), k, 0.8)
+    assert torch.equal(ops.color_jitter_(tgt.to(img.clone()), prm, off).cpu(), img), 'gate off must leave the image untouched'
+    ky, kx = ouda.blur_kernel_size(40), ouda.blur_kernel_size(56)
+    assert (ky, kx) == (ops.blur_kernel_size(40), ops.blur_kernel_size(56)) and ky != kx
+    refb = ouda.gaussian_blur_hw(img, ky, kx, 0.8)
+    tx, ty = tgt.to(ops.gaussian_taps(kx, 0.8)), tgt.to(ops.gaussian_taps(ky, 0.8))
+    outb = ops.gaussian_blur_(tgt.to(img.clone()), tx, ty, on)
     assert_close(outb, refb, 1e-5, atol=1e-6, name='gaussian blur')
+    assert torch.equal(ops.gaussian_blur_(tgt.to(img.clone()), tx, ty, off).cpu(), img), 'gate off must leave the image untouched'
 
 
 def _attention_ref(q, kv, B, N, Nk, heads, C, scale):
