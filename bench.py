@@ -273,13 +273,15 @@ def run_dacs(args, rank, world, dev, dist):
     dacs.attach_flat_store(opt)
     reducer = GradAllReducer(opt.flat_g, wire_dtype=torch.bfloat16, force=args.force_reducer)
     if reducer.active:
-        # overlap inside the LAST backward pass of the iteration: the decode head and the image encoder (back-propagated once
-        # per pass) start their slices as they finish; the event encoder (twice per pass) and the rest go in finish()
+        # overlap inside the LAST backward pass of the iteration: the decode head and both encoders (each back-propagated once
+        # per pass -- the event encoder sees events + ISR as one batch) start their slices as they finish; the fusion blocks
+        # and the small norm / bias group go in finish()
         student = dacs.model
         ranges = {('decode_head', id(student.decode_head)): opt.ranges_of(student, ['decode_head.'])}
-        for s in range(1, 5):
-            ranges[(f'backbone.stage{s}', id(student.backbone_image))] = opt.ranges_of(
-                student, [f'backbone_image.patch_embed{s}.', f'backbone_image.block{s}.', f'backbone_image.norm{s}.'])
+        for name in ('backbone_image', 'backbone_events'):
+            for s in range(1, 5):
+                ranges[(f'backbone.stage{s}', id(getattr(student, name)))] = opt.ranges_of(
+                    student, [f'{name}.patch_embed{s}.', f'{name}.block{s}.', f'{name}.norm{s}.'])
 
         def _ready(tag, module=None):
             for lo, hi in ranges.get((tag, id(module)), ()):

@@ -213,13 +213,32 @@ class MixVisionTransformer(nn.Module):
         for i, blk in enumerate(live):
             blk._dp_pool = [masks, 2 * i]
 
-    def fwd(self, img, save=True):
-        """img: NCHW fp32 [B,3,H,W] (the reference's input layout).  Returns ([(feat [B*N,C], H, W)] * 4, saved)."""
-        B, Cin, H, W = img.shape
-        x = torch.empty(B * H * W, Cin, dtype=rt.compute_dtype(), device=img.device)
-        ops.permute4(img.contiguous(), x, (B, Cin, H, W), (0, 2, 3, 1))
+    def feature_shapes(self, H, W):
+        """(H_s, W_s) of the four stage outputs for an H x W input (patch embeds: k7 s4 p3, then k3 s2 p1)"""
+        out = []
+        for s in range(4):
+            k, st = (7, 4) if s == 0 else (3, 2)
+            H, W = K.conv_out_size(H, W, k, st, k // 2)
+            out.append((H, W))
+        return out
+
+    def fwd(self, img, save=True, out_feats=None):
+        """img: NCHW fp32 [B,3,H,W] (the reference's input layout), or a LIST of such tensors run as ONE batch (the event
+        encoder sees the events and the ISR of a sample with the same weights, encoder_decoder.py:703-712: one pass over 2B
+        samples instead of two over B).  out_feats: optional list of 4 pre-allocated [Btot*N_s, C_s] tensors the stage outputs
+        are written into (slices of the decode head's joint feature buffers).
+        Returns ([(feat [Btot*N,C], H, W)] * 4, saved)."""
+        imgs = list(img) if isinstance(img, (list, tuple)) else [img]
+        _, Cin, H, W = imgs[0].shape
+        B = sum(t.shape[0] for t in imgs)
+        x = torch.empty(B * H * W, Cin, dtype=rt.compute_dtype(), device=imgs[0].device)
+        row = 0
+        for t in imgs:
+            b = t.shape[0]
+            ops.permute4(t.contiguous(), x[row:row + b * H * W], (b, Cin, H, W), (0, 2, 3, 1))
+            row += b * H * W
         feats, saved = [], []
-        self._draw_drop_path(B, img.device)
+        self._draw_drop_path(B, x.device)
         for s in range(1, 5):
             pe = getattr(self, f'patch_embed{s}')
             x, H, W, sv_pe = pe.fwd(x, B, H, W)
@@ -230,7 +249,7 @@ class MixVisionTransformer(nn.Module):
                 sv_blocks.append(sv)
             nrm = getattr(self, f'norm{s}')
             xin = x
-            x, m, r = ops.layernorm_fwd(xin, nrm.weight, nrm.bias, self.eps)
+            x, m, r = ops.layernorm_fwd(xin, nrm.weight, nrm.bias, self.eps, out=out_feats[s - 1] if out_feats is not None else None)
             feats.append((x, H, W))
             saved.append((sv_pe, sv_blocks, (xin, m, r), H, W))
         return feats, (saved, B) if save else None

@@ -26,6 +26,8 @@ __global__ void bn_reduce_kernel(const T* __restrict__ x, float* __restrict__ ws
   __shared__ float red[2][4][64][4];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int c = (blockIdx.x * 64 + cx) * 4;
+  x += (long)blockIdx.z * M * C;                      // group z: rows [z*M, (z+1)*M), its own statistics
+  ws += (long)blockIdx.z * (kBnSlots + 1) * 2 * C;
   const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
   float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
   if (c < C) {
@@ -66,28 +68,40 @@ __global__ void bn_reduce_kernel(const T* __restrict__ x, float* __restrict__ ws
   }
 }
 
+// One thread per channel; the G groups' running-statistics updates are applied one after the other in `order` (the shared
+// decoder's BatchNorm sees image, events, fusion, ISR features in that order: daformer_head.py:305-319), which is what makes a
+// grouped call equal to G separate calls.
+struct BnOrder { int g[8]; };
 template <typename T>
 __global__ void bn_finalize_kernel(const T* __restrict__ x, const float* __restrict__ ws, float* __restrict__ mean,
                                    float* __restrict__ rstd, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var, long M, int C, float eps, float momentum) {
+                                   float* __restrict__ running_var, long M, int C, float eps, float momentum, int G,
+                                   BnOrder order) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const float shift = ldf(x + c);
-  float s = 0.f, q = 0.f;
-  for (int k = 0; k < kBnSlots; ++k) {
-    s += ws[(long)k * 2 * C + c];
-    q += ws[(long)k * 2 * C + C + c];
-  }
-  const float md = s / (float)M;
-  const float mu = shift + md;
-  float var = q / (float)M - md * md;
-  var = fmaxf(var, 0.f);
-  mean[c] = mu;
-  rstd[c] = rsqrtf(var + eps);
-  if (running_mean) {
+  float rm = running_mean ? running_mean[c] : 0.f, rv = running_mean ? running_var[c] : 0.f;
+  for (int i = 0; i < G; ++i) {
+    const int g = order.g[i];
+    const float shift = ldf(x + (long)g * M * C + c);
+    const float* wg = ws + (long)g * (kBnSlots + 1) * 2 * C;
+    float s = 0.f, q = 0.f;
+    for (int k = 0; k < kBnSlots; ++k) {
+      s += wg[(long)k * 2 * C + c];
+      q += wg[(long)k * 2 * C + C + c];
+    }
+    const float md = s / (float)M;
+    const float mu = shift + md;
+    float var = q / (float)M - md * md;
+    var = fmaxf(var, 0.f);
+    mean[(long)g * C + c] = mu;
+    rstd[(long)g * C + c] = rsqrtf(var + eps);
     const float unb = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+    rm = (1.f - momentum) * rm + momentum * mu;
+    rv = (1.f - momentum) * rv + momentum * unb;
+  }
+  if (running_mean) {
+    running_mean[c] = rm;
+    running_var[c] = rv;
   }
 }
 
@@ -98,6 +112,10 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int c = (blockIdx.x * 64 + cx) * 4;
   if (c >= C) return;
+  x += (long)blockIdx.z * M * C;
+  y += (long)blockIdx.z * M * ldy;
+  mean += (long)blockIdx.z * C;
+  rstd += (long)blockIdx.z * C;
   const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
   float mu[4], rs[4], g[4], b[4];
   ld4(mean + c, mu);
@@ -134,6 +152,11 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restri
   __shared__ float red[2][4][64][4];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int c = (blockIdx.x * 64 + cx) * 4;
+  x += (long)blockIdx.z * M * C;
+  dy += (long)blockIdx.z * M * lddy;
+  mean += (long)blockIdx.z * C;
+  rstd += (long)blockIdx.z * C;
+  ws += (long)blockIdx.z * (kBnSlots + 1) * 2 * C;
   const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
   float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
   if (c < C) {
@@ -184,6 +207,7 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restri
 __global__ void bn_fold_kernel(float* __restrict__ ws, int C2) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= C2) return;
+  ws += (long)blockIdx.z * (kBnSlots + 1) * C2;
   float a = 0.f;
   for (int k = 0; k < kBnSlots; ++k) a += ws[(long)k * C2 + i];
   ws[(long)kBnSlots * C2 + i] = a;
@@ -199,6 +223,12 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int c = (blockIdx.x * 64 + cx) * 4;
   if (c >= C) return;
+  x += (long)blockIdx.z * M * C;
+  dx += (long)blockIdx.z * M * C;
+  dy += (long)blockIdx.z * M * lddy;
+  mean += (long)blockIdx.z * C;
+  rstd += (long)blockIdx.z * C;
+  ws += (long)blockIdx.z * (kBnSlots + 1) * 2 * C;
   const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
   const float invM = 1.f / (float)M;
   float mu[4], rs[4], g[4], b[4], a1[4], a2[4];
@@ -211,8 +241,13 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
   if (blockIdx.y == 0 && ry == 0) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      dbeta[c + j] += a1[j];
-      dgamma[c + j] += a2[j];
+      if (gridDim.z > 1) {   // the groups share gamma / beta: their contributions meet in the same addresses
+        atomicAdd(dbeta + c + j, a1[j]);
+        atomicAdd(dgamma + c + j, a2[j]);
+      } else {
+        dbeta[c + j] += a1[j];
+        dgamma[c + j] += a2[j];
+      }
     }
   }
 #pragma unroll
@@ -257,26 +292,34 @@ static inline int rows_per_block_apply(long M, int gx) {
 }
 }  // namespace
 
-// ws: cmda_bn_ws_floats(C) = 66*C floats of scratch (zeroed here).  Saves mean/rstd [C] for the backward, updates running stats in place.
+// ws: cmda_bn_ws_floats(C) = 66*C floats of scratch PER GROUP (zeroed here).  Saves mean/rstd [groups][C] for the backward,
+// updates running stats in place.  groups > 1: x / y hold `groups` consecutive blocks of M rows, each normalised with its own
+// batch statistics (the shared decoder run once over the image / events / fusion / ISR features); `order` (HOST, may be
+// NULL = 0,1,2..) lists the groups in the order their running-statistic updates are applied.
 extern "C" int64_t cmda_bn_ws_floats(int C) { return (int64_t)(kBnSlots + 1) * 2 * C; }
 
 extern "C" int cmda_bn_train_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                                  float* running_mean, float* running_var, float* ws, int64_t M, int C, float eps,
-                                 float momentum, int relu, int ldy, int coff, int dtype, void* stream) {
+                                 float momentum, int relu, int ldy, int coff, int groups, const int* order, int dtype,
+                                 void* stream) {
   if (M <= 0 || C <= 0) return CMDA_OK;
-  if ((C & 3) || (ldy & 3) || (coff & 3)) return CMDA_ERR_SHAPE;
-  (void)hipMemsetAsync(ws, 0, sizeof(float) * 2 * C * kBnSlots, (hipStream_t)stream);
+  if ((C & 3) || (ldy & 3) || (coff & 3) || groups < 1 || groups > 8) return CMDA_ERR_SHAPE;
+  BnOrder ord;
+  for (int i = 0; i < 8; ++i) ord.g[i] = (order && i < groups) ? order[i] : i;
+  for (int i = 0; i < groups; ++i)
+    if (ord.g[i] < 0 || ord.g[i] >= groups) return CMDA_ERR_SHAPE;
+  (void)hipMemsetAsync(ws, 0, sizeof(float) * (size_t)groups * (kBnSlots + 1) * 2 * C, (hipStream_t)stream);
   const int gx = (C / 4 + 63) / 64;
-  const int rpb = rows_per_block(M, gx);
-  dim3 rgrid(gx, (unsigned)((M + rpb - 1) / rpb));
-  const int arpb = rows_per_block_apply(M, gx);
-  dim3 agrid(gx, (unsigned)((M + arpb - 1) / arpb));
+  const int rpb = rows_per_block(M * groups, gx);
+  dim3 rgrid(gx, (unsigned)((M + rpb - 1) / rpb), groups);
+  const int arpb = rows_per_block_apply(M * groups, gx);
+  dim3 agrid(gx, (unsigned)((M + arpb - 1) / arpb), groups);
   CMDA_DISPATCH_DTYPE(dtype, {
     CMDA_LAUNCH((bn_reduce_kernel<T>), rgrid, dim3(256), 0, stream, (const T*)x, ws, (long)M, C, rpb);
     CMDA_LAUNCH((bn_finalize_kernel<T>), dim3((C + 255) / 256), dim3(256), 0, stream, (const T*)x, ws, mean, rstd,
-                running_mean, running_var, (long)M, C, eps, momentum);
-    CMDA_LAUNCH((bn_apply_kernel<T>), agrid, dim3(256), 0, stream, (const T*)x, mean, rstd, gamma, beta, (T*)y, (long)M, C,
-                relu, ldy, coff, arpb);
+                running_mean, running_var, (long)M, C, eps, momentum, groups, ord);
+    CMDA_LAUNCH((bn_apply_kernel<T>), agrid, dim3(256), 0, stream, (const T*)x, mean, rstd, gamma, beta, (T*)y + coff, (long)M,
+                C, relu, ldy, 0, arpb);
   });
   CMDA_CHECK_LAUNCH();
 }
@@ -294,24 +337,25 @@ extern "C" int cmda_bn_apply(const void* x, const float* mean, const float* rstd
   CMDA_CHECK_LAUNCH();
 }
 
-// dy may be a channel slice [coff, coff+C) of a wider buffer with row pitch lddy; x is the pre-BN tensor [M,C].
+// dy may be a channel slice [coff, coff+C) of a wider buffer with row pitch lddy; x is the pre-BN tensor [groups*M, C];
+// mean / rstd are [groups][C] as saved by the forward call; dgamma / dbeta accumulate over all groups.
 extern "C" int cmda_bn_train_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                                  const float* beta, void* dx, float* dgamma, float* dbeta, float* ws, int64_t M, int C,
-                                 int relu, int lddy, int coff, int dtype, void* stream) {
+                                 int relu, int lddy, int coff, int groups, int dtype, void* stream) {
   if (M <= 0 || C <= 0) return CMDA_OK;
-  if ((C & 3) || (lddy & 3) || (coff & 3)) return CMDA_ERR_SHAPE;
-  (void)hipMemsetAsync(ws, 0, sizeof(float) * 2 * C * kBnSlots, (hipStream_t)stream);
+  if ((C & 3) || (lddy & 3) || (coff & 3) || groups < 1 || groups > 8) return CMDA_ERR_SHAPE;
+  (void)hipMemsetAsync(ws, 0, sizeof(float) * (size_t)groups * (kBnSlots + 1) * 2 * C, (hipStream_t)stream);
   const int gx = (C / 4 + 63) / 64;
-  const int rpb = rows_per_block(M, gx);
-  dim3 rgrid(gx, (unsigned)((M + rpb - 1) / rpb));
-  const int arpb = rows_per_block_apply(M, gx);
-  dim3 agrid(gx, (unsigned)((M + arpb - 1) / arpb));
+  const int rpb = rows_per_block(M * groups, gx);
+  dim3 rgrid(gx, (unsigned)((M + rpb - 1) / rpb), groups);
+  const int arpb = rows_per_block_apply(M * groups, gx);
+  dim3 agrid(gx, (unsigned)((M + arpb - 1) / arpb), groups);
   CMDA_DISPATCH_DTYPE(dtype, {
-    CMDA_LAUNCH((bn_bwd_reduce_kernel<T>), rgrid, dim3(256), 0, stream, (const T*)dy, (const T*)x, mean, rstd, gamma,
-                beta, ws, (long)M, C, relu, lddy, coff, rpb);
-    CMDA_LAUNCH(bn_fold_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, stream, ws, 2 * C);
-    CMDA_LAUNCH((bn_bwd_apply_kernel<T>), agrid, dim3(256), 0, stream, (const T*)dy, (const T*)x, mean, rstd, gamma, beta,
-                ws + (long)kBnSlots * 2 * C, (T*)dx, dgamma, dbeta, (long)M, C, relu, lddy, coff, arpb);
+    CMDA_LAUNCH((bn_bwd_reduce_kernel<T>), rgrid, dim3(256), 0, stream, (const T*)dy + coff, (const T*)x, mean, rstd, gamma,
+                beta, ws, (long)M, C, relu, lddy, 0, rpb);
+    CMDA_LAUNCH(bn_fold_kernel, dim3((2 * C + 255) / 256, 1, groups), dim3(256), 0, stream, ws, 2 * C);
+    CMDA_LAUNCH((bn_bwd_apply_kernel<T>), agrid, dim3(256), 0, stream, (const T*)dy + coff, (const T*)x, mean, rstd, gamma, beta,
+                ws + (long)kBnSlots * 2 * C, (T*)dx, dgamma, dbeta, (long)M, C, relu, lddy, 0, arpb);
   });
   CMDA_CHECK_LAUNCH();
 }

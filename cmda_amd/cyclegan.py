@@ -43,16 +43,23 @@ class ResnetGenerator(nn.Module):
         m += [nn.ReflectionPad2d(3), nn.Conv2d(ngf, output_nc, 7), nn.Tanh()]
         self.model = nn.Sequential(*m)
         self.n_blocks = n_blocks
+        self._ident = {}
 
-    @staticmethod
-    def _inorm(x, B, HW, C, relu, res=None):
-        """InstanceNorm2d(affine=False, eps 1e-5) (+ReLU) (+residual) on NHWC-flat x [B*HW, C], per sample."""
-        one = torch.ones(C, dtype=torch.float32, device=x.device)
-        zero = torch.zeros(C, dtype=torch.float32, device=x.device)
+    def _inorm(self, x, B, HW, C, relu, res=None):
+        """InstanceNorm2d(affine=False, eps 1e-5) (+ReLU) (+residual) on NHWC-flat x [B*HW, C]: the grouped column-statistics
+        kernels with one group per sample (up to 8 samples per launch)."""
+        key = (C, str(x.device))
+        ident = self._ident.get(key)
+        if ident is None:
+            ident = self._ident[key] = (torch.ones(C, dtype=torch.float32, device=x.device),
+                                        torch.zeros(C, dtype=torch.float32, device=x.device))
+        one, zero = ident
         y = torch.empty_like(x)
-        for b in range(B):
-            ops.bn_train_fwd(x[b * HW:(b + 1) * HW], one, zero, y[b * HW:(b + 1) * HW], None, None, HW, C, 1e-5, 0.0, relu)
-        return y if res is None else ops.axpby(y, res, 1.0, 1.0)
+        for b0 in range(0, B, 8):
+            g = min(8, B - b0)
+            ops.bn_train_fwd(x[b0 * HW:(b0 + g) * HW], one, zero, y[b0 * HW:(b0 + g) * HW], None, None, HW, C, 1e-5, 0.0, relu,
+                             groups=g)
+        return y if res is None else ops.axpby(y, res, 1.0, 1.0, out=y)
 
     def _conv(self, x, conv, B, H, W, stride, pad, reflect, act=None):
         y, OH, OW = K.conv_fwd(x, conv.weight, conv.bias, B, H, W, stride, pad, 1, act=act, reflect=reflect)

@@ -45,21 +45,24 @@ class MLP(nn.Module):
         self.proj = nn.Linear(input_dim, embed_dim)
 
 
-def _bn_fwd(bn, x, y, M, C, relu, ldy=None, coff=0):
-    """train: batch stats + running-stat update; eval: running stats.  Returns what the backward needs."""
+def _bn_fwd(bn, x, y, M, C, relu, ldy=None, coff=0, groups=1, order=None):
+    """train: batch stats + running-stat update; eval: running stats.  Returns what the backward needs.  M = ALL rows of x;
+    groups > 1: x is `groups` consecutive blocks of M/groups rows, each with its own batch statistics (one decoder pass over
+    several feature sets, running statistics updated in `order`)."""
     if bn.training:
-        mean, rstd = ops.bn_train_fwd(x, bn.weight, bn.bias, y, bn.running_mean, bn.running_var, M, C, bn.eps,
-                                      bn.momentum, relu, ldy, coff)
+        mean, rstd = ops.bn_train_fwd(x, bn.weight, bn.bias, y, bn.running_mean, bn.running_var, M // groups, C, bn.eps,
+                                      bn.momentum, relu, ldy, coff, groups, order)
     else:
         mean, rstd = bn.running_mean, torch.rsqrt(bn.running_var + bn.eps)
         ops.bn_apply(x, mean, rstd, bn.weight, bn.bias, y, M, C, relu, ldy, coff)
+        mean, rstd = mean.expand(groups, C).contiguous(), rstd.expand(groups, C).contiguous()
     return mean, rstd
 
 
-def _bn_bwd(bn, dy, x, stats, M, C, relu, lddy=None, coff=0):
+def _bn_bwd(bn, dy, x, stats, M, C, relu, lddy=None, coff=0, groups=1):
     mean, rstd = stats
-    return ops.bn_train_bwd(dy, x, mean, rstd, bn.weight, bn.bias, rt.grad(bn.weight), rt.grad(bn.bias), M, C, relu,
-                            lddy, coff)
+    return ops.bn_train_bwd(dy, x, mean, rstd, bn.weight, bn.bias, rt.grad(bn.weight), rt.grad(bn.bias), M // groups, C, relu,
+                            lddy, coff, groups)
 
 
 class ASPPWrapper(nn.Module):
@@ -79,49 +82,50 @@ class ASPPWrapper(nn.Module):
         self.aspp_modules = nn.ModuleList(mods)
         self.bottleneck = ConvModule(len(self.dilations) * channels, channels, 3, padding=1)
 
-    def fwd(self, x, B, H, W):
-        """x [M, Cin] -> feat [M, channels]"""
+    def fwd(self, x, B, H, W, groups=1, order=None):
+        """x [M, Cin] -> feat [M, channels]; B = all images in x; groups / order: see _bn_fwd"""
         M, Cin, Ch = B * H * W, self.in_channels, self.channels
         nb = len(self.dilations)
         cat = torch.empty(M, nb * Ch, dtype=rt.compute_dtype(), device=x.device)
         saved = []
+        g = dict(groups=groups, order=order)
         for j, (d, m) in enumerate(zip(self.dilations, self.aspp_modules)):
             if d == 1:
                 z = K.linear_fwd(x, m.conv.weight, None, M, Cin)
-                st = _bn_fwd(m.bn, z, cat, M, Ch, True, nb * Ch, j * Ch)
+                st = _bn_fwd(m.bn, z, cat, M, Ch, True, nb * Ch, j * Ch, **g)
                 saved.append((z, st))
             else:
                 dwm, pwm = m.depthwise_conv, m.pointwise_conv
                 u = ops.dwconv_fwd(x, rt.wdw(dwm.conv.weight), None, B, H, W, Cin, d, None)
                 ub = torch.empty_like(u)
-                st_u = _bn_fwd(dwm.bn, u, ub, M, Cin, True)
+                st_u = _bn_fwd(dwm.bn, u, ub, M, Cin, True, **g)
                 z = K.linear_fwd(ub, pwm.conv.weight, None, M, Cin)
-                st_z = _bn_fwd(pwm.bn, z, cat, M, Ch, True, nb * Ch, j * Ch)
+                st_z = _bn_fwd(pwm.bn, z, cat, M, Ch, True, nb * Ch, j * Ch, **g)
                 saved.append((u, st_u, ub, z, st_z))
         zb, _, _ = K.conv_fwd(cat, self.bottleneck.conv.weight, None, B, H, W, 1, 1)
         feat = torch.empty_like(zb)
-        st_b = _bn_fwd(self.bottleneck.bn, zb, feat, M, Ch, True)
-        return feat, (x, cat, saved, zb, st_b)
+        st_b = _bn_fwd(self.bottleneck.bn, zb, feat, M, Ch, True, **g)
+        return feat, (x, cat, saved, zb, st_b, groups)
 
     def bwd(self, sv, dfeat, B, H, W):
-        x, cat, saved, zb, st_b = sv
+        x, cat, saved, zb, st_b, groups = sv
         M, Cin, Ch = B * H * W, self.in_channels, self.channels
         nb = len(self.dilations)
-        dzb = _bn_bwd(self.bottleneck.bn, dfeat, zb, st_b, M, Ch, True)
+        dzb = _bn_bwd(self.bottleneck.bn, dfeat, zb, st_b, M, Ch, True, groups=groups)
         dcat = K.conv_bwd(dzb, cat, self.bottleneck.conv.weight, None, B, H, W, 1, 1)
         dx = torch.empty(M, Cin, dtype=rt.compute_dtype(), device=x.device)
         first = True
         for j, (d, m) in enumerate(zip(self.dilations, self.aspp_modules)):
             if d == 1:
                 z, st = saved[j]
-                dz = _bn_bwd(m.bn, dcat, z, st, M, Ch, True, nb * Ch, j * Ch)
+                dz = _bn_bwd(m.bn, dcat, z, st, M, Ch, True, nb * Ch, j * Ch, groups=groups)
                 K.linear_bwd(dz, x, m.conv.weight, None, M, Cin, dx_out=dx, dx_beta=0.0 if first else 1.0)
             else:
                 u, st_u, ub, z, st_z = saved[j]
                 dwm, pwm = m.depthwise_conv, m.pointwise_conv
-                dz = _bn_bwd(pwm.bn, dcat, z, st_z, M, Ch, True, nb * Ch, j * Ch)
+                dz = _bn_bwd(pwm.bn, dcat, z, st_z, M, Ch, True, nb * Ch, j * Ch, groups=groups)
                 dub = K.linear_bwd(dz, ub, pwm.conv.weight, None, M, Cin)
-                du = _bn_bwd(dwm.bn, dub, u, st_u, M, Cin, True)
+                du = _bn_bwd(dwm.bn, dub, u, st_u, M, Cin, True, groups=groups)
                 ops.dwconv_bwd_weight(du, x, rt.grad(dwm.conv.weight).view(Cin, 9), None, B, H, W, Cin, d)
                 ops.dwconv_bwd_data(du, rt.wdw(dwm.conv.weight), B, H, W, Cin, d, out=dx, accumulate=not first)
             first = False
@@ -163,10 +167,10 @@ def ce_losses_fwd(logits, seg_label, seg_weight, ignore_index, loss_weight):
     return loss, accuracy, (logits, label, wgt, lse, H, W, n)
 
 
-def ce_losses_bwd(saved, gscale, mul, ignore_index, loss_weight):
+def ce_losses_bwd(saved, gscale, mul, ignore_index, loss_weight, out=None):
     """d(loss)/d(logits) * gscale (fp32 device scalar or None) * mul"""
     logits, label, wgt, lse, H, W, n = saved
-    return ops.ce_upsample_bwd(logits, label, wgt, lse, gscale, mul * loss_weight / n, H, W, ignore_index)
+    return ops.ce_upsample_bwd(logits, label, wgt, lse, gscale, mul * loss_weight / n, H, W, ignore_index, out=out)
 
 
 # ---------------------------------------------------------------------------------------------- heads
@@ -210,7 +214,8 @@ class _HeadBase(nn.Module):
         return nn.ModuleDict(embeds), build_layer(sum(self.embed_dims), self.channels, **self._fusion_cfg)
 
     # one decoder branch: embeds -> resize+concat -> fuse layer
-    def _branch_fwd(self, embeds, fuse, feats, B):
+    def _branch_fwd(self, embeds, fuse, feats, B, groups=1, order=None):
+        """B = all images in `feats` (groups * per-branch batch when several feature sets share the decoder weights)"""
         f0, H, W = feats[self.in_index[0]]
         M = B * H * W
         tot = sum(self.embed_dims)
@@ -225,7 +230,7 @@ class _HeadBase(nn.Module):
                 emb = K.linear_fwd(f, lin.weight, lin.bias, B * h * w, f.shape[1])
                 ops.bilinear_fwd(emb, cat, B, h, w, H, W, e, tot, off)
             off += e
-        feat, sv = fuse.fwd(cat, B, H, W)
+        feat, sv = fuse.fwd(cat, B, H, W, groups, order) if groups > 1 else fuse.fwd(cat, B, H, W)
         return feat, (sv, feats, H, W)
 
     def _branch_bwd(self, embeds, fuse, saved, dfeat, B):
@@ -247,12 +252,22 @@ class _HeadBase(nn.Module):
         return dfs
 
     # classifier: (Dropout2d) -> 1x1 conv, logits fp32 NHWC
-    def _cls_fwd(self, feat, B, H, W, with_dropout=True):
+    def _cls_fwd(self, feat, B, H, W, with_dropout=True, drop_B=None):
+        """drop_B: only the first drop_B samples get Dropout2d (the image branch of a grouped pass; decode_head.py:570-586:
+        cls_seg has the dropout, cls_seg_events / _fusion do not)"""
         M, Ch = B * H * W, self.channels
         mask = None
         if with_dropout and self.training and self.dropout_ratio > 0 and getattr(self, 'stochastic', True):
             keep = 1.0 - self.dropout_ratio
-            mask = (torch.rand(B, Ch, device=feat.device) < keep).float().div_(keep)
+            forced = getattr(self, 'inject_dropout_mask', None)   # tests: the oracle's Dropout2d mask [drop_B or B, Ch] of 0/1
+            nb = B if drop_B is None else drop_B
+            m = (torch.rand(nb, Ch, device=feat.device) < keep).float() if forced is None else forced.to(feat.device).float()
+            m = m / keep
+            if nb < B:
+                mask = torch.ones(B, Ch, dtype=torch.float32, device=feat.device)
+                mask[:nb].copy_(m)
+            else:
+                mask = m
             featd = ops.sample_scale(feat, mask, B, Ch, per_channel=True)
         else:
             featd = feat
@@ -377,6 +392,84 @@ class DAFormerHeadFusion(_HeadBase):
             dfeat = self._cls_bwd(sv_c, dlogits[key], B, H, W)
             dfeats[fkey] = self._branch_bwd(emb, fuse, sv_b, dfeat, B)
         return dfeats
+
+    # -- one pass of the shared decoder over ALL feature sets --------------------------------------------------------------
+    # With share_decoder the four branches run the SAME weights (daformer_head.py:254-258), so their feature sets travel as one
+    # batch of G*B images: rows [g*B*N, (g+1)*B*N) of each level's joint buffer belong to branch names[g].  GEMMs, depthwise
+    # stencils and the 3x3 bottleneck see 4x larger grids (and a quarter of the launches); BatchNorm keeps per-branch batch
+    # statistics (groups) and applies the running-statistic updates in the reference's branch order; Dropout2d touches the image
+    # branch only.  Results equal the per-branch loop (tests/test_modules.py::test_head_fusion_joint_equals_per_branch).
+    _KEY = {'image': 'image_output', 'fusion': 'fusion_output', 'events': 'events_output', 'isr': 'img_self_res_output'}
+    _REF_ORDER = ('image', 'events', 'fusion', 'isr')   # order forward() runs the branches in (daformer_head.py:305-319)
+
+    def joint_ok(self):
+        return self.share_decoder and isinstance(self.fuse_layer_image, ASPPWrapper)
+
+    def fwd_joint(self, joint, names, B):
+        """joint: list of 4 (J_l [G*B*N_l, C_l], H_l, W_l); names: the G branch names in joint-buffer order, 'image' first"""
+        G = len(names)
+        assert names[0] == 'image' and self.joint_ok()
+        order = sorted(range(G), key=lambda g: self._REF_ORDER.index(names[g]))
+        emb, fuse = self._layers('image')
+        feat, sv_b = self._branch_fwd(emb, fuse, joint, G * B, groups=G, order=order)
+        H, W = sv_b[2], sv_b[3]
+        logits, sv_c = self._cls_fwd(feat, G * B, H, W, with_dropout=True, drop_B=B)
+        out = {k: None for k in self._KEY.values()}
+        for g, n in enumerate(names):
+            out[self._KEY[n]] = logits[g * B:(g + 1) * B]
+        return out, (sv_b, sv_c, H, W, tuple(names), logits)
+
+    def bwd_joint(self, saved, dlogits_joint, B):
+        """dlogits_joint fp32 [G*B,h,w,nc] -> {level: d joint features [G*B*N_l, C_l]}"""
+        sv_b, sv_c, H, W, names, _ = saved
+        G = len(names)
+        emb, fuse = self._layers('image')
+        dfeat = self._cls_bwd(sv_c, dlogits_joint, G * B, H, W)
+        return self._branch_bwd(emb, fuse, sv_b, dfeat, G * B)
+
+    def _loss_mix(self, logits, gt, seg_weight, cfg):
+        """BaseDecodeHeadFusion.forward_train's loss mix, decode_head.py:508-528"""
+        lw = cfg['loss_weight']
+        ii, lwt = self.ignore_index, self.loss_decode.loss_weight
+        if seg_weight is None:
+            seg_weight = torch.ones(gt.shape[0], gt.shape[2], gt.shape[3], dtype=torch.float32, device=gt.device)
+        terms, sv_l = {}, {}
+        for key in ('image_output', 'events_output', 'fusion_output', 'img_self_res_output'):
+            if logits[key] is not None:
+                loss, acc, sv = ce_losses_fwd(logits[key], gt, seg_weight, ii, lwt)
+                terms[key] = (loss, acc)
+                sv_l[key] = sv
+        coef = {'image_output': lw['image']}
+        if 'fusion_output' in terms:
+            coef['fusion_output'] = lw['fusion']
+        if 'img_self_res_output' in terms:
+            coef['img_self_res_output'] = lw['img_self_res']
+            coef['events_output'] = lw['events'] / 2
+        else:
+            coef['events_output'] = lw['events']
+        # the reference accumulates fusion, image, then (isr, events): keep that order of fp32 additions
+        order = [k for k in ('fusion_output', 'image_output', 'img_self_res_output', 'events_output') if k in coef]
+        total = None
+        for k in order:
+            t = terms[k][0] * coef[k]
+            total = t if total is None else total + t
+        acc = terms['fusion_output'][1] if 'fusion_output' in terms else terms['image_output'][1]
+        return {'loss_seg': total, 'acc_seg': acc}, sv_l, coef
+
+    def fwd_train_joint(self, joint, names, B, gt, seg_weight=None, cfg=None):
+        logits, saved = self.fwd_joint(joint, names, B)
+        losses, sv_l, coef = self._loss_mix(logits, gt, seg_weight, cfg)
+        return losses, logits, (saved, sv_l, coef)
+
+    def bwd_train_joint(self, saved_all, B, gscale=None, mul=1.0):
+        saved, sv_l, coef = saved_all
+        names, logits = saved[4], saved[5]
+        ii, lwt = self.ignore_index, self.loss_decode.loss_weight
+        dl = torch.empty_like(logits)
+        for g, n in enumerate(names):
+            k = self._KEY[n]
+            ce_losses_bwd(sv_l[k], gscale, mul * coef[k], ii, lwt, out=dl[g * B:(g + 1) * B])
+        return self.bwd_joint(saved, dl, B)
 
     def fwd_train(self, inputs, B, gt, seg_weight=None, cfg=None):
         lw = cfg['loss_weight']

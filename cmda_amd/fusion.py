@@ -31,12 +31,13 @@ class AttentionAvgFusion(nn.Module):
     def init_weights(self):
         pass  # the reference keeps torch's default initialisation for these blocks (init_cfg=None)
 
-    def fwd(self, feats_i, feats_e, B, save=True):
+    def fwd(self, feats_i, feats_e, B, save=True, into=None):
+        """into: optional list of 4 pre-allocated tensors the fused maps are written into"""
         outs, saved = [], []
         for i, ((xi, H, W), (xe, _, _)) in enumerate(zip(feats_i, feats_e)):
             yi, si = self.basic_block[2 * i].fwd(xi, B, H, W, save=save)
             ye, se = self.basic_block[2 * i + 1].fwd(xe, B, H, W, save=save)
-            outs.append((ops.axpby(yi, ye, 0.5, 0.5), H, W))
+            outs.append((ops.axpby(yi, ye, 0.5, 0.5, out=into[i] if into is not None else None), H, W))
             saved.append((si, se, H, W))
         return outs, saved
 
@@ -78,7 +79,7 @@ class AttentionFusion(nn.Module):
     def init_weights(self):
         pass
 
-    def fwd(self, feats_i, feats_e, B, save=True):
+    def fwd(self, feats_i, feats_e, B, save=True, into=None):
         outs, saved = [], []
         for i, ((xi, H, W), (xe, _, _)) in enumerate(zip(feats_i, feats_e)):
             C, M = self.in_channels[i], B * H * W
@@ -87,6 +88,8 @@ class AttentionFusion(nn.Module):
             ops.copy2d(xe, cat, M, C, C, 2 * C, dst_off=C)
             y, sb = self.basic_block[i].fwd(cat, B, H, W, save=save)
             z, sm = self.linear_block[i].fwd(y, B, H, W)
+            if into is not None:
+                z = ops.copy2d(z, into[i], M, C, C, C)
             outs.append((z, H, W))
             saved.append((sb, sm, H, W))
         return outs, saved

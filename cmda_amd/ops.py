@@ -100,11 +100,11 @@ def gemm(A, B, out, M, N, K, *, a_kstrided=False, b_kstrided=False, ldc=None, ba
     return out
 
 
-def layernorm_fwd(x, gamma, beta, eps, save_stats=True):
-    check_dev(x, gamma, beta)
+def layernorm_fwd(x, gamma, beta, eps, save_stats=True, out=None):
+    check_dev(x, gamma, beta, out)
     C = x.shape[-1]
     rows = x.numel() // C
-    y = torch.empty_like(x)
+    y = torch.empty_like(x) if out is None else out
     mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
     call('cmda_layernorm_fwd', ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), c_i64(rows), c_i32(C),
@@ -278,14 +278,16 @@ def bilinear_bwd(dy, dx, B, IH, IW, OH, OW, C, ldy=None, coff=0):
     return dx
 
 
-def bn_train_fwd(x, gamma, beta, y, running_mean, running_var, M, C, eps, momentum, relu, ldy=None, coff=0):
+def bn_train_fwd(x, gamma, beta, y, running_mean, running_var, M, C, eps, momentum, relu, ldy=None, coff=0, groups=1, order=None):
+    """M = rows PER GROUP; x / y hold `groups` consecutive blocks of M rows (own statistics each); returns mean, rstd [groups, C]"""
     check_dev(x, gamma, beta, y, running_mean, running_var)
-    mean = torch.empty(C, dtype=torch.float32, device=x.device)
-    rstd = torch.empty(C, dtype=torch.float32, device=x.device)
-    ws = torch.empty(L.lib().cmda_bn_ws_floats(C), dtype=torch.float32, device=x.device)
+    mean = torch.empty(groups, C, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(groups, C, dtype=torch.float32, device=x.device)
+    ws = torch.empty(groups * L.lib().cmda_bn_ws_floats(C), dtype=torch.float32, device=x.device)
+    order_c = (ctypes.c_int * groups)(*order) if order is not None else None
     call('cmda_bn_train_fwd', ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), ptr(running_mean),
          ptr(running_var), ptr(ws), c_i64(M), c_i32(C), c_f32(eps), c_f32(momentum), c_i32(int(relu)),
-         c_i32(C if ldy is None else ldy), c_i32(coff), dtype_tag(x), stream_of(x))
+         c_i32(C if ldy is None else ldy), c_i32(coff), c_i32(groups), order_c, dtype_tag(x), stream_of(x))
     return mean, rstd
 
 
@@ -295,13 +297,13 @@ def bn_apply(x, mean, rstd, gamma, beta, y, M, C, relu, ldy=None, coff=0):
          c_i32(int(relu)), c_i32(C if ldy is None else ldy), c_i32(coff), dtype_tag(x), stream_of(x))
 
 
-def bn_train_bwd(dy, x, mean, rstd, gamma, beta, dgamma, dbeta, M, C, relu, lddy=None, coff=0):
+def bn_train_bwd(dy, x, mean, rstd, gamma, beta, dgamma, dbeta, M, C, relu, lddy=None, coff=0, groups=1):
     check_dev(dy, x, mean, rstd, gamma, beta, dgamma, dbeta)
     dx = torch.empty_like(x)
-    ws = torch.empty(L.lib().cmda_bn_ws_floats(C), dtype=torch.float32, device=x.device)
+    ws = torch.empty(groups * L.lib().cmda_bn_ws_floats(C), dtype=torch.float32, device=x.device)
     call('cmda_bn_train_bwd', ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(dx), ptr(dgamma),
          ptr(dbeta), ptr(ws), c_i64(M), c_i32(C), c_i32(int(relu)), c_i32(C if lddy is None else lddy), c_i32(coff),
-         dtype_tag(x), stream_of(x))
+         c_i32(groups), dtype_tag(x), stream_of(x))
     return dx
 
 
@@ -316,10 +318,10 @@ def ce_upsample_fwd(logits, label, weight, H, W, ignore_index=255):
     return acc, lse
 
 
-def ce_upsample_bwd(logits, label, weight, lse, gscale, gscale_mul, H, W, ignore_index=255):
-    check_dev(logits, label, weight, lse, gscale)
+def ce_upsample_bwd(logits, label, weight, lse, gscale, gscale_mul, H, W, ignore_index=255, out=None):
+    check_dev(logits, label, weight, lse, gscale, out)
     B, h, w, nc = logits.shape
-    dl = torch.empty_like(logits)
+    dl = torch.empty_like(logits) if out is None else out
     call('cmda_ce_upsample_bwd', ptr(logits), ptr(label), ptr(weight), ptr(lse), ptr(gscale), c_f32(gscale_mul), ptr(dl),
          c_i32(B), c_i32(h), c_i32(w), c_i32(H), c_i32(W), c_i32(nc), c_i32(ignore_index), stream_of(logits))
     return dl

@@ -232,13 +232,74 @@ class FusionEncoderDecoder(nn.Module):
         if 'events' in sv and d_evt is not None:
             self.backbone_events.bwd(sv['events'], as_list(d_evt))
 
+    # -- joint pass: events + ISR through the event encoder as ONE batch, all feature sets through the shared decoder at once ----
+    def _joint_ok(self, image, events, cfg):
+        cfg = cfg or {}
+        return (image is not None and events is not None and self.fusion_module is not None
+                and not (cfg.get('no_fusion') or cfg.get('fusion_isr') or cfg.get('fusion_all'))
+                and hasattr(self.decode_head, 'joint_ok') and self.decode_head.joint_ok()
+                and getattr(self, 'joint_passes', True))
+
+    def _extract_joint(self, image, events, img_self_res, save):
+        """extract_feat (:698-721) for the default fusion route with the outputs laid out for DAFormerHeadFusion.fwd_joint: per
+        level one buffer J_l [G*B*N_l, C_l] holding [image | fusion | events | ISR] blocks.  The image encoder writes block 0,
+        the event encoder -- run ONCE over the events and the ISR as a 2B batch (same weights, :703-712) -- blocks 2 and 3, the
+        fusion module block 1.  No feature is copied."""
+        B, _, H, W = image.shape
+        names = ('image', 'fusion', 'events') + (('isr',) if img_self_res is not None else ())
+        G = len(names)
+        dims = self.backbone_image.embed_dims
+        shapes = self.backbone_image.feature_shapes(H, W)
+        dev = image.device
+        joint = [torch.empty(G * B * h * w, c, dtype=rt.compute_dtype(), device=dev) for (h, w), c in zip(shapes, dims)]
+        n = [B * h * w for h, w in shapes]
+        f_image, sv_i = self.backbone_image.fwd(image, save=save, out_feats=[J[:m] for J, m in zip(joint, n)])
+        ev_in = [events, img_self_res] if img_self_res is not None else [events]
+        f_ev, sv_e = self.backbone_events.fwd(ev_in, save=save, out_feats=[J[2 * m:G * m] for J, m in zip(joint, n)])
+        f_events = [(J[2 * m:3 * m], h, w) for J, m, (h, w) in zip(joint, n, shapes)]
+        _, sv_f = self.fusion_module.fwd(f_image, f_events, B, save, into=[J[m:2 * m] for J, m in zip(joint, n)])
+        feats = [(J, h, w) for J, (h, w) in zip(joint, shapes)]
+        return feats, names, (sv_i, sv_e, sv_f, n, G), B
+
+    def _extract_joint_bwd(self, sv, dJ, B):
+        """dJ: {level: d J_l}; the gradient blocks are consumed in place (fusion contributions are added into blocks 0 and 2)"""
+        sv_i, sv_e, sv_f, n, G = sv
+        d = [dJ.get(i) for i in range(4)]
+        d_fus = [(t[m:2 * m] if t is not None else None) for t, m in zip(d, n)]
+        di, de = self.fusion_module.bwd(sv_f, d_fus, B)
+        d_img, d_ev = [], []
+        for t, m, a, b in zip(d, n, di, de):
+            if t is None:
+                d_img.append(a)
+                assert b is None, 'event-encoder gradient without a joint gradient buffer'
+                d_ev.append(None)
+                continue
+            if a is not None:
+                ops.axpby(t[:m], a, 1.0, 1.0, out=t[:m])
+            if b is not None:
+                ops.axpby(t[2 * m:3 * m], b, 1.0, 1.0, out=t[2 * m:3 * m])
+            d_img.append(t[:m])
+            d_ev.append(t[2 * m:G * m])
+        self.backbone_image.bwd(sv_i, d_img)
+        self.backbone_events.bwd(sv_e, d_ev)
+
     # -- hand-scheduled training pass ---------------------------------------------------------------------------------
     def train_fwd(self, inputs, gt, seg_weight, cfg):
+        if self._joint_ok(inputs['image'], inputs['events'], cfg):
+            feats, names, sv, B = self._extract_joint(inputs['image'], inputs['events'], inputs.get('img_self_res'), True)
+            losses, logits, sv_h = self.decode_head.fwd_train_joint(feats, names, B, gt, seg_weight, cfg)
+            return losses['loss_seg'], (losses, logits, feats), ('joint', sv, sv_h, B)
         feats, sv, B = self._extract(inputs['image'], inputs['events'], inputs.get('img_self_res'), cfg, True)
         losses, logits, sv_h = self.decode_head.fwd_train(feats, B, gt, seg_weight, cfg)
         return losses['loss_seg'], (losses, logits, feats), (sv, sv_h, B)
 
     def train_bwd(self, saved, gscale):
+        if saved[0] == 'joint':
+            _, sv, sv_h, B = saved
+            dJ = self.decode_head.bwd_train_joint(sv_h, B, gscale)
+            rt.notify_grads_ready('decode_head', self.decode_head)
+            self._extract_joint_bwd(sv, dJ, B)
+            return
         sv, sv_h, B = saved
         dfeats = self.decode_head.bwd_train(sv_h, B, gscale)
         rt.notify_grads_ready('decode_head', self.decode_head)
@@ -260,6 +321,10 @@ class FusionEncoderDecoder(nn.Module):
     def encode_decode_lowres(self, img, events, img_self_res=None, test_cfg=None):
         """dict of fp32 NHWC logits at 1/4 resolution (the fused kernels up-sample on the fly)."""
         with torch.no_grad():
+            if self._joint_ok(img, events, test_cfg):
+                feats, names, _, B = self._extract_joint(img, events, img_self_res, False)
+                out, _ = self.decode_head.fwd_joint(feats, names, B)
+                return out
             feats, _, B = self._extract(img, events, img_self_res, test_cfg, False)
             out, _ = self.decode_head.fwd(feats, B)
         return out

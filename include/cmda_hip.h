@@ -128,16 +128,21 @@ int cmda_bilinear_bwd(const void* dy, void* dx, int B, int IH, int IW, int OH, i
 
 /* ---- Train-mode BatchNorm2d (+ReLU) -- mmcv ConvModule's norm/activate in decode_heads/daformer_head.py:46-62,
  * aspp_head.py:33-43, sep_aspp_head.py:18-27 (batch statistics, running-stat update, eps 1e-5, momentum 0.1).
- * Also used per sample as InstanceNorm2d for cyclegan/cyclegan_model.py:339-374.  ws: cmda_bn_ws_floats(C) floats of scratch. */
+ * groups > 1: x / y / dy / dx hold `groups` consecutive blocks of M rows, each normalised with ITS OWN batch statistics;
+ * mean / rstd are [groups][C]; running statistics receive the groups' updates one after the other in `order` (HOST int
+ * array of `groups` entries, NULL = 0,1,2,..) -- the shared decoder of daformer_head.py:254-258,305-319 run once over the
+ * image / events / fusion / ISR features instead of four times.  Also used with groups = samples (no running statistics)
+ * as InstanceNorm2d for cyclegan/cyclegan_model.py:339-374.  ws: groups * cmda_bn_ws_floats(C) floats of scratch.
+ * groups <= 8. */
 int64_t cmda_bn_ws_floats(int C);
 int cmda_bn_train_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, float*
     running_mean, float* running_var, float* ws, int64_t M, int C, float eps, float momentum, int relu, int ldy, int
-    coff, int dtype, void* stream);
+    coff, int groups, const int* order, int dtype, void* stream);
 int cmda_bn_apply(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, void* y,
     int64_t M, int C, int relu, int ldy, int coff, int dtype, void* stream);
 int cmda_bn_train_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const
     float* beta, void* dx, float* dgamma, float* dbeta, float* ws, int64_t M, int C, int relu, int lddy, int coff, int
-    dtype, void* stream);
+    groups, int dtype, void* stream);
 
 /* ---- Fused up-sample + cross-entropy + accuracy -- BaseDecodeHead(Fusion).losses decode_heads/decode_head.py:588-606
  * (resize -> F.cross_entropy(reduction='none', ignore_index) losses/cross_entropy_loss.py:21-26 -> x weight -> mean over

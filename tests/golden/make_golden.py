@@ -134,9 +134,11 @@ def head_fusion_train():
     cfg = dict(loss_weight={'image': 0.5, 'events': 0.5, 'fusion': 0.5, 'img_self_res': 0.25}, gradual_rate=0.0)
     losses, logits = head.forward_train(inputs, None, gt, None, None, cfg)
     losses['loss_seg'].backward()
+    # the shared decoder's BatchNorm layers have now seen image, events, fusion, ISR features in that order (four updates)
+    bn = {k: v for k, v in head.state_dict().items() if 'running' in k and k.startswith('fuse_layer_image')}
     save('head_fusion_train', loss_seg=losses['loss_seg'], acc_seg=losses['acc_seg'], gt=gt,
          **{k: v for k, v in logits.items()}, **{f'd{k}{i}': f.grad for k, fs in inputs.items() for i, f in enumerate(fs)},
-         **param_grads(head))
+         **param_grads(head), **{'bn.' + k: v for k, v in bn.items()})
     with open(os.path.join(HERE, 'head_fusion_keys.json'), 'w') as f:
         json.dump(sorted(head.state_dict().keys()), f, indent=0)
 

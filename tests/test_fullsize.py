@@ -1,0 +1,252 @@
+"""Parity where the bench runs: full-depth MiT-B5 at 512x512 (stage grids 128/64/32/16, Nk = 256 in every stage: the fused
+attention kernel and the large GEMM tiles in bf16 mode), the full image+events fusion student, the stochastic paths (DropPath,
+Dropout2d) with injected masks, and the pseudo-label kernel bit for bit on the GPU.
+
+The oracle (oracle/, CPU fp32) costs seconds per 512x512 image on the GPU box's host, so these tests are `gpu`-marked except
+the injected-mask test, which is small and also runs in the emulator.
+  fp32 mode: north-star bound 1e-3 relative (max-norm) on logits.
+  bf16 mode: the error of the 52-block model is REPORTED and bounded (logits within 6e-2 of the logit range; argmax
+  agreement >= 97 %), which is what the throughput numbers are quoted at.
+"""
+import functools
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, 'golden'))
+from weights import seeded_fill, seeded_randn  # noqa: E402
+
+import cmda_amd  # noqa: E402,F401
+import cmda_amd.runtime as rt  # noqa: E402
+from cmda_amd import ops  # noqa: E402
+from cmda_amd.registry import build_segmentor  # noqa: E402
+from conftest import Target, assert_close  # noqa: E402
+from oracle import fusion as ofu, head as ohd, mit as omit, segmentor as oseg, uda as ouda  # noqa: E402
+
+DIMS = [64, 128, 320, 512]
+DECODER = dict(embed_dims=256, embed_cfg=dict(type='mlp', act_cfg=None, norm_cfg=None),
+               embed_neck_cfg=dict(type='mlp', act_cfg=None, norm_cfg=None),
+               fusion_cfg=dict(type='aspp', sep=True, dilations=(1, 6, 12, 18), pool=False, act_cfg=dict(type='ReLU'),
+                               norm_cfg=dict(type='BN', requires_grad=True)))
+HEAD = dict(in_channels=DIMS, in_index=[0, 1, 2, 3], channels=256, num_classes=19, norm_cfg=dict(type='BN', requires_grad=True),
+            align_corners=False, loss_decode=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0))
+FCFG = dict(loss_weight={'image': 0.5, 'events': 0.5, 'fusion': 0.5, 'img_self_res': 0.25}, gradual_rate=0.0)
+
+
+def gpu_target():
+    from cmda_amd import _lib
+    _lib._unbind_for_tests()
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU on this machine')
+    return Target('gpu')
+
+
+def labels(B, S, seed):
+    g = torch.Generator().manual_seed(seed)
+    lab = torch.randint(0, 19, (B, 1, S // 32, S // 32), generator=g).repeat_interleave(32, 2).repeat_interleave(32, 3)
+    lab[torch.rand(B, 1, S, S, generator=g) < 0.05] = 255
+    return lab
+
+
+def rel(a, b):
+    return (a.detach().float().cpu() - b.detach().float()).abs().max().item() / (b.detach().abs().max().item() + 1e-30)
+
+
+def grad_report(model, ref, max_tensors=400):
+    """worst max-norm relative error over the parameter gradients + the fraction of tensors within 2e-2"""
+    worst, within, n = 0.0, 0, 0
+    for (n1, p), (n2, q) in zip(model.named_parameters(), ref.named_parameters()):
+        assert n1 == n2
+        if q.grad is None:
+            continue
+        e = rel(p.grad, q.grad)
+        worst = max(worst, e)
+        within += e < 2e-2
+        n += 1
+    return worst, within / max(n, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+def test_mit_b5_daformer_512_vs_oracle(mode):
+    """BASELINE configs[1] at its real size: full MiT-B5 (52 blocks) + DAFormerHead, one 512x512 image, fwd + bwd."""
+    tgt = gpu_target()
+    rt.set_compute_dtype(torch.float32 if mode == 'f32' else torch.bfloat16)
+    cfg = dict(type='EncoderDecoder', backbone=dict(type='mit_b5', style='pytorch', drop_path_rate=0.0),
+               decode_head=dict(type='DAFormerHead', dropout_ratio=0.0, decoder_params=dict(DECODER), **HEAD))
+    model = build_segmentor(cfg)
+    torch.manual_seed(5)
+    model.init_weights()
+    ref = oseg.EncoderDecoder(omit.mit_b5(drop_path_rate=0.0), ohd.DAFormerHead(dropout_ratio=0.0))
+    ref.load_state_dict(model.state_dict())
+    model.to(tgt.device).train()
+    ref.train()
+    img, gt = seeded_randn((1, 3, 512, 512), 5, 'img'), labels(1, 512, 5)
+    losses, logits = model.forward_train(tgt.to(img), None, tgt.to(gt))
+    losses['decode.loss_seg'].backward()
+    rl, rlog = ref.forward_train(img, gt)
+    rl['decode.loss_seg'].backward()
+    torch.cuda.synchronize()
+    e_log = rel(logits, rlog)
+    agree = (logits.argmax(1).cpu() == rlog.argmax(1)).float().mean().item()
+    worst, within = grad_report(model, ref)
+    print(f'[{mode}] 512x512 MiT-B5+DAFormerHead: logits rel err {e_log:.3e}, argmax agreement {agree:.4f}, loss '
+          f'{losses["decode.loss_seg"].item():.6f} vs {rl["decode.loss_seg"].item():.6f}, worst grad rel err {worst:.3e}, '
+          f'{within:.1%} of gradient tensors within 2e-2')
+    if mode == 'f32':
+        assert e_log < 1e-3, f'fp32 logits rel err {e_log}'
+        assert_close(losses['decode.loss_seg'], rl['decode.loss_seg'], 1e-4, name='loss')
+        assert within > 0.97 and worst < 0.2
+    else:
+        assert e_log < 6e-2, f'bf16 logits rel err {e_log}'
+        assert agree > 0.97
+        assert_close(losses['decode.loss_seg'], rl['decode.loss_seg'], 2e-2, name='loss')
+    rt.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+def test_fusion_student_512_vs_oracle(mode):
+    """The bench's student at full width / depth / size: two MiT-B5 encoders (events + ISR batched through the event encoder),
+    AttentionAvgFusion, the shared DAFormerHeadFusion run jointly over the four feature sets, four CE terms, fwd + bwd."""
+    tgt = gpu_target()
+    rt.set_compute_dtype(torch.float32 if mode == 'f32' else torch.bfloat16)
+    bbc = dict(type='mit_b5', style='pytorch', drop_path_rate=0.0)
+    head = dict(type='DAFormerHeadFusion', dropout_ratio=0.0,
+                decoder_params=dict(DECODER, train_type='cs2dsec_image+events_together', share_decoder=True), **HEAD)
+    model = build_segmentor(dict(type='FusionEncoderDecoder', backbone_image=dict(bbc), backbone_events=dict(bbc),
+                                 fusion_module=dict(type='AttentionAvgFusion', in_channels=DIMS, drop_path_rate=0.0),
+                                 decode_head=head, train_type='cs2dsec_image+events_together'))
+    torch.manual_seed(6)
+    model.init_weights()
+    ref = oseg.FusionEncoderDecoder(backbone_image=omit.mit_b5(drop_path_rate=0.0), backbone_events=omit.mit_b5(drop_path_rate=0.0),
+                                    fusion_module=ofu.AttentionAvgFusion(drop_path_rate=0.0),
+                                    decode_head=ohd.DAFormerHeadFusion(dropout_ratio=0.0, share_decoder=True))
+    ref.load_state_dict(model.state_dict())
+    model.to(tgt.device).train()
+    ref.train()
+    S = 512
+    inp = dict(image=seeded_randn((1, 3, S, S), 6, 'img'), events=seeded_randn((1, 3, S, S), 6, 'ev').clamp(-1, 1),
+               img_self_res=seeded_randn((1, 3, S, S), 6, 'isr').clamp(-1, 1))
+    gt = labels(1, S, 6)
+    wgt = torch.rand(1, S, S, generator=torch.Generator().manual_seed(6))
+    losses, pred = model.forward_train({k: tgt.to(v) for k, v in inp.items()}, tgt.to(gt), seg_weight=tgt.to(wgt), cfg=FCFG)
+    losses['decode.loss_seg'].backward()
+    rl, rpred = ref.forward_train(inp, gt, seg_weight=wgt, cfg=FCFG)
+    rl['decode.loss_seg'].backward()
+    torch.cuda.synchronize()
+    errs = {k: rel(pred[k], rpred[k]) for k in pred}
+    worst, within = grad_report(model, ref)
+    print(f'[{mode}] 512x512 fusion student: logits rel err {errs}, loss {losses["decode.loss_seg"].item():.6f} vs '
+          f'{rl["decode.loss_seg"].item():.6f}, worst grad rel err {worst:.3e}, {within:.1%} of gradient tensors within 2e-2')
+    if mode == 'f32':
+        assert max(errs.values()) < 1e-3, errs
+        assert_close(losses['decode.loss_seg'], rl['decode.loss_seg'], 1e-4, name='loss')
+        assert within > 0.97 and worst < 0.2
+    else:
+        assert max(errs.values()) < 6e-2, errs
+        assert_close(losses['decode.loss_seg'], rl['decode.loss_seg'], 2e-2, name='loss')
+    rt.set_compute_dtype(torch.float32)
+
+
+class _InjectedDropPath(nn.Module):
+    """stands in for the oracle's DropPath: pops the next injected per-sample keep mask (already scaled by 1/keep)"""
+
+    def __init__(self, pool):
+        super().__init__()
+        self.pool = pool
+
+    def forward(self, x):
+        m = self.pool.pop(0)
+        return x * m.view(-1, *([1] * (x.dim() - 1)))
+
+
+class _InjectedDropout2d(nn.Module):
+    def __init__(self, mask, keep):
+        super().__init__()
+        self.mask, self.keep = mask, keep
+
+    def forward(self, x):
+        return x * (self.mask / self.keep)[:, :, None, None]
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+def test_stochastic_paths_with_injected_masks(tgt, mode):
+    """DropPath (timm, per sample per residual branch: mix_transformer.py:134,145-146) and Dropout2d (decode_head.py:565-566) are
+    ON in every training step; here both sides get the SAME masks, so the row-scale GEMM epilogue, sample_scale and their
+    backward are compared against the oracle instead of being switched off."""
+    if mode == 'bf16' and tgt.kind == 'emu':
+        pytest.skip('bf16 variant on the GPU only (emulated bf16 MFMA is slow)')
+    dt = torch.float32 if mode == 'f32' else torch.bfloat16
+    rt.set_compute_dtype(dt)
+    depths, dpr, drop = [2, 2, 2, 2], 0.4, 0.3
+    cfg = dict(type='EncoderDecoder',
+               backbone=dict(type='MixVisionTransformer', embed_dims=DIMS, num_heads=[1, 2, 5, 8], qkv_bias=True, depths=depths,
+                             sr_ratios=[8, 4, 2, 1], drop_path_rate=dpr, norm_layer=functools.partial(nn.LayerNorm, eps=1e-6)),
+               decode_head=dict(type='DAFormerHead', dropout_ratio=drop, decoder_params=dict(DECODER), **HEAD))
+    model = build_segmentor(cfg)
+    seeded_fill(model, 13)
+    ref = oseg.EncoderDecoder(omit.MixVisionTransformer(depths=depths, drop_path_rate=dpr), ohd.DAFormerHead(dropout_ratio=drop))
+    ref.load_state_dict(model.state_dict())
+    model.to(tgt.device).train()
+    ref.train()
+    B, S = 3, 64
+    g = torch.Generator().manual_seed(13)
+    rates = [v.item() for v in torch.linspace(0, dpr, sum(depths))]
+    live = [r for r in rates if r > 0]
+    # per live block two masks (attention branch, MLP branch), each [B] of {0, 1/keep}
+    masks = torch.stack([torch.floor((1 - r) + torch.rand(B, generator=g)) / (1 - r) for r in live for _ in range(2)])
+    assert (masks == 0).any() and (masks > 0).any()
+    keep = 1 - drop
+    dmask = (torch.rand(B, 256, generator=g) < keep).float()
+
+    def inject(B_, device):
+        blocks = [blk for s in range(1, 5) for blk in getattr(model.backbone, f'block{s}')]
+        mk = masks.to(device)
+        i = 0
+        for blk in blocks:
+            if blk.drop_path_rate > 0:
+                blk._dp_pool = [mk, 2 * i]
+                i += 1
+    model.backbone._draw_drop_path = inject
+    model.decode_head.inject_dropout_mask = dmask
+    pool = [m for m in masks]
+    for s in range(1, 5):
+        for blk in getattr(ref.backbone, f'block{s}'):
+            if not isinstance(blk.drop_path, nn.Identity):
+                blk.drop_path = _InjectedDropPath(pool)
+    ref.decode_head.dropout = _InjectedDropout2d(dmask, keep)
+    img, gt = seeded_randn((B, 3, S, S), 13, 'img'), labels(B, S, 13)
+    losses, logits = model.forward_train(tgt.to(img), None, tgt.to(gt))
+    losses['decode.loss_seg'].backward()
+    rl, rlog = ref.forward_train(img, gt)
+    rl['decode.loss_seg'].backward()
+    assert not pool, 'the oracle did not consume every injected mask'
+    tol = 1e-3 if mode == 'f32' else 6e-2
+    assert_close(logits, rlog, tol, name='logits with injected DropPath / Dropout2d masks')
+    assert_close(losses['decode.loss_seg'], rl['decode.loss_seg'], 1e-4 if mode == 'f32' else 2e-2, name='loss')
+    worst, within = grad_report(model, ref)
+    assert within > (0.95 if mode == 'f32' else 0.5) and worst < (0.2 if mode == 'f32' else 1.0), (worst, within)
+    rt.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.gpu
+def test_pseudo_label_bit_exact_gpu():
+    """north star: pseudo-label argmax bit-exact.  The kernel's up-sampling is the individually rounded bilinear formula of
+    oracle.uda.upsample_exact; labels must be EQUAL (first-max tie rule included) and the confident-pixel count equal -- at the
+    teacher's real size (2 x 19 x 128 x 128 -> 512 x 512) and at an odd ratio."""
+    tgt = gpu_target()
+    for seed, (B, h, w, H, W) in enumerate([(2, 128, 128, 512, 512), (1, 110, 160, 440, 640), (2, 13, 9, 37, 50)]):
+        g = torch.Generator().manual_seed(100 + seed)
+        logits = torch.randn(B, h, w, 19, generator=g) * 3
+        logits[0, : h // 2, : w // 2, 4] = logits[0, : h // 2, : w // 2, 7]   # exact ties between two classes: first max wins
+        up = ouda.upsample_exact(logits.permute(0, 3, 1, 2).contiguous(), (H, W))
+        prob_ref, lab_ref = torch.softmax(up, 1).max(1)
+        lab, prob, cnt = ops.pseudo_label(tgt.to(logits), H, W, 0.968)
+        assert torch.equal(lab.cpu(), lab_ref), f'{(lab.cpu() != lab_ref).sum().item()} labels differ at {(B, h, w, H, W)}'
+        assert cnt.item() == int((prob_ref >= 0.968).sum()), (cnt.item(), int((prob_ref >= 0.968).sum()))
+        assert_close(prob, prob_ref, 1e-6, name='pseudo prob')

@@ -123,7 +123,11 @@ def test_head_train_golden(tgt, mode):
 
 
 @pytest.mark.parametrize('mode', [torch.float32], indirect=True)
-def test_head_fusion_train_golden(tgt, mode):
+@pytest.mark.parametrize('joint', [False, True], ids=['per_branch', 'joint'])
+def test_head_fusion_train_golden(tgt, mode, joint):
+    """joint: the shared decoder run ONCE over the four feature sets (grouped BatchNorm statistics, Dropout2d on the image block
+    only) must reproduce the reference's four sequential branch passes -- logits, loss mix, input and parameter gradients and
+    the BatchNorm running statistics after the four ordered updates."""
     from cmda_amd import decode_heads as dh
     g = gold('head_fusion_train')
     head = dh.DAFormerHeadFusion(**HEAD_KW, decoder_params=decoder_params(train_type='cs2dsec_image+events_together',
@@ -135,8 +139,18 @@ def test_head_fusion_train_golden(tgt, mode):
     B, H, W = 1, 64, 64
     inputs = {k: feats_nlc(tgt, B, H, W, 41, k) for k in ('f_image', 'f_events', 'f_fusion', 'f_img_self_res')}
     cfg = dict(loss_weight={'image': 0.5, 'events': 0.5, 'fusion': 0.5, 'img_self_res': 0.25})
-    losses, logits, saved = head.fwd_train(inputs, B, tgt.to(g['gt']), None, cfg)
-    dfs = head.bwd_train(saved, B)
+    if joint:
+        names = ('image', 'fusion', 'events', 'isr')
+        fkey = {'image': 'f_image', 'fusion': 'f_fusion', 'events': 'f_events', 'isr': 'f_img_self_res'}
+        feats = [(torch.cat([inputs[fkey[n]][i][0] for n in names]).contiguous(), inputs['f_image'][i][1], inputs['f_image'][i][2])
+                 for i in range(4)]
+        losses, logits, saved = head.fwd_train_joint(feats, names, B, tgt.to(g['gt']), None, cfg)
+        dJ = head.bwd_train_joint(saved, B)
+        dfs = {fkey[n]: {i: dJ[i][gi * (dJ[i].shape[0] // 4):(gi + 1) * (dJ[i].shape[0] // 4)] for i in range(4)}
+               for gi, n in enumerate(names)}
+    else:
+        losses, logits, saved = head.fwd_train(inputs, B, tgt.to(g['gt']), None, cfg)
+        dfs = head.bwd_train(saved, B)
     assert_close(losses['loss_seg'], g['loss_seg'], 1e-5, name='loss')
     assert_close(losses['acc_seg'], g['acc_seg'], 1e-6, name='acc')
     for k, v in logits.items():
@@ -155,6 +169,9 @@ def test_head_fusion_train_golden(tgt, mode):
         tight += worst < 3e-4
     assert tight >= 2
     check_grads(head, g, 5e-4, outlier_frac=1.0, atol=2e-6)
+    for k, v in head.state_dict().items():
+        if 'running' in k and ('bn.' + k) in g:
+            assert_close(v, g['bn.' + k], 1e-4, name=k)
 
 
 @pytest.mark.parametrize('mode', [torch.float32], indirect=True)
