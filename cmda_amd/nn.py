@@ -33,10 +33,11 @@ def linear_bwd(dy, x, weight, bias, M, K, *, need_dx=True, dx_out=None, dx_beta=
     xv = plain_view(x, M, K, ld=x_ld, offset=x_off)
     fused = (bias is not None and rt.tag() == 1 and dyv_k.vec_ok and xv.vec_ok and N % 8 == 0 and K % 8 == 0
              and (dy_ld or N) % 8 == 0 and (x_ld or K) % 8 == 0)
-    ops.gemm(dyv_k, xv, rt.grad(weight), N, K, M, a_kstrided=True, b_kstrided=True, dtype=rt.tag(), atomic=True,
-             splits=0, colsum=rt.grad(bias) if fused else None)  # bias gradient rides along in the wgrad kernel
-    if bias is not None and not fused:
-        ops.colsum(dy, rt.grad(bias), M, N, ld=dy_ld, offset=dy_off)
+    with rt.lane('wgrad', dy, x):   # off the critical dgrad chain (runtime.py: concurrency lanes)
+        ops.gemm(dyv_k, xv, rt.grad(weight), N, K, M, a_kstrided=True, b_kstrided=True, dtype=rt.tag(), atomic=True,
+                 splits=0, colsum=rt.grad(bias) if fused else None)  # bias gradient rides along in the wgrad kernel
+        if bias is not None and not fused:
+            ops.colsum(dy, rt.grad(bias), M, N, ld=dy_ld, offset=dy_off)
     if not need_dx:
         return None
     dx = dx_out if dx_out is not None else torch.empty(M, K, dtype=rt.compute_dtype(), device=dy.device)
@@ -64,12 +65,14 @@ def conv_bwd(dy, x, weight, bias, B, H, W, stride, pad, dil=1, *, need_dx=True, 
     Co, Ci, KH, KW = weight.shape
     OH, OW = conv_out_size(H, W, KH, stride, pad, dil)
     M, K = B * OH * OW, KH * KW * Ci
-    dwg = torch.zeros(Co, K, dtype=torch.float32, device=dy.device)
-    ops.gemm(plain_view(dy, M, Co), conv_view(x, B, H, W, Ci, KH, KW, stride, pad, dil, OH=OH, OW=OW), dwg, Co, K, M,
-             a_kstrided=True, b_kstrided=True, dtype=rt.tag(), atomic=True, splits=0)
-    ops.permute4(dwg, rt.grad(weight), (Co, KH, KW, Ci), (0, 3, 1, 2), accumulate=True)
-    if bias is not None:
-        ops.colsum(dy, rt.grad(bias), M, Co)
+    with rt.lane('wgrad', dy, x):
+        dwg = torch.zeros(Co, K, dtype=torch.float32, device=dy.device)
+        ops.gemm(plain_view(dy, M, Co), conv_view(x, B, H, W, Ci, KH, KW, stride, pad, dil, OH=OH, OW=OW), dwg, Co, K, M,
+                 a_kstrided=True, b_kstrided=True, dtype=rt.tag(), atomic=True, splits=0)
+        ops.permute4(dwg, rt.grad(weight), (Co, KH, KW, Ci), (0, 3, 1, 2), accumulate=True)
+        if bias is not None:
+            ops.colsum(dy, rt.grad(bias), M, Co)
+        rt.keep_alive(dwg)
     if not need_dx:
         return None
     dx = dx_out if dx_out is not None else torch.empty(B * H * W, Ci, dtype=rt.compute_dtype(), device=dy.device)
@@ -180,7 +183,8 @@ def mlp_bwd(dy, mlp, xin, h, act, B, H, W, Cin, dps=None):
     dw = mlp.dwconv.dwconv
     w9 = rt.wdw(dw.weight)
     dz = ops.dwconv_gelu_bwd_prep(h, w9, dw.bias, da, B, H, W, hidden, 1)
-    ops.dwconv_bwd_weight(dz, h, rt.grad(dw.weight).view(hidden, 9), rt.grad(dw.bias), B, H, W, hidden, 1)
+    with rt.lane('wgrad', dz, h):
+        ops.dwconv_bwd_weight(dz, h, rt.grad(dw.weight).view(hidden, 9), rt.grad(dw.bias), B, H, W, hidden, 1)
     dh = ops.dwconv_bwd_data(dz, w9, B, H, W, hidden, 1, out=da)
     return linear_bwd(dh, xin, mlp.fc1.weight, mlp.fc1.bias, M, Cin)
 

@@ -113,16 +113,31 @@ def layernorm_fwd(x, gamma, beta, eps, save_stats=True, out=None):
 
 
 _LN_WS = {}
+_LN_WS_MAX = {}
+LN_LANE = 'main'   # set by runtime.lane: LayerNorm backward passes running side by side must not share one workspace
 
 
 def _ln_ws(device, n):
-    """persistent zero-initialised LayerNorm-backward workspace (the kernel pair leaves it zeroed; calls on one stream
-    are ordered, so one buffer per device is enough)"""
-    key = (device.type, device.index)
+    """persistent zero-initialised LayerNorm-backward workspace (the kernel pair leaves it zeroed; calls on one stream are
+    ordered, so one buffer per device and concurrency lane is enough)"""
+    dkey = (device.type, device.index)
+    _LN_WS_MAX[dkey] = max(_LN_WS_MAX.get(dkey, 64 * 2 * 1024), n)
+    key = dkey + (LN_LANE,)
     ws = _LN_WS.get(key)
     if ws is None or ws.numel() < n:
-        ws = _LN_WS[key] = torch.zeros(max(n, 64 * 2 * 1024), dtype=torch.float32, device=device)
+        ws = _LN_WS[key] = torch.zeros(_LN_WS_MAX[dkey], dtype=torch.float32, device=device)
     return ws
+
+
+def ln_ws_prealloc(device, lanes):
+    """create the workspaces of the given lanes NOW (eagerly), sized for the largest request seen so far -- so that a graph
+    capture never allocates one from its private pool"""
+    dkey = (device.type, device.index)
+    n = _LN_WS_MAX.get(dkey, 64 * 2 * 1024)
+    for ln in lanes:
+        key = dkey + (ln,)
+        if key not in _LN_WS or _LN_WS[key].numel() < n:
+            _LN_WS[key] = torch.zeros(n, dtype=torch.float32, device=device)
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None):

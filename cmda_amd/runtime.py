@@ -106,6 +106,74 @@ def ones1(device):
     return t
 
 
+# ------------------------------------------------------------------ concurrency lanes (HIP streams inside one captured graph)
+# At the reference's 2+2 samples per GPU most kernels are far too small for 256 CUs and a dependent kernel costs ~5 us of
+# launch / drain latency whatever its size, so the step time is (number of dependent kernels) x latency.  Independent work is
+# therefore issued on side streams: (a) the two encoders of the fusion student run side by side, (b) every weight-gradient
+# kernel (consumed only by the optimizer) leaves the critical dgrad chain.  Off by default; DACS switches it on while it
+# captures its hipGraph (forked streams become parallel branches of the graph; eager launches would only pay extra host time).
+_conc = {'on': False, 'streams': {}, 'used': [], 'keep': [], 'lane': 'main'}
+
+
+def set_concurrency(flag):
+    _conc['on'] = bool(flag)
+
+
+def concurrency():
+    return _conc['on']
+
+
+class lane:
+    """`with lane('enc', t1, t2...)`: run the body on the side stream of that name, ordered after everything enqueued so far on
+    the current stream.  The tensors named (inputs allocated on another stream that the body reads) are kept alive until
+    `join_lanes()` -- the caching allocator would otherwise hand their memory to the producer stream again while the side stream
+    is still reading.  `lane('wgrad', ...)` picks the weight-gradient stream of the lane we are in."""
+
+    def __init__(self, name, *keep):
+        self.name, self.keep, self.ctx = name, keep, None
+
+    def __enter__(self):
+        if not _conc['on']:
+            return self
+        name = self.name if self.name != 'wgrad' else 'wgrad_' + _conc['lane']
+        cur = torch.cuda.current_stream()
+        key = (name, cur.device_index)
+        s = _conc['streams'].get(key)
+        if s is None:
+            s = _conc['streams'][key] = torch.cuda.Stream(cur.device)
+        s.wait_stream(cur)
+        if s not in _conc['used']:
+            _conc['used'].append(s)
+        _conc['keep'].extend(self.keep)
+        self.prev_lane = _conc['lane']
+        if self.name != 'wgrad':
+            _conc['lane'] = ops.LN_LANE = self.name
+        self.ctx = torch.cuda.stream(s)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+            _conc['lane'] = ops.LN_LANE = self.prev_lane
+        return False
+
+
+def keep_alive(*tensors):
+    if _conc['on']:
+        _conc['keep'].extend(tensors)
+
+
+def join_lanes():
+    """make the current stream wait for every side stream used since the last join, then release the kept tensors"""
+    if _conc['used']:
+        cur = torch.cuda.current_stream()
+        for s in _conc['used']:
+            cur.wait_stream(s)
+        _conc['used'] = []
+    _conc['keep'] = []
+
+
 _anchors = {}
 
 

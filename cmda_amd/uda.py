@@ -417,11 +417,17 @@ class DACS(nn.Module):
         st_src = {k: v.clone() for k, v in src.items() if isinstance(v, torch.Tensor)}
         st_tgt = {k: v.clone() for k, v in tgt.items() if isinstance(v, torch.Tensor)}
         second = torch.empty_like(st_src['image'])
+        ops.ln_ws_prealloc(dev, ('main', 'enc'))
         torch.cuda.synchronize(dev)
         rt.invalidate()    # every weight re-layout must be recorded INSIDE the graph (it is re-run by each replay)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            out = self._iteration(st_src, st_tgt, cb['d'], use_events_struct, second, direction)
+        rt.set_concurrency(getattr(self, 'graph_lanes', True))   # forked streams = parallel branches of the graph
+        try:
+            with torch.cuda.graph(g):
+                out = self._iteration(st_src, st_tgt, cb['d'], use_events_struct, second, direction)
+                rt.join_lanes()
+        finally:
+            rt.set_concurrency(False)
         rt.invalidate()    # the cached re-layouts now live in the graph's pool and hold data only after a replay
         self._graph = dict(graph=g, src=st_src, tgt=st_tgt, second=second, out=out, key=(use_events_struct, direction))
 

@@ -112,7 +112,8 @@ def run_case(tgt, dims, ch, dtype, B=2, H=64, W=64, iters=1, graph=False, shift_
             p.grad = None
         o = dacs_iter.dacs_iteration(ref, ema, G, src, tg, local_iter=it, forward_cfg=FCFG, isr_parms=ISR, shift_type=shift_type,
                                      draws=oracle_draws(dacs.last_draws))
-        outs.append((dict(log_vars), mix, grads, o, {n: q.grad.clone() for n, q in ref.named_parameters()}))
+        outs.append(({k: v.detach().clone() for k, v in log_vars.items()}, mix, grads, o,
+                     {n: q.grad.clone() for n, q in ref.named_parameters()}))
     return dacs, ema, outs
 
 
@@ -179,7 +180,10 @@ def test_dacs_graph_replay_matches_oracle():
     tgt = Target('gpu')
     dacs, ema, outs = run_case(tgt, SMALL['dims'], SMALL['ch'], torch.float32, iters=3, graph=True)
     assert dacs._graph is not None, 'the iteration was not captured'
-    for out in outs:
+    for it, out in enumerate(outs):
+        print(f'iteration {it}: source loss {out[0]["decode.loss_seg"].item():.6f} vs {out[3]["decode.loss_seg"].item():.6f}, mix loss '
+              f'{out[0]["mix.decode.loss_seg"].item():.6f} vs {out[3]["mix.decode.loss_seg"].item():.6f}; draws {dacs.last_draws["choice"]:.3f}')
+    for it, out in enumerate(outs):
         check_iteration(out, True, 1e-4, 5e-2)
     for (n1, p), (n2, q) in zip(dacs.ema_model.named_parameters(), ema.named_parameters()):
         assert_close(p.data, q.data, 1e-6, name='ema ' + n1)
