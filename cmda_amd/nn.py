@@ -72,7 +72,6 @@ def conv_bwd(dy, x, weight, bias, B, H, W, stride, pad, dil=1, *, need_dx=True, 
         ops.permute4(dwg, rt.grad(weight), (Co, KH, KW, Ci), (0, 3, 1, 2), accumulate=True)
         if bias is not None:
             ops.colsum(dy, rt.grad(bias), M, Co)
-        rt.keep_alive(dwg)
     if not need_dx:
         return None
     dx = dx_out if dx_out is not None else torch.empty(B * H * W, Ci, dtype=rt.compute_dtype(), device=dy.device)

@@ -112,11 +112,13 @@ def ones1(device):
 # therefore issued on side streams: (a) the two encoders of the fusion student run side by side, (b) every weight-gradient
 # kernel (consumed only by the optimizer) leaves the critical dgrad chain.  Off by default; DACS switches it on while it
 # captures its hipGraph (forked streams become parallel branches of the graph; eager launches would only pay extra host time).
-_conc = {'on': False, 'streams': {}, 'used': [], 'keep': [], 'lane': 'main'}
+_conc = {'on': False, 'streams': {}, 'stack': ['main'], 'used': {}, 'keep': {}}
 
 
 def set_concurrency(flag):
     _conc['on'] = bool(flag)
+    _conc['stack'], _conc['used'], _conc['keep'] = ['main'], {}, {}
+    ops.LN_LANE = 'main'
 
 
 def concurrency():
@@ -124,10 +126,11 @@ def concurrency():
 
 
 class lane:
-    """`with lane('enc', t1, t2...)`: run the body on the side stream of that name, ordered after everything enqueued so far on
-    the current stream.  The tensors named (inputs allocated on another stream that the body reads) are kept alive until
-    `join_lanes()` -- the caching allocator would otherwise hand their memory to the producer stream again while the side stream
-    is still reading.  `lane('wgrad', ...)` picks the weight-gradient stream of the lane we are in."""
+    """`with lane('enc', t1, t2...)`: run the body on the side stream `<current lane>/enc`, ordered after everything enqueued
+    so far on the current stream (re-entering a lane therefore adds exactly that dependency).  Lanes nest.  The tensors
+    named (inputs allocated on another stream that the body reads) are kept alive until the enclosing lane calls
+    `join_lanes()` -- the caching allocator would otherwise hand their memory to the producer stream again while the side
+    stream is still reading."""
 
     def __init__(self, name, *keep):
         self.name, self.keep, self.ctx = name, keep, None
@@ -135,19 +138,18 @@ class lane:
     def __enter__(self):
         if not _conc['on']:
             return self
-        name = self.name if self.name != 'wgrad' else 'wgrad_' + _conc['lane']
+        parent = _conc['stack'][-1]
+        full = parent + '/' + self.name
         cur = torch.cuda.current_stream()
-        key = (name, cur.device_index)
+        key = (full, cur.device_index)
         s = _conc['streams'].get(key)
         if s is None:
             s = _conc['streams'][key] = torch.cuda.Stream(cur.device)
         s.wait_stream(cur)
-        if s not in _conc['used']:
-            _conc['used'].append(s)
-        _conc['keep'].extend(self.keep)
-        self.prev_lane = _conc['lane']
-        if self.name != 'wgrad':
-            _conc['lane'] = ops.LN_LANE = self.name
+        _conc['used'][full] = s
+        _conc['keep'].setdefault(full, []).extend(self.keep)
+        _conc['stack'].append(full)
+        ops.LN_LANE = full
         self.ctx = torch.cuda.stream(s)
         self.ctx.__enter__()
         return self
@@ -155,23 +157,27 @@ class lane:
     def __exit__(self, *exc):
         if self.ctx is not None:
             self.ctx.__exit__(*exc)
-            _conc['lane'] = ops.LN_LANE = self.prev_lane
+            _conc['stack'].pop()
+            ops.LN_LANE = _conc['stack'][-1]
         return False
 
 
-def keep_alive(*tensors):
-    if _conc['on']:
-        _conc['keep'].extend(tensors)
+def join_lanes(name=None):
+    """make the current lane's stream wait for the lane `name` forked below it (and everything forked below that), or for every
+    lane below it when no name is given; then release what those lanes kept alive"""
+    if not _conc['on']:
+        return
+    me = _conc['stack'][-1]
+    root = me + '/' + name if name else None
 
-
-def join_lanes():
-    """make the current stream wait for every side stream used since the last join, then release the kept tensors"""
-    if _conc['used']:
-        cur = torch.cuda.current_stream()
-        for s in _conc['used']:
-            cur.wait_stream(s)
-        _conc['used'] = []
-    _conc['keep'] = []
+    def hit(k):
+        return (k == root or k.startswith(root + '/')) if root else k.startswith(me + '/')
+    cur = None
+    for full in [k for k in _conc['used'] if hit(k)]:
+        cur = cur or torch.cuda.current_stream()
+        cur.wait_stream(_conc['used'].pop(full))
+    for k in [k for k in _conc['keep'] if hit(k)]:
+        del _conc['keep'][k]
 
 
 _anchors = {}

@@ -88,7 +88,7 @@ class EncoderDecoder(nn.Module):
         dfs = self.decode_head.bwd_train(sv_h, B, gscale)
         rt.notify_grads_ready('decode_head', self.decode_head)
         self.backbone.bwd(sv_b, [dfs.get(i) for i in range(4)])
-        rt.join_lanes()
+        rt.join_lanes('wgrad')
 
     def forward_train(self, img, img_metas=None, gt_semantic_seg=None, seg_weight=None, return_feat=False):
         holder = {}
@@ -258,7 +258,7 @@ class FusionEncoderDecoder(nn.Module):
         with rt.lane('enc', *ev_in, *joint):   # the two encoders are independent until the fusion module: side by side
             f_ev, sv_e = self.backbone_events.fwd(ev_in, save=save, out_feats=[J[2 * m:G * m] for J, m in zip(joint, n)])
         f_image, sv_i = self.backbone_image.fwd(image, save=save, out_feats=[J[:m] for J, m in zip(joint, n)])
-        rt.join_lanes()
+        rt.join_lanes('enc')
         f_events = [(J[2 * m:3 * m], h, w) for J, m, (h, w) in zip(joint, n, shapes)]
         _, sv_f = self.fusion_module.fwd(f_image, f_events, B, save, into=[J[m:2 * m] for J, m in zip(joint, n)])
         feats = [(J, h, w) for J, (h, w) in zip(joint, shapes)]
@@ -286,7 +286,8 @@ class FusionEncoderDecoder(nn.Module):
         with rt.lane('enc', *[t for t in d if t is not None]):
             self.backbone_events.bwd(sv_e, d_ev)
         self.backbone_image.bwd(sv_i, d_img)
-        rt.join_lanes()
+        rt.join_lanes('enc')
+        rt.join_lanes('wgrad')
 
     # -- hand-scheduled training pass ---------------------------------------------------------------------------------
     def train_fwd(self, inputs, gt, seg_weight, cfg):
@@ -309,7 +310,7 @@ class FusionEncoderDecoder(nn.Module):
         dfeats = self.decode_head.bwd_train(sv_h, B, gscale)
         rt.notify_grads_ready('decode_head', self.decode_head)
         self._extract_bwd(sv, dfeats, B)
-        rt.join_lanes()
+        rt.join_lanes('wgrad')
 
     def forward_train(self, inputs, gt_semantic_seg, seg_weight=None, return_feat=False, cfg=None):
         holder = {}

@@ -320,10 +320,6 @@ class DACS(nn.Module):
         if tt == 'cs2dz_image+raw-isr':
             night_image = tgt['warp_image'] if 'warp_image' in tgt else tgt['image']
         else:
-            if self.cyclegan_itrd2en is not None:   # Image Motion-Extractor (dacs.py:400-404), frozen, no grad
-                day_events = self.cyclegan_itrd2en.forward_mean3(src['img_time_res'])
-            else:
-                day_events = src['img_time_res']
             night_image, night_events = tgt['warp_image'], tgt['events_vg']
         B, _, H, W = day_image.shape
         dev = day_image.device
@@ -335,66 +331,86 @@ class DACS(nn.Module):
         student, teacher = self.get_model(), self.get_ema_model()
         cfg_s = self._cfg_student(use_events)
         one = rt.ones1(dev)
+        lab = day_label.view(B, H, W)
+        classes = ctl['classes']
+        # Schedule.  The reference runs source step, teacher, mixing, mixed step one after the other (dacs.py:489-860), but the
+        # only data dependencies are: mixing needs the teacher's pseudo-labels and the generator's events; the mixed BACKWARD
+        # must follow the source backward (both accumulate into the same gradients); the student's BatchNorm running statistics
+        # must see the source forward before the mixed forward.  So lane 'T' carries teacher -> mixing -> mixed FORWARD next to
+        # the main lane's generator -> source forward -> source backward; the mixed backward follows the join.  With the lanes
+        # switched off (eager launches) the same code simply runs in program order.
 
-        # ---- source (dacs.py:489-523) ------------------------------------------------------------------------------------------
+        # ---- teacher pseudo-labels (dacs.py:653-711) -----------------------------------------------------------------------------
+        with rt.lane('T', night_image, teacher_second, *[v for v in tgt.values() if isinstance(v, torch.Tensor)]):
+            if tt != 'cs2dz_image+raw-isr' and self.fuse_both_ice_and_e:
+                ema = teacher.encode_decode_lowres(night_image, night_events, tgt['warp_img_self_res'], dict(self.forward_cfg, fusion_all=True))
+            elif tt != 'cs2dz_image+raw-isr' and self.isr_another_fusion and not use_events:
+                ema = teacher.encode_decode_lowres(night_image, teacher_second, test_cfg=dict(self.forward_cfg, fusion_isr=True))
+            else:
+                ema = teacher.encode_decode_lowres(night_image, teacher_second, test_cfg=self.forward_cfg)
+            pseudo_label, _, count = ops.pseudo_label(ema['fusion_output'], H, W, self.pseudo_threshold, want_prob=False)
+            pseudo_weight = ops.pseudo_weight(count, B, H, W, self.psweight_ignore_top, self.psweight_ignore_bottom)
+            gt_pixel_weight = torch.ones(B, H, W, dtype=torch.float32, device=dev)
+            mixed_lbl = ops.class_mix_label(lab, pseudo_label, lab, classes).view(B, 1, H, W)
+            mixed_weight = ops.class_mix(gt_pixel_weight.view(B, 1, H, W), pseudo_weight.view(B, 1, H, W), lab, classes).view(B, H, W)
+            # ClassMix + strong augmentation + ISR of the mixed image (dacs.py:716-771; dacs_transforms.py:64-98, kornia
+            # semantics): the on/off gates and the per-sample parameters are read from the control block by the kernels
+            mixed_img = ops.class_mix(day_image, night_image, lab, classes)
+            if self.color_jitter_p < 1.0:
+                ops.color_jitter_(mixed_img, ctl['jitter'], ctl['jitter_on'])
+            if self.blur:
+                ops.gaussian_blur_(mixed_img, ctl['taps_x'], ctl['taps_y'], ctl['blur_on'])
+            gray = ops.isr_gray(mixed_img)
+            mixed_isr = ops.isr_from_gray(gray, self.isr_parms['val_range'], self.isr_parms['_threshold'],
+                                          self.isr_parms['_clip_range'], self.isr_parms['shift_pixel'], direction, dirs_dev=ctl['dirs'])
+
+        # ---- Image Motion-Extractor (dacs.py:400-404), frozen, no grad ------------------------------------------------------------
+        if tt != 'cs2dz_image+raw-isr':
+            if self.cyclegan_itrd2en is not None:
+                day_events = self.cyclegan_itrd2en.forward_mean3(src['img_time_res'])
+            else:
+                day_events = src['img_time_res']
+        mixed_events = None
+        if day_events is not None:
+            with rt.lane('T', day_events):
+                mixed_events = ops.class_mix(day_events, night_events, lab, classes)
+
+        # ---- source forward (dacs.py:489-523) ------------------------------------------------------------------------------------
         if tt == 'cs2dz_image+raw-isr':
             inputs = {'image': day_image, 'events': day_isr}
         elif tt == 'cs2dsec_image+events_together':
             inputs = {'image': day_image, 'events': day_events, 'img_self_res': day_isr}
         else:
             inputs = {'image': day_image, 'events': day_events if use_events else day_isr}
-        loss, (losses, _, _), saved = student.train_fwd(inputs, day_label, None, cfg_s)
+        loss, (losses, _, _), saved_src = student.train_fwd(inputs, day_label, None, cfg_s)
         log_vars['decode.loss_seg'], log_vars['decode.acc_seg'], log_vars['loss'] = loss, losses['acc_seg'], loss
-        student.train_bwd(saved, one)
-        del saved
 
-        # ---- teacher pseudo-labels (dacs.py:653-711) -----------------------------------------------------------------------------
-        if tt != 'cs2dz_image+raw-isr' and self.fuse_both_ice_and_e:
-            ema = teacher.encode_decode_lowres(night_image, night_events, tgt['warp_img_self_res'], dict(self.forward_cfg, fusion_all=True))
-        elif tt != 'cs2dz_image+raw-isr' and self.isr_another_fusion and not use_events:
-            ema = teacher.encode_decode_lowres(night_image, teacher_second, test_cfg=dict(self.forward_cfg, fusion_isr=True))
-        else:
-            ema = teacher.encode_decode_lowres(night_image, teacher_second, test_cfg=self.forward_cfg)
-        pseudo_label, _, count = ops.pseudo_label(ema['fusion_output'], H, W, self.pseudo_threshold, want_prob=False)
-        pseudo_weight = ops.pseudo_weight(count, B, H, W, self.psweight_ignore_top, self.psweight_ignore_bottom)
-        gt_pixel_weight = torch.ones(B, H, W, dtype=torch.float32, device=dev)
-
-        # ---- ClassMix + strong augmentation + ISR of the mixed image (dacs.py:716-771) --------------------------------------------
-        lab = day_label.view(B, H, W)
-        classes = ctl['classes']
-        mixed_img = ops.class_mix(day_image, night_image, lab, classes)
-        # strong_transform's colour jitter / Gaussian blur of the mixed image (dacs_transforms.py:64-98; kornia semantics): the
-        # on/off gates and the per-sample parameters are read from the control block by the kernels
-        if self.color_jitter_p < 1.0:
-            ops.color_jitter_(mixed_img, ctl['jitter'], ctl['jitter_on'])
-        if self.blur:
-            ops.gaussian_blur_(mixed_img, ctl['taps_x'], ctl['taps_y'], ctl['blur_on'])
-        mixed_events = ops.class_mix(day_events, night_events, lab, classes) if day_events is not None else None
-        gray = ops.isr_gray(mixed_img)
-        mixed_isr = ops.isr_from_gray(gray, self.isr_parms['val_range'], self.isr_parms['_threshold'],
-                                      self.isr_parms['_clip_range'], self.isr_parms['shift_pixel'], direction, dirs_dev=ctl['dirs'])
-        mixed_lbl = ops.class_mix_label(lab, pseudo_label, lab, classes).view(B, 1, H, W)
-        mixed_weight = ops.class_mix(gt_pixel_weight.view(B, 1, H, W), pseudo_weight.view(B, 1, H, W), lab, classes).view(B, H, W)
-
-        # ---- mixed (dacs.py:820-860) ---------------------------------------------------------------------------------------------
+        # ---- mixed forward (dacs.py:820-860), after the source forward (BatchNorm running statistics), next to the source backward
         if tt == 'cs2dz_image+raw-isr':
             inputs = {'image': mixed_img, 'events': mixed_isr}
         elif tt == 'cs2dsec_image+events_together':
             inputs = {'image': mixed_img, 'events': mixed_events, 'img_self_res': mixed_isr}
         else:
             inputs = {'image': mixed_img, 'events': mixed_events if use_events else mixed_isr}
-        loss, (losses, _, _), saved = student.train_fwd(inputs, mixed_lbl, mixed_weight, cfg_s)
+        with rt.lane('T'):
+            loss, (losses, _, _), saved_mix = student.train_fwd(inputs, mixed_lbl, mixed_weight, cfg_s)
         log_vars['mix.decode.loss_seg'], log_vars['mix.decode.acc_seg'] = loss, losses['acc_seg']
         log_vars['loss'] = loss   # _parse_losses of the mixed step overwrites 'loss' (dacs.py:851-857)
+
+        # ---- source backward, then (gradients accumulate) mixed backward -----------------------------------------------------------
+        student.train_bwd(saved_src, one)
+        del saved_src
+        rt.join_lanes('T')
         # the second (last) backward pass of the iteration: gradients reported final by this pass are final for the step, so a
         # data-parallel driver may start their all-reduce underneath the rest of the pass (runtime.grad_ready_hook)
         prev_hook = rt.grad_ready_hook
         if getattr(self, 'final_pass_grad_hook', None) is not None and not (dev.type == 'cuda' and torch.cuda.is_current_stream_capturing()):
             rt.grad_ready_hook = self.final_pass_grad_hook
         try:
-            student.train_bwd(saved, one)
+            student.train_bwd(saved_mix, one)
         finally:
             rt.grad_ready_hook = prev_hook
+        del saved_mix
         extras = dict(mixed_img=mixed_img, mixed_lbl=mixed_lbl, mixed_isr=mixed_isr, pseudo_weight=mixed_weight,
                       pseudo_label=pseudo_label, classes=classes, mixed_events=mixed_events, day_events=day_events,
                       teacher_logits=ema, pseudo_count=count)
@@ -417,7 +433,7 @@ class DACS(nn.Module):
         st_src = {k: v.clone() for k, v in src.items() if isinstance(v, torch.Tensor)}
         st_tgt = {k: v.clone() for k, v in tgt.items() if isinstance(v, torch.Tensor)}
         second = torch.empty_like(st_src['image'])
-        ops.ln_ws_prealloc(dev, ('main', 'enc'))
+        ops.ln_ws_prealloc(dev, ('main', 'main/enc'))
         torch.cuda.synchronize(dev)
         rt.invalidate()    # every weight re-layout must be recorded INSIDE the graph (it is re-run by each replay)
         g = torch.cuda.CUDAGraph()
