@@ -292,8 +292,8 @@ def run_dacs(args, rank, world, dev, dist):
     it = [0]
     if not args.no_graph:
         dacs.enable_graph(warmup_iters=2)     # iterations 0-1 eager, iteration 2 captures the hipGraph, then replays
-        if os.environ.get('CMDA_BENCH_NO_LANES'):   # A/B switch for the concurrency lanes inside the graph (tools/gpu)
-            dacs.graph_lanes = False
+        if os.environ.get('CMDA_BENCH_LANES') is not None:   # A/B switch for the concurrency lanes inside the graph (tools/gpu)
+            dacs.graph_lane_set = set(x for x in os.environ['CMDA_BENCH_LANES'].split(',') if x)
 
     def step():
         opt.zero_grad()

@@ -109,15 +109,22 @@ def ones1(device):
 # ------------------------------------------------------------------ concurrency lanes (HIP streams inside one captured graph)
 # At the reference's 2+2 samples per GPU most kernels are far too small for 256 CUs and a dependent kernel costs ~5 us of
 # launch / drain latency whatever its size, so the step time is (number of dependent kernels) x latency.  Independent work is
-# therefore issued on side streams: (a) the two encoders of the fusion student run side by side, (b) every weight-gradient
-# kernel (consumed only by the optimizer) leaves the critical dgrad chain.  Off by default; DACS switches it on while it
-# captures its hipGraph (forked streams become parallel branches of the graph; eager launches would only pay extra host time).
-_conc = {'on': False, 'streams': {}, 'stack': ['main'], 'used': {}, 'keep': {}}
+# therefore issued on side streams: 'enc' = the two encoders of the fusion student side by side; 'T' = teacher -> mixing ->
+# mixed forward next to the source pass (uda.DACS._iteration); 'wgrad' = every weight-gradient kernel (consumed only by the
+# optimizer) off the critical dgrad chain.  Off by default; DACS switches it on while it captures its hipGraph (forked streams
+# become parallel branches of the graph; eager launches would only pay extra host time).
+# Measured on MI355X, full DACS step at 2+2 samples (ms per step, gpurun r02d-f): no lanes 146; enc 104; T 128; enc+T 102;
+# wgrad alone 156, enc+wgrad 129-138, wgrad+T 154 -- the fine-grained wgrad forks (one cross-stream edge per weight gradient,
+# ~3 k per step) cost more than they hide, so the default set is {enc, T}.
+_conc = {'on': False, 'streams': {}, 'stack': ['main'], 'used': {}, 'keep': {}, 'enabled': {'enc', 'T'}, 'touched': []}
 
 
-def set_concurrency(flag):
+def set_concurrency(flag, lanes=None):
+    """lanes: subset of {'enc', 'wgrad', 'T'} to use (default: enc + T, see above)"""
+    if lanes is not None:
+        _conc['enabled'] = set(lanes)
     _conc['on'] = bool(flag)
-    _conc['stack'], _conc['used'], _conc['keep'] = ['main'], {}, {}
+    _conc['stack'], _conc['used'], _conc['keep'], _conc['touched'] = ['main'], {}, {}, []
     ops.LN_LANE = 'main'
 
 
@@ -136,9 +143,13 @@ class lane:
         self.name, self.keep, self.ctx = name, keep, None
 
     def __enter__(self):
-        if not _conc['on']:
+        if not _conc['on'] or self.name not in _conc['enabled']:
             return self
         parent = _conc['stack'][-1]
+        if self.name == 'enc' and parent != 'main':
+            # lane T (teacher / mixed forward) is off the critical path, its encoders may as well run one after the other --
+            # and hipStreamEndCapture of ROCm 7.2 crashes when a stream forked from T is joined back into T (measured)
+            return self
         full = parent + '/' + self.name
         cur = torch.cuda.current_stream()
         key = (full, cur.device_index)
@@ -147,6 +158,8 @@ class lane:
             s = _conc['streams'][key] = torch.cuda.Stream(cur.device)
         s.wait_stream(cur)
         _conc['used'][full] = s
+        if s not in _conc['touched']:
+            _conc['touched'].append(s)
         _conc['keep'].setdefault(full, []).extend(self.keep)
         _conc['stack'].append(full)
         ops.LN_LANE = full
@@ -160,6 +173,16 @@ class lane:
             _conc['stack'].pop()
             ops.LN_LANE = _conc['stack'][-1]
         return False
+
+
+def join_all_touched():
+    """end of a capture: the origin stream waits once more for EVERY side stream used since concurrency was switched on (those
+    joined into another side stream included), so that no forked stream is left joined only transitively"""
+    if _conc['touched']:
+        cur = torch.cuda.current_stream()
+        for s in _conc['touched']:
+            cur.wait_stream(s)
+        _conc['touched'] = []
 
 
 def join_lanes(name=None):

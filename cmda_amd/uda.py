@@ -437,11 +437,12 @@ class DACS(nn.Module):
         torch.cuda.synchronize(dev)
         rt.invalidate()    # every weight re-layout must be recorded INSIDE the graph (it is re-run by each replay)
         g = torch.cuda.CUDAGraph()
-        rt.set_concurrency(getattr(self, 'graph_lanes', True))   # forked streams = parallel branches of the graph
+        rt.set_concurrency(bool(getattr(self, 'graph_lanes', True)), getattr(self, 'graph_lane_set', None))   # forked streams = parallel graph branches
         try:
             with torch.cuda.graph(g):
                 out = self._iteration(st_src, st_tgt, cb['d'], use_events_struct, second, direction)
                 rt.join_lanes()
+                rt.join_all_touched()
         finally:
             rt.set_concurrency(False)
         rt.invalidate()    # the cached re-layouts now live in the graph's pool and hold data only after a replay

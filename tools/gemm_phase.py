@@ -47,6 +47,16 @@ def main():
         a, b, o = r(M, K), r(K, N), torch.empty(M, N, dtype=dt, device=dev)
         run(name, lambda: ops.gemm(ops.plain_view(a, M, K), ops.plain_view(b, K, N), o, M, N, K, b_kstrided=True, dtype=tag), 1 << 30)
 
+    # the DACS step's own shapes (2 + 2 samples per GPU: the event encoder sees 4 x 1024 stage-3 tokens, the image encoder 2 x 1024)
+    nt('s3 q    NT 4096x320x320 (B=4)', 4096, 320, 320)
+    nt('s3 q    NT 2048x320x320 (B=2)', 2048, 320, 320)
+    nt('s3 fc1  NT 4096x1280x320', 4096, 1280, 320)
+    nt('s3 fc2  NT 4096x320x1280', 4096, 320, 1280)
+    nn('s3 dfc1 NN 4096x320x1280', 4096, 320, 1280)
+    nn('s3 dq   NN 4096x320x320', 4096, 320, 320)
+    nt('s1 fc1  NT 65536x256x64', 65536, 256, 64)
+    nt('s2 fc1  NT 16384x512x128', 16384, 512, 128)
+    nt('s4 fc2  NT 1024x512x2048', 1024, 512, 2048)
     nt('s3 q    NT 16384x320x320', 16384, 320, 320)
     nt('s3 fc1  NT 16384x1280x320', 16384, 1280, 320)
     nt('s3 fc2  NT 16384x320x1280', 16384, 320, 1280)

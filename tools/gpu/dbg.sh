@@ -1,1 +1,1 @@
-python -m pytest tests/test_dacs.py -m gpu -x -q -s -k graph 2>&1 | grep -v "^$" | grep "iteration\|passed\|failed\|Error" | head
+CMDA_HIP_LIB=build/libcmda_hip_timing.so python tools/gemm_phase.py 2>&1 | grep -v amdgpu.ids | head -14
