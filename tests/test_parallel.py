@@ -147,19 +147,20 @@ def test_backward_reports_stages_in_order_and_staged_grads_match():
 
 @pytest.mark.gpu
 def test_dacs_final_pass_hook_reports_final_gradients():
-    """DACS arms runtime.grad_ready_hook only around its LAST backward pass; what it reports for the decode head and the
-    image encoder (one backward per pass) equals the gradient at the end of the iteration."""
+    """DACS arms runtime.grad_ready_hook only around its LAST backward pass; what it reports for the decode head and both
+    encoders (each back-propagated once per pass: the event encoder sees events + ISR as one batch) equals the gradient at
+    the end of the iteration."""
     import random
     import numpy as np
     import cmda_amd.runtime as rt
     from cmda_amd import optim
     from cmda_amd.registry import build_train_model
-    from test_dacs import make_cfg
+    from test_dacs import SMALL, make_cfg
     from weights import seeded_fill, seeded_randn
     dev = torch.device('cuda:0')
     rt.set_compute_dtype(torch.float32)
     B, H, W = 2, 64, 64
-    dacs = build_train_model(make_cfg())
+    dacs = build_train_model(make_cfg(SMALL['dims'], SMALL['ch'], generator=False))
     seeded_fill(dacs.model, 7)
     seeded_fill(dacs.ema_model, 8)
     dacs.to(dev).train()
@@ -167,9 +168,10 @@ def test_dacs_final_pass_hook_reports_final_gradients():
     dacs.attach_flat_store(opt)
     student = dacs.model
     ranges = {('decode_head', id(student.decode_head)): opt.ranges_of(student, ['decode_head.'], min_elems=0)}
-    for s in range(1, 5):
-        ranges[(f'backbone.stage{s}', id(student.backbone_image))] = opt.ranges_of(
-            student, [f'backbone_image.patch_embed{s}.', f'backbone_image.block{s}.', f'backbone_image.norm{s}.'], min_elems=0)
+    for name in ('backbone_image', 'backbone_events'):
+        for s in range(1, 5):
+            ranges[(f'backbone.stage{s}', id(getattr(student, name)))] = opt.ranges_of(
+                student, [f'{name}.patch_embed{s}.', f'{name}.block{s}.', f'{name}.norm{s}.'], min_elems=0)
     seen, snaps = [], {}
 
     def hook(tag, module=None):
@@ -190,9 +192,9 @@ def test_dacs_final_pass_hook_reports_final_gradients():
     dacs(**batch)
     torch.cuda.synchronize()
     assert rt.grad_ready_hook is None                       # disarmed again after the pass
-    assert seen[0][0] == 'decode_head' and len(snaps) == 5  # head + four image-encoder stages, reported once each
+    assert seen[0][0] == 'decode_head' and len(snaps) == 9  # head + four stages of each encoder, reported once each
     assert [t for t, img, _ in seen if img] == [f'backbone.stage{s}' for s in (4, 3, 2, 1)]
-    assert sum(1 for _, _, evt in seen if evt) == 8         # the event encoder runs twice per pass (isr + events)
+    assert [t for t, _, evt in seen if evt] == [f'backbone.stage{s}' for s in (4, 3, 2, 1)]
     for key, parts in snaps.items():
         for (lo, hi), snap in zip(ranges[key], parts):
             assert torch.equal(snap, opt.flat_g[lo:hi]), f'{key[0]}: changed after being reported'

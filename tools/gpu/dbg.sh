@@ -1,1 +1,1 @@
-CMDA_HIP_LIB=build/libcmda_hip_timing.so python tools/gemm_phase.py 2>&1 | grep -v amdgpu.ids | head -14
+python -m pytest tests -m gpu -q -s 2>&1 | grep -v "^$" | grep "injected\|512x512\|passed\|failed\|FAILED\|Error" | cut -c1-400
