@@ -8,8 +8,10 @@ the bare state dict or {'state_dict': ...} / {'model': ...}), and `save_checkpoi
 same file layout, same key handling, so checkpoints written by either side load in the other (the state-dict keys of every
 module here equal the reference's: tests/golden/*_keys.json).
 
-After loading, the kernels' cached compute copies of the parameters are invalidated (runtime.invalidate) and, when the
-model's parameters live in a FlatAdamW store, `optimizer.sync_bf16()` must be called by the owner of the optimizer.
+After loading, the kernels' cached compute copies of the parameters are invalidated (runtime.invalidate) and every live
+bf16 mirror of a loaded parameter (FlatAdamW's flat mirror of the student, DACS's flat mirror of the EMA teacher) is
+re-cast from the fp32 master in place, so a load is self-healing whatever store the parameters were re-homed into.
+`strip_for_release` restates function.py:28-37 (drop `ema_model.*` / `cyclegan*` keys from a training checkpoint).
 """
 import re
 import time
@@ -39,6 +41,11 @@ def load_state_dict(module, state_dict, strict=False, logger=None):
     with torch.no_grad():
         for k, v in usable.items():
             own[k].copy_(v)   # in place: parameters re-homed into flat optimizer buffers keep their storage
+        # live bf16 compute mirrors (runtime.w returns them without consulting the cache): refresh from the new masters
+        for p in module.parameters():
+            mirror = getattr(p, '_cmda_bf16', None)
+            if mirror is not None:
+                mirror.copy_(p.data)
     rt.invalidate()
     msg = []
     if unexpected:
@@ -84,6 +91,14 @@ def save_checkpoint(model, filename, optimizer=None, meta=None):
         meta.setdefault('CLASSES', module.CLASSES)
     ckpt = {'meta': meta, 'state_dict': weights_to_cpu(module.state_dict())}
     if optimizer is not None:
-        ckpt['optimizer'] = optimizer.state_dict() if hasattr(optimizer, 'state_dict') else optimizer
+        if not hasattr(optimizer, 'state_dict'):
+            raise TypeError(f'{type(optimizer).__name__} has no state_dict(): refusing to pickle the optimizer object')
+        ckpt['optimizer'] = optimizer.state_dict()
     torch.save(ckpt, filename)
     return ckpt
+
+
+def strip_for_release(state_dict):
+    """function.py:28-37 (`--function convert_pth`): the released checkpoint is the training state dict without the EMA
+    teacher and the Motion-Extractor generator -- every key containing 'ema_model' or 'cyclegan' is dropped."""
+    return OrderedDict((k, v) for k, v in state_dict.items() if 'ema_model' not in k and 'cyclegan' not in k)

@@ -46,6 +46,8 @@ class FlatAdamW:
         for n, p in uniq:
             groups.setdefault(_group_of(n, custom_keys), []).append(p)
         self._names = {id(p): n for n, p in uniq}
+        self._order = [p for _, p in named if id(p) in seen]          # model.named_parameters() order, unique
+        self._order = list({id(p): p for p in self._order}.values())
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         dev = uniq[0][1].device
         total = sum((p.numel() + 7) // 8 * 8 for _, p in uniq)  # 8-element slots: 16-byte aligned in fp32 AND in the bf16 mirror
@@ -110,6 +112,44 @@ class FlatAdamW:
                            self.lr * lm * lr_scale, self.betas[0], self.betas[1], self.eps, self.weight_decay * dm,
                            self.step_count, p_bf16=self.flat_bf16[start:end] if self.flat_bf16 is not None else None)
         rt.invalidate()
+
+
+    # -- torch.optim.AdamW-compatible state (the layout mmcv's CheckpointHook saves and runner.resume restores) ----------------
+    def _slot(self, p):
+        o = (p.data.data_ptr() - self.flat_p.data_ptr()) // 4
+        return o, o + p.numel()
+
+    def state_dict(self):
+        """{'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [...]} keyed by parameter index in
+        model.named_parameters() order, one group per parameter (mmcv's DefaultOptimizerConstructor with paramwise_cfg builds
+        one group per parameter), tensors on the CPU."""
+        state, groups = {}, []
+        seg_of = lambda o: next((lm, dm) for s, e, lm, dm in self.segments if s <= o < e)  # noqa: E731
+        for i, p in enumerate(self._order):
+            lo, hi = self._slot(p)
+            lm, dm = seg_of(lo)
+            if self.step_count > 0:
+                state[i] = {'step': self.step_count, 'exp_avg': self.flat_m[lo:hi].view(p.shape).detach().cpu().clone(),
+                            'exp_avg_sq': self.flat_v[lo:hi].view(p.shape).detach().cpu().clone()}
+            groups.append({'lr': self.lr * lm, 'betas': tuple(self.betas), 'eps': self.eps, 'weight_decay': self.weight_decay * dm,
+                           'amsgrad': False, 'params': [i]})
+        return {'state': state, 'param_groups': groups}
+
+    def load_state_dict(self, sd):
+        """restores the Adam moments and the step count (same parameter order as state_dict / torch.optim.AdamW)"""
+        steps = set()
+        with torch.no_grad():
+            for i, p in enumerate(self._order):
+                st = sd['state'].get(i, sd['state'].get(str(i)))
+                if st is None:
+                    continue
+                lo, hi = self._slot(p)
+                self.flat_m[lo:hi].copy_(st['exp_avg'].reshape(-1))
+                self.flat_v[lo:hi].copy_(st['exp_avg_sq'].reshape(-1))
+                steps.add(int(st['step']))
+        if len(steps) > 1:
+            raise ValueError(f'per-parameter step counts differ ({sorted(steps)}): the fused update keeps one step count')
+        self.step_count = steps.pop() if steps else 0
 
 
 def poly_warm_scale(it, max_iters=40000, power=1.0, warmup_iters=1500, warmup_ratio=1e-6):

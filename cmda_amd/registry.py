@@ -51,6 +51,11 @@ DATASETS = Registry('dataset')
 PIPELINES = Registry('pipeline')
 
 
+def build_from_cfg(cfg, registry, default_args=None):
+    """mmcv.utils.build_from_cfg (third-party, restated): registry.build with default_args applied via setdefault"""
+    return registry.build(cfg, default_args)
+
+
 def build_backbone(cfg):
     return BACKBONES.build(cfg)
 

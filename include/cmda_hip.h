@@ -205,6 +205,33 @@ int cmda_color_jitter(float* img, int B, int H, int W, const float* mean3, const
 int cmda_gaussian_blur(float* img, float* tmp, const float* taps_x, const float* taps_y, int planes, int H, int W, int kx,
     int ky, const int* enable, void* stream);
 
+/* ---- Loader-side preprocessing on the device -- mmseg/datasets/dsec.py:189-339 (target __getitem__:
+ * crop -> flip -> PIL BILINEAR resize -> ToTensor/Normalize; 'L' luma for the real-time ISR), :341-366 (get_events_vg: rectify
+ * gather, t normalisation), :314-322 (crop / flip / F.interpolate of the voxel grid); mmseg/datasets/cityscapes_ic.py:147-210
+ * (source: resize -> crop -> flip); create_cityscapes_image_change.py:16-35 (time residual PNG).
+ * cmda_pil_resize_u8: src uint8 [B][IH][IW][C] (HWC, C = 1 or 3); samp = DEVICE int32 [B][8] {src_x0, src_y0, flip_src, out_x0,
+ *   out_y0, flip_out, 0, 0}; the resize sees the in_w x in_h window at (src_x0, src_y0), mirrored when flip_src; the OW x OH window
+ *   of the resized image at (out_x0, out_y0), mirrored when flip_out, is produced.  hbounds/hkk/vbounds/vkk = Pillow's coefficient
+ *   tables (DEVICE int32: bounds [out][2] = {first tap, tap count}, kk [out][ksize] fixed point with 22 fraction bits), built by the
+ *   caller exactly as Pillow's precompute_coeffs / normalize_coeffs_8bpc do.  tmp: B*in_h*OW*C bytes.  Outputs (each may be NULL):
+ *   out_u8 [B][OH][OW][C]; out_f fp32 NCHW [B][3 if (C==1 && rep3) else C][OH][OW] = (u8/255 - fshift3[c]) / fscale3[c] (HOST
+ *   pointers: torchvision ToTensor + Normalize(mean=fshift3, std=fscale3)); out_gray [B][OH][OW] = PIL 'L' luma (C == 3).
+ * cmda_time_residual_u8: uint8 'L' frames now / front [B][H][W], lut = fp32[256] log(g + log_add); mm = uint32 [B][4] scratch.
+ * cmda_event_prep: raw events (t int64 us, x / y int32 pixel, p uint8) -> t_norm, rectified x / y (rect_map fp32 [H][W][2] or NULL),
+ *   polarity as fp32, the inputs of cmda_events_to_voxel_grid.
+ * cmda_crop_flip_resize_f32: in fp32 [B][C][IH][IW], window cw x ch at samp[b].{src_x0,src_y0}, mirrored when flip_src, bilinear
+ *   (align_corners=False) to OH x OW, every channel written `rep` times (enforce_3_channels). */
+int cmda_pil_resize_u8(const uint8_t* src, int B, int IH, int IW, int C, const int* samp, int in_w, int in_h, const int* hbounds,
+    const int* hkk, int hksize, const int* vbounds, const int* vkk, int vksize, int OW, int OH, uint8_t* tmp, uint8_t* out_u8,
+    float* out_f, uint8_t* out_gray, const float* fscale3, const float* fshift3, int rep3, void* stream);
+int cmda_luma_u8(const uint8_t* rgb, uint8_t* out, int64_t npix, void* stream);   /* PIL convert('L') of interleaved uint8 RGB */
+int cmda_time_residual_u8(const uint8_t* now, const uint8_t* front, const float* lut, uint32_t* mm, uint8_t* out, int B, int H,
+    int W, float threshold, float clip, void* stream);
+int cmda_event_prep(const int64_t* t, const int32_t* x, const int32_t* y, const uint8_t* p, const float* rect_map, int H, int W,
+    float* t_norm, float* xr, float* yr, float* pol, int64_t N, void* stream);
+int cmda_crop_flip_resize_f32(const float* in, float* out, const int* samp, int B, int C, int IH, int IW, int cw, int ch, int OH,
+    int OW, int rep, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

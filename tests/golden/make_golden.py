@@ -181,6 +181,100 @@ def voxel():
 
 
 @case
+def pipeline():
+    """Loader-side preprocessing on synthetic raw data, step by step as the reference's loaders do it:
+      target  mmseg/datasets/dsec.py:189-339 (__getitem__: crop -> flip -> PIL resize -> transform; real-time ISR; events crop /
+              flip / F.interpolate / x3) and :341-366 (get_events_vg) -- the file reads are replaced by the synthetic arrays, the
+              arithmetic is the reference's own (events_to_voxel_grid, events_norm, get_image_change_from_pil imported unmodified;
+              PIL and torch ops called exactly as the loader calls them; torchvision ToTensor / Normalize restated: absent here);
+      source  mmseg/datasets/cityscapes_ic.py:147-210 (resize -> crop -> flip of image and time residual, ISR of the cropped image);
+      time residual  create_cityscapes_image_change.py:16-35 get_image_change with its __main__ constants (:169-172)."""
+    import importlib.util
+    import torch.nn.functional as F
+    from PIL import Image, ImageOps
+    dsec = ref_shim.load('mmseg.datasets.dsec')
+    g = torch.Generator().manual_seed(81)
+    mean, std = torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1), torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
+
+    def to_tensor_norm(pil):           # torchvision ToTensor + Normalize (third-party, restated)
+        t = torch.from_numpy(np.asarray(pil).copy()).permute(2, 0, 1).float().div(255)
+        return (t - mean) / std
+
+    def smooth_u8(h, w, c):            # blocky + noisy synthetic frame
+        base = torch.rand((h // 4 + 1, w // 4 + 1, c), generator=g).repeat_interleave(4, 0).repeat_interleave(4, 1)[:h, :w]
+        return ((base * 0.8 + 0.2 * torch.rand((h, w, c), generator=g)) * 255).to(torch.uint8).numpy()
+    out = {}
+    # ---- target (DSEC), scaled-down geometry: frame 60x80, crop 40x40, resize to 52x52
+    FH, FW, CROP, RES = 60, 80, 40, 52
+    isr_p = dict(val_range=[0.01, 1.01], _threshold=0.005, _clip_range=0.1, shift_pixel=1)
+    frame = smooth_u8(FH, FW, 3)
+    N = 4000
+    t_us = torch.sort(torch.randint(0, 50000, (N,), generator=g))[0].numpy().astype(np.int64) + 1234567
+    ex = torch.randint(0, FW, (N,), generator=g).numpy().astype(np.int32)
+    ey = torch.randint(0, FH, (N,), generator=g).numpy().astype(np.int32)
+    ep = torch.randint(0, 2, (N,), generator=g).numpy().astype(np.uint8)
+    yy, xx = np.meshgrid(np.arange(FH, dtype=np.float32), np.arange(FW, dtype=np.float32), indexing='ij')
+    rect = np.stack([np.clip(xx + 0.6 * np.sin(yy / 7.0), 0, FW - 1.001), np.clip(yy + 0.4 * np.cos(xx / 5.0), 0, FH - 1.001)],
+                    axis=-1).astype(np.float32)                        # rectify_map[y, x] = (x_rect, y_rect)
+    out.update(t_frame=frame, t_t=t_us, t_x=ex, t_y=ey, t_p=ep, t_rect=rect)
+    # get_events_vg :341-366
+    et = (t_us - t_us[0]).astype('float32')
+    et = torch.from_numpy(et / et[-1])
+    pol = torch.from_numpy(ep.astype('float32'))
+    xy = rect[ey, ex]
+    erx, ery = torch.from_numpy(xy[:, 0].astype('float32')), torch.from_numpy(xy[:, 1].astype('float32'))
+    vg = dsec.events_to_voxel_grid(et, erx, ery, pol, FW, FH, num_bins=1, normalize_flag=False)
+    clip = (N - 1) / 500000 * 1.5 * 100     # events_finish - events_start = N-1; x100 keeps the tiny synthetic grid off the clip
+    vg = dsec.events_norm(vg, clip_range=clip, final_range=1.0, enforce_no_events_zero=True)
+    out['t_vg'] = vg
+    for tag, (x, y, flip, direction) in {'a': (7, 3, False, 'rightdown'), 'b': (40, 20, True, 'leftup')}.items():
+        pil = Image.fromarray(frame).convert('RGB')
+        pil = pil.crop(box=(x, y, x + CROP, y + CROP))
+        if flip:
+            pil = ImageOps.mirror(pil)       # RandomHorizontalFlip(p=1)
+        pil = pil.resize(size=(RES, RES), resample=Image.BILINEAR)
+        out[f't_{tag}_warp_u8'] = np.asarray(pil).copy()
+        out[f't_{tag}_warp_image'] = to_tensor_norm(pil)
+        isr = ns.ds_utils.get_image_change_from_pil(pil, width=RES, height=RES, shift_direction=direction, **isr_p)
+        out[f't_{tag}_isr'] = isr.repeat(3, 1, 1)
+        ev = vg[:, y: y + CROP, x: x + CROP]
+        if flip:
+            ev = torch.flip(ev, dims=[-1])
+        ev = F.interpolate(ev[None], size=(RES, RES), mode='bilinear', align_corners=False)[0]
+        out[f't_{tag}_events_vg'] = ev.repeat(3, 1, 1)
+        out[f't_{tag}_params'] = np.array([x, y, int(flip)])
+    # ---- source (Cityscapes), scaled down: frame 64x128 -> resize 64x32 (2:1, the antialiased branch) -> crop 32x32
+    SH, SW = 64, 128
+    f_now, f_prev = smooth_u8(SH, SW, 3), None
+    f_prev = np.clip(f_now.astype(np.int32) + (torch.randn((SH, SW, 3), generator=g) * 18).numpy().astype(np.int32), 0, 255).astype(np.uint8)
+    out.update(s_now=f_now, s_prev=f_prev)
+    sys.modules['mmseg.models.cyclegan'].define_G = ns.cyclegan.define_G   # the script's only package-level import
+    spec = importlib.util.spec_from_file_location('ccic', '/root/reference/create_cityscapes_image_change.py')
+    ccic = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ccic)
+    ccic.log_add, ccic.threshold, ccic.clip_range = 50, 0.1, 0.8       # its __main__ constants (:169-172)
+    tr_pil = ccic.get_image_change(Image.fromarray(f_now).convert('L'), Image.fromarray(f_prev).convert('L'))
+    out['s_time_res_u8'] = np.asarray(tr_pil).copy()
+    for tag, (x, y, flip) in {'a': (5, 0, False), 'b': (31, 0, True)}.items():
+        raw = Image.fromarray(f_now).convert('RGB')
+        rs = raw.resize(size=(SW // 2, SH // 2), resample=Image.BILINEAR)
+        cr = rs.crop(box=(x, y, x + 32, y + 32))
+        if flip:
+            cr = ImageOps.mirror(cr)
+        out[f's_{tag}_image'] = to_tensor_norm(cr)
+        isr = ns.ds_utils.get_image_change_from_pil(cr, width=32, height=32, shift_direction='rightdown', **isr_p)
+        out[f's_{tag}_isr'] = isr.repeat(3, 1, 1)
+        itr = tr_pil.convert('L').resize(size=(SW // 2, SH // 2), resample=Image.BILINEAR)
+        itr = itr.crop(box=(x, y, x + 32, y + 32))
+        if flip:
+            itr = ImageOps.mirror(itr)
+        itr = np.asarray(itr, dtype=np.float32)
+        out[f's_{tag}_img_time_res'] = ((torch.from_numpy(itr)[None] / 255.0 - 0.5) / 0.5).repeat(3, 1, 1)
+        out[f's_{tag}_params'] = np.array([x, y, int(flip)])
+    save('pipeline', **out)
+
+
+@case
 def classmix():
     tr = ns.dacs_transforms
     g = torch.Generator().manual_seed(71)

@@ -56,3 +56,55 @@ def test_pretrained_layouts_and_nonstrict(tmp_path):
     ptrs = [p.data_ptr() for p in m.parameters()]
     ck.load_state_dict(m, a.state_dict(), strict=True)
     assert ptrs == [p.data_ptr() for p in m.parameters()]
+
+
+def test_load_refreshes_live_bf16_mirrors():
+    """after FlatAdamW / attach_flat_store re-homed the parameters, runtime.w() returns the live bf16 mirror without
+    consulting the cache -- a load must re-cast it from the new fp32 masters."""
+    import cmda_amd.runtime as rt
+    torch.manual_seed(2)
+    a, b = _b0(), _b0()
+    for p in a.parameters():
+        torch.nn.init.normal_(p, std=0.1)
+    for p in b.parameters():           # what FlatAdamW does on the GPU in bf16 mode: a persistent bf16 mirror per parameter
+        p._cmda_bf16 = p.data.bfloat16()
+    old = rt.compute_dtype()
+    rt._state['dtype'] = torch.bfloat16
+    try:
+        ck.load_state_dict(b, a.state_dict(), strict=True)
+        for (n, p), (_, q) in zip(b.named_parameters(), a.named_parameters()):
+            assert torch.equal(rt.w(p), q.data.bfloat16()), n
+    finally:
+        rt._state['dtype'] = old
+
+
+def test_flat_adamw_state_dict_roundtrip_and_release_strip(tmp_path):
+    """optimizer state in torch.optim.AdamW's layout ({'state': {i: step/exp_avg/exp_avg_sq}, 'param_groups'}), restored into
+    the flat buffers; save_checkpoint refuses optimizers without state_dict; function.py:28-37's stripping."""
+    from cmda_amd import optim
+    torch.manual_seed(3)
+    m = _b0()
+    opt = optim.FlatAdamW(m, lr=6e-5, weight_decay=0.01, custom_keys=dict(norm=dict(decay_mult=0.0)))
+    opt.step_count = 7
+    opt.flat_m.normal_()
+    opt.flat_v.uniform_()
+    f = os.path.join(tmp_path, 'iter_7.pth')
+    ck.save_checkpoint(m, f, optimizer=opt, meta=dict(iter=7))
+    saved = torch.load(f, weights_only=False)
+    assert set(saved) == {'meta', 'state_dict', 'optimizer'}
+    osd = saved['optimizer']
+    names = [n for n, _ in m.named_parameters()]
+    assert len(osd['param_groups']) == len(names) and [g['params'] for g in osd['param_groups']] == [[i] for i in range(len(names))]
+    assert set(osd['param_groups'][0]) == {'lr', 'betas', 'eps', 'weight_decay', 'amsgrad', 'params'}
+    wd = {n: g['weight_decay'] for n, g in zip(names, osd['param_groups'])}
+    assert wd['block1.0.norm1.weight'] == 0.0 and wd['block1.0.attn.q.weight'] == 0.01
+    i = names.index('block2.0.mlp.fc1.weight')
+    assert osd['state'][i]['step'] == 7 and osd['state'][i]['exp_avg'].shape == dict(m.named_parameters())[names[i]].shape
+    m2 = _b0()
+    o2 = optim.FlatAdamW(m2, lr=6e-5, weight_decay=0.01, custom_keys=dict(norm=dict(decay_mult=0.0)))
+    o2.load_state_dict(osd)
+    assert torch.equal(o2.flat_m, opt.flat_m) and torch.equal(o2.flat_v, opt.flat_v) and o2.step_count == 7
+    with pytest.raises(TypeError):
+        ck.save_checkpoint(m, f, optimizer=object())
+    full = {'model.backbone.a': 1, 'ema_model.backbone.a': 2, 'cyclegan_itrd2en.model.1.weight': 3, 'model.decode_head.b': 4}
+    assert list(ck.strip_for_release(full)) == ['model.backbone.a', 'model.decode_head.b']
