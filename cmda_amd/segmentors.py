@@ -105,9 +105,17 @@ class EncoderDecoder(nn.Module):
             return ops.upsample_logits_nchw(logits, H, W)
 
     def simple_test(self, img, img_meta=None, rescale=True):
-        """encoder_decoder.py:274-285 with test_cfg mode 'whole': per-image label maps (numpy), argmax over the up-sampled
-        logits (softmax is monotone, the reference's inference() softmax does not change the argmax)."""
-        return list(self.encode_decode(img, img_meta).argmax(dim=1).cpu().numpy())
+        """encoder_decoder.py:222-285 with test_cfg mode 'whole': logits at the input size, resized to img_meta['ori_shape'] when
+        `rescale`, flipped back when the test pipeline flipped; per-image label maps (numpy) -- the reference's soft-max before
+        the argmax is monotone and skipped."""
+        seg_logit = self.encode_decode(img, img_meta)
+        meta = (img_meta[0] if isinstance(img_meta, (list, tuple)) else img_meta) or {}
+        if rescale and meta.get('ori_shape') is not None and tuple(meta['ori_shape'][:2]) != tuple(seg_logit.shape[2:]):
+            h, w = meta['ori_shape'][:2]
+            seg_logit = ops.upsample_logits_nchw(seg_logit.permute(0, 2, 3, 1).contiguous(), h, w)
+        if meta.get('flip'):
+            seg_logit = seg_logit.flip(dims=(3,) if meta['flip_direction'] == 'horizontal' else (2,))
+        return list(seg_logit.argmax(dim=1).cpu().numpy())
 
 
 class _Capture:
@@ -345,8 +353,38 @@ class FusionEncoderDecoder(nn.Module):
             return {k: (ops.upsample_logits_nchw(v, H, W) if v is not None else None) for k, v in out.items()}
         return ops.upsample_logits_nchw(out[test_cfg['output_type'] + '_output'], H, W)
 
-    def simple_test(self, rescale=True, **kwargs):
+    def whole_inference(self, rescale, **kwargs):
+        """encoder_decoder.py:897-936: logits at the input size, resized once more to img_metas['ori_shape'] when `rescale`"""
         img = kwargs['warp_image'] if 'warp_image' in kwargs else kwargs['image']
-        events = kwargs.get('events_vg') if self.train_type in {'cs2dsec_image+events', 'cs2dsec_image+events_together'} else None
-        logit = self.encode_decode(img, events, test_cfg=kwargs.get('test_cfg', {'output_type': 'fusion'}))
-        return list(torch.softmax(logit, dim=1).argmax(dim=1).cpu().numpy())
+        test_cfg = kwargs.get('test_cfg') or {'output_type': 'fusion'}
+        if self.train_type in {'cs2dsec_image+events', 'cs2dsec_image+events_together'} and 'events_vg' in kwargs:
+            events = kwargs['events_vg']
+        elif self.train_type == 'cs2dz_image+raw-isr' and test_cfg['output_type'] == 'image_isr':
+            events = kwargs['night_isr']
+        else:
+            events = None
+        if self.train_type == 'cs2dz_image+raw-isr':
+            test_cfg = {'output_type': 'fusion'} if test_cfg['output_type'] == 'image_isr' else {'output_type': 'image'}
+        seg_logit = self.encode_decode(img, events, test_cfg=test_cfg)
+        meta = kwargs.get('img_metas')
+        if rescale and meta is not None:
+            meta = meta[0] if isinstance(meta, (list, tuple)) else meta
+            size = tuple(meta['ori_shape'][:2])
+            if size != tuple(seg_logit.shape[2:]):
+                seg_logit = ops.upsample_logits_nchw(seg_logit.permute(0, 2, 3, 1).contiguous(), size[0], size[1])
+        return seg_logit
+
+    def inference(self, rescale, **kwargs):
+        """encoder_decoder.py:938-971 (test_cfg.mode 'whole'): soft-max of the logits, flipped back when the test pipeline flipped"""
+        seg_logit = self.whole_inference(rescale, **kwargs)
+        output = torch.softmax(seg_logit, dim=1)
+        meta = kwargs.get('img_metas')
+        meta = (meta[0] if isinstance(meta, (list, tuple)) else meta) or {}
+        if meta.get('flip'):
+            assert meta['flip_direction'] in ('horizontal', 'vertical')
+            output = output.flip(dims=(3,) if meta['flip_direction'] == 'horizontal' else (2,))
+        return output
+
+    def simple_test(self, rescale=True, **kwargs):
+        """encoder_decoder.py:973-984: per-image label maps (numpy)"""
+        return list(self.inference(rescale, **kwargs).argmax(dim=1).cpu().numpy())

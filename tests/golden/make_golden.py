@@ -275,6 +275,40 @@ def pipeline():
 
 
 @case
+def metrics():
+    """mmseg/core/evaluation/metrics.py: intersect_and_union :27-87, total_intersect_and_union :90-126, eval_metrics :259-328
+    (mIoU / mDice / mFscore, nan_to_num) on seeded label maps (half the DSEC evaluation size), incl. ignore pixels, a class absent from
+    prediction and ground truth (NaN), reduce_zero_label and label_map."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('ref_metrics', '/root/reference/mmseg/core/evaluation/metrics.py')
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    rng = np.random.RandomState(91)
+    nc = 19
+    preds = [rng.randint(0, nc, (220, 320)) for _ in range(3)]
+    gts = [rng.randint(0, nc, (220, 320)) for _ in range(3)]
+    for g_, p_ in zip(gts, preds):
+        g_[rng.rand(*g_.shape) < 0.1] = 255
+        g_[g_ == 7] = 3
+        p_[p_ == 7] = 2
+    out = {f'pred{i}': p_.astype(np.uint8) for i, p_ in enumerate(preds)}
+    out.update({f'gt{i}': g_.astype(np.uint8) for i, g_ in enumerate(gts)})
+    for k, v in zip(('inter', 'union', 'area_pred', 'area_label'), m.total_intersect_and_union(preds, gts, nc, 255)):
+        out['tot_' + k] = v
+    for k, v in zip(('inter', 'union', 'area_pred', 'area_label'), m.intersect_and_union(preds[0], gts[0], nc, 255)):
+        out['one_' + k] = v
+    r = m.eval_metrics(preds, gts, nc, 255, metrics=['mIoU', 'mDice'])
+    out.update({'m_' + k: v for k, v in r.items()})
+    r0 = m.eval_metrics(preds, gts, nc, 255, metrics=['mIoU'], nan_to_num=0)
+    out.update({'m0_' + k: v for k, v in r0.items()})
+    rz = m.intersect_and_union(preds[1], gts[1], nc - 1, 255, reduce_zero_label=True)
+    out.update({f'rz_{k}': v for k, v in zip(('inter', 'union', 'area_pred', 'area_label'), rz)})
+    lm = m.intersect_and_union(preds[2], gts[2], nc, 255, label_map={5: 4, 9: 255})
+    out.update({f'lm_{k}': v for k, v in zip(('inter', 'union', 'area_pred', 'area_label'), lm)})
+    save('metrics', **out)
+
+
+@case
 def classmix():
     tr = ns.dacs_transforms
     g = torch.Generator().manual_seed(71)

@@ -257,3 +257,98 @@ def test_pseudo_label_bit_exact_gpu():
         assert torch.equal(lab.cpu(), lab_ref), f'{(lab.cpu() != lab_ref).sum().item()} labels differ at {(B, h, w, H, W)}'
         assert cnt.item() == int((prob_ref >= 0.968).sum()), (cnt.item(), int((prob_ref >= 0.968).sum()))
         assert_close(prob, prob_ref, 1e-6, name='pseudo prob')
+
+
+@pytest.mark.gpu
+def test_fusion_simple_test_440x640_vs_oracle():
+    """FusionEncoderDecoder.simple_test(warp_image, events_vg) at the DSEC evaluation size 440x640, FULL depth
+    (encoder_decoder.py:897-984): token grids 110x160 / 55x80 / 28x40 / 14x20, Nk = 260 / 260 / 280 / 280 keys (beyond the fused
+    attention kernel: the GEMM + soft-max path), the joint decoder pass with three feature sets, logits resized to the input size,
+    soft-max, argmax; then mIoU of both label maps against the same ground truth (north star: mIoU within 1e-3)."""
+    from cmda_amd import metrics
+    tgt = gpu_target()
+    bbc = dict(type='mit_b5', style='pytorch', drop_path_rate=0.1)
+    head = dict(type='DAFormerHeadFusion', dropout_ratio=0.1,
+                decoder_params=dict(DECODER, train_type='cs2dsec_image+events_together', share_decoder=True), **HEAD)
+    model = build_segmentor(dict(type='FusionEncoderDecoder', backbone_image=dict(bbc), backbone_events=dict(bbc),
+                                 fusion_module=dict(type='AttentionAvgFusion', in_channels=DIMS, drop_path_rate=0.1),
+                                 decode_head=head, train_type='cs2dsec_image+events_together', test_cfg=dict(mode='whole')))
+    torch.manual_seed(7)
+    model.init_weights()
+    ref = oseg.FusionEncoderDecoder(backbone_image=omit.mit_b5(drop_path_rate=0.1), backbone_events=omit.mit_b5(drop_path_rate=0.1),
+                                    fusion_module=ofu.AttentionAvgFusion(drop_path_rate=0.1),
+                                    decode_head=ohd.DAFormerHeadFusion(dropout_ratio=0.1, share_decoder=True))
+    ref.load_state_dict(model.state_dict())
+    model.to(tgt.device).eval()
+    ref.eval()
+    img = seeded_randn((1, 3, 440, 640), 7, 'img')
+    ev = seeded_randn((1, 3, 440, 640), 7, 'ev').clamp(-1, 1)
+    meta = dict(ori_shape=(440, 640, 3), img_shape=(440, 640, 3), flip=False)
+    with torch.no_grad():
+        want = ref.encode_decode(img, ev, test_cfg={'output_type': 'fusion'})
+    want_pred = torch.softmax(want, 1).argmax(1)[0].numpy()
+    gt = labels(1, 640, 7)[0, 0, :440].numpy()
+    m_ref = metrics.mean_iou([torch.from_numpy(want_pred)], [torch.from_numpy(gt)], 19, 255)['mIoU'].item()
+    for dt, tol, agree_min, miou_tol in ((torch.float32, 1e-3, 0.9995, 1e-3), (torch.bfloat16, 6e-2, 0.97, 2e-2)):
+        rt.set_compute_dtype(dt)
+        try:
+            got = model.encode_decode(tgt.to(img), tgt.to(ev), test_cfg={'output_type': 'fusion'}).float().cpu()
+            pred = model.simple_test(True, warp_image=tgt.to(img), events_vg=tgt.to(ev), img_metas=meta)[0]
+        finally:
+            rt.set_compute_dtype(torch.float32)
+        e = rel(got, want)
+        agree = float((pred == want_pred).mean())
+        m = metrics.mean_iou([torch.from_numpy(pred)], [torch.from_numpy(gt)], 19, 255)['mIoU'].item()
+        print(f'[{dt}] 440x640 fusion simple_test: logits rel err {e:.3e}, label agreement {agree:.5f}, mIoU {m:.5f} vs {m_ref:.5f}')
+        assert pred.shape == (440, 640) and e < tol and agree >= agree_min and abs(m - m_ref) <= miou_tol
+    # rescale to a different ori_shape (a test pipeline that resized the image): the second bilinear resize of :926-934
+    meta2 = dict(ori_shape=(480, 700, 3), flip=True, flip_direction='horizontal')
+    pred2 = model.simple_test(True, warp_image=tgt.to(img), events_vg=tgt.to(ev), img_metas=meta2)[0]
+    want2 = torch.softmax(ohd.resize(want, (480, 700)), 1).flip(dims=(3,)).argmax(1)[0].numpy()
+    assert pred2.shape == (480, 700) and float((pred2 == want2).mean()) > 0.9995
+
+
+@pytest.mark.gpu
+def test_checkpoint_roundtrip_gpu(tmp_path):
+    """a training checkpoint in the reference's layout ({meta, state_dict with model.* / ema_model.* /
+    cyclegan_itrd2en.*, optimizer}) -> function.py:28-37 stripping -> loaded into a FRESH student whose parameters already live in
+    a bf16 FlatAdamW store -> identical logits; the optimizer moments survive the round trip."""
+    import os
+    from cmda_amd import checkpoint as ck, optim
+    from cmda_amd.registry import build_train_model
+    from test_dacs import SMALL, make_cfg
+    tgt = gpu_target()
+    rt.set_compute_dtype(torch.bfloat16)
+    try:
+        torch.manual_seed(3)
+        a = build_train_model(make_cfg(SMALL['dims'], SMALL['ch'])).to(tgt.device).train()
+        seeded_fill(a.model, 21)
+        opt_a = optim.FlatAdamW(a.model, lr=6e-5, weight_decay=0.01)
+        a.attach_flat_store(opt_a)
+        opt_a.step_count = 5
+        opt_a.flat_m.normal_()
+        opt_a.flat_v.uniform_()
+        f = os.path.join(tmp_path, 'iter_5.pth')
+        ck.save_checkpoint(a, f, optimizer=opt_a, meta=dict(iter=5))
+        saved = torch.load(f, weights_only=False)
+        keys = list(saved['state_dict'])
+        assert any(k.startswith('model.') for k in keys) and any(k.startswith('ema_model.') for k in keys)
+        assert any(k.startswith('cyclegan_itrd2en.model.') for k in keys)
+        released = ck.strip_for_release(saved['state_dict'])
+        assert released and all(k.startswith('model.') for k in released)
+        g = os.path.join(tmp_path, 'iter_5_state_dict.pth')
+        torch.save(dict(released), g)
+        b = build_train_model(make_cfg(SMALL['dims'], SMALL['ch'])).to(tgt.device).train()
+        seeded_fill(b.model, 22)                          # different weights, then re-homed into the flat bf16 store ...
+        opt_b = optim.FlatAdamW(b.model, lr=6e-5, weight_decay=0.01)
+        b.attach_flat_store(opt_b)
+        ck.load_checkpoint(b, g, strict=False)            # ... and only then loaded: the live bf16 mirrors must follow
+        opt_b.load_state_dict(saved['optimizer'])
+        assert torch.equal(opt_b.flat_m, opt_a.flat_m) and opt_b.step_count == 5
+        img, ev = tgt.to(seeded_randn((1, 3, 64, 64), 3, 'i')), tgt.to(seeded_randn((1, 3, 64, 64), 3, 'e'))
+        a.eval(), b.eval()
+        la = a.model.encode_decode(img, ev)
+        lb = b.model.encode_decode(img, ev)
+        assert torch.equal(la, lb), 'logits differ after the checkpoint round trip'
+    finally:
+        rt.set_compute_dtype(torch.float32)

@@ -46,3 +46,49 @@ def test_reduce_zero_label_and_label_map():
     assert i.tolist() == [1, 1, 1] and l.tolist() == [1, 1, 1] and p.tolist() == [1, 1, 1]
     i, u, p, l = metrics.intersect_and_union(pred, torch.tensor([[9, 1, 2, 2]]), 3, 255, label_map={9: 0})
     assert i.tolist() == [1, 1, 2]
+
+
+def _gold():
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    return {k: v for k, v in np.load(os.path.join(here, 'golden', 'metrics.npz')).items()}
+
+
+def _check_against_reference(device):
+    """tests/golden/metrics.npz = outputs of the reference's own mmseg/core/evaluation/metrics.py (make_golden.py::metrics)"""
+    g = _gold()
+    nc = 19
+    preds = [torch.from_numpy(g[f'pred{i}'].astype(np.int64)).to(device) for i in range(3)]
+    gts = [torch.from_numpy(g[f'gt{i}'].astype(np.int64)).to(device) for i in range(3)]
+    names = ('inter', 'union', 'area_pred', 'area_label')
+    for k, v in zip(names, metrics.total_intersect_and_union(preds, gts, nc, 255)):
+        assert np.array_equal(v.cpu().numpy(), g['tot_' + k].astype(np.float64)), k
+    for k, v in zip(names, metrics.intersect_and_union(preds[0], gts[0], nc, 255)):
+        assert np.array_equal(v.cpu().numpy(), g['one_' + k].astype(np.float64)), k
+    r = metrics.eval_metrics(preds, gts, nc, 255, ('mIoU', 'mDice'))
+    for k in ('aAcc', 'IoU', 'Acc', 'Dice'):
+        np.testing.assert_allclose(r[k].cpu().numpy(), g['m_' + k], rtol=1e-6, equal_nan=True, err_msg=k)   # the reference is fp32
+    assert np.isnan(g['m_IoU'][7]) and np.isnan(r['IoU'][7].item())
+    r0 = metrics.eval_metrics(preds, gts, nc, 255, ('mIoU',), nan_to_num=0)
+    for k in ('aAcc', 'IoU', 'Acc'):
+        np.testing.assert_allclose(r0[k].cpu().numpy(), g['m0_' + k], rtol=1e-6, err_msg=k)
+    for k, v in zip(names, metrics.intersect_and_union(preds[1], gts[1], nc - 1, 255, reduce_zero_label=True)):
+        assert np.array_equal(v.cpu().numpy(), g['rz_' + k].astype(np.float64)), 'reduce_zero_label ' + k
+    for k, v in zip(names, metrics.intersect_and_union(preds[2], gts[2], nc, 255, label_map={5: 4, 9: 255})):
+        assert np.array_equal(v.cpu().numpy(), g['lm_' + k].astype(np.float64)), 'label_map ' + k
+    miou = metrics.mean_iou(preds, gts, nc, 255)
+    assert abs(miou['mIoU'].item() - np.nanmean(g['m_IoU'].astype(np.float64))) < 1e-6
+
+
+def test_metrics_match_reference_golden_cpu():
+    _check_against_reference(torch.device('cpu'))
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_metrics_match_reference_golden_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU on this machine')
+    _check_against_reference(torch.device('cuda:0'))
