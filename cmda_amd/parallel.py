@@ -6,7 +6,8 @@ section 0).
 Design for MI355X: the student's gradients already live in ONE contiguous fp32 buffer (cmda_amd.optim.FlatAdamW), so
 the exchange is a handful of large collectives on contiguous memory instead of ~1100 per-tensor hooks.  xGMI is
 point-to-point (7 links x ~153 GB/s per GPU): large buckets keep every link busy, and the optional bf16 wire format
-halves the bytes (177.8 M gradients = 711 MB fp32 / 356 MB bf16).  Buckets are issued on a side HIP stream so the
+halves the bytes (177.8 M gradients = 711 MB fp32 / 356 MB bf16); each bucket is exchanged as reduce-scatter + all-gather
+(every link carries 1/world of the bucket in each phase).  Buckets are issued on a side HIP stream so the
 collective of bucket k overlaps the cast of bucket k+1; per-rank BatchNorm statistics, ClassMix class draws and the
 pseudo-weight stay rank-local exactly as in the reference's batch-2 step.
 """
@@ -62,6 +63,12 @@ class GradAllReducer:
         self._wire = None
         if wire_dtype != flat_grad.dtype:
             self._wire = torch.empty(min(n, bucket_elems), dtype=wire_dtype, device=flat_grad.device)
+        # reduce-scatter + all-gather where the backend has them (RCCL); gloo (the CPU tests) keeps all_reduce
+        self._rs_ag = bool(self.active and flat_grad.is_cuda and dist.get_backend(group) == 'nccl')
+        if self._rs_ag:
+            cap = min(n, bucket_elems) + self.world
+            self._wire_rs = torch.empty(cap, dtype=wire_dtype, device=flat_grad.device)
+            self._shard = torch.empty(-(-cap // self.world), dtype=wire_dtype, device=flat_grad.device)
         self._started = []  # [lo, hi) slices already issued this step
 
     def _reduce(self, lo, hi):
@@ -69,7 +76,22 @@ class GradAllReducer:
         for s in range(lo, hi, self.bucket_elems):
             e = min(hi, s + self.bucket_elems)
             seg = self.flat[s:e]
-            if self._wire is not None:
+            if self._rs_ag:
+                # RCCL: reduce-scatter + all-gather on the wire buffer.  xGMI is point-to-point (7 links per GPU): the direct
+                # reduce-scatter keeps every link busy with 1/world of the bucket, the mean is taken on the owned shard only
+                # (1/world of the multiplies), and the all-gather returns the averaged bucket.
+                n = e - s
+                per = -(-n // self.world)
+                w = self._wire_rs[:per * self.world]
+                w[:n].copy_(seg)
+                if per * self.world > n:
+                    w[n:].zero_()
+                shard = self._shard[:per]
+                dist.reduce_scatter_tensor(shard, w, group=self.group)
+                shard.mul_(inv)
+                dist.all_gather_into_tensor(w, shard, group=self.group)
+                seg.copy_(w[:n])
+            elif self._wire is not None:
                 w = self._wire[:e - s]
                 w.copy_(seg)
                 dist.all_reduce(w, group=self.group)

@@ -198,3 +198,91 @@ def test_dacs_final_pass_hook_reports_final_gradients():
     for key, parts in snaps.items():
         for (lo, hi), snap in zip(ranges[key], parts):
             assert torch.equal(snap, opt.flat_g[lo:hi]), f'{key[0]}: changed after being reported'
+
+
+def _dacs_worker(rank, world, port, out):
+    """one data-parallel rank of the DACS step on the CPU emulator: own batch, rank-local BatchNorm / ClassMix / pseudo-weight,
+    gradients exchanged through GradAllReducer with the final-pass staging (decode head + both encoders start their slices from
+    DACS.final_pass_grad_hook inside the LAST backward pass, the rest in finish())"""
+    import random
+    import sys
+    import numpy as np
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.join(here, 'golden'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(3)
+    from cmda_amd import _lib, optim
+    from conftest import EMU_LIB
+    _lib._bind_for_tests(EMU_LIB)
+    import cmda_amd.runtime as rt
+    from cmda_amd.registry import build_train_model
+    from oracle import dacs_iter
+    import test_dacs as T
+    from weights import seeded_fill, seeded_randn
+    rt.set_compute_dtype(torch.float32)
+    dims, ch, B, H, W = T.SMALL['dims'], T.SMALL['ch'], 1, 64, 64
+    dacs = build_train_model(T.make_cfg(dims, ch, generator=False))
+    seeded_fill(dacs.model, 7)        # identical replicas on every rank
+    seeded_fill(dacs.ema_model, 8)
+    dacs.train()
+    opt = optim.FlatAdamW(dacs.model, lr=6e-5, weight_decay=0.01)
+    dacs.attach_flat_store(opt)
+    g = torch.Generator().manual_seed(40 + rank)   # rank-local shard of the global batch
+    lab = torch.randint(0, 6, (B, 1, H // 8, W // 8), generator=g).repeat_interleave(8, 2).repeat_interleave(8, 3)
+    src = dict(image=seeded_randn((B, 3, H, W), 40 + rank, 'img'), img_time_res=seeded_randn((B, 3, H, W), 40 + rank, 'itr').clamp(-1, 1),
+               img_self_res=seeded_randn((B, 3, H, W), 40 + rank, 'isr').clamp(-1, 1), label=lab)
+    tg = dict(warp_image=seeded_randn((B, 3, H, W), 40 + rank, 'nimg'), events_vg=seeded_randn((B, 3, H, W), 40 + rank, 'nev').clamp(-1, 1),
+              warp_img_self_res=seeded_randn((B, 3, H, W), 40 + rank, 'nisr').clamp(-1, 1))
+    torch.manual_seed(11 + rank), random.seed(11 + rank), np.random.seed(11 + rank)   # rank-local draws
+    # the single-rank oracle step on this rank's shard (its own teacher, its own BatchNorm statistics)
+    ref, ema = T.oracle_student(dims, ch), T.oracle_student(dims, ch)
+    seeded_fill(ref, 7).train()
+    seeded_fill(ema, 8).train()
+    # --- the data-parallel step
+    reducer = GradAllReducer(opt.flat_g, bucket_elems=1 << 20)
+    student = dacs.model
+    ranges = {('decode_head', id(student.decode_head)): opt.ranges_of(student, ['decode_head.'], min_elems=0)}
+    for name in ('backbone_image', 'backbone_events'):
+        for s in range(1, 5):
+            ranges[(f'backbone.stage{s}', id(getattr(student, name)))] = opt.ranges_of(
+                student, [f'{name}.patch_embed{s}.', f'{name}.block{s}.', f'{name}.norm{s}.'], min_elems=0)
+    started = []
+
+    def hook(tag, module=None):
+        for lo, hi in ranges.get((tag, id(module)), ()):
+            reducer.start_range(lo, hi)
+            started.append((lo, hi))
+    dacs.final_pass_grad_hook = hook
+    opt.zero_grad()
+    dacs(source=src, target=tg)
+    reducer.finish()
+    o = dacs_iter.dacs_iteration(ref, ema, None, src, tg, local_iter=0, forward_cfg=T.FCFG, isr_parms=T.ISR, shift_type='random',
+                                 draws=T.oracle_draws(dacs.last_draws))
+    del o
+    # expected: the mean over ranks of the independent single-rank oracle gradients
+    worst, n_checked = 0.0, 0
+    for (n1, p), (n2, q) in zip(dacs.model.named_parameters(), ref.named_parameters()):
+        assert n1 == n2
+        gq = q.grad.clone()
+        dist.all_reduce(gq)
+        gq /= world
+        worst = max(worst, ((p.grad - gq).abs().max() / (gq.abs().max() + 1e-12)).item())
+        n_checked += 1
+    out[rank] = dict(worst=worst, n=n_checked, staged=len(started), staged_elems=sum(hi - lo for lo, hi in started),
+                     total=opt.flat_g.numel())
+    dist.destroy_process_group()
+
+
+def test_dacs_data_parallel_world2_matches_mean_of_oracle_steps():
+    """global batch 2 over 2 ranks == 2 independent reference-style steps whose gradients are averaged (BatchNorm
+    statistics, ClassMix class draws and the pseudo-weight stay rank-local)."""
+    world = 2
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_dacs_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        for r in range(world):
+            assert out[r]['worst'] < 5e-2, out[r]
+            assert out[r]['staged'] >= 9 and out[r]['staged_elems'] > 0.5 * out[r]['total'], out[r]   # most bytes start inside the last pass
+            assert out[r]['n'] > 100
