@@ -87,8 +87,9 @@ class Block(nn.Module):
         return K.block_fwd(x, self, B, H, W, self.dim, self.num_heads, self.sr_ratio, eps=self.eps, dp1=dp1, dp2=dp2,
                            save=save)
 
-    def bwd(self, saved, dy, B, H, W):
-        return K.block_bwd(dy, self, saved, B, H, W, self.dim, self.num_heads, self.sr_ratio, eps=self.eps)
+    def bwd(self, saved, dy, B, H, W, dy_scaled=None, next_scale=None):
+        return K.block_bwd(dy, self, saved, B, H, W, self.dim, self.num_heads, self.sr_ratio, eps=self.eps, dy_scaled=dy_scaled,
+                           next_scale=next_scale)
 
     def forward(self, x, H, W):
         """Reference signature: x [B,N,C] -> [B,N,C] (autograd-enabled bridge over fwd/bwd)."""
@@ -269,10 +270,22 @@ class MixVisionTransformer(nn.Module):
                 dnext = None
                 continue
             nrm = getattr(self, f'norm{s}')
-            dx = ops.layernorm_bwd(d, xin, nrm.weight, m, r, rt.grad(nrm.weight), rt.grad(nrm.bias))
             blocks = getattr(self, f'block{s}')
-            for blk, sv in zip(reversed(blocks), reversed(sv_blocks)):
-                dx = blk.bwd(sv, dx, B, H, W)
+            # every LayerNorm backward also writes its result scaled by the DropPath factor of the block that consumes it next
+            # (saved[-1] = that block's MLP-branch factor), so no separate scaling kernel runs
+            scales = [sv[-1] for sv in sv_blocks]
+            N = H * W
+            dx = ops.layernorm_bwd(d, xin, nrm.weight, m, r, rt.grad(nrm.weight), rt.grad(nrm.bias), out_scale=scales[-1],
+                                   rows_per_scale=N)
+            dxs = None
+            if scales[-1] is not None:
+                dx, dxs = dx
+            for i in range(len(blocks) - 1, -1, -1):
+                nxt = scales[i - 1] if i > 0 else None
+                dx = blocks[i].bwd(sv_blocks[i], dx, B, H, W, dy_scaled=dxs, next_scale=nxt)
+                dxs = None
+                if nxt is not None:
+                    dx, dxs = dx
             dnext = getattr(self, f'patch_embed{s}').bwd(sv_pe, dx, B, need_dx=(s > 1))
             rt.notify_grads_ready(f'backbone.stage{s}', self)
         return None

@@ -42,6 +42,61 @@ __global__ void permute4_kernel(const TS* __restrict__ src, TD* __restrict__ dst
   }
 }
 
+// dst = cast(src); src = 0 -- drains a persistent fp32 accumulation workspace (attention dK|dV: atomics from many query blocks)
+// and leaves it zeroed for its next user, so neither a memset nor a separate cast launch is needed per call
+template <typename TD>
+__global__ void cast_clear_kernel(float* __restrict__ src, TD* __restrict__ dst, long n4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float v[4];
+    ld4(src + i * 4, v);
+    st4(dst + i * 4, v);
+    const float z[4] = {0.f, 0.f, 0.f, 0.f};
+    st4(src + i * 4, z);
+  }
+}
+
+// Batched form: one launch re-lays-out MANY tensors (every conv / depthwise weight of the student and the teacher after an
+// optimizer / EMA step: ~470 tiny launches otherwise, and the 2 + 2 step is bound by launch count).  desc[t] describes tensor t;
+// blocks[b] = {tensor, first element} gives every thread block its 1024-element chunk.  Sources are fp32 masters.
+struct PermuteDesc {
+  const float* src;
+  void* dst;
+  int d[4];
+  int p[4];
+  int flipmask;
+  int dst_bf16;
+  long total;
+};
+
+__global__ void permute4_batch_kernel(const PermuteDesc* __restrict__ desc, const int* __restrict__ blocks) {
+  const int bk_x = blocks[2 * blockIdx.x], bk_y = blocks[2 * blockIdx.x + 1];
+  const PermuteDesc D = desc[bk_x];
+  const long ss[4] = {(long)D.d[1] * D.d[2] * D.d[3], (long)D.d[2] * D.d[3], (long)D.d[3], 1};
+  const int e1 = D.d[D.p[1]], e2 = D.d[D.p[2]], e3 = D.d[D.p[3]];
+  const long base = (long)bk_y * 1024;
+  for (int k = threadIdx.x; k < 1024; k += blockDim.x) {
+    const long i = base + k;
+    if (i >= D.total) break;
+    long t = i;
+    int idx[4];
+    idx[3] = (int)(t % e3); t /= e3;
+    idx[2] = (int)(t % e2); t /= e2;
+    idx[1] = (int)(t % e1); t /= e1;
+    idx[0] = (int)t;
+    long so = 0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      int v = idx[a];
+      const int ax = D.p[a];
+      if ((D.flipmask >> ax) & 1) v = D.d[ax] - 1 - v;
+      so += (long)v * ss[ax];
+    }
+    const float v = D.src[so];
+    if (D.dst_bf16) stf(reinterpret_cast<bf16_t*>(D.dst) + i, v);
+    else reinterpret_cast<float*>(D.dst)[i] = v;
+  }
+}
+
 // identity permutation = a dtype cast (the flat fp32 -> bf16 parameter mirrors: up to 178 M elements per call): 4 elements per
 // thread, no index arithmetic
 template <typename TS, typename TD>
@@ -256,6 +311,22 @@ extern "C" int cmda_permute4(const void* src, void* dst, int d0, int d1, int d2,
   if (src_dtype == CMDA_BF16 && dst_dtype == CMDA_F32) return launch_permute<bf16_t, float>(src, dst, d, p, flipmask, accumulate, stream);
   if (src_dtype == CMDA_BF16 && dst_dtype == CMDA_BF16) return launch_permute<bf16_t, bf16_t>(src, dst, d, p, flipmask, accumulate, stream);
   return CMDA_ERR_DTYPE;
+}
+
+extern "C" int cmda_cast_clear(float* src, void* dst, int64_t n, int dst_dtype, void* stream) {
+  if (n <= 0) return CMDA_OK;
+  if ((n & 3) || ((uintptr_t)src % 16) || ((uintptr_t)dst % 8)) return CMDA_ERR_SHAPE;
+  CMDA_DISPATCH_DTYPE(dst_dtype, CMDA_LAUNCH((cast_clear_kernel<T>), dim3(grid_for(n, 4)), dim3(256), 0, stream, src, (T*)dst, (long)(n / 4)));
+  CMDA_CHECK_LAUNCH();
+}
+
+// desc: DEVICE array of `cmda_permute_desc_t` (include/cmda_hip.h); blocks: DEVICE int32 [nblocks][2] = {tensor index, chunk index}
+// with one entry per 1024 destination elements of every tensor
+extern "C" int cmda_permute4_batch(const void* desc, const int* blocks, int nblocks, void* stream) {
+  if (nblocks <= 0) return CMDA_OK;
+  static_assert(sizeof(PermuteDesc) == 64, "descriptor layout is part of the ABI");
+  CMDA_LAUNCH(permute4_batch_kernel, dim3(nblocks), dim3(256), 0, stream, (const PermuteDesc*)desc, blocks);
+  CMDA_CHECK_LAUNCH();
 }
 
 extern "C" int cmda_colsum(const void* x, float* out, int64_t M, int N, int64_t ld, int dtype, void* stream) {

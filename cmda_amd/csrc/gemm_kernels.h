@@ -200,6 +200,14 @@ struct Stager {
 // the row loop is specialised on the activation and has nothing but uniform scalar branches around its loads (the first,
 // generic version of this loop spent ~7 us per 128x128 tile in branchy per-element code -- more than the k-loop of the
 // short-K GEMMs).
+// column of the atomic (split-K / weight-gradient) store: plain, or -- conv weight gradients -- the GEMM column (kh,kw,ci) moved
+// to the parameter's own [Co][Ci][KH][KW] layout, so that the gradient needs no staging buffer and no permute-accumulate pass
+static __device__ __forceinline__ long atomic_col(const GemmParams& p, long n) {
+  if (p.c_perm_ci <= 0) return n;
+  const long cell = n / p.c_perm_ci;
+  return (n - cell * p.c_perm_ci) * p.c_perm_cells + cell;
+}
+
 template <int ACT>
 static __device__ __forceinline__ float epi_act(float x) {
   if (ACT == 1) return fmaxf(x, 0.f);
@@ -477,7 +485,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const long m = m0 + wm * 16 * TM + i * 16 + 4 * g + r;
-          if (m < p.M && n < p.N) atomicAdd(reinterpret_cast<float*>(p.C) + cb + m * p.ldc + n, p.alpha * acc[i][j][r]);
+          if (m < p.M && n < p.N) atomicAdd(reinterpret_cast<float*>(p.C) + cb + m * p.ldc + atomic_col(p, n), p.alpha * acc[i][j][r]);
         }
       }
     return;
@@ -776,7 +784,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void gemm_glds_kernel(Gem
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const long m = m0 + wm * 16 * TM + i * 16 + 4 * g + r;
-          if (m < p.M && n < p.N) atomicAdd(reinterpret_cast<float*>(p.C) + cb + m * p.ldc + n, p.alpha * acc[i][j][r]);
+          if (m < p.M && n < p.N) atomicAdd(reinterpret_cast<float*>(p.C) + cb + m * p.ldc + atomic_col(p, n), p.alpha * acc[i][j][r]);
         }
       }
     return;

@@ -95,11 +95,16 @@ __global__ void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__
 // adds per address, and the grid can be as wide as the rows want.)
 // NV = vector passes per lane (ceil(C/4 / lanes per row)): a compile-time bound, so that C = 320 (2 passes) does not carry
 // the registers of the C = 1024 case (4 passes) -- 128 VGPRs / 4 waves per SIMD before, and the kernel is latency-bound
+// out_scale / dx_scaled (optional): a second output dx * out_scale[row / rows_per_scale] -- the per-sample DropPath factor of the
+// residual branch that consumes this gradient next (timm DropPath, mix_transformer.py:145-146), so that no separate scaling
+// kernel runs.  dgamma / dbeta non-null = DIRECT mode (small grids): the block partials go straight into the parameter
+// gradients with fp32 atomics and no finalize launch follows.
 template <typename T, int NV>
 __global__ void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
                               const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                               const T* __restrict__ dres, T* __restrict__ dx, float* __restrict__ ws, long rows,
-                              int C, int lpr) {
+                              int C, int lpr, const float* __restrict__ out_scale, long rows_per_scale,
+                              T* __restrict__ dx_scaled, float* __restrict__ dgamma, float* __restrict__ dbeta) {
   __shared__ float red[2][1024 * NV];  // [gamma/beta][slot = wave*rows_per_wave + group][channel]  (slots*C <= 1024*NV)
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
@@ -160,6 +165,12 @@ __global__ void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
           for (int j = 0; j < 4; ++j) o[j] += r[j];
         }
         st4(dx + row * C + vi * 4, o);
+        if (dx_scaled) {
+          const float sc = out_scale[row / rows_per_scale];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] *= sc;
+          st4(dx_scaled + row * C + vi * 4, o);
+        }
       }
     }
   }
@@ -183,8 +194,13 @@ __global__ void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
       sg += red[0][w * C + c];
       sb += red[1][w * C + c];
     }
-    atomicAdd(&ws[((long)(blockIdx.x % kSlots) * 2 + 0) * C + c], sg);
-    atomicAdd(&ws[((long)(blockIdx.x % kSlots) * 2 + 1) * C + c], sb);
+    if (dgamma) {
+      atomicAdd(dgamma + c, sg);
+      atomicAdd(dbeta + c, sb);
+    } else {
+      atomicAdd(&ws[((long)(blockIdx.x % kSlots) * 2 + 0) * C + c], sg);
+      atomicAdd(&ws[((long)(blockIdx.x % kSlots) * 2 + 1) * C + c], sb);
+    }
   }
 }
 
@@ -249,20 +265,28 @@ extern "C" int64_t cmda_layernorm_bwd_ws_floats(int64_t rows, int C) { (void)row
 
 extern "C" int cmda_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                                   const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, float* ws,
-                                  int64_t rows, int C, int dtype, void* stream) {
+                                  int64_t rows, int C, const float* out_scale, int64_t rows_per_scale, void* dx_scaled,
+                                  int dtype, void* stream) {
   if (rows <= 0) return CMDA_OK;
-  if (C <= 0 || (C & 3) || C > kMaxVec * 256) return CMDA_ERR_SHAPE;
+  if (C <= 0 || (C & 3) || C > kMaxVec * 256 || (dx_scaled && (!out_scale || rows_per_scale <= 0))) return CMDA_ERR_SHAPE;
   const int wpb = 4, lpr = lanes_per_row(C);
-  const int grid = (int)ln_bwd_grid(rows, C);
+  int grid = (int)ln_bwd_grid(rows, C);
   const int nv = ((C >> 2) + lpr - 1) / lpr;
+  // Small problems (the 2 + 2 samples per GPU of the UDA step: <= 16 k rows) are bound by launch count, not bandwidth: at most
+  // 128 blocks add their partials straight into dgamma / dbeta (<= 128 atomics per address) and the finalize launch is dropped.
+  const bool direct = rows * (long)C <= (1L << 23);
+  if (direct) grid = std::min(grid, 128);
+  float* dg = direct ? dgamma : nullptr;
+  float* db = direct ? dbeta : nullptr;
 #define CMDA_LN_BWD(NVV)                                                                                                 \
   CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((ln_bwd_kernel<T, NVV>), dim3(grid), dim3(64 * wpb), 0, stream, (const T*)dy, \
-                                         (const T*)x, gamma, mean, rstd, (const T*)dres, (T*)dx, ws, (long)rows, C, lpr))
+                                         (const T*)x, gamma, mean, rstd, (const T*)dres, (T*)dx, ws, (long)rows, C, lpr, \
+                                         out_scale, (long)rows_per_scale, (T*)dx_scaled, dg, db))
   if (nv <= 1) { CMDA_LN_BWD(1); }
   else if (nv == 2) { CMDA_LN_BWD(2); }
   else { CMDA_LN_BWD(4); }
 #undef CMDA_LN_BWD
-  CMDA_LAUNCH(ln_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, stream, ws, dgamma, dbeta,
-              std::min(grid, kSlots), C);
+  if (!direct)
+    CMDA_LAUNCH(ln_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, stream, ws, dgamma, dbeta, std::min(grid, kSlots), C);
   CMDA_CHECK_LAUNCH();
 }

@@ -66,11 +66,14 @@ def conv_bwd(dy, x, weight, bias, B, H, W, stride, pad, dil=1, *, need_dx=True, 
     OH, OW = conv_out_size(H, W, KH, stride, pad, dil)
     M, K = B * OH * OW, KH * KW * Ci
     with rt.lane('wgrad', dy, x):
-        dwg = torch.zeros(Co, K, dtype=torch.float32, device=dy.device)
-        ops.gemm(plain_view(dy, M, Co), conv_view(x, B, H, W, Ci, KH, KW, stride, pad, dil, OH=OH, OW=OW), dwg, Co, K, M,
-                 a_kstrided=True, b_kstrided=True, dtype=rt.tag(), atomic=True, splits=0)
-        ops.permute4(dwg, rt.grad(weight), (Co, KH, KW, Ci), (0, 3, 1, 2), accumulate=True)
-        if bias is not None:
+        # dW[co, (kh,kw,ci)] accumulated with atomics straight into the parameter's [Co,Ci,KH,KW] gradient (c_perm): no staging
+        # buffer, no permute-accumulate pass; the bias gradient rides along in the same kernel when the operands allow
+        dyv = plain_view(dy, M, Co)
+        fused = (bias is not None and rt.tag() == 1 and dyv.vec_ok and Co % 8 == 0 and K % 8 == 0 and Ci % 8 == 0)
+        ops.gemm(dyv, conv_view(x, B, H, W, Ci, KH, KW, stride, pad, dil, OH=OH, OW=OW), rt.grad(weight), Co, K, M,
+                 a_kstrided=True, b_kstrided=True, dtype=rt.tag(), atomic=True, splits=0, c_perm=(Ci, KH * KW),
+                 colsum=rt.grad(bias) if fused else None)
+        if bias is not None and not fused:
             ops.colsum(dy, rt.grad(bias), M, Co)
     if not need_dx:
         return None
@@ -113,10 +116,11 @@ def attention_bwd(do, q, kv, P, B, N, Nk, heads, C, scale):
     hd = C // heads
     dev = do.device
     tag = rt.tag()
-    dkv32 = torch.zeros(B * Nk, 2 * C, dtype=torch.float32, device=dev)
-    if P is None:  # fused forward ran
+    if P is None:  # fused forward ran (bf16): dK|dV accumulate in the persistent zeroed workspace, drained by one cast+clear
+        dkv32 = ops.zero_ws(dev, B * Nk * 2 * C).view(B * Nk, 2 * C)
         dq = ops.attention_fused_bwd(q, kv, do, dkv32, B, N, Nk, heads, C, scale)
-        return dq, ops.cast(dkv32, rt.compute_dtype())
+        return dq, ops.cast_clear(dkv32, rt.compute_dtype())
+    dkv32 = torch.zeros(B * Nk, 2 * C, dtype=torch.float32, device=dev)
     Pv = dict(batch_stride=heads * N * Nk, batch2_stride=N * Nk)
     sp = 0  # auto split-K
     # dV_h = P_h^T dO_h
@@ -173,11 +177,12 @@ def block_fwd(x, p, B, H, W, C, heads, sr, *, eps=1e-6, dp1=None, dp2=None, save
     return x2, saved
 
 
-def mlp_bwd(dy, mlp, xin, h, act, B, H, W, Cin, dps=None):
-    """Backward of Mlp (fc1 -> dwconv3x3 -> GELU -> fc2); returns d(xin)."""
+def mlp_bwd(dy, mlp, xin, h, act, B, H, W, Cin, dps=None, dy_scaled=None):
+    """Backward of Mlp (fc1 -> dwconv3x3 -> GELU -> fc2); returns d(xin).  dy_scaled: dy * dps already computed by the producer
+    of dy (the LayerNorm backward's second output)."""
     M = B * H * W
     hidden = mlp.fc1.weight.shape[0]
-    dys = dy if dps is None else ops.sample_scale(dy, dps, B, dy.shape[1])
+    dys = dy if dps is None else (dy_scaled if dy_scaled is not None else ops.sample_scale(dy, dps, B, dy.shape[1]))
     da = linear_bwd(dys, act, mlp.fc2.weight, mlp.fc2.bias, M, hidden)
     dw = mlp.dwconv.dwconv
     w9 = rt.wdw(dw.weight)
@@ -188,15 +193,20 @@ def mlp_bwd(dy, mlp, xin, h, act, B, H, W, Cin, dps=None):
     return linear_bwd(dh, xin, mlp.fc1.weight, mlp.fc1.bias, M, Cin)
 
 
-def block_bwd(dy, p, saved, B, H, W, C, heads, sr, *, eps=1e-6):
+def block_bwd(dy, p, saved, B, H, W, C, heads, sr, *, eps=1e-6, dy_scaled=None, next_scale=None):
+    """dy_scaled: dy * dp2 (this block's MLP-branch DropPath factor) when the producer of dy already wrote it; next_scale: the
+    per-sample factor the CONSUMER of this block's input gradient wants applied -> returns (dx, dx * next_scale)."""
     (x, m1, r1, xn, q, xs_pre, ms, rs, xs, kv, P, o, x1, m2, r2, xn2, h, act, Nk, dp1, dp2) = saved
     N = H * W
     M = B * N
     a = p.attn
     hd = C // heads
-    dxn2 = mlp_bwd(dy, p.mlp, xn2, h, act, B, H, W, C, dp2)
-    dx1 = ops.layernorm_bwd(dxn2, x1, p.norm2.weight, m2, r2, rt.grad(p.norm2.weight), rt.grad(p.norm2.bias), dres=dy)
-    dps = dx1 if dp1 is None else ops.sample_scale(dx1, dp1, B, C)
+    dxn2 = mlp_bwd(dy, p.mlp, xn2, h, act, B, H, W, C, dp2, dy_scaled)
+    if dp1 is None:
+        dps = dx1 = ops.layernorm_bwd(dxn2, x1, p.norm2.weight, m2, r2, rt.grad(p.norm2.weight), rt.grad(p.norm2.bias), dres=dy)
+    else:   # the attention branch's DropPath factor rides along as the LayerNorm backward's second output
+        dx1, dps = ops.layernorm_bwd(dxn2, x1, p.norm2.weight, m2, r2, rt.grad(p.norm2.weight), rt.grad(p.norm2.bias), dres=dy,
+                                     out_scale=dp1, rows_per_scale=N)
     do = linear_bwd(dps, o, a.proj.weight, a.proj.bias, M, C)
     dq, dkv = attention_bwd(do, q, kv, P, B, N, Nk, heads, C, hd ** -0.5)
     dxs = linear_bwd(dkv, xs, a.kv.weight, a.kv.bias, B * Nk, C)
@@ -206,4 +216,5 @@ def block_bwd(dy, p, saved, B, H, W, C, heads, sr, *, eps=1e-6):
     else:
         dxn = dxs
     linear_bwd(dq, xn, a.q.weight, a.q.bias, M, C, dx_out=dxn, dx_beta=1.0)
-    return ops.layernorm_bwd(dxn, x, p.norm1.weight, m1, r1, rt.grad(p.norm1.weight), rt.grad(p.norm1.bias), dres=dx1)
+    return ops.layernorm_bwd(dxn, x, p.norm1.weight, m1, r1, rt.grad(p.norm1.weight), rt.grad(p.norm1.bias), dres=dx1,
+                             out_scale=next_scale, rows_per_scale=N)

@@ -48,7 +48,7 @@ GEMM_TILE_HINT = 0
 
 def gemm(A, B, out, M, N, K, *, a_kstrided=False, b_kstrided=False, ldc=None, batch=1, c_batch_stride=0,
          batch2=1, c_batch2_stride=0, res_batch2_stride=0, splits=1, alpha=1.0, beta=0.0, bias=None, act=None, res=None, ldres=None, res_batch_stride=0,
-         rowscale=None, rows_per_scale=1, atomic=False, dtype=None, c_offset=0, colsum=None, c_patch=None):
+         rowscale=None, rows_per_scale=1, atomic=False, dtype=None, c_offset=0, colsum=None, c_patch=None, c_perm=None):
     """out[m,n] = epi(alpha * sum_k A(m,k) B(n,k)); A/B are `View`s built by plain_view / conv_view."""
     check_dev(out, bias, res, rowscale)
     out_f32 = out.dtype == torch.float32
@@ -79,6 +79,9 @@ def gemm(A, B, out, M, N, K, *, a_kstrided=False, b_kstrided=False, ldc=None, ba
     p.c_vec_ok = int(ok)
     p.colsum = colsum.data_ptr() if colsum is not None else None
     p.tile_hint = GEMM_TILE_HINT
+    if c_perm is not None:   # (Ci, KH*KW): atomic store of a conv weight gradient in the parameter's [Co,Ci,KH,KW] layout
+        assert atomic and batch == 1 and batch2 == 1
+        p.c_perm_ci, p.c_perm_cells = c_perm
     if c_patch is not None:  # (OW, KH, KW*Ci): store rows (b,oh,ow) x cols (kh,kw,ci) un-patchified into NHWC
         assert res is None and batch == 1 and batch2 == 1 and not atomic
         p.c_patch_ow, p.c_patch_kh, p.c_patch_kwci = c_patch
@@ -140,15 +143,17 @@ def ln_ws_prealloc(device, lanes):
             _LN_WS[key] = torch.zeros(n, dtype=torch.float32, device=device)
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None):
-    check_dev(dy, x, gamma, mean, rstd, dgamma, dbeta, dres)
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, out_scale=None, rows_per_scale=0):
+    """returns dx, or (dx, dx * out_scale[row // rows_per_scale]) when a per-sample scale is given (DropPath of the consumer)"""
+    check_dev(dy, x, gamma, mean, rstd, dgamma, dbeta, dres, out_scale)
     C = x.shape[-1]
     rows = x.numel() // C
     dx = torch.empty_like(x)
+    dxs = torch.empty_like(x) if out_scale is not None else None
     ws = _ln_ws(x.device, L.lib().cmda_layernorm_bwd_ws_floats(rows, C))
     call('cmda_layernorm_bwd', ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dgamma),
-         ptr(dbeta), ptr(ws), c_i64(rows), c_i32(C), dtype_tag(x), stream_of(x))
-    return dx
+         ptr(dbeta), ptr(ws), c_i64(rows), c_i32(C), ptr(out_scale), c_i64(rows_per_scale), ptr(dxs), dtype_tag(x), stream_of(x))
+    return dx if out_scale is None else (dx, dxs)
 
 
 def permute4(src, dst, dims, perm, flipmask=0, accumulate=False):
@@ -158,6 +163,40 @@ def permute4(src, dst, dims, perm, flipmask=0, accumulate=False):
     p = list(perm) + list(range(len(perm), 4))
     call('cmda_permute4', ptr(src), ptr(dst), *[c_i32(v) for v in d], *[c_i32(v) for v in p], c_i32(flipmask),
          c_i32(int(accumulate)), dtype_tag(src), dtype_tag(dst), stream_of(src))
+    return dst
+
+
+def permute4_batch(desc, blocks, nblocks):
+    """desc: DEVICE uint8 tensor holding an array of cmda_permute_desc_t; blocks: DEVICE int32 [nblocks, 2]"""
+    check_dev(desc, blocks)
+    call('cmda_permute4_batch', ptr(desc), ptr(blocks), c_i32(nblocks), stream_of(desc))
+
+
+_ZERO_WS = {}
+
+
+def zero_ws(device, n):
+    """persistent fp32 accumulation workspace, ZERO on entry by contract: whoever accumulates into it drains it with cast_clear
+    (one buffer per device and concurrency lane; calls on one stream are ordered)"""
+    key = (device.type, device.index, LN_LANE)
+    ws = _ZERO_WS.get(key)
+    if ws is None or ws.numel() < n:
+        ws = _ZERO_WS[key] = torch.zeros(max(n, 1 << 20), dtype=torch.float32, device=device)
+    return ws[:n]
+
+
+def zero_ws_prealloc(device, lanes, n=1 << 22):
+    for ln in lanes:
+        key = (device.type, device.index, ln)
+        if key not in _ZERO_WS or _ZERO_WS[key].numel() < n:
+            _ZERO_WS[key] = torch.zeros(n, dtype=torch.float32, device=device)
+
+
+def cast_clear(src32, dtype):
+    """returns src32 cast to `dtype` and zeroes src32 (one launch)"""
+    check_dev(src32)
+    dst = torch.empty(src32.shape, dtype=dtype, device=src32.device)
+    call('cmda_cast_clear', ptr(src32), ptr(dst), c_i64(src32.numel()), dtype_tag(dst), stream_of(src32))
     return dst
 
 

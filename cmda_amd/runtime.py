@@ -11,6 +11,8 @@ writes the masters without touching torch's version counters).
 Parameter gradients are accumulated by the kernels straight into `param.grad` (fp32, allocated zero on first use):
 autograd never sees them, which is what lets two backward passes per step accumulate with no extra traffic.
 """
+import weakref
+
 import torch
 
 from . import ops
@@ -24,7 +26,8 @@ def set_compute_dtype(dtype):
     assert dtype in (torch.float32, torch.bfloat16)
     _state['dtype'] = dtype
     _frozen.clear()
-    invalidate()
+    _cache.clear()
+    _plans.clear()
 
 
 def compute_dtype():
@@ -36,7 +39,66 @@ def tag():
 
 
 def invalidate():
-    _cache.clear()
+    """The fp32 masters changed (optimizer step, EMA update, checkpoint load): refresh every compute copy made so far.
+    The copies keep their storage (their addresses may be baked into a captured hipGraph) and ALL of them are rewritten by ONE
+    batched launch (cmda_permute4_batch) -- the per-tensor lazy re-layouts this replaces were ~470 launches per iteration of a
+    step that is bound by its launch count."""
+    _refresh()
+
+
+class _Entry:
+    __slots__ = ('ref', 'dst', 'dims', 'perm', 'flip')
+
+    def __init__(self, param, dst, dims, perm, flip):
+        self.ref, self.dst, self.dims, self.perm, self.flip = weakref.ref(param), dst, dims, perm, flip
+
+
+def _refresh():
+    dead = [k for k, e in _cache.items() if e.ref() is None or e.ref().device != e.dst.device]
+    for k in dead:
+        del _cache[k]
+    if not _cache:
+        return
+    live = list(_cache.values())
+    by_dev = {}
+    for e in live:
+        by_dev.setdefault(e.dst.device, []).append(e)
+    for dev, entries in by_dev.items():
+        key = (dev, tuple((id(e), e.ref().data.data_ptr()) for e in entries))
+        plan = _plans.get(dev)
+        if plan is None or plan['key'] != key:
+            import numpy as np
+            desc = np.zeros(len(entries), dtype=[('src', '<u8'), ('dst', '<u8'), ('d', '<i4', 4), ('p', '<i4', 4), ('flip', '<i4'),
+                                                   ('bf16', '<i4'), ('total', '<i8')])
+            blocks = []
+            for t, e in enumerate(entries):
+                d = list(e.dims) + [1] * (4 - len(e.dims))
+                pm = list(e.perm) + list(range(len(e.perm), 4))
+                total = 1
+                for v in d:
+                    total *= v
+                desc[t] = (e.ref().data.data_ptr(), e.dst.data_ptr(), d, pm, e.flip, int(e.dst.dtype == torch.bfloat16), total)
+                blocks += [(t, c) for c in range((total + 1023) // 1024)]
+            plan = _plans[dev] = dict(key=key, nblocks=len(blocks),
+                                      desc=torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()).to(dev),
+                                      blocks=torch.tensor(blocks, dtype=torch.int32).to(dev))
+        ops.permute4_batch(plan['desc'], plan['blocks'], plan['nblocks'])
+
+
+_plans = {}
+
+
+def _compute_copy(param, kind, dst_shape, dst_dtype, dims, perm, flip=0):
+    key = (id(param), kind)
+    store = _frozen if getattr(param, '_cmda_frozen', False) else _cache
+    e = store.get(key)
+    if e is not None and (e.ref() is not param or e.dst.device != param.device or e.dst.dtype != dst_dtype):
+        e = None
+    if e is None:
+        dst = torch.empty(dst_shape, dtype=dst_dtype, device=param.device)
+        ops.permute4(param.data, dst, dims, perm, flipmask=flip)
+        e = store[key] = _Entry(param, dst, dims, perm, flip)
+    return e.dst
 
 
 def w(param):
@@ -46,43 +108,21 @@ def w(param):
     live = getattr(param, '_cmda_bf16', None)  # maintained by optim.FlatAdamW's fused update
     if live is not None:
         return live
-    key = (id(param), 'w')
-    t = _cache.get(key)
-    if t is None:
-        t = ops.cast(param.data, _state['dtype'])
-        _cache[key] = t
-    return t
+    return _compute_copy(param, 'w', param.shape, _state['dtype'], (param.numel(), 1, 1, 1), (0, 1, 2, 3))
 
 
 def wconv(param, kind='khwc'):
     """Conv weight [Co,Ci,KH,KW] repacked for the implicit GEMM (see module docstring)."""
-    key = (id(param), kind)
-    store = _frozen if getattr(param, '_cmda_frozen', False) else _cache
-    t = store.get(key)
-    if t is not None and t.device != param.device:
-        t = None
-    if t is None:
-        Co, Ci, KH, KW = param.shape
-        if kind == 'khwc':
-            t = torch.empty(Co, KH * KW * Ci, dtype=_state['dtype'], device=param.device)
-            ops.permute4(param.data, t, (Co, Ci, KH, KW), (0, 2, 3, 1))
-        else:
-            t = torch.empty(Ci, KH * KW * Co, dtype=_state['dtype'], device=param.device)
-            ops.permute4(param.data, t, (Co, Ci, KH, KW), (1, 2, 3, 0), flipmask=0b1100)
-        store[key] = t
-    return t
+    Co, Ci, KH, KW = param.shape
+    if kind == 'khwc':
+        return _compute_copy(param, kind, (Co, KH * KW * Ci), _state['dtype'], (Co, Ci, KH, KW), (0, 2, 3, 1))
+    return _compute_copy(param, kind, (Ci, KH * KW * Co), _state['dtype'], (Co, Ci, KH, KW), (1, 2, 3, 0), flip=0b1100)
 
 
 def wdw(param):
     """Depthwise 3x3 weight [C,1,3,3] -> tap-major fp32 [9,C] (coalesced per-tap reads in dwconv.hip)."""
-    key = (id(param), 'dw')
-    t = _cache.get(key)
-    if t is None:
-        C = param.shape[0]
-        t = torch.empty(9, C, dtype=torch.float32, device=param.device)
-        ops.permute4(param.data, t, (C, 9, 1, 1), (1, 0, 2, 3))
-        _cache[key] = t
-    return t
+    C = param.shape[0]
+    return _compute_copy(param, 'dw', (9, C), torch.float32, (C, 9, 1, 1), (1, 0, 2, 3))
 
 
 def grad(param):

@@ -434,6 +434,7 @@ class DACS(nn.Module):
         st_tgt = {k: v.clone() for k, v in tgt.items() if isinstance(v, torch.Tensor)}
         second = torch.empty_like(st_src['image'])
         ops.ln_ws_prealloc(dev, ('main', 'main/enc'))
+        ops.zero_ws_prealloc(dev, ('main', 'main/enc'))
         torch.cuda.synchronize(dev)
         rt.invalidate()    # every weight re-layout must be recorded INSIDE the graph (it is re-run by each replay)
         g = torch.cuda.CUDAGraph()

@@ -79,6 +79,10 @@ typedef struct cmda_gemm_params_t {
   /* 0: the library's tile heuristics; 1..4: force tile 64x64 / 128x64 / 128x128 / 256x256 (tuning sweeps, tests of the
    * rarely chosen tiles); -1: register-staged kernel instead of the LDS-DMA one. */
   int32_t tile_hint;
+  /* atomic stores only, c_perm_ci > 0: GEMM column n = cell * c_perm_ci + ci (cell = kh*KW + kw, the im2col column order) is
+   * stored at column ci * c_perm_cells + cell -- a convolution's weight gradient accumulated straight into the parameter's
+   * [Co][Ci][KH][KW] gradient. */
+  int32_t c_perm_ci, c_perm_cells;
 } cmda_gemm_params_t;
 
 int cmda_gemm(const cmda_gemm_params_t* p, void* stream);
@@ -90,7 +94,10 @@ int cmda_layernorm_fwd(const void* x, const float* gamma, const float* beta, voi
     int64_t rows, int C, float eps, int dtype, void* stream);
 int64_t cmda_layernorm_bwd_ws_floats(int64_t rows, int C);
 int cmda_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres,
-    void* dx, float* dgamma, float* dbeta, float* ws, int64_t rows, int C, int dtype, void* stream);
+    void* dx, float* dgamma, float* dbeta, float* ws, int64_t rows, int C, const float* out_scale, int64_t rows_per_scale,
+    void* dx_scaled, int dtype, void* stream);
+/* out_scale / rows_per_scale / dx_scaled (all or none): second output dx * out_scale[row / rows_per_scale] -- the per-sample
+ * DropPath factor (timm DropPath, mix_transformer.py:145-146) of the residual branch that consumes this gradient next. */
 
 /* ---- Row softmax of attention scores -- `attn.softmax(dim=-1)` mix_transformer.py:97-98 (in place, alpha = head_dim^-0.5);
  * bwd writes dS = alpha * P * (dP - sum P dP) over dP. */
@@ -165,6 +172,20 @@ int cmda_upsample_logits_nchw(const float* logits, float* out, int B, int h, int
  * mix_transformer.py:134,145-146; nn.Dropout2d decode_head.py:565-566), strided 2-D copy (torch.cat fusion/attention_fusion.py:52). */
 int cmda_permute4(const void* src, void* dst, int d0, int d1, int d2, int d3, int p0, int p1, int p2, int p3, int
     flipmask, int accumulate, int src_dtype, int dst_dtype, void* stream);
+/* one launch for many re-layouts (all conv / depthwise weights after an optimizer or EMA step): desc = DEVICE array of
+ * cmda_permute_desc_t, blocks = DEVICE int32 [nblocks][2] {tensor index, 1024-element chunk index}; fp32 sources. */
+typedef struct cmda_permute_desc_t {
+  const float* src;
+  void* dst;
+  int32_t d[4];       /* source dims */
+  int32_t p[4];       /* dst axis a = source axis p[a] */
+  int32_t flipmask;   /* bit ax set: source axis ax reversed */
+  int32_t dst_bf16;   /* 1: dst is bf16, 0: fp32 */
+  int64_t total;      /* d[0]*d[1]*d[2]*d[3] */
+} cmda_permute_desc_t;
+/* dst (activation dtype) = src; src (fp32, n % 4 == 0) = 0: drains a persistent accumulation workspace and leaves it zeroed */
+int cmda_cast_clear(float* src, void* dst, int64_t n, int dst_dtype, void* stream);
+int cmda_permute4_batch(const void* desc, const int* blocks, int nblocks, void* stream);
 int cmda_colsum(const void* x, float* out, int64_t M, int N, int64_t ld, int dtype, void* stream);
 int cmda_axpby(const void* x, const void* y, void* out, float a, float b, int64_t n, int dtype, void* stream);
 int cmda_sample_scale(const void* x, const float* scale, void* out, int B, int64_t per_sample, int C, int per_channel,
