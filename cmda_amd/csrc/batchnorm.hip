@@ -308,7 +308,7 @@ extern "C" int cmda_bn_train_fwd(const void* x, const float* gamma, const float*
   for (int i = 0; i < 8; ++i) ord.g[i] = (order && i < groups) ? order[i] : i;
   for (int i = 0; i < groups; ++i)
     if (ord.g[i] < 0 || ord.g[i] >= groups) return CMDA_ERR_SHAPE;
-  (void)hipMemsetAsync(ws, 0, sizeof(float) * (size_t)groups * (kBnSlots + 1) * 2 * C, (hipStream_t)stream);
+  cmda_zero_async(ws, sizeof(float) * (size_t)groups * (kBnSlots + 1) * 2 * C, stream);
   const int gx = (C / 4 + 63) / 64;
   const int rpb = rows_per_block(M * groups, gx);
   dim3 rgrid(gx, (unsigned)((M + rpb - 1) / rpb), groups);
@@ -344,7 +344,7 @@ extern "C" int cmda_bn_train_bwd(const void* dy, const void* x, const float* mea
                                  int relu, int lddy, int coff, int groups, int dtype, void* stream) {
   if (M <= 0 || C <= 0) return CMDA_OK;
   if ((C & 3) || (lddy & 3) || (coff & 3) || groups < 1 || groups > 8) return CMDA_ERR_SHAPE;
-  (void)hipMemsetAsync(ws, 0, sizeof(float) * (size_t)groups * (kBnSlots + 1) * 2 * C, (hipStream_t)stream);
+  cmda_zero_async(ws, sizeof(float) * (size_t)groups * (kBnSlots + 1) * 2 * C, stream);
   const int gx = (C / 4 + 63) / 64;
   const int rpb = rows_per_block(M * groups, gx);
   dim3 rgrid(gx, (unsigned)((M + rpb - 1) / rpb), groups);

@@ -213,6 +213,23 @@ static __device__ __forceinline__ float gelu_erf_grad(float x) {
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Zero-fill as a KERNEL (never hipMemsetAsync): inside a captured hipGraph a memset becomes a memset NODE, and on ROCm 7.2 those
+// were observed to run out of order with the neighbouring kernel nodes of the same stream when the graph is replayed (BatchNorm
+// / InstanceNorm statistics accumulated on top of a workspace that was cleared too late: flaky NaNs and wrong losses from the
+// second replay on, tools/dbg/lanes_dbg.py).  A kernel node is ordered like every other kernel.  Every translation unit that
+// needs it gets its own copy (anonymous namespace).
+namespace {
+__global__ void cmda_zero_words_kernel(unsigned* __restrict__ p, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static inline void cmda_zero_async(void* p, size_t bytes, void* stream) {  // bytes % 4 == 0
+  const long n = (long)(bytes / 4);
+  if (n <= 0) return;
+  const int grid = (int)(n + 255) / 256 > 1024 ? 1024 : (int)((n + 255) / 256);
+  CMDA_LAUNCH(cmda_zero_words_kernel, dim3(grid), dim3(256), 0, stream, (unsigned*)p, n);
+}
+}  // namespace
+
 #ifdef CMDA_EMU
 #define CMDA_CHECK_LAUNCH() return CMDA_OK
 #else

@@ -248,7 +248,7 @@ extern "C" int cmda_isr_from_gray(const uint8_t* gray, const float* lut, const i
 // events as 4 fp32 arrays of length N (t sorted); grid fp32 [bins,H,W] (zeroed here)
 extern "C" int cmda_events_to_voxel_grid(const float* t, const float* x, const float* y, const float* pol, float* grid,
                                          int64_t N, int bins, int H, int W, void* stream) {
-  (void)hipMemsetAsync(grid, 0, sizeof(float) * (size_t)bins * H * W, (hipStream_t)stream);
+  cmda_zero_async(grid, sizeof(float) * (size_t)bins * H * W, stream);
   if (N <= 0) return CMDA_OK;
   CMDA_LAUNCH(voxel_scatter_kernel, dim3(grid_for(N)), dim3(256), 0, stream, t, x, y, pol, grid, (long)N, bins, H, W);
   CMDA_CHECK_LAUNCH();
@@ -260,7 +260,7 @@ extern "C" int cmda_events_norm(const float* events, float* out, void* ws, int64
   if (n <= 0) return CMDA_OK;
   double* dws = (double*)ws;
   uint32_t* mm = (uint32_t*)(dws + 3);
-  (void)hipMemsetAsync(dws, 0, 3 * sizeof(double), (hipStream_t)stream);
+  cmda_zero_async(dws, 3 * sizeof(double), stream);
   CMDA_LAUNCH(minmax_init_kernel, dim3(1), dim3(256), 0, stream, (unsigned*)mm, 1);
   CMDA_LAUNCH(events_stats_kernel, dim3(grid_for(n)), dim3(256), 0, stream, events, dws, (long)n);
   CMDA_LAUNCH(events_minmax_kernel, dim3(grid_for(n)), dim3(256), 0, stream, events, (const double*)dws, (unsigned*)mm,

@@ -640,12 +640,16 @@ template <int TM, int TN> struct GldsStages { static constexpr int value = 2; };
 // NW = 4 waves (2 x 2): tiles 64x64 / 128x64 / 128x128.  NW = 8 waves (4 x 2, 512 threads, one block per CU): the 256x256
 // tile for the large GEMMs -- the k-loop is bound by the per-CU L2->LDS rate, and a 256x256 tile moves half the bytes
 // per FLOP of a 128x128 one.  Its epilogue goes through LDS one wave-row (64 rows) at a time.
-template <int TM, int TN, bool AKS, bool BKS, bool ACONV, bool BCONV, int NW = 4>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void gemm_glds_kernel(GemmParams p) {
+// NSV = 0: the throughput configuration (GldsStages: 2 stages, most resident blocks -- right when the grid is many waves of
+// blocks deep).  NSV = 4: the LATENCY configuration for grids that fit the chip in one wave anyway (the 2 + 2-sample UDA step:
+// every Linear of an encoder is 160-320 blocks): with 2 stages every k-tile exposes a full load latency (K = 1280: 8.9 us of an
+// 11.4 us kernel, tools/gemm_phase.py), with 4 stages three tiles are in flight and the lone block's k-loop drops ~3x.
+template <int TM, int TN, bool AKS, bool BKS, bool ACONV, bool BCONV, int NW = 4, int NSV = 0>
+__global__ __launch_bounds__(64 * NW, (NW == 8 || NSV * (TM * 16 * (NW / 2) + TN * 32) * 128 > 65536) ? 1 : 2) void gemm_glds_kernel(GemmParams p) {
   typedef bf16_t T;
   constexpr int WM = NW / 2, NTHR = 64 * NW;
   constexpr int BM = 16 * TM * WM, BN = 32 * TN, BK = 64;
-  constexpr int NS = GldsStages<TM, TN>::value;
+  constexpr int NS = NSV ? NSV : GldsStages<TM, TN>::value;
   constexpr int SZ_A = BM * BK, SZ_B = BN * BK;                       // elements per stage
   constexpr int PITCH_C = BN + 4;
   constexpr int EPI_ROWS = NW == 8 ? 16 * TM : BM;                    // rows staged per epilogue pass
@@ -822,22 +826,36 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void gemm_glds_kernel(Gem
   CMDA_STAMP(5);
 }
 
+template <int TM, int TN, int NW, int NSV>
+int launch_glds_ns(const GemmParams& p, const dim3& grid, void* stream) {
+  const dim3 blk(64 * NW);
+  const bool aks = p.a_kstrided != 0, bks = p.b_kstrided != 0, ac = p.A.conv != 0, bc = p.B.conv != 0;
+  if (!aks && !bks && !ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, false, false, false, false, NW, NSV>), grid, blk, 0, stream, p);
+  else if (!aks && bks && !ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, false, true, false, false, NW, NSV>), grid, blk, 0, stream, p);
+  else if (aks && bks && !ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, true, true, false, false, NW, NSV>), grid, blk, 0, stream, p);
+  else if (aks && !bks && !ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, true, false, false, false, NW, NSV>), grid, blk, 0, stream, p);
+  else if (!aks && !bks && ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, false, false, true, false, NW, NSV>), grid, blk, 0, stream, p);
+  else if (aks && bks && !ac && bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, true, true, false, true, NW, NSV>), grid, blk, 0, stream, p);
+  else return CMDA_ERR_UNSUPPORTED;
+  CMDA_CHECK_LAUNCH();
+}
+
 template <int TM, int TN, int NW = 4>
 int launch_glds(const GemmParams& p, void* stream) {
   constexpr int BM = 16 * TM * (NW / 2), BN = 32 * TN;
   const long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  if (tiles > 0x7fffffffL || (long)p.batch * p.batch2 * p.splits > 65535) return CMDA_ERR_SHAPE;
-  dim3 grid((unsigned)tiles, 1, (unsigned)(p.batch * p.batch2 * p.splits));
-  const dim3 blk(64 * NW);
-  const bool aks = p.a_kstrided != 0, bks = p.b_kstrided != 0, ac = p.A.conv != 0, bc = p.B.conv != 0;
-  if (!aks && !bks && !ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, false, false, false, false, NW>), grid, blk, 0, stream, p);
-  else if (!aks && bks && !ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, false, true, false, false, NW>), grid, blk, 0, stream, p);
-  else if (aks && bks && !ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, true, true, false, false, NW>), grid, blk, 0, stream, p);
-  else if (aks && !bks && !ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, true, false, false, false, NW>), grid, blk, 0, stream, p);
-  else if (!aks && !bks && ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, false, false, true, false, NW>), grid, blk, 0, stream, p);
-  else if (aks && bks && !ac && bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, true, true, false, true, NW>), grid, blk, 0, stream, p);
-  else return CMDA_ERR_UNSUPPORTED;
-  CMDA_CHECK_LAUNCH();
+  const long zz = (long)p.batch * p.batch2 * p.splits;
+  if (tiles > 0x7fffffffL || zz > 65535) return CMDA_ERR_SHAPE;
+  dim3 grid((unsigned)tiles, 1, (unsigned)zz);
+  if constexpr (NW == 4) {
+    // latency configuration: the whole grid is resident at once even at 4 stages (64x64: 64 KiB -> 2 blocks per CU; the wider
+    // tiles: 96 / 128 KiB -> 1 block per CU) and every block runs >= 3 k-tiles
+    constexpr long kStage = (long)(BM + BN) * 128;
+    const long resident = 256L * (4 * kStage <= 65536 ? 2 : 1);
+    const long nkt = ((long)p.K + 63) / 64 / (p.splits > 0 ? p.splits : 1);
+    if (tiles * zz <= resident && nkt >= 3) return launch_glds_ns<TM, TN, NW, 4>(p, grid, stream);
+  }
+  return launch_glds_ns<TM, TN, NW, 0>(p, grid, stream);
 }
 
 template <typename T, int TM, int TN>

@@ -97,14 +97,13 @@ __global__ void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__
 // the registers of the C = 1024 case (4 passes) -- 128 VGPRs / 4 waves per SIMD before, and the kernel is latency-bound
 // out_scale / dx_scaled (optional): a second output dx * out_scale[row / rows_per_scale] -- the per-sample DropPath factor of the
 // residual branch that consumes this gradient next (timm DropPath, mix_transformer.py:145-146), so that no separate scaling
-// kernel runs.  dgamma / dbeta non-null = DIRECT mode (small grids): the block partials go straight into the parameter
-// gradients with fp32 atomics and no finalize launch follows.
+// kernel runs.
 template <typename T, int NV>
 __global__ void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
                               const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                               const T* __restrict__ dres, T* __restrict__ dx, float* __restrict__ ws, long rows,
                               int C, int lpr, const float* __restrict__ out_scale, long rows_per_scale,
-                              T* __restrict__ dx_scaled, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                              T* __restrict__ dx_scaled) {
   __shared__ float red[2][1024 * NV];  // [gamma/beta][slot = wave*rows_per_wave + group][channel]  (slots*C <= 1024*NV)
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
@@ -194,13 +193,8 @@ __global__ void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
       sg += red[0][w * C + c];
       sb += red[1][w * C + c];
     }
-    if (dgamma) {
-      atomicAdd(dgamma + c, sg);
-      atomicAdd(dbeta + c, sb);
-    } else {
-      atomicAdd(&ws[((long)(blockIdx.x % kSlots) * 2 + 0) * C + c], sg);
-      atomicAdd(&ws[((long)(blockIdx.x % kSlots) * 2 + 1) * C + c], sb);
-    }
+    atomicAdd(&ws[((long)(blockIdx.x % kSlots) * 2 + 0) * C + c], sg);
+    atomicAdd(&ws[((long)(blockIdx.x % kSlots) * 2 + 1) * C + c], sb);
   }
 }
 
@@ -228,6 +222,27 @@ __global__ void ln_bwd_finalize_kernel(float* __restrict__ ws, float* __restrict
     dgamma[c] += a;
     dbeta[c] += b2;
   }
+}
+
+// Deferred form: MANY LayerNorm layers' workspaces folded by ONE launch at the end of a backward pass (the parameter gradients
+// are only read by the optimizer; ~700 finalize launches per UDA step otherwise).  desc[i] = one layer; grid.x = layer,
+// grid.y = channel chunks of 256.
+struct LnFoldDesc { float* ws; float* dgamma; float* dbeta; int C; int nslots; };
+__global__ void ln_fold_batch_kernel(const LnFoldDesc* __restrict__ desc) {
+  const LnFoldDesc D = desc[blockIdx.x];
+  const int c = blockIdx.y * blockDim.x + threadIdx.x;
+  if (c >= D.C) return;
+  float sg = 0.f, sb = 0.f;
+  for (int k = 0; k < D.nslots; ++k) {
+    float* a = D.ws + ((long)k * 2 + 0) * D.C + c;
+    float* b = D.ws + ((long)k * 2 + 1) * D.C + c;
+    sg += *a;
+    sb += *b;
+    *a = 0.f;  // leave the workspace zeroed for the next pass
+    *b = 0.f;
+  }
+  D.dgamma[c] += sg;
+  D.dbeta[c] += sb;
 }
 
 }  // namespace
@@ -272,21 +287,27 @@ extern "C" int cmda_layernorm_bwd(const void* dy, const void* x, const float* ga
   const int wpb = 4, lpr = lanes_per_row(C);
   int grid = (int)ln_bwd_grid(rows, C);
   const int nv = ((C >> 2) + lpr - 1) / lpr;
-  // Small problems (the 2 + 2 samples per GPU of the UDA step: <= 16 k rows) are bound by launch count, not bandwidth: at most
-  // 128 blocks add their partials straight into dgamma / dbeta (<= 128 atomics per address) and the finalize launch is dropped.
-  const bool direct = rows * (long)C <= (1L << 23);
-  if (direct) grid = std::min(grid, 128);
-  float* dg = direct ? dgamma : nullptr;
-  float* db = direct ? dbeta : nullptr;
 #define CMDA_LN_BWD(NVV)                                                                                                 \
   CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((ln_bwd_kernel<T, NVV>), dim3(grid), dim3(64 * wpb), 0, stream, (const T*)dy, \
                                          (const T*)x, gamma, mean, rstd, (const T*)dres, (T*)dx, ws, (long)rows, C, lpr, \
-                                         out_scale, (long)rows_per_scale, (T*)dx_scaled, dg, db))
+                                         out_scale, (long)rows_per_scale, (T*)dx_scaled))
   if (nv <= 1) { CMDA_LN_BWD(1); }
   else if (nv == 2) { CMDA_LN_BWD(2); }
   else { CMDA_LN_BWD(4); }
 #undef CMDA_LN_BWD
-  if (!direct)
+  // dgamma == NULL: deferred -- the partial sums stay in `ws` (a workspace owned by this layer) until cmda_layernorm_fold_batch
+  if (dgamma)
     CMDA_LAUNCH(ln_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, stream, ws, dgamma, dbeta, std::min(grid, kSlots), C);
   CMDA_CHECK_LAUNCH();
 }
+
+// desc: DEVICE array of n records {float* ws; float* dgamma; float* dbeta; int32 C; int32 nslots} (24 bytes + padding to 32):
+// dgamma / dbeta += the sums over the nslots partial rows of ws ([nslots][2][C]), ws zeroed.  max_c = the largest C.
+extern "C" int cmda_layernorm_fold_batch(const void* desc, int n, int max_c, void* stream) {
+  if (n <= 0) return CMDA_OK;
+  static_assert(sizeof(LnFoldDesc) == 32, "descriptor layout is part of the ABI");
+  CMDA_LAUNCH(ln_fold_batch_kernel, dim3(n, (max_c + 255) / 256), dim3(256), 0, stream, (const LnFoldDesc*)desc);
+  CMDA_CHECK_LAUNCH();
+}
+
+extern "C" int cmda_layernorm_slots(void) { return kSlots; }

@@ -143,6 +143,55 @@ def ln_ws_prealloc(device, lanes):
             _LN_WS[key] = torch.zeros(n, dtype=torch.float32, device=device)
 
 
+# Deferred LayerNorm parameter gradients: inside `ln_deferral()` every layernorm_bwd leaves its per-block partial sums in a
+# workspace owned by that layer (keyed by its dgamma buffer) and ONE cmda_layernorm_fold_batch launch at the end of the scope
+# folds all of them into dgamma / dbeta -- the ~700 finalize launches per UDA step this replaces only fed the optimizer.
+_LN_DEFER = {'depth': 0, 'regions': {}, 'touched': {}, 'plans': {}}
+
+
+class ln_deferral:
+    def __enter__(self):
+        _LN_DEFER['depth'] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _LN_DEFER['depth'] -= 1
+        if _LN_DEFER['depth'] == 0 and exc[0] is None:
+            ln_fold_deferred()
+        return False
+
+
+def _ln_region(dgamma, dbeta, C):
+    key = dgamma.data_ptr()
+    r = _LN_DEFER['regions'].get(key)
+    if r is None or r[0].device != dgamma.device:
+        nslots = L.lib().cmda_layernorm_slots()
+        r = _LN_DEFER['regions'][key] = (torch.zeros(nslots * 2 * C, dtype=torch.float32, device=dgamma.device), dgamma, dbeta, C, nslots)
+    _LN_DEFER['touched'][key] = r
+    return r[0]
+
+
+def ln_fold_deferred():
+    """fold every workspace touched since the last fold into its dgamma / dbeta: one launch per device"""
+    touched, _LN_DEFER['touched'] = _LN_DEFER['touched'], {}
+    if not touched:
+        return
+    import numpy as np
+    by_dev = {}
+    for key, r in touched.items():
+        by_dev.setdefault(r[0].device, []).append((key, r))
+    for dev, items in by_dev.items():
+        pkey = (dev, tuple(k for k, _ in items))
+        plan = _LN_DEFER['plans'].get(pkey)
+        if plan is None:
+            desc = np.zeros(len(items), dtype=[('ws', '<u8'), ('dg', '<u8'), ('db', '<u8'), ('C', '<i4'), ('n', '<i4')])
+            for i, (_, (ws, dg, db, C, nslots)) in enumerate(items):
+                desc[i] = (ws.data_ptr(), dg.data_ptr(), db.data_ptr(), C, nslots)
+            plan = _LN_DEFER['plans'][pkey] = (torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()).to(dev), len(items),
+                                               max(r[3] for _, r in items))
+        call('cmda_layernorm_fold_batch', ptr(plan[0]), c_i32(plan[1]), c_i32(plan[2]), stream_of(plan[0]))
+
+
 def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, out_scale=None, rows_per_scale=0):
     """returns dx, or (dx, dx * out_scale[row // rows_per_scale]) when a per-sample scale is given (DropPath of the consumer)"""
     check_dev(dy, x, gamma, mean, rstd, dgamma, dbeta, dres, out_scale)
@@ -150,9 +199,12 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, out_scale=
     rows = x.numel() // C
     dx = torch.empty_like(x)
     dxs = torch.empty_like(x) if out_scale is not None else None
-    ws = _ln_ws(x.device, L.lib().cmda_layernorm_bwd_ws_floats(rows, C))
-    call('cmda_layernorm_bwd', ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dgamma),
-         ptr(dbeta), ptr(ws), c_i64(rows), c_i32(C), ptr(out_scale), c_i64(rows_per_scale), ptr(dxs), dtype_tag(x), stream_of(x))
+    if _LN_DEFER['depth'] > 0:
+        ws, dg, db = _ln_region(dgamma, dbeta, C), None, None
+    else:
+        ws, dg, db = _ln_ws(x.device, L.lib().cmda_layernorm_bwd_ws_floats(rows, C)), dgamma, dbeta
+    call('cmda_layernorm_bwd', ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dg),
+         ptr(db), ptr(ws), c_i64(rows), c_i32(C), ptr(out_scale), c_i64(rows_per_scale), ptr(dxs), dtype_tag(x), stream_of(x))
     return dx if out_scale is None else (dx, dxs)
 
 

@@ -39,11 +39,20 @@ def tag():
 
 
 def invalidate():
-    """The fp32 masters changed (optimizer step, EMA update, checkpoint load): refresh every compute copy made so far.
-    The copies keep their storage (their addresses may be baked into a captured hipGraph) and ALL of them are rewritten by ONE
-    batched launch (cmda_permute4_batch) -- the per-tensor lazy re-layouts this replaces were ~470 launches per iteration of a
-    step that is bound by its launch count."""
-    _refresh()
+    """The fp32 masters changed (optimizer step, EMA update, checkpoint load): every compute copy made so far is stale.
+    The copies keep their storage (their addresses may be baked into a captured hipGraph); the next `refresh()` -- the first
+    use of any copy, or the explicit call at the head of a training iteration -- rewrites ALL of them with ONE batched launch
+    (cmda_permute4_batch); the per-tensor lazy re-layouts this replaces were ~470 launches per iteration of a step that is
+    bound by its launch count."""
+    _state['stale'] = True
+
+
+def refresh(force=False):
+    """bring the compute copies up to date (one launch); `force`: launch even if nothing was invalidated -- a captured
+    iteration starts with this node so that every replay sees the masters of its own iteration"""
+    if force or _state.get('stale'):
+        _state['stale'] = False
+        _refresh()
 
 
 class _Entry:
@@ -91,6 +100,8 @@ _plans = {}
 def _compute_copy(param, kind, dst_shape, dst_dtype, dims, perm, flip=0):
     key = (id(param), kind)
     store = _frozen if getattr(param, '_cmda_frozen', False) else _cache
+    if _state.get('stale') and store is _cache:
+        refresh()
     e = store.get(key)
     if e is not None and (e.ref() is not param or e.dst.device != param.device or e.dst.dtype != dst_dtype):
         e = None
@@ -146,25 +157,81 @@ def ones1(device):
     return t
 
 
-# ------------------------------------------------------------------ concurrency lanes (HIP streams inside one captured graph)
+# ------------------------------------------------------------------ concurrency lanes + segmented hipGraph capture
 # At the reference's 2+2 samples per GPU most kernels are far too small for 256 CUs and a dependent kernel costs ~5 us of
 # launch / drain latency whatever its size, so the step time is (number of dependent kernels) x latency.  Independent work is
-# therefore issued on side streams: 'enc' = the two encoders of the fusion student side by side; 'T' = teacher -> mixing ->
-# mixed forward next to the source pass (uda.DACS._iteration); 'wgrad' = every weight-gradient kernel (consumed only by the
-# optimizer) off the critical dgrad chain.  Off by default; DACS switches it on while it captures its hipGraph (forked streams
-# become parallel branches of the graph; eager launches would only pay extra host time).
-# Measured on MI355X, full DACS step at 2+2 samples (ms per step, gpurun r02d-f): no lanes 146; enc 104; T 128; enc+T 102;
-# wgrad alone 156, enc+wgrad 129-138, wgrad+T 154 -- the fine-grained wgrad forks (one cross-stream edge per weight gradient,
-# ~3 k per step) cost more than they hide, so the default set is {enc, T}.
-_conc = {'on': False, 'streams': {}, 'stack': ['main'], 'used': {}, 'keep': {}, 'enabled': {'enc', 'T'}, 'touched': []}
+# therefore issued on side streams ("lanes"): 'enc' = the two encoders of the fusion student side by side; 'T' = teacher ->
+# mixing -> mixed forward next to the source pass (uda.DACS._iteration); 'wgrad' = every weight-gradient kernel off the
+# critical dgrad chain.  Off by default; DACS switches it on while it captures (eager launches would only pay host time).
+#
+# Measured on MI355X, full DACS step at 2+2 samples (ms per step, gpurun r02d-f), lanes as forked streams inside ONE captured
+# graph: no lanes 146; enc 104; T 128; enc+T 102; wgrad alone 156, enc+wgrad 129-138, wgrad+T 154 -- the fine-grained wgrad
+# forks (one cross-stream edge per weight gradient, ~3 k per step) cost more than they hide.
+# But: hipGraphLaunch of a graph WITH parallel branches costs the host ~7 us per node (76 ms for the 11 k-node iteration: the
+# step was host-bound inside the launch call), while a LINEAR graph launches at ~0.3 us per node (3.5 ms).  Hence the
+# segmented form (SegmentedCapture): every stretch of one lane between two fork / join points is captured as its OWN
+# single-stream graph, all sharing one memory pool, and the lanes are real streams at replay time -- the recorded program is
+# a short list of `replay segment k on stream s` and `stream a waits for stream b` steps (~40 per iteration).  Segmented,
+# GPU-bound (host 4 ms per iteration): no lanes 151; enc 104-107; T 124; enc+T 109-114 -- a THIRD concurrent queue costs more
+# than it hides (GPU_MAX_HW_QUEUES=8: 176), so the default set is {enc}: two queues, everything that can run in pairs does.
+_conc = {'on': False, 'streams': {}, 'stack': ['main'], 'sstack': [], 'used': {}, 'keep': {}, 'enabled': {'enc'}, 'seg': None}
 
 
-def set_concurrency(flag, lanes=None):
-    """lanes: subset of {'enc', 'wgrad', 'T'} to use (default: enc + T, see above)"""
+class SegmentedCapture:
+    """records an iteration as linear hipGraph segments + the stream program that orders them (see above)"""
+
+    def __init__(self, device):
+        self.device = device
+        self.pool = torch.cuda.graph_pool_handle()
+        self.main = torch.cuda.Stream(device)
+        self.program = []      # ('replay', graph, stream) | ('wait', waiter, waited)
+        self.active = None
+        self.n_nodes = 0
+
+    def begin(self, stream):
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize(self.device)
+        ctx = torch.cuda.stream(stream)
+        ctx.__enter__()
+        g.capture_begin(self.pool)
+        self.active = (g, stream, ctx)
+
+    def end(self):
+        g, stream, ctx = self.active
+        g.capture_end()
+        ctx.__exit__(None, None, None)
+        self.program.append(('replay', g, stream))
+        self.active = None
+
+    def cut(self, waits=(), resume=None):
+        """close the running segment, record `waits` = [(waiter, waited)], open the next segment on `resume`"""
+        stream = self.active[1]
+        self.end()
+        for waiter, waited in waits:
+            self.program.append(('wait', waiter, waited))
+        self.begin(resume if resume is not None else stream)
+
+    def replay(self):
+        cur = torch.cuda.current_stream(self.device)
+        self.main.wait_stream(cur)
+        for op, a, b in self.program:
+            if op == 'replay':
+                with torch.cuda.stream(b):
+                    a.replay()
+            else:
+                a.wait_stream(b)
+        cur.wait_stream(self.main)
+
+
+def set_concurrency(flag, lanes=None, seg=None):
+    """lanes: subset of {'enc', 'wgrad', 'T'} to use (default: enc, see above); seg: a SegmentedCapture whose main segment
+    is already open -- lanes then cut segments instead of forking streams inside one capture"""
     if lanes is not None:
         _conc['enabled'] = set(lanes)
     _conc['on'] = bool(flag)
-    _conc['stack'], _conc['used'], _conc['keep'], _conc['touched'] = ['main'], {}, {}, []
+    _conc['seg'] = seg if flag else None
+    _conc['stack'], _conc['used'], _conc['keep'] = ['main'], {}, {}
+    _conc['sstack'] = [seg.main] if (flag and seg is not None) else []
     ops.LN_LANE = 'main'
 
 
@@ -174,60 +241,62 @@ def concurrency():
 
 class lane:
     """`with lane('enc', t1, t2...)`: run the body on the side stream `<current lane>/enc`, ordered after everything enqueued
-    so far on the current stream (re-entering a lane therefore adds exactly that dependency).  Lanes nest.  The tensors
+    so far on the current lane (re-entering a lane therefore adds exactly that dependency).  Lanes nest.  The tensors
     named (inputs allocated on another stream that the body reads) are kept alive until the enclosing lane calls
     `join_lanes()` -- the caching allocator would otherwise hand their memory to the producer stream again while the side
     stream is still reading."""
 
     def __init__(self, name, *keep):
-        self.name, self.keep, self.ctx = name, keep, None
+        self.name, self.keep, self.on = name, keep, False
 
     def __enter__(self):
         if not _conc['on'] or self.name not in _conc['enabled']:
             return self
         parent = _conc['stack'][-1]
         if self.name == 'enc' and parent != 'main':
-            # lane T (teacher / mixed forward) is off the critical path, its encoders may as well run one after the other --
-            # and hipStreamEndCapture of ROCm 7.2 crashes when a stream forked from T is joined back into T (measured)
-            return self
+            return self   # lane T is off the critical path: its encoders run one after the other
+        seg = _conc['seg']
         full = parent + '/' + self.name
-        cur = torch.cuda.current_stream()
-        key = (full, cur.device_index)
+        dev = seg.device if seg is not None else torch.cuda.current_device()
+        key = (full, str(dev))
         s = _conc['streams'].get(key)
         if s is None:
-            s = _conc['streams'][key] = torch.cuda.Stream(cur.device)
-        s.wait_stream(cur)
+            s = _conc['streams'][key] = torch.cuda.Stream(dev)
         _conc['used'][full] = s
-        if s not in _conc['touched']:
-            _conc['touched'].append(s)
         _conc['keep'].setdefault(full, []).extend(self.keep)
         _conc['stack'].append(full)
         ops.LN_LANE = full
-        self.ctx = torch.cuda.stream(s)
-        self.ctx.__enter__()
+        self.on = True
+        if seg is not None:
+            seg.cut(waits=[(s, _conc['sstack'][-1])], resume=s)
+            _conc['sstack'].append(s)
+        else:   # forked streams inside the surrounding (single) capture, or plain eager streams
+            s.wait_stream(torch.cuda.current_stream())
+            self.ctx = torch.cuda.stream(s)
+            self.ctx.__enter__()
         return self
 
     def __exit__(self, *exc):
-        if self.ctx is not None:
-            self.ctx.__exit__(*exc)
+        if self.on:
+            seg = _conc['seg']
             _conc['stack'].pop()
             ops.LN_LANE = _conc['stack'][-1]
+            if seg is not None:
+                _conc['sstack'].pop()
+                seg.cut(resume=_conc['sstack'][-1])
+            else:
+                self.ctx.__exit__(*exc)
         return False
 
 
-def join_all_touched():
-    """end of a capture: the origin stream waits once more for EVERY side stream used since concurrency was switched on (those
-    joined into another side stream included), so that no forked stream is left joined only transitively"""
-    if _conc['touched']:
-        cur = torch.cuda.current_stream()
-        for s in _conc['touched']:
-            cur.wait_stream(s)
-        _conc['touched'] = []
+def keep_alive(*tensors):
+    if _conc['on']:
+        _conc['keep'].setdefault(_conc['stack'][-1], []).extend(tensors)
 
 
 def join_lanes(name=None):
-    """make the current lane's stream wait for the lane `name` forked below it (and everything forked below that), or for every
-    lane below it when no name is given; then release what those lanes kept alive"""
+    """make the current lane wait for the lane `name` forked below it (and everything forked below that), or for every lane
+    below it when no name is given; then release what those lanes kept alive"""
     if not _conc['on']:
         return
     me = _conc['stack'][-1]
@@ -235,10 +304,16 @@ def join_lanes(name=None):
 
     def hit(k):
         return (k == root or k.startswith(root + '/')) if root else k.startswith(me + '/')
-    cur = None
-    for full in [k for k in _conc['used'] if hit(k)]:
-        cur = cur or torch.cuda.current_stream()
-        cur.wait_stream(_conc['used'].pop(full))
+    joined = [_conc['used'].pop(full) for full in [k for k in _conc['used'] if hit(k)]]
+    if joined:
+        seg = _conc['seg']
+        if seg is not None:
+            cur = _conc['sstack'][-1]
+            seg.cut(waits=[(cur, s) for s in joined], resume=cur)
+        else:
+            cur = torch.cuda.current_stream()
+            for s in joined:
+                cur.wait_stream(s)
     for k in [k for k in _conc['keep'] if hit(k)]:
         del _conc['keep'][k]
 
@@ -266,4 +341,5 @@ grad_ready_hook = None
 
 def notify_grads_ready(tag, module=None):
     if grad_ready_hook is not None:
+        ops.ln_fold_deferred()   # "final" includes the LayerNorm parameter gradients still sitting in their workspaces
         grad_ready_hook(tag, module)

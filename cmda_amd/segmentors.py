@@ -85,9 +85,10 @@ class EncoderDecoder(nn.Module):
 
     def train_bwd(self, saved, gscale):
         sv_b, sv_h, B = saved
-        dfs = self.decode_head.bwd_train(sv_h, B, gscale)
-        rt.notify_grads_ready('decode_head', self.decode_head)
-        self.backbone.bwd(sv_b, [dfs.get(i) for i in range(4)])
+        with ops.ln_deferral():   # LayerNorm parameter gradients of the whole pass folded by one launch at the end
+            dfs = self.decode_head.bwd_train(sv_h, B, gscale)
+            rt.notify_grads_ready('decode_head', self.decode_head)
+            self.backbone.bwd(sv_b, [dfs.get(i) for i in range(4)])
         rt.join_lanes('wgrad')
 
     def forward_train(self, img, img_metas=None, gt_semantic_seg=None, seg_weight=None, return_feat=False):
@@ -308,17 +309,18 @@ class FusionEncoderDecoder(nn.Module):
         return losses['loss_seg'], (losses, logits, feats), (sv, sv_h, B)
 
     def train_bwd(self, saved, gscale):
-        if saved[0] == 'joint':
-            _, sv, sv_h, B = saved
-            dJ = self.decode_head.bwd_train_joint(sv_h, B, gscale)
+        with ops.ln_deferral():   # LayerNorm parameter gradients of the whole pass folded by one launch at the end
+            if saved[0] == 'joint':
+                _, sv, sv_h, B = saved
+                dJ = self.decode_head.bwd_train_joint(sv_h, B, gscale)
+                rt.notify_grads_ready('decode_head', self.decode_head)
+                self._extract_joint_bwd(sv, dJ, B)
+                return
+            sv, sv_h, B = saved
+            dfeats = self.decode_head.bwd_train(sv_h, B, gscale)
             rt.notify_grads_ready('decode_head', self.decode_head)
-            self._extract_joint_bwd(sv, dJ, B)
-            return
-        sv, sv_h, B = saved
-        dfeats = self.decode_head.bwd_train(sv_h, B, gscale)
-        rt.notify_grads_ready('decode_head', self.decode_head)
-        self._extract_bwd(sv, dfeats, B)
-        rt.join_lanes('wgrad')
+            self._extract_bwd(sv, dfeats, B)
+            rt.join_lanes('wgrad')
 
     def forward_train(self, inputs, gt_semantic_seg, seg_weight=None, return_feat=False, cfg=None):
         holder = {}

@@ -315,6 +315,7 @@ class DACS(nn.Module):
         the control block; `teacher_second` = the teacher's second input (events or ISR, already chosen); `use_events` /
         `direction` only select code paths that are fixed per configuration (student inputs of 'cs2dsec_image+events')."""
         tt = self.train_type
+        rt.refresh(force=True)   # first node of the iteration: all re-laid-out weight copies follow this iteration's masters
         day_image, day_isr, day_label = src['image'], src['img_self_res'], src['label']
         day_events = night_events = None
         if tt == 'cs2dz_image+raw-isr':
@@ -436,17 +437,22 @@ class DACS(nn.Module):
         ops.ln_ws_prealloc(dev, ('main', 'main/enc'))
         ops.zero_ws_prealloc(dev, ('main', 'main/enc'))
         torch.cuda.synchronize(dev)
-        rt.invalidate()    # every weight re-layout must be recorded INSIDE the graph (it is re-run by each replay)
-        g = torch.cuda.CUDAGraph()
-        rt.set_concurrency(bool(getattr(self, 'graph_lanes', True)), getattr(self, 'graph_lane_set', None))   # forked streams = parallel graph branches
+        rt.refresh(force=True)   # every copy exists and is current before the capture starts
+        lanes = getattr(self, 'graph_lane_set', None)
+        seg = rt.SegmentedCapture(dev)
+        g = seg
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        rt.set_concurrency(bool(getattr(self, 'graph_lanes', True)), lanes, seg=seg)
         try:
-            with torch.cuda.graph(g):
-                out = self._iteration(st_src, st_tgt, cb['d'], use_events_struct, second, direction)
-                rt.join_lanes()
-                rt.join_all_touched()
+            seg.begin(seg.main)
+            out = self._iteration(st_src, st_tgt, cb['d'], use_events_struct, second, direction)
+            rt.join_lanes()
+            seg.end()
         finally:
             rt.set_concurrency(False)
-        rt.invalidate()    # the cached re-layouts now live in the graph's pool and hold data only after a replay
+        torch.cuda.synchronize(dev)
         self._graph = dict(graph=g, src=st_src, tgt=st_tgt, second=second, out=out, key=(use_events_struct, direction))
 
     def forward_train(self, **kwargs):

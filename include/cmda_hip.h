@@ -96,6 +96,12 @@ int64_t cmda_layernorm_bwd_ws_floats(int64_t rows, int C);
 int cmda_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres,
     void* dx, float* dgamma, float* dbeta, float* ws, int64_t rows, int C, const float* out_scale, int64_t rows_per_scale,
     void* dx_scaled, int dtype, void* stream);
+/* dgamma == NULL (deferred): the per-block partial sums stay in `ws` -- then a zero-initialised workspace owned by this LayerNorm
+ * layer alone -- until cmda_layernorm_fold_batch folds MANY layers' workspaces into their dgamma / dbeta in one launch
+ * (desc: DEVICE array of n 32-byte records {float* ws; float* dgamma; float* dbeta; int32 C; int32 nslots}; nslots =
+ * cmda_layernorm_slots(); max_c = largest C).  The workspaces are left zeroed. */
+int cmda_layernorm_fold_batch(const void* desc, int n, int max_c, void* stream);
+int cmda_layernorm_slots(void);
 /* out_scale / rows_per_scale / dx_scaled (all or none): second output dx * out_scale[row / rows_per_scale] -- the per-sample
  * DropPath factor (timm DropPath, mix_transformer.py:145-146) of the residual branch that consumes this gradient next. */
 
