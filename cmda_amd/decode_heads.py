@@ -406,27 +406,35 @@ class DAFormerHeadFusion(_HeadBase):
     def joint_ok(self):
         return self.share_decoder and isinstance(self.fuse_layer_image, ASPPWrapper)
 
-    def fwd_joint(self, joint, names, B):
-        """joint: list of 4 (J_l [G*B*N_l, C_l], H_l, W_l); names: the G branch names in joint-buffer order, 'image' first"""
-        G = len(names)
+    def fwd_joint(self, joint, names, B, passes=1):
+        """joint: list of 4 (J_l [G*P*B*N_l, C_l], H_l, W_l); names: the G branch names in joint-buffer order, 'image' first.
+        passes = P > 1: every branch block holds the B samples of P independent forward passes one after the other (the source
+        and the mixed pass of one DACS iteration run the same weights, dacs.py:489-523 / :820-860): BatchNorm then keeps G*P
+        groups of B samples and updates the running statistics pass by pass, branch by branch, as P separate calls would.
+        Returns the logits of pass 0 as a dict (P == 1) or a list of P dicts."""
+        G, P = len(names), passes
         assert names[0] == 'image' and self.joint_ok()
         order = sorted(range(G), key=lambda g: self._REF_ORDER.index(names[g]))
+        order = [g * P + p for p in range(P) for g in order]
         emb, fuse = self._layers('image')
-        feat, sv_b = self._branch_fwd(emb, fuse, joint, G * B, groups=G, order=order)
+        feat, sv_b = self._branch_fwd(emb, fuse, joint, G * P * B, groups=G * P, order=order)
         H, W = sv_b[2], sv_b[3]
-        logits, sv_c = self._cls_fwd(feat, G * B, H, W, with_dropout=True, drop_B=B)
-        out = {k: None for k in self._KEY.values()}
-        for g, n in enumerate(names):
-            out[self._KEY[n]] = logits[g * B:(g + 1) * B]
-        return out, (sv_b, sv_c, H, W, tuple(names), logits)
+        logits, sv_c = self._cls_fwd(feat, G * P * B, H, W, with_dropout=True, drop_B=P * B)
+        outs = []
+        for p in range(P):
+            out = {k: None for k in self._KEY.values()}
+            for g, n in enumerate(names):
+                out[self._KEY[n]] = logits[(g * P + p) * B:(g * P + p + 1) * B]
+            outs.append(out)
+        return (outs[0] if P == 1 else outs), (sv_b, sv_c, H, W, tuple(names), logits, P)
 
     def bwd_joint(self, saved, dlogits_joint, B):
-        """dlogits_joint fp32 [G*B,h,w,nc] -> {level: d joint features [G*B*N_l, C_l]}"""
-        sv_b, sv_c, H, W, names, _ = saved
+        """dlogits_joint fp32 [G*P*B,h,w,nc] -> {level: d joint features [G*P*B*N_l, C_l]}"""
+        sv_b, sv_c, H, W, names, _, P = saved
         G = len(names)
         emb, fuse = self._layers('image')
-        dfeat = self._cls_bwd(sv_c, dlogits_joint, G * B, H, W)
-        return self._branch_bwd(emb, fuse, sv_b, dfeat, G * B)
+        dfeat = self._cls_bwd(sv_c, dlogits_joint, G * P * B, H, W)
+        return self._branch_bwd(emb, fuse, sv_b, dfeat, G * P * B)
 
     def _loss_mix(self, logits, gt, seg_weight, cfg):
         """BaseDecodeHeadFusion.forward_train's loss mix, decode_head.py:508-528"""
@@ -457,49 +465,34 @@ class DAFormerHeadFusion(_HeadBase):
         acc = terms['fusion_output'][1] if 'fusion_output' in terms else terms['image_output'][1]
         return {'loss_seg': total, 'acc_seg': acc}, sv_l, coef
 
-    def fwd_train_joint(self, joint, names, B, gt, seg_weight=None, cfg=None):
-        logits, saved = self.fwd_joint(joint, names, B)
-        losses, sv_l, coef = self._loss_mix(logits, gt, seg_weight, cfg)
-        return losses, logits, (saved, sv_l, coef)
+    def fwd_train_joint(self, joint, names, B, gt, seg_weight=None, cfg=None, passes=1):
+        """passes > 1: gt / seg_weight are lists (one per pass); returns lists of losses and logits"""
+        logits, saved = self.fwd_joint(joint, names, B, passes)
+        if passes == 1:
+            losses, sv_l, coef = self._loss_mix(logits, gt, seg_weight, cfg)
+            return losses, logits, (saved, [sv_l], coef)
+        losses, sv_ls = [], []
+        for p in range(passes):
+            l, sv_l, coef = self._loss_mix(logits[p], gt[p], seg_weight[p], cfg)
+            losses.append(l)
+            sv_ls.append(sv_l)
+        return losses, logits, (saved, sv_ls, coef)
 
     def bwd_train_joint(self, saved_all, B, gscale=None, mul=1.0):
-        saved, sv_l, coef = saved_all
-        names, logits = saved[4], saved[5]
+        saved, sv_ls, coef = saved_all
+        names, logits, P = saved[4], saved[5], saved[6]
         ii, lwt = self.ignore_index, self.loss_decode.loss_weight
         dl = torch.empty_like(logits)
         for g, n in enumerate(names):
             k = self._KEY[n]
-            ce_losses_bwd(sv_l[k], gscale, mul * coef[k], ii, lwt, out=dl[g * B:(g + 1) * B])
+            for p in range(P):
+                ce_losses_bwd(sv_ls[p][k], gscale, mul * coef[k], ii, lwt, out=dl[(g * P + p) * B:(g * P + p + 1) * B])
         return self.bwd_joint(saved, dl, B)
 
     def fwd_train(self, inputs, B, gt, seg_weight=None, cfg=None):
-        lw = cfg['loss_weight']
         logits, saved = self.fwd(inputs, B)
-        ii, lwt = self.ignore_index, self.loss_decode.loss_weight
-        if seg_weight is None:
-            seg_weight = torch.ones(gt.shape[0], gt.shape[2], gt.shape[3], dtype=torch.float32, device=gt.device)
-        terms, sv_l = {}, {}
-        for key in ('image_output', 'events_output', 'fusion_output', 'img_self_res_output'):
-            if logits[key] is not None:
-                loss, acc, sv = ce_losses_fwd(logits[key], gt, seg_weight, ii, lwt)
-                terms[key] = (loss, acc)
-                sv_l[key] = sv
-        coef = {'image_output': lw['image']}
-        if 'fusion_output' in terms:
-            coef['fusion_output'] = lw['fusion']
-        if 'img_self_res_output' in terms:
-            coef['img_self_res_output'] = lw['img_self_res']
-            coef['events_output'] = lw['events'] / 2
-        else:
-            coef['events_output'] = lw['events']
-        # the reference accumulates fusion, image, then (isr, events): keep that order of fp32 additions
-        order = [k for k in ('fusion_output', 'image_output', 'img_self_res_output', 'events_output') if k in coef]
-        total = None
-        for k in order:
-            t = terms[k][0] * coef[k]
-            total = t if total is None else total + t
-        acc = terms['fusion_output'][1] if 'fusion_output' in terms else terms['image_output'][1]
-        return {'loss_seg': total, 'acc_seg': acc}, logits, (saved, sv_l, coef)
+        losses, sv_l, coef = self._loss_mix(logits, gt, seg_weight, cfg)
+        return losses, logits, (saved, sv_l, coef)
 
     def bwd_train(self, saved_all, B, gscale=None, mul=1.0):
         saved, sv_l, coef = saved_all

@@ -254,16 +254,22 @@ class FusionEncoderDecoder(nn.Module):
         """extract_feat (:698-721) for the default fusion route with the outputs laid out for DAFormerHeadFusion.fwd_joint: per
         level one buffer J_l [G*B*N_l, C_l] holding [image | fusion | events | ISR] blocks.  The image encoder writes block 0,
         the event encoder -- run ONCE over the events and the ISR as a 2B batch (same weights, :703-712) -- blocks 2 and 3, the
-        fusion module block 1.  No feature is copied."""
-        B, _, H, W = image.shape
+        fusion module block 1.  No feature is copied.  Every input may be a LIST of P tensors (the samples of P passes that run
+        the same weights, `train_fwd_passes`): B below is then the total over the passes and each block holds pass 0's samples,
+        then pass 1's, ..."""
+        as_list = lambda t: list(t) if isinstance(t, (list, tuple)) else [t]
+        image, events = as_list(image), as_list(events)
+        img_self_res = as_list(img_self_res) if img_self_res is not None else None
+        B = sum(t.shape[0] for t in image)
+        H, W = image[0].shape[2:]
         names = ('image', 'fusion', 'events') + (('isr',) if img_self_res is not None else ())
         G = len(names)
         dims = self.backbone_image.embed_dims
         shapes = self.backbone_image.feature_shapes(H, W)
-        dev = image.device
+        dev = image[0].device
         joint = [torch.empty(G * B * h * w, c, dtype=rt.compute_dtype(), device=dev) for (h, w), c in zip(shapes, dims)]
         n = [B * h * w for h, w in shapes]
-        ev_in = [events, img_self_res] if img_self_res is not None else [events]
+        ev_in = events + (img_self_res or [])
         with rt.lane('enc', *ev_in, *joint):   # the two encoders are independent until the fusion module: side by side
             f_ev, sv_e = self.backbone_events.fwd(ev_in, save=save, out_feats=[J[2 * m:G * m] for J, m in zip(joint, n)])
         f_image, sv_i = self.backbone_image.fwd(image, save=save, out_feats=[J[:m] for J, m in zip(joint, n)])
@@ -308,11 +314,27 @@ class FusionEncoderDecoder(nn.Module):
         losses, logits, sv_h = self.decode_head.fwd_train(feats, B, gt, seg_weight, cfg)
         return losses['loss_seg'], (losses, logits, feats), (sv, sv_h, B)
 
+    def train_fwd_passes(self, passes, cfg):
+        """P training passes with the same weights as ONE pass over P*B samples (passes: list of (inputs, gt, seg_weight)): the
+        source and the mixed step of a DACS iteration (dacs.py:489-523, :820-860) differ only in their inputs and targets, and
+        the reference's `backward()` calls just add their gradients up.  Per-pass state -- BatchNorm batch statistics and the
+        order of the running-statistic updates, the loss normalisation -- is kept per pass (DAFormerHeadFusion.fwd_joint).
+        Returns ([(loss, losses)] per pass, saved); `train_bwd(saved, gscale)` back-propagates the SUM of the pass losses."""
+        first = passes[0][0]
+        assert self._joint_ok(first['image'], first['events'], cfg)
+        P = len(passes)
+        isr = [p[0]['img_self_res'] for p in passes] if first.get('img_self_res') is not None else None
+        feats, names, sv, Bt = self._extract_joint([p[0]['image'] for p in passes], [p[0]['events'] for p in passes], isr, True)
+        losses, logits, sv_h = self.decode_head.fwd_train_joint(feats, names, Bt // P, [p[1] for p in passes],
+                                                                [p[2] for p in passes], cfg, passes=P)
+        return [(l['loss_seg'], l) for l in losses], ('joint', sv, sv_h, Bt, P)
+
     def train_bwd(self, saved, gscale):
         with ops.ln_deferral():   # LayerNorm parameter gradients of the whole pass folded by one launch at the end
             if saved[0] == 'joint':
-                _, sv, sv_h, B = saved
-                dJ = self.decode_head.bwd_train_joint(sv_h, B, gscale)
+                _, sv, sv_h, B = saved[:4]
+                P = saved[4] if len(saved) > 4 else 1
+                dJ = self.decode_head.bwd_train_joint(sv_h, B // P, gscale)
                 rt.notify_grads_ready('decode_head', self.decode_head)
                 self._extract_joint_bwd(sv, dJ, B)
                 return

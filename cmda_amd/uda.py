@@ -335,11 +335,10 @@ class DACS(nn.Module):
         lab = day_label.view(B, H, W)
         classes = ctl['classes']
         # Schedule.  The reference runs source step, teacher, mixing, mixed step one after the other (dacs.py:489-860), but the
-        # only data dependencies are: mixing needs the teacher's pseudo-labels and the generator's events; the mixed BACKWARD
-        # must follow the source backward (both accumulate into the same gradients); the student's BatchNorm running statistics
-        # must see the source forward before the mixed forward.  So lane 'T' carries teacher -> mixing -> mixed FORWARD next to
-        # the main lane's generator -> source forward -> source backward; the mixed backward follows the join.  With the lanes
-        # switched off (eager launches) the same code simply runs in program order.
+        # only data dependencies are: mixing needs the teacher's pseudo-labels and the generator's events; the student's
+        # gradients are the sum over both steps; its BatchNorm running statistics see the source step before the mixed step.
+        # So: teacher -> mixing (lane 'T') next to the generator (main lane), then the student ONCE over source + mixed samples.
+        # With the lanes switched off (eager launches) the same code simply runs in program order.
 
         # ---- teacher pseudo-labels (dacs.py:653-711) -----------------------------------------------------------------------------
         with rt.lane('T', night_image, teacher_second, *[v for v in tgt.values() if isinstance(v, torch.Tensor)]):
@@ -376,42 +375,61 @@ class DACS(nn.Module):
             with rt.lane('T', day_events):
                 mixed_events = ops.class_mix(day_events, night_events, lab, classes)
 
-        # ---- source forward (dacs.py:489-523) ------------------------------------------------------------------------------------
+        # ---- student inputs: source (dacs.py:489-523) and mixed (dacs.py:820-860) ---------------------------------------------------
         if tt == 'cs2dz_image+raw-isr':
-            inputs = {'image': day_image, 'events': day_isr}
+            in_src = {'image': day_image, 'events': day_isr}
+            in_mix = {'image': mixed_img, 'events': mixed_isr}
         elif tt == 'cs2dsec_image+events_together':
-            inputs = {'image': day_image, 'events': day_events, 'img_self_res': day_isr}
+            in_src = {'image': day_image, 'events': day_events, 'img_self_res': day_isr}
+            in_mix = {'image': mixed_img, 'events': mixed_events, 'img_self_res': mixed_isr}
         else:
-            inputs = {'image': day_image, 'events': day_events if use_events else day_isr}
-        loss, (losses, _, _), saved_src = student.train_fwd(inputs, day_label, None, cfg_s)
-        log_vars['decode.loss_seg'], log_vars['decode.acc_seg'], log_vars['loss'] = loss, losses['acc_seg'], loss
-
-        # ---- mixed forward (dacs.py:820-860), after the source forward (BatchNorm running statistics), next to the source backward
-        if tt == 'cs2dz_image+raw-isr':
-            inputs = {'image': mixed_img, 'events': mixed_isr}
-        elif tt == 'cs2dsec_image+events_together':
-            inputs = {'image': mixed_img, 'events': mixed_events, 'img_self_res': mixed_isr}
-        else:
-            inputs = {'image': mixed_img, 'events': mixed_events if use_events else mixed_isr}
-        with rt.lane('T'):
-            loss, (losses, _, _), saved_mix = student.train_fwd(inputs, mixed_lbl, mixed_weight, cfg_s)
-        log_vars['mix.decode.loss_seg'], log_vars['mix.decode.acc_seg'] = loss, losses['acc_seg']
-        log_vars['loss'] = loss   # _parse_losses of the mixed step overwrites 'loss' (dacs.py:851-857)
-
-        # ---- source backward, then (gradients accumulate) mixed backward -----------------------------------------------------------
-        student.train_bwd(saved_src, one)
-        del saved_src
-        rt.join_lanes('T')
-        # the second (last) backward pass of the iteration: gradients reported final by this pass are final for the step, so a
-        # data-parallel driver may start their all-reduce underneath the rest of the pass (runtime.grad_ready_hook)
+            in_src = {'image': day_image, 'events': day_events if use_events else day_isr}
+            in_mix = {'image': mixed_img, 'events': mixed_events if use_events else mixed_isr}
+        hook = getattr(self, 'final_pass_grad_hook', None)
+        if hook is not None and dev.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+            hook = None
         prev_hook = rt.grad_ready_hook
-        if getattr(self, 'final_pass_grad_hook', None) is not None and not (dev.type == 'cuda' and torch.cuda.is_current_stream_capturing()):
-            rt.grad_ready_hook = self.final_pass_grad_hook
-        try:
-            student.train_bwd(saved_mix, one)
-        finally:
-            rt.grad_ready_hook = prev_hook
-        del saved_mix
+
+        if (getattr(self, 'fused_student_passes', True) and hasattr(student, 'train_fwd_passes')
+                and student._joint_ok(in_src['image'], in_src['events'], cfg_s)):
+            # ONE student pass over the source and the mixed samples: both steps run the same weights (the optimizer steps after
+            # both, dacs.py:523 / :860 only accumulate gradients), so the 2B samples travel as one batch -- half the launches,
+            # twice the rows per GEMM.  What is per step in the reference stays per step: BatchNorm batch statistics and the order
+            # of the running-statistic updates (source first), the loss normalisation, DropPath / Dropout2d draws per sample.
+            rt.join_lanes('T')
+            ((l_src, d_src), (l_mix, d_mix)), saved = student.train_fwd_passes(
+                [(in_src, day_label, None), (in_mix, mixed_lbl, mixed_weight)], cfg_s)
+            log_vars['decode.loss_seg'], log_vars['decode.acc_seg'] = l_src, d_src['acc_seg']
+            log_vars['mix.decode.loss_seg'], log_vars['mix.decode.acc_seg'] = l_mix, d_mix['acc_seg']
+            log_vars['loss'] = l_mix   # _parse_losses of the mixed step overwrites 'loss' (dacs.py:851-857)
+            # the only backward pass of the iteration: gradients it reports final are final for the step, so a data-parallel
+            # driver may start their all-reduce underneath the rest of the pass (runtime.grad_ready_hook)
+            if hook is not None:
+                rt.grad_ready_hook = hook
+            try:
+                student.train_bwd(saved, one)
+            finally:
+                rt.grad_ready_hook = prev_hook
+            del saved
+        else:
+            # two passes (routes the joint pass does not cover): the mixed forward runs after the source forward (BatchNorm
+            # running statistics), next to the source backward; the mixed backward follows the join (gradients accumulate)
+            loss, (losses, _, _), saved_src = student.train_fwd(in_src, day_label, None, cfg_s)
+            log_vars['decode.loss_seg'], log_vars['decode.acc_seg'], log_vars['loss'] = loss, losses['acc_seg'], loss
+            with rt.lane('T'):
+                loss, (losses, _, _), saved_mix = student.train_fwd(in_mix, mixed_lbl, mixed_weight, cfg_s)
+            log_vars['mix.decode.loss_seg'], log_vars['mix.decode.acc_seg'] = loss, losses['acc_seg']
+            log_vars['loss'] = loss   # _parse_losses of the mixed step overwrites 'loss' (dacs.py:851-857)
+            student.train_bwd(saved_src, one)
+            del saved_src
+            rt.join_lanes('T')
+            if hook is not None:   # the second (last) backward pass: see above
+                rt.grad_ready_hook = hook
+            try:
+                student.train_bwd(saved_mix, one)
+            finally:
+                rt.grad_ready_hook = prev_hook
+            del saved_mix
         extras = dict(mixed_img=mixed_img, mixed_lbl=mixed_lbl, mixed_isr=mixed_isr, pseudo_weight=mixed_weight,
                       pseudo_label=pseudo_label, classes=classes, mixed_events=mixed_events, day_events=day_events,
                       teacher_logits=ema, pseudo_count=count)

@@ -114,6 +114,14 @@ def run_case(tgt, dims, ch, dtype, B=2, H=64, W=64, iters=1, graph=False, shift_
                                      draws=oracle_draws(dacs.last_draws))
         outs.append(({k: v.detach().clone() for k, v in log_vars.items()}, mix, grads, o,
                      {n: q.grad.clone() for n, q in ref.named_parameters()}))
+    # BatchNorm running statistics of the student after the iterations: source step first, then the mixed step, branch by branch
+    mine = dict(dacs.model.named_buffers())
+    seen = 0
+    for n, b in ref.named_buffers():
+        if 'running_' in n:
+            assert_close(mine[n], b, 1e-4 if dtype == torch.float32 else 5e-2, atol=1e-5, name='student ' + n)
+            seen += 1
+    assert seen > 0
     return dacs, ema, outs
 
 
