@@ -242,10 +242,21 @@ def gemm_roofline(step, workload):
     step()
     torch.cuda.synchronize()
     prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
-    gemm_ms = sum(e0.elapsed_time(e1) for _, e0, e1, _ in prof)
-    gemm_flops = sum(f for f, _, _, _ in prof)
-    gemm_bytes = sum(b for _, _, _, b in prof)
+    gemm_ms = sum(e0.elapsed_time(e1) for _, e0, e1, _, _ in prof)
+    gemm_flops = sum(f for f, _, _, _, _ in prof)
+    gemm_bytes = sum(b for _, _, _, b, _ in prof)
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    if os.environ.get('CMDA_BENCH_GEMM_HIST'):   # per-shape table for tuning (tools/gpu): where the GEMM time of a step goes
+        hist = {}
+        for f, e0, e1, _, key in prof:
+            h = hist.setdefault(key, [0, 0.0, 0.0])
+            h[0] += 1
+            h[1] += e0.elapsed_time(e1)
+            h[2] += f
+        with open(os.environ['CMDA_BENCH_GEMM_HIST'], 'w') as fh:
+            fh.write('M N K batch splits conv a_kstr b_kstr atomic out_f32 | calls ms_total us_avg TFLOP/s\n')
+            for key, (c, ms, f) in sorted(hist.items(), key=lambda kv: -kv[1][1]):
+                fh.write(' '.join(str(int(v)) for v in key) + f' | {c} {ms:.3f} {ms / c * 1e3:.1f} {f / ms / 1e9:.1f}\n')
     pmc = profile_json(f'pmc_traffic_{workload}')
     roof = {'bound': 'mfma', 'kernel': 'gemm_glds_kernel + gemm_kernel (bf16 MFMA tile GEMM / implicit-GEMM conv family, all '
                                        'template instances)',

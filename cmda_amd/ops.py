@@ -97,7 +97,8 @@ def gemm(A, B, out, M, N, K, *, a_kstrided=False, b_kstrided=False, ldc=None, ba
         def _unique(v):  # bytes of the tensor behind an operand view (an im2col view re-reads, the tensor is counted once)
             return (v.R // max(1, v.OH * v.OW) * v.H * v.W * v.C if v.conv else v.R * v.Cc * nb) * es
         cbytes = M * N * nb * (4 if out_f32 else es) * (2 if (atomic or beta != 0.0) else 1)
-        GEMM_PROFILE.append((2.0 * M * N * K * nb, e0, e1, _unique(A) + _unique(B) + cbytes + (M * N * nb * es if res is not None else 0)))
+        GEMM_PROFILE.append((2.0 * M * N * K * nb, e0, e1, _unique(A) + _unique(B) + cbytes + (M * N * nb * es if res is not None else 0),
+                             (M, N, K, nb, splits, bool(A.conv or B.conv), bool(a_kstrided), bool(b_kstrided), bool(atomic), out_f32)))
         return out
     call('cmda_gemm', ctypes.byref(p), stream_of(out))
     return out
