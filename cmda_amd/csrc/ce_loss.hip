@@ -14,7 +14,7 @@
 // tensor): logits stay NHWC fp32 at 1/4 resolution (L2 resident, 1.2 MB per sample) and each thread rebuilds the 19
 // class scores of one full-resolution pixel on the fly.  HBM-bound; algorithmic bytes per sample:
 // fwd  19*h*w*4 + H*W*(8 label + 4 weight + 4 lse out); bwd the same + 19*h*w*4 written.
-// Backward is a deterministic gather over the 1/4-resolution grid (no atomics); tiled through LDS when the tile fits.
+// Backward is a deterministic gather over the 1/4-resolution grid (no atomics), one thread per (pixel, class).
 #include "bilinear.h"
 
 namespace {
@@ -136,12 +136,13 @@ __global__ void ce_bwd_kernel(const float* __restrict__ logits, const long long*
   }
 }
 
-// Tiled version of the same gather (used whenever the tile's full-resolution footprint fits in LDS): a block owns 8 x 4
-// low-resolution pixels.  Phase 1 computes weight * (softmax - onehot) of every full-resolution pixel of the footprint ONCE
-// into LDS (the per-pixel kernel above rebuilds the 19 up-sampled scores of each full-resolution pixel for every one of
-// the ~4 low-resolution pixels it touches, and only 1024 blocks of it exist); phase 2 is the same ordered gather, one
-// thread per (low-resolution pixel, class), reading LDS.
-constexpr int kTileX = 8, kTileY = 4, kMaxTilePx = 960;
+// The same gather with one thread per (low-resolution pixel, class) -- the form that runs whenever the up-sampling factor is
+// <= 6 (the path's is 4).  exp(s_c - lse) needs no other class (the forward saved lse), so nothing is shared through LDS and
+// nothing is synchronised: 19 adjacent lanes read the same label / weight / lse (one broadcast load) and 19 consecutive
+// logits (one coalesced line); per full-resolution row the thread keeps the 2 x 3 low-resolution logits its column can touch
+// in registers and rebuilds each pixel's score with the forward's own bilin_mix (same rounding, so the softmax is the
+// forward's).  B*h*w*nc threads (622 k at 2 x 128 x 128 x 19) instead of 1024 LDS-bound blocks.
+constexpr int kMaxTapsX = 16;
 
 static __device__ __forceinline__ void lo_hi_range(int y, int h, int H, float ish, int& Y0, int& Y1) {
   Y0 = (int)floorf(((float)y - 0.5f) * ish - 0.5f) - 1;
@@ -152,85 +153,66 @@ static __device__ __forceinline__ void lo_hi_range(int y, int h, int H, float is
   Y1 = min(Y1, H - 1);
 }
 
-__global__ __launch_bounds__(256) void ce_bwd_tile_kernel(const float* __restrict__ logits, const long long* __restrict__ label,
-                                                          const float* __restrict__ weight, const float* __restrict__ lse,
-                                                          const float* __restrict__ gscale_ptr, float gscale_mul,
-                                                          float* __restrict__ dlogits, int B, int h, int w, int H, int W,
-                                                          int nc, int ignore_index) {
-  CMDA_DYN_SMEM(tile_raw);
-  float* tile = reinterpret_cast<float*>(tile_raw);  // [TH][TW][nc]
+__global__ __launch_bounds__(256) void ce_bwd_gather_kernel(const float* __restrict__ logits, const long long* __restrict__ label,
+                                                            const float* __restrict__ weight, const float* __restrict__ lse,
+                                                            const float* __restrict__ gscale_ptr, float gscale_mul,
+                                                            float* __restrict__ dlogits, int B, int h, int w, int H, int W,
+                                                            int nc, int ignore_index) {
+  const long total = (long)B * h * w * nc;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
   const float sh = (float)h / (float)H, sw = (float)w / (float)W;
   const float ish = (float)H / (float)h, isw = (float)W / (float)w;
-  const int tiles_x = (w + kTileX - 1) / kTileX, tiles_y = (h + kTileY - 1) / kTileY;
-  const int bt = blockIdx.x;
-  const int b = bt / (tiles_x * tiles_y), tr = bt - b * tiles_x * tiles_y;
-  const int y0 = (tr / tiles_x) * kTileY, x0 = (tr % tiles_x) * kTileX;
-  const int y1 = min(y0 + kTileY, h) - 1, x1 = min(x0 + kTileX, w) - 1;
-  int Ya, Yb, Xa, Xb, t0, t1;
-  lo_hi_range(y0, h, H, ish, Ya, t1);
-  lo_hi_range(y1, h, H, ish, t0, Yb);
-  lo_hi_range(x0, w, W, isw, Xa, t1);
-  lo_hi_range(x1, w, W, isw, t0, Xb);
-  const int TW = Xb - Xa + 1, TH = Yb - Ya + 1;
-  // interpolation weight of every footprint row / column onto each of the tile's low-resolution rows / columns
-  float* wyt = tile + (long)TW * TH * nc;  // [kTileY][TH]
-  float* wxt = wyt + kTileY * TH;          // [kTileX][TW]
-  for (int i = threadIdx.x; i < kTileY * TH + kTileX * TW; i += blockDim.x) {
-    if (i < kTileY * TH) {
-      const int ly = i / TH, Y = Ya + i % TH;
-      const BilinTap t = bilin_tap(Y, h, H, sh);
-      wyt[i] = (t.i0 == y0 + ly ? t.l0 : 0.f) + (t.i1 == y0 + ly ? t.l1 : 0.f);
-    } else {
-      const int j = i - kTileY * TH;
-      const int lx = j / TW, X = Xa + j % TW;
-      const BilinTap t = bilin_tap(X, w, W, sw);
-      wxt[j] = (t.i0 == x0 + lx ? t.l0 : 0.f) + (t.i1 == x0 + lx ? t.l1 : 0.f);
-    }
-  }
-  // ---- phase 1: weight * (p - onehot) per full-resolution pixel of the footprint
-  for (int i = threadIdx.x; i < TW * TH; i += blockDim.x) {
-    const int Y = Ya + i / TW, X = Xa + i % TW;
-    const long pi = ((long)b * H + Y) * W + X;
-    const long long lab = label[pi];
-    float* t = tile + (long)i * nc;
-    const float coef = (lab == ignore_index || lab < 0 || lab >= nc) ? 0.f : (weight ? weight[pi] : 1.f);
-    if (coef == 0.f) {
-      for (int c = 0; c < nc; ++c) t[c] = 0.f;
-      continue;
-    }
-    const BilinTap ty = bilin_tap(Y, h, H, sh), tx = bilin_tap(X, w, W, sw);
-    float s[kMaxClasses];
-    upsample_scores<kMaxClasses>(logits, b, h, w, nc, ty, tx, s);
-    const float l = lse[pi];
+  const int c = (int)(i % nc);
+  const long p = i / nc;
+  const int x = (int)(p % w);
+  const long t = p / w;
+  const int y = (int)(t % h);
+  const int b = (int)(t / h);
+  int Y0, Y1, X0, X1;
+  lo_hi_range(y, h, H, ish, Y0, Y1);
+  lo_hi_range(x, w, W, isw, X0, X1);
+  // the column taps of this thread's x, once: weight onto x and which of the three cached columns each tap reads
+  float wxs[kMaxTapsX], lx0[kMaxTapsX], lx1[kMaxTapsX];
+  unsigned sel0 = 0, sel1 = 0;  // bit k: tap 0 reads column x (else x-1); tap 1 reads column x (else x+1)
+  const int nX = X1 - X0 + 1;
 #pragma unroll
-    for (int c = 0; c < kMaxClasses; ++c)
-      if (c < nc) t[c] = coef * (__expf(s[c] - l) - (c == (int)lab ? 1.f : 0.f));
-  }
-  __syncthreads();
-  // ---- phase 2: ordered gather, thread = (low-resolution pixel, class)
-  const float gscale = (gscale_ptr ? *gscale_ptr : 1.f) * gscale_mul;
-  const int npx = (y1 - y0 + 1) * (x1 - x0 + 1), tw = x1 - x0 + 1;
-  for (int o = threadIdx.x; o < npx * nc; o += blockDim.x) {
-    const int px = o / nc, c = o - px * nc;
-    const int y = y0 + px / tw, x = x0 + px % tw;
-    int Y0, Y1, X0, X1;
-    lo_hi_range(y, h, H, ish, Y0, Y1);
-    lo_hi_range(x, w, W, isw, X0, X1);
-    float g = 0.f;
-    const float* wyr = wyt + (y - y0) * TH - Ya;
-    const float* wxr = wxt + (x - x0) * TW - Xa;
-    for (int Y = Y0; Y <= Y1; ++Y) {
-      const float wy = wyr[Y];
-      if (wy == 0.f) continue;
-      const float* trow = tile + ((long)(Y - Ya) * TW - Xa) * nc + c;
-      for (int X = X0; X <= X1; ++X) {
-        const float wx = wxr[X];
-        if (wx == 0.f) continue;
-        g += wy * wx * trow[(long)X * nc];
-      }
+  for (int k = 0; k < kMaxTapsX; ++k) {
+    wxs[k] = 0.f; lx0[k] = 0.f; lx1[k] = 0.f;
+    if (k < nX) {
+      const BilinTap tx = bilin_tap(X0 + k, w, W, sw);
+      wxs[k] = (tx.i0 == x ? tx.l0 : 0.f) + (tx.i1 == x ? tx.l1 : 0.f);
+      lx0[k] = tx.l0;
+      lx1[k] = tx.l1;
+      sel0 |= (tx.i0 == x ? 1u : 0u) << k;
+      sel1 |= (tx.i1 == x ? 1u : 0u) << k;
     }
-    dlogits[(((long)b * h + y) * w + x) * nc + c] = gscale * g;
   }
+  const int xm = max(x - 1, 0), xp = min(x + 1, w - 1);
+  const float* Lb = logits + (long)b * h * w * nc + c;
+  float g = 0.f;
+  for (int Y = Y0; Y <= Y1; ++Y) {
+    const BilinTap ty = bilin_tap(Y, h, H, sh);
+    const float wy = (ty.i0 == y ? ty.l0 : 0.f) + (ty.i1 == y ? ty.l1 : 0.f);
+    if (wy == 0.f) continue;
+    const float* r0 = Lb + (long)ty.i0 * w * nc;
+    const float* r1 = Lb + (long)ty.i1 * w * nc;
+    const float a0 = r0[(long)xm * nc], a1 = r0[(long)x * nc], a2 = r0[(long)xp * nc];
+    const float b0 = r1[(long)xm * nc], b1 = r1[(long)x * nc], b2 = r1[(long)xp * nc];
+    const long rowp = ((long)b * H + Y) * W + X0;
+#pragma unroll
+    for (int k = 0; k < kMaxTapsX; ++k) {
+      if (k >= nX || wxs[k] == 0.f) continue;
+      const long long lab = label[rowp + k];
+      if (lab == ignore_index || lab < 0 || lab >= nc) continue;
+      const float coef = wy * wxs[k] * (weight ? weight[rowp + k] : 1.f);
+      if (coef == 0.f) continue;
+      const bool s0 = (sel0 >> k) & 1u, s1 = (sel1 >> k) & 1u;
+      const float sc = bilin_mix(s0 ? a1 : a0, s1 ? a1 : a2, s0 ? b1 : b0, s1 ? b1 : b2, lx0[k], lx1[k], ty.l0, ty.l1);
+      g += coef * (__expf(sc - lse[rowp + k]) - (c == (int)lab ? 1.f : 0.f));
+    }
+  }
+  dlogits[i] = (gscale_ptr ? *gscale_ptr : 1.f) * gscale_mul * g;
 }
 
 // label = first arg-max of the up-sampled scores; prob = 1 / sum exp(s - max); count += (prob >= thr)
@@ -321,20 +303,13 @@ extern "C" int cmda_ce_upsample_bwd(const float* logits, const int64_t* label, c
                                     int H, int W, int nc, int ignore_index, void* stream) {
   if ((long)B * h * w <= 0) return CMDA_OK;
   if (nc <= 0 || nc > kMaxClasses) return CMDA_ERR_SHAPE;
-  // worst-case full-resolution footprint of an 8 x 4 tile (the kernel's own lo_hi_range adds <= 3 pixels per side)
-  const long TW = (long)ceil((double)(kTileX + 1) * W / w) + 4, TH = (long)ceil((double)(kTileY + 1) * H / h) + 4;
-  if (TW * TH <= kMaxTilePx && h <= H && w <= W) {
-    const long tiles = (long)B * ((w + kTileX - 1) / kTileX) * ((h + kTileY - 1) / kTileY);
-    if (tiles > 0x7fffffffL) return CMDA_ERR_SHAPE;
-#ifndef CMDA_EMU
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(ce_bwd_tile_kernel),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                       (kMaxTilePx * kMaxClasses + 1024) * (int)sizeof(float));  // > 64 KiB needs opt-in
-    if (attr != hipSuccess) return CMDA_ERR_HIP;
-#endif
-    CMDA_LAUNCH(ce_bwd_tile_kernel, dim3((unsigned)tiles), dim3(256),
-                (size_t)((TW * TH * nc + kTileY * TH + kTileX * TW) * sizeof(float)), stream, logits,
-                (const long long*)label, weight, lse, gscale_ptr, gscale_mul, dlogits, B, h, w, H, W, nc, ignore_index);
+  // column taps one low-resolution pixel can receive (lo_hi_range's window): the register-resident form holds up to 16
+  const long taps = (long)ceil(2.0 * W / w) + 4;
+  if (taps <= kMaxTapsX && h <= H && w <= W) {
+    const long blocks = ((long)B * h * w * nc + 255) / 256;
+    if (blocks > 0x7fffffffL) return CMDA_ERR_SHAPE;
+    CMDA_LAUNCH(ce_bwd_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, logits, (const long long*)label, weight, lse,
+                gscale_ptr, gscale_mul, dlogits, B, h, w, H, W, nc, ignore_index);
     CMDA_CHECK_LAUNCH();
   }
   CMDA_LAUNCH(ce_bwd_kernel, dim3(grid_for((long)B * h * w)), dim3(256), 0, stream, logits, (const long long*)label,
