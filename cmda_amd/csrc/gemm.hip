@@ -62,7 +62,7 @@ int launch_dtype(GemmParams& p, void* stream) {
     else if (blocks(128, 64) * sp >= 2048) tile = 1;
     else tile = 2;
   }
-  if (p.tile_hint >= 1 && p.tile_hint <= 4) tile = p.tile_hint - 1;  // caller's explicit tile choice (tuning sweeps, tests)
+  if ((p.tile_hint & 15) >= 1 && (p.tile_hint & 15) <= 4 && p.tile_hint > 0) tile = (p.tile_hint & 15) - 1;  // caller's explicit tile choice (tuning sweeps, tests)
   if constexpr (sizeof(T) == 2) {
     const bool no_glds = p.tile_hint < 0;  // caller asks for the register-staged kernel (tuning sweeps)
     // LDS-DMA path: every operand mode with aligned 16-byte chunks; transposed-conv / reflect views and operands

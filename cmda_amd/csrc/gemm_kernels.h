@@ -853,6 +853,10 @@ int launch_glds(const GemmParams& p, void* stream) {
     constexpr long kStage = (long)(BM + BN) * 128;
     const long resident = 256L * (4 * kStage <= 65536 ? 2 : 1);
     const long nkt = ((long)p.K + 63) / 64 / (p.splits > 0 ? p.splits : 1);
+    const int force = p.tile_hint > 0 ? (p.tile_hint >> 4) : 0;   // tuning sweeps (tools/gemm_sweep.py): stages in bits 4.. of the hint
+    if (force) return force == 4 ? launch_glds_ns<TM, TN, NW, 4>(p, grid, stream) : launch_glds_ns<TM, TN, NW, 0>(p, grid, stream);
+    // (deeper than 4 -- 8 x 16 KiB on the 64x64 tile, 6 x 24 KiB on 128x64, one block per CU -- measured slower on every shape
+    // of the step: profiles/r02_gemm_sweep.txt)
     if (tiles * zz <= resident && nkt >= 3) return launch_glds_ns<TM, TN, NW, 4>(p, grid, stream);
   }
   return launch_glds_ns<TM, TN, NW, 0>(p, grid, stream);

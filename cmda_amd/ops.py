@@ -158,7 +158,7 @@ class ln_deferral:
     def __exit__(self, *exc):
         _LN_DEFER['depth'] -= 1
         if _LN_DEFER['depth'] == 0 and exc[0] is None:
-            ln_fold_deferred()
+            ln_fold_deferred(all_lanes=True)
         return False
 
 
@@ -168,13 +168,21 @@ def _ln_region(dgamma, dbeta, C):
     if r is None or r[0].device != dgamma.device:
         nslots = L.lib().cmda_layernorm_slots()
         r = _LN_DEFER['regions'][key] = (torch.zeros(nslots * 2 * C, dtype=torch.float32, device=dgamma.device), dgamma, dbeta, C, nslots)
-    _LN_DEFER['touched'][key] = r
+    _LN_DEFER['touched'].setdefault(LN_LANE, {})[key] = r
     return r[0]
 
 
-def ln_fold_deferred():
-    """fold every workspace touched since the last fold into its dgamma / dbeta: one launch per device"""
-    touched, _LN_DEFER['touched'] = _LN_DEFER['touched'], {}
+def ln_fold_deferred(all_lanes=False):
+    """fold every workspace touched since the last fold into its dgamma / dbeta: one launch per device.  Only the CURRENT
+    concurrency lane's workspaces by default (another lane's LayerNorm backward kernels may still be running on their stream);
+    the end of the scope, which follows the lanes' joins, folds them all."""
+    if all_lanes:
+        touched = {}
+        for d in _LN_DEFER['touched'].values():
+            touched.update(d)
+        _LN_DEFER['touched'] = {}
+    else:
+        touched = _LN_DEFER['touched'].pop(LN_LANE, {})
     if not touched:
         return
     import numpy as np
@@ -182,15 +190,34 @@ def ln_fold_deferred():
     for key, r in touched.items():
         by_dev.setdefault(r[0].device, []).append((key, r))
     for dev, items in by_dev.items():
+        items.sort(key=lambda kv: kv[0])
         pkey = (dev, tuple(k for k, _ in items))
         plan = _LN_DEFER['plans'].get(pkey)
         if plan is None:
             desc = np.zeros(len(items), dtype=[('ws', '<u8'), ('dg', '<u8'), ('db', '<u8'), ('C', '<i4'), ('n', '<i4')])
             for i, (_, (ws, dg, db, C, nslots)) in enumerate(items):
                 desc[i] = (ws.data_ptr(), dg.data_ptr(), db.data_ptr(), C, nslots)
-            plan = _LN_DEFER['plans'][pkey] = (torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()).to(dev), len(items),
-                                               max(r[3] for _, r in items))
-        call('cmda_layernorm_fold_batch', ptr(plan[0]), c_i32(plan[1]), c_i32(plan[2]), stream_of(plan[0]))
+            raw = torch.from_numpy(desc.view(np.uint8).reshape(-1).copy())
+            if dev.type == 'cuda':
+                # The table lives in PINNED HOST memory the kernel reads in place (a few KB per launch): a new set of layers may
+                # show up while a stream is capturing (the per-lane folds of a segmented capture differ from the eager
+                # iteration's), and neither a host-to-device copy nor an allocation is capturable -- a slice of an arena
+                # allocated up front is.
+                arena = _LN_DEFER.get('arena')
+                if arena is None:
+                    if torch.cuda.is_current_stream_capturing():
+                        raise RuntimeError('LayerNorm gradient fold: run one eager backward pass before capturing')
+                    arena = _LN_DEFER['arena'] = [torch.empty(1 << 20, dtype=torch.uint8, pin_memory=True), 0]
+                lo = arena[1]
+                if lo + raw.numel() > arena[0].numel():
+                    raise RuntimeError('LayerNorm gradient fold: descriptor arena exhausted')
+                tab = arena[0][lo:lo + raw.numel()]
+                tab.copy_(raw)   # host-to-host
+                arena[1] = lo + (raw.numel() + 63) // 64 * 64
+            else:
+                tab = raw
+            plan = _LN_DEFER['plans'][pkey] = (tab, len(items), max(r[3] for _, r in items), dev)
+        call('cmda_layernorm_fold_batch', ptr(plan[0]), c_i32(plan[1]), c_i32(plan[2]), stream_of(items[0][1][0]))
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, out_scale=None, rows_per_scale=0):

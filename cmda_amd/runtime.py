@@ -184,7 +184,7 @@ class SegmentedCapture:
         self.device = device
         self.pool = torch.cuda.graph_pool_handle()
         self.main = torch.cuda.Stream(device)
-        self.program = []      # ('replay', graph, stream) | ('wait', waiter, waited)
+        self.program = []      # ('replay', graph, stream) | ('wait', waiter, waited) | ('call', fn, stream)
         self.active = None
         self.n_nodes = 0
 
@@ -211,6 +211,15 @@ class SegmentedCapture:
             self.program.append(('wait', waiter, waited))
         self.begin(resume if resume is not None else stream)
 
+    def call(self, fn):
+        """close the running segment and record a HOST call at this point of its stream: at replay `fn()` runs with that stream
+        current, after everything recorded so far has been enqueued on it (a gradient exchange starts here, on its own stream,
+        underneath the segments that follow)"""
+        stream = self.active[1]
+        self.end()
+        self.program.append(('call', fn, stream))
+        self.begin(stream)
+
     def replay(self):
         cur = torch.cuda.current_stream(self.device)
         self.main.wait_stream(cur)
@@ -218,6 +227,9 @@ class SegmentedCapture:
             if op == 'replay':
                 with torch.cuda.stream(b):
                     a.replay()
+            elif op == 'call':
+                with torch.cuda.stream(b):
+                    a()
             else:
                 a.wait_stream(b)
         cur.wait_stream(self.main)
@@ -340,6 +352,12 @@ grad_ready_hook = None
 
 
 def notify_grads_ready(tag, module=None):
-    if grad_ready_hook is not None:
-        ops.ln_fold_deferred()   # "final" includes the LayerNorm parameter gradients still sitting in their workspaces
-        grad_ready_hook(tag, module)
+    hook = grad_ready_hook
+    if hook is None:
+        return
+    ops.ln_fold_deferred()   # "final" includes the LayerNorm parameter gradients still sitting in their workspaces
+    seg = _conc['seg']
+    if seg is not None and seg.active is not None:
+        seg.call(lambda: hook(tag, module))   # segmented capture: the hook becomes a host step of the replay program
+    else:
+        hook(tag, module)

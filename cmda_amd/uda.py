@@ -386,8 +386,8 @@ class DACS(nn.Module):
             in_src = {'image': day_image, 'events': day_events if use_events else day_isr}
             in_mix = {'image': mixed_img, 'events': mixed_events if use_events else mixed_isr}
         hook = getattr(self, 'final_pass_grad_hook', None)
-        if hook is not None and dev.type == 'cuda' and torch.cuda.is_current_stream_capturing():
-            hook = None
+        if hook is not None and dev.type == 'cuda' and torch.cuda.is_current_stream_capturing() and rt._conc['seg'] is None:
+            hook = None   # one monolithic capture cannot call out; the segmented capture records the hook as a host step
         prev_hook = rt.grad_ready_hook
 
         if (getattr(self, 'fused_student_passes', True) and hasattr(student, 'train_fwd_passes')

@@ -200,6 +200,67 @@ def test_dacs_final_pass_hook_reports_final_gradients():
             assert torch.equal(snap, opt.flat_g[lo:hi]), f'{key[0]}: changed after being reported'
 
 
+@pytest.mark.gpu
+def test_dacs_final_pass_hook_inside_segmented_graph():
+    """the same with the iteration captured as linear hipGraph segments (runtime.SegmentedCapture): the hook is recorded as a
+    HOST step of the replay program, runs with the reporting lane's stream current after that lane's earlier segments were
+    enqueued, and what it snapshots there (stream-ordered) equals the gradient at the end of the iteration -- eager
+    iteration 0, capturing iteration 1, replayed iteration 2."""
+    import random
+    import numpy as np
+    import cmda_amd.runtime as rt
+    from cmda_amd import optim
+    from cmda_amd.registry import build_train_model
+    from test_dacs import SMALL, make_cfg
+    from weights import seeded_fill, seeded_randn
+    dev = torch.device('cuda:0')
+    rt.set_compute_dtype(torch.float32)
+    B, H, W = 2, 64, 64
+    dacs = build_train_model(make_cfg(SMALL['dims'], SMALL['ch'], generator=False))
+    seeded_fill(dacs.model, 7)
+    seeded_fill(dacs.ema_model, 8)
+    dacs.to(dev).train()
+    opt = optim.FlatAdamW(dacs.model, custom_keys=dict(head=dict(lr_mult=10.0), norm=dict(decay_mult=0.0)))
+    dacs.attach_flat_store(opt)
+    student = dacs.model
+    ranges = {('decode_head', id(student.decode_head)): opt.ranges_of(student, ['decode_head.'], min_elems=0)}
+    for name in ('backbone_image', 'backbone_events'):
+        for s in range(1, 5):
+            ranges[(f'backbone.stage{s}', id(getattr(student, name)))] = opt.ranges_of(
+                student, [f'{name}.patch_embed{s}.', f'{name}.block{s}.', f'{name}.norm{s}.'], min_elems=0)
+    seen, snaps = [], {}
+
+    def hook(tag, module=None):
+        key = (tag, id(module))
+        seen.append((tag, module is student.backbone_image, module is student.backbone_events))
+        if key in ranges:
+            snaps[key] = [opt.flat_g[lo:hi].clone() for lo, hi in ranges[key]]
+    dacs.final_pass_grad_hook = hook
+    g = torch.Generator().manual_seed(3)
+    lab = torch.randint(0, 6, (B, 1, H // 8, W // 8), generator=g).repeat_interleave(8, 2).repeat_interleave(8, 3)
+    src = dict(image=seeded_randn((B, 3, H, W), 7, 'img'), img_time_res=seeded_randn((B, 3, H, W), 7, 'itr'),
+               img_self_res=seeded_randn((B, 3, H, W), 7, 'isr').clamp(-1, 1), label=lab)
+    tg = dict(warp_image=seeded_randn((B, 3, H, W), 7, 'nimg'), events_vg=seeded_randn((B, 3, H, W), 7, 'nev').clamp(-1, 1),
+              warp_img_self_res=seeded_randn((B, 3, H, W), 7, 'nisr').clamp(-1, 1))
+    batch = dict(source={k: v.to(dev) for k, v in src.items()}, target={k: v.to(dev) for k, v in tg.items()})
+    torch.manual_seed(11), random.seed(11), np.random.seed(11)
+    dacs.enable_graph(warmup_iters=1)
+    for it in range(3):
+        seen.clear(), snaps.clear()
+        opt.zero_grad()
+        dacs(**batch)
+        torch.cuda.synchronize()
+        assert (dacs._graph is not None) == (it >= 1)
+        assert rt.grad_ready_hook is None
+        assert seen[0][0] == 'decode_head' and len(snaps) == 9, (it, seen)
+        assert [t for t, img, _ in seen if img] == [f'backbone.stage{s}' for s in (4, 3, 2, 1)]
+        assert [t for t, _, evt in seen if evt] == [f'backbone.stage{s}' for s in (4, 3, 2, 1)]
+        assert opt.flat_g.abs().sum().item() > 0
+        for key, parts in snaps.items():
+            for (lo, hi), snap in zip(ranges[key], parts):
+                assert torch.equal(snap, opt.flat_g[lo:hi]), f'iteration {it}, {key[0]}: changed after being reported'
+
+
 def _dacs_worker(rank, world, port, out):
     """one data-parallel rank of the DACS step on the CPU emulator: own batch, rank-local BatchNorm / ClassMix / pseudo-weight,
     gradients exchanged through GradAllReducer with the final-pass staging (decode head + both encoders start their slices from

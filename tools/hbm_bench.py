@@ -1,6 +1,7 @@
-"""Micro-benchmark of the HBM-bound kernels at the config-2 (MiT-B5, 512x512, per-GPU batch 16) shapes.
+"""Micro-benchmark of the HBM-bound kernels at the MiT-B5 512x512 stage shapes for a given encoder batch (the DACS step at
+2 + 2 samples: 8 = event encoder over events + ISR of the source and the mixed samples, 4 = image encoder, 2 = teacher).
 
-    python tools/hbm_bench.py [--batch 16]
+    python tools/hbm_bench.py [--batch 8]
 prints per kernel: avg microseconds, algorithmic GB/s (DESIGN.md section 5 byte counts) and the fraction of 8 TB/s.
 """
 import argparse
@@ -27,7 +28,7 @@ def timeit(fn, iters=20):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--batch', type=int, default=16)
+    ap.add_argument('--batch', type=int, default=8)
     a = ap.parse_args()
     B = a.batch
     dev = 'cuda'
@@ -63,6 +64,20 @@ def main():
         dg, dbeta = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
         rec(f'ln fwd R{R} C{C}', timeit(lambda: ops.layernorm_fwd(x, g, b, 1e-6)), 2 * R * C * 2)
         rec(f'ln bwd R{R} C{C}', timeit(lambda: ops.layernorm_bwd(dy, x, g, mean, rstd, dg, dbeta)), 3 * R * C * 2)
+    # decode head BatchNorm (train mode, + ReLU): joint map of G*P*B = 4 branches x 2 steps x 2 samples = 8 groups of 2 x 128 x 128
+    G = 8
+    Mg = 2 * 128 * 128
+    for C in (256,):
+        x = torch.randn(G * Mg, C, device=dev).to(bf)
+        dy = torch.randn_like(x)
+        y = torch.empty_like(x)
+        g, b = torch.randn(C, device=dev), torch.randn(C, device=dev)
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        dg, dbeta = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        mean, rstd = ops.bn_train_fwd(x, g, b, y, rm, rv, Mg, C, 1e-5, 0.1, True, groups=G)
+        n = G * Mg * C
+        rec(f'bn fwd(+relu) {G}x{Mg} C{C}', timeit(lambda: ops.bn_train_fwd(x, g, b, y, rm, rv, Mg, C, 1e-5, 0.1, True, groups=G)), 3 * n * 2)
+        rec(f'bn bwd {G}x{Mg} C{C}', timeit(lambda: ops.bn_train_bwd(dy, x, mean, rstd, g, b, dg, dbeta, Mg, C, True, groups=G)), 5 * n * 2)
     # attention softmax per stage: rows = B*heads*N, L = N/sr^2
     for (N, heads, L) in ((16384, 1, 256), (4096, 2, 256), (1024, 5, 256), (256, 8, 256)):
         R = B * heads * N
