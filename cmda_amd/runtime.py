@@ -174,7 +174,7 @@ def ones1(device):
 # a short list of `replay segment k on stream s` and `stream a waits for stream b` steps (~40 per iteration).  Segmented,
 # GPU-bound (host 4 ms per iteration): no lanes 151; enc 104-107; T 124; enc+T 109-114 -- a THIRD concurrent queue costs more
 # than it hides (GPU_MAX_HW_QUEUES=8: 176), so the default set is {enc}: two queues, everything that can run in pairs does.
-_conc = {'on': False, 'streams': {}, 'stack': ['main'], 'sstack': [], 'used': {}, 'keep': {}, 'enabled': {'enc'}, 'seg': None}
+_conc = {'on': False, 'streams': {}, 'stack': ['main'], 'sstack': [], 'used': {}, 'keep': {}, 'enabled': {'enc'}, 'seg': None, 'seen': set()}
 
 
 class SegmentedCapture:
@@ -242,7 +242,7 @@ def set_concurrency(flag, lanes=None, seg=None):
         _conc['enabled'] = set(lanes)
     _conc['on'] = bool(flag)
     _conc['seg'] = seg if flag else None
-    _conc['stack'], _conc['used'], _conc['keep'] = ['main'], {}, {}
+    _conc['stack'], _conc['used'], _conc['keep'], _conc['seen'] = ['main'], {}, {}, set()
     _conc['sstack'] = [seg.main] if (flag and seg is not None) else []
     ops.LN_LANE = 'main'
 
@@ -256,10 +256,13 @@ class lane:
     so far on the current lane (re-entering a lane therefore adds exactly that dependency).  Lanes nest.  The tensors
     named (inputs allocated on another stream that the body reads) are kept alive until the enclosing lane calls
     `join_lanes()` -- the caching allocator would otherwise hand their memory to the producer stream again while the side
-    stream is still reading."""
+    stream is still reading.
+    independent=True: the body reads nothing the current lane produced since the side lane was last entered, so re-entering adds
+    NO dependency -- the body queues up behind the side lane's earlier work only and overlaps whatever the current lane has
+    enqueued in between (the first entry of an iteration still orders the lane after the current one)."""
 
-    def __init__(self, name, *keep):
-        self.name, self.keep, self.on = name, keep, False
+    def __init__(self, name, *keep, independent=False):
+        self.name, self.keep, self.on, self.independent = name, keep, False, independent
 
     def __enter__(self):
         if not _conc['on'] or self.name not in _conc['enabled']:
@@ -279,11 +282,14 @@ class lane:
         _conc['stack'].append(full)
         ops.LN_LANE = full
         self.on = True
+        order = not (self.independent and full in _conc['seen'])
+        _conc['seen'].add(full)
         if seg is not None:
-            seg.cut(waits=[(s, _conc['sstack'][-1])], resume=s)
+            seg.cut(waits=[(s, _conc['sstack'][-1])] if order else [], resume=s)
             _conc['sstack'].append(s)
         else:   # forked streams inside the surrounding (single) capture, or plain eager streams
-            s.wait_stream(torch.cuda.current_stream())
+            if order:
+                s.wait_stream(torch.cuda.current_stream())
             self.ctx = torch.cuda.stream(s)
             self.ctx.__enter__()
         return self

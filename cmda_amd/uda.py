@@ -367,7 +367,11 @@ class DACS(nn.Module):
         # ---- Image Motion-Extractor (dacs.py:400-404), frozen, no grad ------------------------------------------------------------
         if tt != 'cs2dz_image+raw-isr':
             if self.cyclegan_itrd2en is not None:
-                day_events = self.cyclegan_itrd2en.forward_mean3(src['img_time_res'])
+                # frozen weights, static input: queued behind the teacher's event encoder on the side lane, next to the
+                # teacher's fusion / decoder / pseudo-label / mixing work on this one
+                with rt.lane('enc', src['img_time_res'], independent=True):
+                    day_events = self.cyclegan_itrd2en.forward_mean3(src['img_time_res'])
+                rt.join_lanes('enc')
             else:
                 day_events = src['img_time_res']
         mixed_events = None
