@@ -335,7 +335,8 @@ def run_dacs(args, rank, world, dev, dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     losses = {k: round(float(v), 5) for k, v in lv.items() if 'loss' in k}
-    graph_mode = 'one hipGraph per iteration (EMA update, control-block copy, AdamW outside)' if dacs._graph is not None else 'eager'
+    graph_mode = ('linear hipGraph segments replayed on two streams (runtime.SegmentedCapture); EMA update, control-block copy, '
+                  'AdamW outside') if dacs._graph is not None else 'eager'
     dacs.disable_graph()                      # the roofline leg brackets every GEMM launch with events: eager
     roofline = gemm_roofline(step, 'dacs') if rank == 0 else None
     if rank == 0:

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Concurrency timeline of the LAST iteration in a rocprofv3 --kernel-trace CSV of `bench.py` (graph replay): how long 0, 1, 2, ...
+kernels were running at once, which kernel families ran alone, and the longest stretches with a single queue busy.
+usage: timeline.py DIR"""
+import collections
+import csv
+import glob
+import re
+import sys
+
+f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
+rows = []
+for r in csv.DictReader(open(f)):
+    n = r['Kernel_Name'].replace('void (anonymous namespace)::', '').replace('(anonymous namespace)::', '')
+    n = re.sub(r'\(.*', '', n)[:48]
+    rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), n, r.get('Queue_Id', '?')))
+rows.sort()
+# iterations are delimited by the EMA kernel (first kernel of an iteration outside the graph)
+marks = [i for i, r in enumerate(rows) if r[2].startswith('ema_kernel')]
+if len(marks) >= 2:
+    lo, hi = marks[-2], marks[-1]
+else:
+    lo, hi = 0, len(rows)
+it = rows[lo:hi]
+t0, t1 = it[0][0], max(r[1] for r in it)
+print(f'iteration: {len(it)} kernels, {(t1 - t0) / 1e6:.2f} ms wall, kernel time {sum(r[1] - r[0] for r in it) / 1e6:.2f} ms, '
+      f'queues {sorted(set(r[3] for r in it))}')
+ev = []
+for s, e, n, q in it:
+    ev.append((s, 1, n))
+    ev.append((e, -1, n))
+ev.sort()
+level, last = 0, t0
+hist = collections.Counter()
+alone = collections.Counter()
+running = collections.Counter()
+for t, d, n in ev:
+    hist[level] += t - last
+    if level == 1:
+        for k, v in running.items():
+            if v > 0:
+                alone[k] += t - last
+    last = t
+    level += d
+    running[n] += d
+for k in sorted(hist):
+    print(f'  {k} kernels running: {hist[k] / 1e6:7.2f} ms')
+print('time alone on the chip, by kernel (ms):')
+for k, v in alone.most_common(25):
+    print(f'  {v / 1e6:7.2f}  {k}')
+# gaps (idle chip) by the kernel that follows
+gap_after = collections.Counter()
+end = t0
+for s, e, n, q in it:
+    if s > end:
+        gap_after[n] += s - end
+    end = max(end, e)
+print('idle time before kernel (ms):')
+for k, v in gap_after.most_common(12):
+    print(f'  {v / 1e6:7.2f}  {k}')
