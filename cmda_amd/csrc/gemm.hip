@@ -54,7 +54,7 @@ int launch_dtype(GemmParams& p, void* stream) {
     // measured with the lean epilogue (profiles/README.md, forced-tile sweep): the 128x128 tile wins from ~1 block per CU up
     // 256x256 (8 waves, one block per CU) from ~4 blocks per CU on deep contractions: 8192^3 1302 -> 1060 us, the head's
     // 3x3 bottleneck conv 2134 -> 1570 us; short-K or narrow problems lose to the 128x128 tile
-    if (sizeof(T) == 2 && p.N >= 256 && p.K >= 256 && blocks(256, 256) * sp >= 1024) tile = 3;
+    if (sizeof(T) == 2 && p.N >= 256 && p.K >= 256 && (blocks(256, 256) * sp >= 1024 || (blocks(256, 256) * sp >= 200 && p.K >= 2048))) tile = 3;  // (4096^3: one block per CU, 1113 vs 883 TFLOP/s on 128x128)
     // N = 320 (64 x odd): the last 128-wide tile column would be half empty -- with enough blocks the 128x64 tile wins
     // (batch 64, M = 65536: q 42.2 -> 38.9 us, dfc1 110.8 -> 99.6 us; at batch 16 the 128x128 tile is still ahead)
     else if (p.N > 64 && (p.N & 127) > 0 && (p.N & 127) <= 64 && blocks(128, 64) * sp >= 2048) tile = 1;

@@ -669,8 +669,26 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || NSV * (TM * 16 * (NW / 2) + TN
     const int q = ntile / 8, rr = ntile % 8, xcd = bt % 8, loc = bt / 8;
     bt = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
   }
-  const long m0 = (long)(bt / tiles_n) * BM;
-  const long n0 = (long)(bt % tiles_n) * BN;
+  // Inside an XCD's contiguous range the tiles are walked in groups of GM tile rows, column by column: the ~32 (one block per
+  // CU) or ~64 blocks an XCD runs at once then cover a GM x (32/GM) patch of the output instead of one row of it, and share
+  // GM A panels + 32/GM B panels through that XCD's L2 instead of 1 + 32 (8192^3 on the 256x256 tile: 2 MB of DMA per k-tile
+  // per XCD of which 1.06 MB unique row-major, 0.38 MB unique grouped -- the row-major walk ran at the memory-side rate).
+  long mt, nt;
+  {
+    constexpr int GM = NW == 8 ? 4 : 8;
+    const int tiles_m = (int)((p.M + BM - 1) / BM);
+    if (tiles_n >= 2 * GM && tiles_m >= GM && !(p.tile_hint > 0 && (p.tile_hint & 256))) {
+      const int gsz = GM * tiles_n, gid = bt / gsz, first = gid * GM;
+      const int gm = min(tiles_m - first, GM), r = bt - gid * gsz;
+      mt = first + r % gm;
+      nt = r / gm;
+    } else {
+      mt = bt / tiles_n;
+      nt = bt % tiles_n;
+    }
+  }
+  const long m0 = mt * BM;
+  const long n0 = nt * BN;
   const int z = blockIdx.z;
   const int bz = z / p.splits;
   const int split = z - bz * p.splits;
@@ -853,7 +871,7 @@ int launch_glds(const GemmParams& p, void* stream) {
     constexpr long kStage = (long)(BM + BN) * 128;
     const long resident = 256L * (4 * kStage <= 65536 ? 2 : 1);
     const long nkt = ((long)p.K + 63) / 64 / (p.splits > 0 ? p.splits : 1);
-    const int force = p.tile_hint > 0 ? (p.tile_hint >> 4) : 0;   // tuning sweeps (tools/gemm_sweep.py): stages in bits 4.. of the hint
+    const int force = p.tile_hint > 0 ? ((p.tile_hint >> 4) & 15) : 0;   // tuning sweeps (tools/gemm_sweep.py): stages in bits 4.. of the hint
     if (force) return force == 4 ? launch_glds_ns<TM, TN, NW, 4>(p, grid, stream) : launch_glds_ns<TM, TN, NW, 0>(p, grid, stream);
     // (deeper than 4 -- 8 x 16 KiB on the 64x64 tile, 6 x 24 KiB on 128x64, one block per CU -- measured slower on every shape
     // of the step: profiles/r02_gemm_sweep.txt)

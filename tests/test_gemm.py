@@ -141,3 +141,24 @@ def test_gemm_unpatchify_store(tgt):
                  beta=beta, c_patch=(OW, k, k * Ci))
         ref = want.permute(0, 2, 3, 1).reshape(-1, Ci) + beta * prev
         assert_close(dx, ref, 2e-5, name=f'unpatchify beta={beta}')
+
+
+@pytest.mark.parametrize('hint,M,N', [(3, 600, 1100), (3, 520, 1024), (2, 1100, 1060), (4, 1030, 2100)])
+def test_gemm_grouped_tile_walk(tgt, hint, M, N):
+    """wide outputs walk their tiles in groups of GM tile rows, column by column (L2 reuse inside an XCD): every tile must still
+    be computed exactly once, ragged last group and ragged edges included.  hint = forced tile (3: 64x64, 2: 128x64, 4: 256x256)."""
+    K = 64
+    torch.manual_seed(hint * 100 + M)
+    a, b = torch.randn(M, K).to(torch.bfloat16), torch.randn(N, K).to(torch.bfloat16)
+    ref = a.float() @ b.float().t()
+    out = torch.full((M, N), float('nan'), dtype=torch.bfloat16, device=tgt.device)
+    ops.GEMM_TILE_HINT = hint
+    try:
+        ops.gemm(ops.plain_view(tgt.to(a), M, K), ops.plain_view(tgt.to(b), N, K), out, M, N, K, dtype=1)
+        assert_close(out, ref, 1.5e-2, name='grouped walk')
+        ops.GEMM_TILE_HINT = hint | 256   # the row-major walk (tuning switch) gives the same matrix
+        out2 = torch.empty_like(out)
+        ops.gemm(ops.plain_view(tgt.to(a), M, K), ops.plain_view(tgt.to(b), N, K), out2, M, N, K, dtype=1)
+        assert torch.equal(out.cpu(), out2.cpu())
+    finally:
+        ops.GEMM_TILE_HINT = 0

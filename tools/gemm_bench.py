@@ -28,6 +28,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--dtype', default='bf16')
     ap.add_argument('--batch', type=int, default=16)
+    ap.add_argument('--big', action='store_true', help='only the large square-ish GEMMs, with and without the grouped tile walk')
     ap.add_argument('--splits', type=int, default=0, help='force the split-K count of the weight-gradient GEMMs')
     args = ap.parse_args()
     dt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
@@ -57,6 +58,20 @@ def main():
         dy, dw = r(M, Co), torch.zeros(Co, K, device=dev)
         rows.append((name + ' wgrad', 2.0 * M * Co * K, timeit(lambda: ops.gemm(ops.plain_view(dy, M, Co), ops.conv_view(x, B, H, W, Ci, k, k, 1, k // 2), dw, Co, K, M, a_kstrided=True, b_kstrided=True, dtype=tag, atomic=True, splits=0), 10)))
 
+    if args.big:
+        for hint, tag_ in ((0, 'grouped walk'), (256 | 4, 'row-major 256^2'), (4, 'grouped 256^2'), (1, 'grouped 128^2'), (256 | 1, 'row-major 128^2')):
+            ops.GEMM_TILE_HINT = hint
+            rows.append((f'--- {tag_} (tile_hint {hint})', 0.0, 1.0))
+            nt('NT 8192x8192x8192', 8192, 8192, 8192)
+            nt('NT 4096x4096x4096', 4096, 4096, 4096)
+            nt('NT 16384x4096x4096', 16384, 4096, 4096)
+            nn('NN 8192x8192x8192', 8192, 8192, 8192)
+            nt('NT 65536x1280x320', 65536, 1280, 320)
+            nt('NT 65536x2048x512', 65536, 2048, 512)
+        ops.GEMM_TILE_HINT = 0
+        for name, fl, us in rows:
+            print(f'{name:38s} {us:10.1f} us  {fl / us / 1e6:8.1f} TFLOP/s')
+        return
     Bt = args.batch
     T1, T2, T3, T4 = Bt * 16384, Bt * 4096, Bt * 1024, Bt * 256
     nt(f's3 fc1   NT {T3}x1280x320', T3, 1280, 320)
