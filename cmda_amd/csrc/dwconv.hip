@@ -259,6 +259,102 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const T* __restrict_
   }
 }
 
+// Fused MixFFN backward step: dz = da * gelu'(conv(x) + bias)  AND  dw[c,tap] += sum dz * x[pix+tap], dbias[c] += sum dz in
+// ONE pass over x / da (the prep and weight-gradient kernels above each walk the same 3 x (RUN+2) window of x; fused, the
+// window is loaded once, dz never has to be re-read and one launch per MixFFN backward disappears).  Same block shape and
+// reduction as dw_bwd_weight_kernel; the weight gradient sees dz before its rounding to bf16.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void dw_gelu_bwd_fused_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ bias, const T* __restrict__ da,
+                                                                T* __restrict__ dz, float* __restrict__ dw,
+                                                                float* __restrict__ dbias, RunGeom g, int C,
+                                                                int runs_per_block, int gx_groups) {
+  constexpr int RUN = 4;  // (8 as in the other kernels needs all 256 VGPRs in bf16: one wave per SIMD)
+  __shared__ float red[4][64][41];
+  const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+  const BlockXY blk = xcd_block(gx_groups);
+  const int c = (blk.bx * 64 + cx) * 4;
+  const long r0 = blk.by * runs_per_block;
+  const long r1 = min(g.nruns, r0 + runs_per_block);
+  float acc[9][4], accb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[t][j] = 0.f;
+  if (c < C) {
+    float wr[9][4], bs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) ld4(w + t * C + c, wr[t]);
+    if (bias) ld4(bias + c, bs);
+    for (long run = r0 + py; run < r1; run += 4) {
+      RunPos r;
+      if (!decode_run(g, run, RUN, r)) continue;
+      Raw<T> raw[3][RUN + 2], rda[RUN];
+      load_window<T, RUN>(x + c, g, r, C, raw);
+#pragma unroll
+      for (int i = 0; i < RUN; ++i) {
+        const int wx = r.w0 + i * g.dil;
+        const bool ok = wx < g.W;
+        rda[i].load(da + (r.row_base + (ok ? wx : r.w0)) * C + c, ok);
+      }
+      float win[3][3][4];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        raw[kh][0].unpack(win[0][kh]);
+        raw[kh][1].unpack(win[1][kh]);
+      }
+#pragma unroll
+      for (int i = 0; i < RUN; ++i) {
+        const int wx = r.w0 + i * g.dil;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) raw[kh][i + 2].unpack(win[(i + 2) % 3][kh]);
+        float z[4] = {bs[0], bs[1], bs[2], bs[3]};
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) z[j] += win[(i + kw) % 3][kh][j] * wr[kh * 3 + kw][j];
+        float gd[4];
+        rda[i].unpack(gd);  // zero beyond the row end
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gd[j] *= gelu_erf_grad(z[j]);
+        if (wx < g.W) st4(dz + (r.row_base + wx) * C + c, gd);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) accb[j] += gd[j];
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[kh * 3 + kw][j] += gd[j] * win[(i + kw) % 3][kh][j];
+      }
+    }
+  }
+  {
+    float* slot = red[py][cx];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) slot[t * 4 + j] = acc[t][j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) slot[36 + j] = accb[j];
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < 64 * 40; k += blockDim.x) {
+    const int gx = k / 40, v = k - gx * 40;
+    const int cc = (blk.bx * 64 + gx) * 4;
+    if (cc >= C) continue;
+    const float s = red[0][gx][v] + red[1][gx][v] + red[2][gx][v] + red[3][gx][v];
+    if (v < 36) {
+      const int t = v >> 2, j = v & 3;
+      atomicAdd(dw + (cc + j) * 9 + t, s);
+    } else if (dbias) {
+      atomicAdd(dbias + cc + (v - 36), s);
+    }
+  }
+}
+
 static inline bool too_big(long n) { return n >= (1L << 32); }
 static inline int run_len(int dtype) { return dtype == CMDA_BF16 ? RunLen<bf16_t>::value : RunLen<float>::value; }
 
@@ -310,5 +406,23 @@ extern "C" int cmda_dwconv3x3_bwd_weight(const void* dz, const void* x, float* d
   dim3 grid((unsigned)((g.nruns + rpb - 1) / rpb * gx));
   CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((dw_bwd_weight_kernel<T>), grid, dim3(256), 0, stream, (const T*)dz,
                                          (const T*)x, dw, dbias, g, C, rpb, gx));
+  CMDA_CHECK_LAUNCH();
+}
+
+// dz = da * gelu'(conv(x) + bias); dw [C][9] += sum dz * x(tap); dbias [C] += sum dz   (dw / dbias ACCUMULATED; w tap-major [9][C])
+extern "C" int cmda_dwconv3x3_gelu_bwd_fused(const void* x, const float* w, const float* bias, const void* da, void* dz,
+                                             float* dw, float* dbias, int B, int H, int W, int C, int dil, int dtype,
+                                             void* stream) {
+  const long npix = (long)B * H * W;
+  if (npix * C <= 0) return CMDA_OK;
+  if ((C & 3) || dil < 1) return CMDA_ERR_SHAPE;
+  const RunGeom g = run_geom(B, H, W, dil, 4);
+  if (too_big(npix) || too_big(g.nruns)) return CMDA_ERR_SHAPE;
+  const int gx = (C / 4 + 63) / 64;
+  int rpb = 128;   // as cmda_dwconv3x3_bwd_weight: >= 4 runs per thread, otherwise ~3 blocks per CU
+  while (rpb > 16 && (g.nruns + rpb - 1) / rpb * gx < 768) rpb >>= 1;
+  dim3 grid((unsigned)((g.nruns + rpb - 1) / rpb * gx));
+  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((dw_gelu_bwd_fused_kernel<T>), grid, dim3(256), 0, stream, (const T*)x, w, bias,
+                                         (const T*)da, (T*)dz, dw, dbias, g, C, rpb, gx));
   CMDA_CHECK_LAUNCH();
 }

@@ -186,9 +186,7 @@ def mlp_bwd(dy, mlp, xin, h, act, B, H, W, Cin, dps=None, dy_scaled=None):
     da = linear_bwd(dys, act, mlp.fc2.weight, mlp.fc2.bias, M, hidden)
     dw = mlp.dwconv.dwconv
     w9 = rt.wdw(dw.weight)
-    dz = ops.dwconv_gelu_bwd_prep(h, w9, dw.bias, da, B, H, W, hidden, 1)
-    with rt.lane('wgrad', dz, h):
-        ops.dwconv_bwd_weight(dz, h, rt.grad(dw.weight).view(hidden, 9), rt.grad(dw.bias), B, H, W, hidden, 1)
+    dz = ops.dwconv_gelu_bwd_fused(h, w9, dw.bias, da, rt.grad(dw.weight).view(hidden, 9), rt.grad(dw.bias), B, H, W, hidden, 1)
     dh = ops.dwconv_bwd_data(dz, w9, B, H, W, hidden, 1, out=da)
     return linear_bwd(dh, xin, mlp.fc1.weight, mlp.fc1.bias, M, Cin)
 

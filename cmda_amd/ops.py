@@ -384,6 +384,15 @@ def dwconv_gelu_bwd_prep(x, w, bias, da, B, H, W, C, dil=1):
     return dz
 
 
+def dwconv_gelu_bwd_fused(x, w, bias, da, dw, dbias, B, H, W, C, dil=1):
+    """dz = da * gelu'(conv(x) + bias) and the depthwise weight / bias gradients (accumulated) in one pass; returns dz"""
+    check_dev(x, w, bias, da, dw, dbias)
+    dz = torch.empty_like(x)
+    call('cmda_dwconv3x3_gelu_bwd_fused', ptr(x), ptr(w), ptr(bias), ptr(da), ptr(dz), ptr(dw), ptr(dbias), c_i32(B), c_i32(H),
+         c_i32(W), c_i32(C), c_i32(dil), dtype_tag(x), stream_of(x))
+    return dz
+
+
 def dwconv_bwd_data(dy, w, B, H, W, C, dil=1, out=None, accumulate=False):
     check_dev(dy, w, out)
     dx = torch.empty_like(dy) if out is None else out

@@ -131,6 +131,10 @@ int cmda_dwconv3x3_bwd_data(const void* dy, const float* w, void* dx, int B, int
     accumulate, int dtype, void* stream);
 int cmda_dwconv3x3_bwd_weight(const void* dz, const void* x, float* dw, float* dbias, int B, int H, int W, int C, int
     dil, int dtype, void* stream);
+/* gelu_bwd_prep + bwd_weight of the MixFFN DWConv (mix_transformer.py:37-44,443-455 under autograd) in one pass over x / da:
+ * dz written, dw [C][9] and dbias [C] accumulated. */
+int cmda_dwconv3x3_gelu_bwd_fused(const void* x, const float* w, const float* bias, const void* da, void* dz, float* dw,
+    float* dbias, int B, int H, int W, int C, int dil, int dtype, void* stream);
 
 /* ---- Bilinear resize (align_corners=False), fused with the channel-concat write -- resize() + torch.cat at
  * decode_heads/daformer_head.py:263-275 (ops/wrappers.py:9-28).  y/dy is a channel slice [coff,coff+C) of rows of pitch ldy. */

@@ -152,13 +152,14 @@ def test_gemm_grouped_tile_walk(tgt, hint, M, N):
     a, b = torch.randn(M, K).to(torch.bfloat16), torch.randn(N, K).to(torch.bfloat16)
     ref = a.float() @ b.float().t()
     out = torch.full((M, N), float('nan'), dtype=torch.bfloat16, device=tgt.device)
+    ad, bd = tgt.to(a), tgt.to(b)   # (views hold raw pointers: the device copies must outlive the launch)
     ops.GEMM_TILE_HINT = hint
     try:
-        ops.gemm(ops.plain_view(tgt.to(a), M, K), ops.plain_view(tgt.to(b), N, K), out, M, N, K, dtype=1)
+        ops.gemm(ops.plain_view(ad, M, K), ops.plain_view(bd, N, K), out, M, N, K, dtype=1)
         assert_close(out, ref, 1.5e-2, name='grouped walk')
         ops.GEMM_TILE_HINT = hint | 256   # the row-major walk (tuning switch) gives the same matrix
         out2 = torch.empty_like(out)
-        ops.gemm(ops.plain_view(tgt.to(a), M, K), ops.plain_view(tgt.to(b), N, K), out2, M, N, K, dtype=1)
+        ops.gemm(ops.plain_view(ad, M, K), ops.plain_view(bd, N, K), out2, M, N, K, dtype=1)
         assert torch.equal(out.cpu(), out2.cpu())
     finally:
         ops.GEMM_TILE_HINT = 0

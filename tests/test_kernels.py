@@ -100,6 +100,12 @@ def test_dwconv(tgt, dt, tol, dil, act, shape):
     assert_close(dw, wr.grad.view(C, 9), tol, name='dw dweight')
     if act:
         assert_close(db, br.grad, tol, name='dw dbias')
+    if act == 'gelu':   # the fused form of the two calls above (one pass over x / da)
+        dw2, db2 = torch.zeros(C, 9, device=tgt.device), torch.zeros(C, device=tgt.device)
+        dz2 = ops.dwconv_gelu_bwd_fused(xd, wd, bd, dyd, dw2, db2, B, H, W, C, dil)
+        assert_close(dz2, dz, 1e-6 if dt == torch.float32 else 4e-3, name='fused dz')
+        assert_close(dw2, wr.grad.view(C, 9), tol, name='fused dweight')
+        assert_close(db2, br.grad, tol, name='fused dbias')
 
 
 @pytest.mark.parametrize('dt,tol', DT)
