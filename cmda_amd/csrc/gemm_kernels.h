@@ -609,8 +609,13 @@ struct DmaSrc {
         s0[j] = nci; s1[j] = nkh; s2[j] = nkw;
       }
       if (c + 8 > v.Cc) return zero;
-      const int ih = (cbc[j] >> 16) + kh * v.dil, iw = (int)(short)(cbc[j] & 0xffff) + kw * v.dil;
-      if (ih < 0 || ih >= v.H || iw < 0 || iw >= v.W) return zero;
+      int ih = (cbc[j] >> 16) + kh * v.dil, iw = (int)(short)(cbc[j] & 0xffff) + kw * v.dil;
+      if (v.reflect) {
+        ih = reflect_idx(ih, v.H);
+        iw = reflect_idx(iw, v.W);
+      } else if (ih < 0 || ih >= v.H || iw < 0 || iw >= v.W) {
+        return zero;
+      }
       return base + ((long)(ca[j] + ih) * v.W + iw) * v.C + ci;
     } else {
       const long r = (long)kt * BK + line[j];
@@ -625,8 +630,13 @@ struct DmaSrc {
         s0[j] = nb; s1[j] = noh; s2[j] = now;
       }
       if (r >= v.R) return zero;
-      const int ih = oh * v.stride + (cbc[j] >> 16), iw = ow * v.stride + (int)(short)(cbc[j] & 0xffff);
-      if (ih < 0 || ih >= v.H || iw < 0 || iw >= v.W) return zero;
+      int ih = oh * v.stride + (cbc[j] >> 16), iw = ow * v.stride + (int)(short)(cbc[j] & 0xffff);
+      if (v.reflect) {
+        ih = reflect_idx(ih, v.H);
+        iw = reflect_idx(iw, v.W);
+      } else if (ih < 0 || ih >= v.H || iw < 0 || iw >= v.W) {
+        return zero;
+      }
       return base + ((long)(b * v.H + ih) * v.W + iw) * v.C + ca[j];
     }
   }
