@@ -74,6 +74,29 @@ __global__ void permute4_batch_kernel(const PermuteDesc* __restrict__ desc, cons
   const long ss[4] = {(long)D.d[1] * D.d[2] * D.d[3], (long)D.d[2] * D.d[3], (long)D.d[3], 1};
   const int e1 = D.d[D.p[1]], e2 = D.d[D.p[2]], e3 = D.d[D.p[3]];
   const long base = (long)bk_y * 1024;
+  if (D.dst_bf16 == 2) {
+    // drain mode (conv weight gradients accumulated in the GEMM's own [Co][KH][KW][Ci] order): walk the SOURCE in order,
+    // dst (fp32, permuted layout) += src, src = 0 -- the shadow is left zeroed for the next backward pass
+    const long es[4] = {(long)e1 * e2 * e3, (long)e2 * e3, (long)e3, 1};   // dst strides
+    long dstr[4] = {0, 0, 0, 0};                                              // dst stride of SOURCE axis ax
+#pragma unroll
+    for (int a = 0; a < 4; ++a) dstr[D.p[a]] = es[a];
+    float* src = const_cast<float*>(D.src);
+    float* dst = reinterpret_cast<float*>(D.dst);
+    for (int k = threadIdx.x; k < 1024; k += blockDim.x) {
+      const long i = base + k;
+      if (i >= D.total) break;
+      const float v = src[i];
+      if (v == 0.f) continue;
+      long t = i;
+      const int i3 = (int)(t % D.d[3]); t /= D.d[3];
+      const int i2 = (int)(t % D.d[2]); t /= D.d[2];
+      const int i1 = (int)(t % D.d[1]); t /= D.d[1];
+      dst[t * dstr[0] + i1 * dstr[1] + i2 * dstr[2] + i3 * dstr[3]] += v;
+      src[i] = 0.f;
+    }
+    return;
+  }
   for (int k = threadIdx.x; k < 1024; k += blockDim.x) {
     const long i = base + k;
     if (i >= D.total) break;

@@ -20,14 +20,14 @@ int launch_dtype(GemmParams& p, void* stream) {
     tile = 2;
     if (p.M > 64 && p.N > 64) {
       // (the im2col-view weight gradient spills on the 256x256 tile: 11.7 ms against 9.6 ms on 128x128 at batch 64)
-      if (sizeof(T) == 2 && p.M >= 256 && p.N >= 256 && blocks(256, 256) >= 32 && !p.B.conv) tile = 3;
+      if (sizeof(T) == 2 && p.M >= 256 && p.N >= 256 && blocks(256, 256) >= 32 && p.B.conv != 1) tile = 3;
       else if (blocks(128, 128) >= 64 || (blocks(128, 128) >= 16 && nkt >= 1024)) tile = 0;  // very deep K: split further
       else if (blocks(128, 64) >= 48) tile = 1;  // e.g. the 320x1280 MixFFN weight gradients (57 vs 72 us on 64x64 tiles)
     }
     const long b = tile == 3 ? blocks(256, 256) : tile == 0 ? blocks(128, 128) : tile == 1 ? blocks(128, 64) : blocks(64, 64);
     // im2col weight gradients (very deep K, output of a few MB): let the wave-quantisation search below look as far as two
     // full waves of the 128x128 tile (144 tiles x 7 splits: 9.6 ms against 11.2 ms at 3 splits, batch 64)
-    long s = ((p.B.conv ? 1024 : 512) + b - 1) / b;
+    long s = ((p.B.conv == 1 ? 1024 : 512) + b - 1) / b;
     s = std::min<long>(s, std::max(1, nkt / 8));
     const long out_bytes = (long)p.M * p.N * 4 * zb;
     s = std::min<long>(s, std::max<long>(16, (32L << 20) / std::max<long>(out_bytes, 1)));  // atomic traffic bound
@@ -69,9 +69,11 @@ int launch_dtype(GemmParams& p, void* stream) {
     // too large for 32-bit tile arithmetic stay on the register-staged kernel
     auto dma_ok = [](const GemmView& v) {
       return v.vec_ok && v.in_dil <= 1 && v.R < (1L << 31) && v.Cc < (1L << 31) &&
-             (!v.conv || (v.H < 32768 && v.W < 32768)) && (v.conv || (v.ld % 8) == 0) && (v.Cc % 8) == 0;
+             (!v.conv || (v.H < 32768 && v.W < 32768)) && (v.conv || (v.ld % 8) == 0) && (v.Cc % 8) == 0 &&
+             (v.conv != 2 || ((v.KW * v.C) % 64 == 0 && v.KH == v.stride && v.KW == v.stride && v.pad == 0 && v.dil == 1 &&
+                              v.H == v.OH * v.stride && v.W == v.OW * v.stride));
     };
-    const bool ac = p.A.conv != 0, bc = p.B.conv != 0, aks = p.a_kstrided != 0, bks = p.b_kstrided != 0;
+    const bool ac = p.A.conv == 1, bc = p.B.conv == 1, aks = p.a_kstrided != 0, bks = p.b_kstrided != 0;  // conv == 2: patch view, plain fills
     const bool kind_ok = (!ac && !bc) || (ac && !bc && !aks && !bks) || (!ac && bc && aks && bks);
     const bool nt_plain = kind_ok && dma_ok(p.A) && dma_ok(p.B);
     if (p.colsum && !(nt_plain && !no_glds && aks)) return CMDA_ERR_UNSUPPORTED;

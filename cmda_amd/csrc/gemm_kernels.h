@@ -557,7 +557,12 @@ struct DmaSrc {
         fixed[j] = r < v.R ? (int)r : -1;
         if (fixed[j] >= 0) {
           if (!conv) {
-            ptr[j] = base + r * v.ld + chunk[j] * 8;
+            if (v.conv == 2) {  // patch view: row (q = b*OH + oh, ow) starts at q * (s*W*C) + ow * (s*C)
+              const unsigned ru = (unsigned)r, q = ru / (unsigned)v.OW, ow = ru - q * (unsigned)v.OW;
+              ptr[j] = base + (long)q * v.stride * v.W * v.C + (long)ow * v.stride * v.C + chunk[j] * 8;
+            } else {
+              ptr[j] = base + r * v.ld + chunk[j] * 8;
+            }
           } else {
             const unsigned ohw = (unsigned)(v.OH * v.OW), ru = (unsigned)r;
             const unsigned b = ru / ohw, rem = ru - b * ohw, oh = rem / (unsigned)v.OW, ow = rem - oh * (unsigned)v.OW;
@@ -574,7 +579,15 @@ struct DmaSrc {
         fixed[j] = c + 8 <= v.Cc ? (int)c : -1;
         if (fixed[j] >= 0) {
           if (!conv) {
-            ptr[j] = base + (long)ln * v.ld + c;
+            if (v.conv == 2) {  // patch view: column (kh, jj) sits at kh * (W*C) + jj; the pixel row advances with the k-tiles
+              const unsigned seg = (unsigned)(v.KW * v.C), cu = (unsigned)c, kh = cu / seg;
+              ptr[j] = base + (long)kh * v.W * v.C + (cu - kh * seg);
+              const unsigned ru = (unsigned)((long)kt0 * BK + ln);
+              s1[j] = (int)(ru / (unsigned)v.OW);
+              s2[j] = (int)(ru - (unsigned)s1[j] * (unsigned)v.OW);
+            } else {
+              ptr[j] = base + (long)ln * v.ld + c;
+            }
           } else {
             const unsigned cu = (unsigned)c, cell = cu / (unsigned)v.C, ci = cu - cell * (unsigned)v.C;
             const unsigned kh = cell / (unsigned)v.KW, kw = cell - kh * (unsigned)v.KW;
@@ -598,7 +611,14 @@ struct DmaSrc {
     if (fixed[j] < 0) return zero;
     if (!KS) {
       const long c = (long)kt * BK + chunk[j] * 8;
-      if (!conv) return c + 8 > v.Cc ? zero : static_cast<const void*>(ptr[j] + (long)kt * BK);
+      if (!conv) {
+        if (c + 8 > v.Cc) return zero;
+        if (v.conv == 2) {  // k-tile kt lies inside one (kh) segment of KW*C contiguous elements (KW*C % 64 == 0)
+          const unsigned seg = (unsigned)(v.KW * v.C), c0 = (unsigned)(kt * BK), kh = c0 / seg;
+          return ptr[j] + (long)kh * v.W * v.C + (c0 - kh * seg);
+        }
+        return ptr[j] + (long)kt * BK;
+      }
       const int ci = s0[j], kh = s1[j], kw = s2[j];
       {  // advance to the next k-tile: +64 channels, carrying into (kw, kh)
         int nci = ci + BK, nkw = kw, nkh = kh;
@@ -619,7 +639,18 @@ struct DmaSrc {
       return base + ((long)(ca[j] + ih) * v.W + iw) * v.C + ci;
     } else {
       const long r = (long)kt * BK + line[j];
-      if (!conv) return r >= v.R ? zero : static_cast<const void*>(ptr[j] + (long)kt * BK * v.ld);
+      if (!conv) {
+        if (v.conv == 2) {
+          const int q = s1[j], ow = s2[j];
+          {  // advance to the next k-tile: +64 output pixels, carrying into q = b*OH + oh
+            int now = ow + BK, nq = q;
+            while (now >= v.OW) { now -= v.OW; ++nq; }
+            s1[j] = nq; s2[j] = now;
+          }
+          return r >= v.R ? zero : static_cast<const void*>(ptr[j] + (long)q * v.stride * v.W * v.C + (long)ow * v.stride * v.C);
+        }
+        return r >= v.R ? zero : static_cast<const void*>(ptr[j] + (long)kt * BK * v.ld);
+      }
       const int b = s0[j], oh = s1[j], ow = s2[j];
       {  // advance to the next k-tile: +64 output pixels, carrying into (oh, b)
         int now = ow + BK, noh = oh, nb = b;
@@ -857,7 +888,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || NSV * (TM * 16 * (NW / 2) + TN
 template <int TM, int TN, int NW, int NSV>
 int launch_glds_ns(const GemmParams& p, const dim3& grid, void* stream) {
   const dim3 blk(64 * NW);
-  const bool aks = p.a_kstrided != 0, bks = p.b_kstrided != 0, ac = p.A.conv != 0, bc = p.B.conv != 0;
+  const bool aks = p.a_kstrided != 0, bks = p.b_kstrided != 0, ac = p.A.conv == 1, bc = p.B.conv == 1;  // (2 = patch view: plain fills)
   if (!aks && !bks && !ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, false, false, false, false, NW, NSV>), grid, blk, 0, stream, p);
   else if (!aks && bks && !ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, false, true, false, false, NW, NSV>), grid, blk, 0, stream, p);
   else if (aks && bks && !ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, true, true, false, false, NW, NSV>), grid, blk, 0, stream, p);

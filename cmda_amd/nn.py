@@ -66,13 +66,19 @@ def conv_bwd(dy, x, weight, bias, B, H, W, stride, pad, dil=1, *, need_dx=True, 
     OH, OW = conv_out_size(H, W, KH, stride, pad, dil)
     M, K = B * OH * OW, KH * KW * Ci
     with rt.lane('wgrad', dy, x):
-        # dW[co, (kh,kw,ci)] accumulated with atomics straight into the parameter's [Co,Ci,KH,KW] gradient (c_perm): no staging
-        # buffer, no permute-accumulate pass; the bias gradient rides along in the same kernel when the operands allow
+        # dW[co, (kh,kw,ci)] accumulated with atomics; outside a deferral scope straight into the parameter's [Co,Ci,KH,KW]
+        # gradient (c_perm: no staging buffer); the bias gradient rides along in the same kernel when the operands allow
         dyv = plain_view(dy, M, Co)
         fused = (bias is not None and rt.tag() == 1 and dyv.vec_ok and Co % 8 == 0 and K % 8 == 0 and Ci % 8 == 0)
-        ops.gemm(dyv, conv_view(x, B, H, W, Ci, KH, KW, stride, pad, dil, OH=OH, OW=OW), rt.grad(weight), Co, K, M,
-                 a_kstrided=True, b_kstrided=True, dtype=rt.tag(), atomic=True, splits=0, c_perm=(Ci, KH * KW),
-                 colsum=rt.grad(bias) if fused else None)
+        shadow = ops.conv_grad_shadow(rt.grad(weight))
+        if shadow is not None:   # inside a pass: coalesced atomics into the [Co,KH,KW,Ci] shadow, drained once per pass
+            ops.gemm(dyv, conv_view(x, B, H, W, Ci, KH, KW, stride, pad, dil, OH=OH, OW=OW), shadow, Co, K, M,
+                     a_kstrided=True, b_kstrided=True, dtype=rt.tag(), atomic=True, splits=0,
+                     colsum=rt.grad(bias) if fused else None)
+        else:
+            ops.gemm(dyv, conv_view(x, B, H, W, Ci, KH, KW, stride, pad, dil, OH=OH, OW=OW), rt.grad(weight), Co, K, M,
+                     a_kstrided=True, b_kstrided=True, dtype=rt.tag(), atomic=True, splits=0, c_perm=(Ci, KH * KW),
+                     colsum=rt.grad(bias) if fused else None)
         if bias is not None and not fused:
             ops.colsum(dy, rt.grad(bias), M, Co)
     if not need_dx:

@@ -33,7 +33,10 @@ def conv_view(x, B, H, W, C, KH, KW, stride, pad, dil=1, OH=None, OW=None, in_di
         OW = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
     ch = _chunk(x)
     vec_ok = int(x.data_ptr() % 16 == 0 and C % ch == 0)
-    return View(ptr=x.data_ptr(), ld=0, R=B * OH * OW, Cc=KH * KW * C, batch_stride=0, batch2_stride=0, conv=1, H=H, W=W, C=C,
+    # non-overlapping patches (the spatial-reduction convolutions): the same matrix, but its rows / K segments are contiguous
+    # runs the kernels can fill like a plain operand (conv = 2)
+    patch = (KH == KW == stride and pad == 0 and dil == 1 and in_dil == 1 and not reflect and H == OH * stride and W == OW * stride)
+    return View(ptr=x.data_ptr(), ld=0, R=B * OH * OW, Cc=KH * KW * C, batch_stride=0, batch2_stride=0, conv=2 if patch else 1, H=H, W=W, C=C,
                 OH=OH, OW=OW, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil, in_dil=in_dil, reflect=reflect,
                 vec_ok=vec_ok)
 
@@ -150,6 +153,30 @@ def ln_ws_prealloc(device, lanes):
 _LN_DEFER = {'depth': 0, 'regions': {}, 'touched': {}, 'plans': {}}
 
 
+_ARENA = {}
+
+
+def _host_table(raw, dev):
+    """A small descriptor table the kernels read in place.  On the GPU it lives in PINNED HOST memory (a few KB per launch over the
+    bus): a new set of layers may show up while a stream is capturing (the per-lane folds of a segmented capture differ from the
+    eager iteration's), and neither a host-to-device copy nor an allocation is capturable -- a slice of an arena allocated up
+    front is."""
+    if dev.type != 'cuda':
+        return raw
+    arena = _ARENA.get('a')
+    if arena is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('descriptor arena: run one eager backward pass before capturing')
+        arena = _ARENA['a'] = [torch.empty(16 << 20, dtype=torch.uint8, pin_memory=True), 0]
+    lo = arena[1]
+    if lo + raw.numel() > arena[0].numel():
+        raise RuntimeError('descriptor arena exhausted')
+    tab = arena[0][lo:lo + raw.numel()]
+    tab.copy_(raw)   # host-to-host
+    arena[1] = lo + (raw.numel() + 63) // 64 * 64
+    return tab
+
+
 class ln_deferral:
     def __enter__(self):
         _LN_DEFER['depth'] += 1
@@ -176,6 +203,7 @@ def ln_fold_deferred(all_lanes=False):
     """fold every workspace touched since the last fold into its dgamma / dbeta: one launch per device.  Only the CURRENT
     concurrency lane's workspaces by default (another lane's LayerNorm backward kernels may still be running on their stream);
     the end of the scope, which follows the lanes' joins, folds them all."""
+    conv_grad_drain(all_lanes)
     if all_lanes:
         touched = {}
         for d in _LN_DEFER['touched'].values():
@@ -197,27 +225,61 @@ def ln_fold_deferred(all_lanes=False):
             desc = np.zeros(len(items), dtype=[('ws', '<u8'), ('dg', '<u8'), ('db', '<u8'), ('C', '<i4'), ('n', '<i4')])
             for i, (_, (ws, dg, db, C, nslots)) in enumerate(items):
                 desc[i] = (ws.data_ptr(), dg.data_ptr(), db.data_ptr(), C, nslots)
-            raw = torch.from_numpy(desc.view(np.uint8).reshape(-1).copy())
-            if dev.type == 'cuda':
-                # The table lives in PINNED HOST memory the kernel reads in place (a few KB per launch): a new set of layers may
-                # show up while a stream is capturing (the per-lane folds of a segmented capture differ from the eager
-                # iteration's), and neither a host-to-device copy nor an allocation is capturable -- a slice of an arena
-                # allocated up front is.
-                arena = _LN_DEFER.get('arena')
-                if arena is None:
-                    if torch.cuda.is_current_stream_capturing():
-                        raise RuntimeError('LayerNorm gradient fold: run one eager backward pass before capturing')
-                    arena = _LN_DEFER['arena'] = [torch.empty(1 << 20, dtype=torch.uint8, pin_memory=True), 0]
-                lo = arena[1]
-                if lo + raw.numel() > arena[0].numel():
-                    raise RuntimeError('LayerNorm gradient fold: descriptor arena exhausted')
-                tab = arena[0][lo:lo + raw.numel()]
-                tab.copy_(raw)   # host-to-host
-                arena[1] = lo + (raw.numel() + 63) // 64 * 64
-            else:
-                tab = raw
+            tab = _host_table(torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()), dev)
             plan = _LN_DEFER['plans'][pkey] = (tab, len(items), max(r[3] for _, r in items), dev)
         call('cmda_layernorm_fold_batch', ptr(plan[0]), c_i32(plan[1]), c_i32(plan[2]), stream_of(items[0][1][0]))
+
+
+# Deferred convolution weight gradients: inside the same scope a conv weight gradient is accumulated by the GEMM's atomics in the
+# GEMM's own column order (kh, kw, ci) -- coalesced -- into a persistent zeroed fp32 shadow [Co,KH,KW,Ci] of the parameter's
+# gradient, and ONE batched launch per fold point moves all shadows into the [Co,Ci,KH,KW] gradients and clears them (the
+# permuted atomic store it replaces cost 20-84 us per spatial-reduction conv against 10-14 us, tools/dbg/srconv_dbg.py).
+_CG = {'regions': {}, 'touched': {}, 'plans': {}}
+
+
+def conv_grad_shadow(grad):
+    """grad: fp32 [Co,Ci,KH,KW] parameter gradient -> its [Co, KH*KW*Ci] shadow, or None outside a deferral scope"""
+    if _LN_DEFER['depth'] == 0:
+        return None
+    key = grad.data_ptr()
+    r = _CG['regions'].get(key)
+    if r is None or r[0].device != grad.device:
+        Co, Ci, KH, KW = grad.shape
+        r = _CG['regions'][key] = (torch.zeros(Co, KH * KW * Ci, dtype=torch.float32, device=grad.device), grad)
+    _CG['touched'].setdefault(LN_LANE, {})[key] = r
+    return r[0]
+
+
+def conv_grad_drain(all_lanes=False):
+    if all_lanes:
+        touched = {}
+        for d in _CG['touched'].values():
+            touched.update(d)
+        _CG['touched'] = {}
+    else:
+        touched = _CG['touched'].pop(LN_LANE, {})
+    if not touched:
+        return
+    import numpy as np
+    by_dev = {}
+    for key, r in touched.items():
+        by_dev.setdefault(r[0].device, []).append((key, r))
+    for dev, items in by_dev.items():
+        items.sort(key=lambda kv: kv[0])
+        pkey = (dev, tuple(k for k, _ in items))
+        plan = _CG['plans'].get(pkey)
+        if plan is None:
+            desc = np.zeros(len(items), dtype=[('src', '<u8'), ('dst', '<u8'), ('d', '<i4', 4), ('p', '<i4', 4), ('flip', '<i4'),
+                                               ('mode', '<i4'), ('total', '<i8')])
+            blocks = []
+            for i, (_, (sh, g)) in enumerate(items):
+                Co, Ci, KH, KW = g.shape
+                desc[i] = (sh.data_ptr(), g.data_ptr(), (Co, KH, KW, Ci), (0, 3, 1, 2), 0, 2, g.numel())
+                blocks += [(i, b) for b in range((g.numel() + 1023) // 1024)]
+            tab = _host_table(torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()), dev)
+            blk = _host_table(torch.from_numpy(np.asarray(blocks, dtype=np.int32).reshape(-1).view(np.uint8).copy()), dev)
+            plan = _CG['plans'][pkey] = (tab, blk, len(blocks))
+        call('cmda_permute4_batch', ptr(plan[0]), ptr(plan[1]), c_i32(plan[2]), stream_of(items[0][1][0]))
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, out_scale=None, rows_per_scale=0):

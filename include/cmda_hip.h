@@ -43,7 +43,8 @@ typedef struct cmda_view_t {
   int64_t R, Cc;        /* extent of r and c */
   int64_t batch_stride; /* elements between batch entries (grid z, outer) */
   int64_t batch2_stride; /* elements between inner batch entries (e.g. attention heads) */
-  int32_t conv;         /* 0 plain, 1 im2col view */
+  int32_t conv;         /* 0 plain, 1 im2col view, 2 im2col view of a kernel == stride, pad 0, dil 1 convolution with H = OH*stride,
+                           W = OW*stride (non-overlapping patches: same matrix as 1, filled like a plain operand) */
   int32_t H, W, C;      /* conv: input height/width/channels (NHWC) */
   int32_t OH, OW;       /* conv: output height/width */
   int32_t KH, KW, stride, pad, dil;
@@ -190,7 +191,8 @@ typedef struct cmda_permute_desc_t {
   int32_t d[4];       /* source dims */
   int32_t p[4];       /* dst axis a = source axis p[a] */
   int32_t flipmask;   /* bit ax set: source axis ax reversed */
-  int32_t dst_bf16;   /* 1: dst is bf16, 0: fp32 */
+  int32_t dst_bf16;   /* 1: dst is bf16, 0: fp32; 2: DRAIN -- dst (fp32) += src and src = 0, walking the source in order (the
+                         conv weight-gradient shadows in GEMM order -> the parameter's own layout) */
   int64_t total;      /* d[0]*d[1]*d[2]*d[3] */
 } cmda_permute_desc_t;
 /* dst (activation dtype) = src; src (fp32, n % 4 == 0) = 0: drains a persistent accumulation workspace and leaves it zeroed */
