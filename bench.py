@@ -183,6 +183,30 @@ def synthetic_pairs(B, S, seed, dev, n_events=500000):
                 target=dict(warp_image=warp, events_vg=ev, warp_img_self_res=isr(warp)))
 
 
+def loader_pairs(B, S, seed, dev, n_events=500000):
+    """The same batch schema produced by the on-device loader pipeline (cmda_amd/datasets.py + pipeline.py):
+    synthetic RAW streams -- 2048x1024 uint8 Cityscapes-like frames with their previous frame and label maps, 640x480 DSEC-like
+    frames with `n_events` raw events per sample and a rectification map -- go through PIL-exact resize, random crop / flip,
+    ToTensor + Normalize, the time residual, the Content-Extractor (ISR), event rectification -> voxel grid -> events_norm ->
+    crop 400 -> bilinear 512, exactly as configs/fusion/cs2dsec_image+events_together_b5.py wires them (cityscapes_ic.py:147-272,
+    dsec.py:189-366).  Built once, outside the timed region; resident in HBM."""
+    import random
+    from cmda_amd import datasets
+    cfg = dict(type='UDADataset',
+               source=dict(type='CityscapesICDataset', image_resize_size=(2 * S, S), image_crop_size=(S, S),
+                           outputs={'image', 'label', 'img_time_res', 'img_self_res'}, isr_parms=dict(ISR_PARMS),
+                           shift_type='random', synthetic_length=64, device=dev),
+               target=dict(type='DSECDataset', crop_size=(400, 400), after_crop_resize_size=(S, S), events_bins=1,
+                           isr_parms=dict(ISR_PARMS), outputs={'warp_image', 'events_vg', 'warp_img_self_res'},
+                           shift_type='random', synthetic_length=64, synthetic_events=n_events, device=dev))
+    ds = datasets.build_dataset(cfg)
+    random.seed(seed)
+    first = (seed * 7919) % (len(ds) - B)
+    batch = ds.get_batch(list(range(first, first + B)))
+    return dict(source={k: v.contiguous() for k, v in batch['source'].items()},
+                target={k: v.contiguous() for k, v in batch['target'].items()})
+
+
 def cpu_baseline_dacs(size):
     """The oracle's DACS iteration (oracle/dacs_iter.py: generator, EMA, source fwd/bwd, teacher, ClassMix + jitter + blur +
     ISR, mixed fwd/bwd) on ONE (source, target) pair, fp32, timed once on the host cores -- a bounded sample of the same
@@ -298,7 +322,7 @@ def run_dacs(args, rank, world, dev, dist):
             for lo, hi in ranges.get((tag, id(module)), ()):
                 reducer.start_range(lo, hi)
         dacs.final_pass_grad_hook = _ready
-    batch = synthetic_pairs(B, args.size, 100 + rank, dev)
+    batch = (loader_pairs if args.data == 'loader' else synthetic_pairs)(B, args.size, 100 + rank, dev)
     torch.manual_seed(1000 + rank)            # per-rank DropPath / Dropout / ClassMix streams
     it = [0]
     if not args.no_graph:
@@ -355,8 +379,12 @@ def run_dacs(args, rank, world, dev, dist):
                                             '(SURVEY.md 8d)', 'image_size': args.size, 'parallelism': f'dp{world}',
                           'rccl_ranks': dist.get_world_size() if dist is not None else 1,
                           'student_parameters_M': round(nparam / 1e6, 1), 'launch': graph_mode, 'generator': 'ResnetGenerator 9 blocks, in the step',
-                          'synthetic_inputs': 'SURVEY.md 8d: 500k events/sample through the voxel kernel, ISR through the ISR '
-                                              'kernels, sparse time residual, block labels with 5 % ignore'},
+                          'synthetic_inputs': ('synthetic RAW streams (2048x1024 frames + previous frames + labels; 640x480 frames + 500k raw '
+                                               'events/sample + rectification map) through the on-device loader pipeline of SURVEY.md 8 f3: '
+                                               'PIL-exact resize, crop / flip, time residual, ISR, event rectification -> voxel grid -> '
+                                               'events_norm -> crop 400 -> 512') if args.data == 'loader' else
+                                              ('SURVEY.md 8d: 500k events/sample through the voxel kernel, ISR through the ISR '
+                                               'kernels, sparse time residual, block labels with 5 % ignore')},
                'losses': losses,
                'model_gflop_per_pair': GFLOP_PER_PAIR_UDA,
                'model_tflops_achieved': round(GFLOP_PER_PAIR_UDA * value / 1e3 / world, 2),
@@ -445,6 +473,9 @@ def run_supervised(args, rank, world, dev, dist):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--data', choices=['loader', 'direct'], default='loader',
+                    help='dacs workload: batch built by the on-device loader pipeline from synthetic raw streams (default) or directly '
+                         'from the voxel / ISR kernels (section 8d)')
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=int(os.environ.get('CMDA_BENCH_BATCH', 0)),

@@ -11,6 +11,7 @@ writes the masters without touching torch's version counters).
 Parameter gradients are accumulated by the kernels straight into `param.grad` (fp32, allocated zero on first use):
 autograd never sees them, which is what lets two backward passes per step accumulate with no extra traffic.
 """
+import warnings
 import weakref
 
 import torch
@@ -198,7 +199,9 @@ class SegmentedCapture:
 
     def end(self):
         g, stream, ctx = self.active
-        g.capture_end()
+        with warnings.catch_warnings():   # a stretch between two joins may hold no kernel at all: an empty segment is fine
+            warnings.simplefilter('ignore', UserWarning)
+            g.capture_end()
         ctx.__exit__(None, None, None)
         self.program.append(('replay', g, stream))
         self.active = None
