@@ -88,8 +88,9 @@ class Block(nn.Module):
                            save=save)
 
     def bwd(self, saved, dy, B, H, W, dy_scaled=None, next_scale=None):
-        return K.block_bwd(dy, self, saved, B, H, W, self.dim, self.num_heads, self.sr_ratio, eps=self.eps, dy_scaled=dy_scaled,
-                           next_scale=next_scale)
+        with rt.lane_batch('wgrad'):   # the block's weight gradients: one entry of the side lane after its dgrad chain (if enabled)
+            return K.block_bwd(dy, self, saved, B, H, W, self.dim, self.num_heads, self.sr_ratio, eps=self.eps, dy_scaled=dy_scaled,
+                               next_scale=next_scale)
 
     def forward(self, x, H, W):
         """Reference signature: x [B,N,C] -> [B,N,C] (autograd-enabled bridge over fwd/bwd)."""

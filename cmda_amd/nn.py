@@ -33,11 +33,12 @@ def linear_bwd(dy, x, weight, bias, M, K, *, need_dx=True, dx_out=None, dx_beta=
     xv = plain_view(x, M, K, ld=x_ld, offset=x_off)
     fused = (bias is not None and rt.tag() == 1 and dyv_k.vec_ok and xv.vec_ok and N % 8 == 0 and K % 8 == 0
              and (dy_ld or N) % 8 == 0 and (x_ld or K) % 8 == 0)
-    with rt.lane('wgrad', dy, x):   # off the critical dgrad chain (runtime.py: concurrency lanes)
+    def wgrad():   # off the critical dgrad chain when a block-level batch is open (runtime.lane_batch)
         ops.gemm(dyv_k, xv, rt.grad(weight), N, K, M, a_kstrided=True, b_kstrided=True, dtype=rt.tag(), atomic=True,
                  splits=0, colsum=rt.grad(bias) if fused else None)  # bias gradient rides along in the wgrad kernel
         if bias is not None and not fused:
             ops.colsum(dy, rt.grad(bias), M, N, ld=dy_ld, offset=dy_off)
+    rt.side('wgrad', wgrad, dy, x)
     if not need_dx:
         return None
     dx = dx_out if dx_out is not None else torch.empty(M, K, dtype=rt.compute_dtype(), device=dy.device)
@@ -65,7 +66,7 @@ def conv_bwd(dy, x, weight, bias, B, H, W, stride, pad, dil=1, *, need_dx=True, 
     Co, Ci, KH, KW = weight.shape
     OH, OW = conv_out_size(H, W, KH, stride, pad, dil)
     M, K = B * OH * OW, KH * KW * Ci
-    with rt.lane('wgrad', dy, x):
+    def wgrad():
         # dW[co, (kh,kw,ci)] accumulated with atomics; outside a deferral scope straight into the parameter's [Co,Ci,KH,KW]
         # gradient (c_perm: no staging buffer); the bias gradient rides along in the same kernel when the operands allow
         dyv = plain_view(dy, M, Co)
@@ -81,6 +82,7 @@ def conv_bwd(dy, x, weight, bias, B, H, W, stride, pad, dil=1, *, need_dx=True, 
                      colsum=rt.grad(bias) if fused else None)
         if bias is not None and not fused:
             ops.colsum(dy, rt.grad(bias), M, Co)
+    rt.side('wgrad', wgrad, dy, x)
     if not need_dx:
         return None
     dx = dx_out if dx_out is not None else torch.empty(B * H * W, Ci, dtype=rt.compute_dtype(), device=dy.device)

@@ -175,6 +175,8 @@ def ones1(device):
 # a short list of `replay segment k on stream s` and `stream a waits for stream b` steps (~40 per iteration).  Segmented,
 # GPU-bound (host 4 ms per iteration): no lanes 151; enc 104-107; T 124; enc+T 109-114 -- a THIRD concurrent queue costs more
 # than it hides (GPU_MAX_HW_QUEUES=8: 176), so the default set is {enc}: two queues, everything that can run in pairs does.
+# Also measured: the weight gradients of every transformer block as ONE side-lane entry after the block's dgrad chain
+# (lane_batch('wgrad'): 4 queues, ~200 forks per step): 83.0 against 79.8 ms -- kept as an option, off.
 _conc = {'on': False, 'streams': {}, 'stack': ['main'], 'sstack': [], 'used': {}, 'keep': {}, 'enabled': {'enc'}, 'seg': None, 'seen': set()}
 
 
@@ -245,7 +247,7 @@ def set_concurrency(flag, lanes=None, seg=None):
         _conc['enabled'] = set(lanes)
     _conc['on'] = bool(flag)
     _conc['seg'] = seg if flag else None
-    _conc['stack'], _conc['used'], _conc['keep'], _conc['seen'] = ['main'], {}, {}, set()
+    _conc['stack'], _conc['used'], _conc['keep'], _conc['seen'], _conc['batch'] = ['main'], {}, {}, set(), None
     _conc['sstack'] = [seg.main] if (flag and seg is not None) else []
     ops.LN_LANE = 'main'
 
@@ -310,6 +312,41 @@ class lane:
         return False
 
 
+class lane_batch:
+    """`with lane_batch('wgrad'):` -- work handed to `side('wgrad', fn, ...)` inside the scope is collected and run at the end of
+    the scope in ONE entry of the side lane (one fork per transformer block instead of one per weight gradient: the weight
+    gradients leave the dependent dgrad chain without ~3 k cross-stream edges per step).  Without the lane: runs in place."""
+
+    def __init__(self, name):
+        self.name, self.active = name, False
+
+    def __enter__(self):
+        self.active = _conc['on'] and self.name in _conc['enabled'] and _conc.get('batch') is None
+        if self.active:
+            _conc['batch'] = (self.name, [], [])
+        return self
+
+    def __exit__(self, *exc):
+        if self.active:
+            name, fns, keep = _conc['batch']
+            _conc['batch'] = None
+            if fns and exc[0] is None:
+                with lane(name, *keep):
+                    for fn in fns:
+                        fn()
+        return False
+
+
+def side(name, fn, *keep):
+    """run fn() now, or -- inside an active lane_batch of that name -- later on the side lane (`keep`: the tensors fn reads)"""
+    b = _conc.get('batch')
+    if b is not None and b[0] == name:
+        b[1].append(fn)
+        b[2].extend(keep)
+    else:
+        fn()
+
+
 def keep_alive(*tensors):
     if _conc['on']:
         _conc['keep'].setdefault(_conc['stack'][-1], []).extend(tensors)
@@ -364,6 +401,7 @@ def notify_grads_ready(tag, module=None):
     hook = grad_ready_hook
     if hook is None:
         return
+    join_lanes('wgrad')      # "final" includes the weight gradients still queued on the side lane ...
     ops.ln_fold_deferred()   # "final" includes the LayerNorm parameter gradients still sitting in their workspaces
     seg = _conc['seg']
     if seg is not None and seg.active is not None:
