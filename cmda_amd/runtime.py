@@ -176,7 +176,8 @@ def ones1(device):
 # GPU-bound (host 4 ms per iteration): no lanes 151; enc 104-107; T 124; enc+T 109-114 -- a THIRD concurrent queue costs more
 # than it hides (GPU_MAX_HW_QUEUES=8: 176), so the default set is {enc}: two queues, everything that can run in pairs does.
 # Also measured: the weight gradients of every transformer block as ONE side-lane entry after the block's dgrad chain
-# (lane_batch('wgrad'): 4 queues, ~200 forks per step): 83.0 against 79.8 ms -- kept as an option, off.
+# (lane_batch('wgrad'): 4 queues, ~200 forks per step): 83.0 against 79.8 ms -- kept as an option, off; and the event
+# encoder's two input sets as separate passes on a second side lane (3 queues, +50 % event-encoder launches): 95.6 against 79.6.
 _conc = {'on': False, 'streams': {}, 'stack': ['main'], 'sstack': [], 'used': {}, 'keep': {}, 'enabled': {'enc'}, 'seg': None, 'seen': set()}
 
 
