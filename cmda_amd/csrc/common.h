@@ -197,18 +197,29 @@ static inline void dma_wait() { emu::wave_barrier(); }  // emulated lanes are fi
 // erf by Abramowitz & Stegun 7.1.26 (|abs error| < 1.5e-7, i.e. fp32 round-off level): ~12 VALU ops instead of the
 // ~40 of libm's erff -- the exact-erf GELU of the reference (nn.GELU, mix_transformer.py:26) stays well inside the parity
 // bound while the MixFFN stencil kernels stop being VALU-bound.
-static __device__ __forceinline__ float erf_as(float x) {
-  const float ax = fabsf(x);
-  const float t = 1.0f / (1.0f + 0.3275911f * ax);
+#ifdef CMDA_EMU
+static inline float fast_rcp(float x) { return 1.0f / x; }
+#else
+static __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }  // v_rcp_f32 (1 ulp), not the ~10-op IEEE division
+#endif
+// returns erf(u) and leaves exp(-u^2) in e (the GELU derivative needs the same exponential for its pdf term)
+static __device__ __forceinline__ float erf_as_e(float u, float& e) {
+  const float ax = fabsf(u);
+  const float t = fast_rcp(1.0f + 0.3275911f * ax);
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float r = 1.0f - poly * __expf(-ax * ax);
-  return x < 0.f ? -r : r;
+  e = __expf(-ax * ax);
+  const float r = 1.0f - poly * e;
+  return u < 0.f ? -r : r;
+}
+static __device__ __forceinline__ float erf_as(float x) {
+  float e;
+  return erf_as_e(x, e);
 }
 static __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
 static __device__ __forceinline__ float gelu_erf_grad(float x) {
-  const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  float e;  // exp(-(x / sqrt 2)^2) = exp(-x^2 / 2): also the Gaussian of the pdf term
+  const float cdf = 0.5f * (1.0f + erf_as_e(x * 0.70710678118654752440f, e));
+  return cdf + x * (0.39894228040143267794f * e);
 }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
