@@ -309,7 +309,7 @@ class DACS(nn.Module):
                 return dict(self.forward_cfg, fusion_isr=True)
         return self.forward_cfg
 
-    # -- the device work of one iteration: no host reads, no host-dependent launch shapes (capturable as ONE hipGraph) ----------
+    # -- the device work of one iteration: no host reads, no host-dependent launch shapes (capturable: hipGraph segments) ----------
     def _iteration(self, src, tgt, ctl, use_events, teacher_second, direction):
         """dacs.py:397-860 minus the host decisions (`_draw`), the EMA update and the optimizer step.  `ctl` = device views of
         the control block; `teacher_second` = the teacher's second input (events or ISR, already chosen); `use_events` /
@@ -337,7 +337,8 @@ class DACS(nn.Module):
         # Schedule.  The reference runs source step, teacher, mixing, mixed step one after the other (dacs.py:489-860), but the
         # only data dependencies are: mixing needs the teacher's pseudo-labels and the generator's events; the student's
         # gradients are the sum over both steps; its BatchNorm running statistics see the source step before the mixed step.
-        # So: teacher -> mixing (lane 'T') next to the generator (main lane), then the student ONCE over source + mixed samples.
+        # So: teacher -> mixing, the generator queued on the side lane behind the teacher's event encoder, then the student ONCE over
+        # source + mixed samples (lane 'T' -- the teacher on its own lane -- exists as an option and is off: runtime.py).
         # With the lanes switched off (eager launches) the same code simply runs in program order.
 
         # ---- teacher pseudo-labels (dacs.py:653-711) -----------------------------------------------------------------------------
@@ -441,9 +442,10 @@ class DACS(nn.Module):
 
     # -- hipGraph replay of the iteration ------------------------------------------------------------------------------------------
     def enable_graph(self, warmup_iters=2):
-        """Capture `_iteration` into ONE hipGraph after `warmup_iters` eager iterations and replay it from then on: at the
-        reference's 2+2 samples per GPU the eager step is bound by the host's launch rate (~17 k launches), not by the GPU.
-        Only the EMA update, the control-block copy and the optimizer step stay outside the graph."""
+        """Capture `_iteration` after `warmup_iters` eager iterations -- as a chain of linear hipGraph segments replayed on the
+        concurrency lanes' streams (runtime.SegmentedCapture) -- and replay it from then on: at the reference's 2+2 samples per
+        GPU the eager step is bound by the host's launch rate, not by the GPU.  Only the EMA update, the control-block copy and
+        the optimizer step stay outside."""
         self._graph_warmup = warmup_iters
         self._graph = None
 
