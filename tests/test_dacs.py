@@ -33,7 +33,8 @@ ISR = dict(val_range=[0.01, 1.01], _threshold=0.005, _clip_range=0.1, shift_pixe
 FCFG = dict(loss_weight={'image': 0.5, 'events': 0.5, 'fusion': 0.5, 'img_self_res': 0.25}, gradual_rate=0.0)
 
 
-def make_cfg(dims, ch, generator=True, blur=True, jitter_p=0.2, shift_type='random'):
+def make_cfg(dims, ch, generator=True, blur=True, jitter_p=0.2, shift_type='random', train_type='cs2dsec_image+events_together',
+             fusion='AttentionAvgFusion', ignore_top=0, ignore_bottom=0):
     bb = dict(type='MixVisionTransformer', embed_dims=dims, num_heads=[1, 2, 5, 8], qkv_bias=True,
               depths=DEPTHS, sr_ratios=[8, 4, 2, 1], drop_path_rate=0.0,
               norm_layer=functools.partial(torch.nn.LayerNorm, eps=1e-6))
@@ -43,24 +44,25 @@ def make_cfg(dims, ch, generator=True, blur=True, jitter_p=0.2, shift_type='rand
                                     embed_neck_cfg=dict(type='mlp', act_cfg=None, norm_cfg=None),
                                     fusion_cfg=dict(type='aspp', sep=True, dilations=(1, 6, 12, 18), pool=False,
                                                     act_cfg=dict(type='ReLU'), norm_cfg=dict(type='BN', requires_grad=True)),
-                                    train_type='cs2dsec_image+events_together', share_decoder=True),
+                                    train_type=train_type, share_decoder=True),
                 loss_decode=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0))
     model = dict(type='FusionEncoderDecoder', backbone_image=dict(bb), backbone_events=dict(bb),
-                 fusion_module=dict(type='AttentionAvgFusion', in_channels=dims, drop_path_rate=0.0), decode_head=head,
-                 train_type='cs2dsec_image+events_together', train_cfg=dict(), test_cfg=dict(mode='whole'))
-    uda = dict(type='DACS', alpha=0.999, pseudo_threshold=0.968, pseudo_weight_ignore_top=0, pseudo_weight_ignore_bottom=0,
+                 fusion_module=dict(type=fusion, in_channels=dims, drop_path_rate=0.0), decode_head=head,
+                 train_type=train_type, train_cfg=dict(), test_cfg=dict(mode='whole'))
+    uda = dict(type='DACS', alpha=0.999, pseudo_threshold=0.968, pseudo_weight_ignore_top=ignore_top,
+               pseudo_weight_ignore_bottom=ignore_bottom,
                imnet_feature_dist_lambda=0, imnet_feature_dist_classes=None, imnet_feature_dist_scale_min_ratio=None,
                mix='class', blur=blur, color_jitter_strength=0.2, color_jitter_probability=jitter_p, debug_img_interval=1000,
-               print_grad_magnitude=False, train_type='cs2dsec_image+events_together', forward_cfg=dict(FCFG),
+               print_grad_magnitude=False, train_type=train_type, forward_cfg=dict(FCFG),
                cyclegan_itrd2en_path='random' if generator else '', img_self_res_reg='no', mixed_image_to_mixed_isr=True,
                random_choice_thres='0.5', shift_type=shift_type, isr_parms=dict(ISR), sky_mask=None)
     return dict(model=model, uda=uda, runner=dict(type='IterBasedRunner', max_iters=40000))
 
 
-def oracle_student(dims, ch):
+def oracle_student(dims, ch, fusion='AttentionAvgFusion'):
     return oseg.FusionEncoderDecoder(backbone_image=omit.MixVisionTransformer(embed_dims=dims, depths=DEPTHS, drop_path_rate=0.0),
                                      backbone_events=omit.MixVisionTransformer(embed_dims=dims, depths=DEPTHS, drop_path_rate=0.0),
-                                     fusion_module=ofu.AttentionAvgFusion(in_channels=dims, drop_path_rate=0.0),
+                                     fusion_module=getattr(ofu, fusion)(in_channels=dims, drop_path_rate=0.0),
                                      decode_head=ohd.DAFormerHeadFusion(in_channels=dims, channels=ch, embed_dims=ch,
                                                                         dropout_ratio=0.0, share_decoder=True))
 
@@ -84,16 +86,19 @@ def oracle_draws(d):
     return out
 
 
-def run_case(tgt, dims, ch, dtype, B=2, H=64, W=64, iters=1, graph=False, shift_type='random'):
+def run_case(tgt, dims, ch, dtype, B=2, H=64, W=64, iters=1, graph=False, shift_type='random', **variant):
+    """variant: train_type / fusion / ignore_top / ignore_bottom / generator of the second reference config (cs2dz_image+raw-isr)"""
     rt.set_compute_dtype(dtype)
-    dacs = build_train_model(make_cfg(dims, ch, shift_type=shift_type))
+    dacs = build_train_model(make_cfg(dims, ch, shift_type=shift_type, **variant))
     seeded_fill(dacs.model, 7)
     seeded_fill(dacs.ema_model, 8)  # different from the student: iteration 0 must overwrite it
-    seeded_fill(dacs.cyclegan_itrd2en, 9)
+    if dacs.cyclegan_itrd2en is not None:
+        seeded_fill(dacs.cyclegan_itrd2en, 9)
     dacs.to(tgt.device).train()
     src, tg = make_batch(B, H, W)
     batch = dict(source={k: tgt.to(v) for k, v in src.items()}, target={k: tgt.to(v) for k, v in tg.items()})
-    ref, ema, G = oracle_student(dims, ch), oracle_student(dims, ch), ocg.ResnetGenerator().eval()
+    fus = variant.get('fusion', 'AttentionAvgFusion')
+    ref, ema, G = oracle_student(dims, ch, fus), oracle_student(dims, ch, fus), ocg.ResnetGenerator().eval()
     seeded_fill(ref, 7).train()
     seeded_fill(ema, 8).train()
     seeded_fill(G, 9)
@@ -110,8 +115,10 @@ def run_case(tgt, dims, ch, dtype, B=2, H=64, W=64, iters=1, graph=False, shift_
         grads = {n: p.grad.detach().cpu().clone() for n, p in dacs.model.named_parameters()}
         for p in ref.parameters():
             p.grad = None
-        o = dacs_iter.dacs_iteration(ref, ema, G, src, tg, local_iter=it, forward_cfg=FCFG, isr_parms=ISR, shift_type=shift_type,
-                                     draws=oracle_draws(dacs.last_draws))
+        o = dacs_iter.dacs_iteration(ref, ema, G if dacs.cyclegan_itrd2en is not None else None, src, tg, local_iter=it,
+                                     forward_cfg=FCFG, isr_parms=ISR, shift_type=shift_type, draws=oracle_draws(dacs.last_draws),
+                                     train_type=variant.get('train_type', 'cs2dsec_image+events_together'),
+                                     ignore_top=variant.get('ignore_top', 0), ignore_bottom=variant.get('ignore_bottom', 0))
         outs.append(({k: v.detach().clone() for k, v in log_vars.items()}, mix, grads, o,
                      {n: q.grad.clone() for n, q in ref.named_parameters()}))
     # BatchNorm running statistics of the student after the iterations: source step first, then the mixed step, branch by branch
@@ -127,7 +134,8 @@ def run_case(tgt, dims, ch, dtype, B=2, H=64, W=64, iters=1, graph=False, shift_
 
 def check_iteration(out, exact, tol_loss, tol_grad, label_agree=0.999):
     log_vars, mix, grads, o, ref_grads = out
-    assert_close(mix['day_events'], o['day_events'], 2e-4 if exact else 6e-2, name='generator output (day events)')
+    if o['day_events'] is not None:
+        assert_close(mix['day_events'], o['day_events'], 2e-4 if exact else 6e-2, name='generator output (day events)')
     agree = (mix['pseudo_label'].cpu() == o['pseudo_label']).float().mean().item()
     assert agree > label_agree, f'pseudo-label agreement {agree}'
     if exact:
@@ -152,6 +160,20 @@ def test_dacs_iteration_matches_oracle(tgt):
     dacs, ema, outs = run_case(tgt, SMALL['dims'], SMALL['ch'], torch.float32)
     d = dacs.last_draws
     assert d['jitter'] is not None and len(d['jitter']) == 2 and d['jitter'][0] != d['jitter'][1], 'per-sample jitter draws'
+    check_iteration(outs[0], True, 1e-4, 5e-2)
+    for (n1, p), (n2, q) in zip(dacs.ema_model.named_parameters(), ema.named_parameters()):
+        assert_close(p.data, q.data, 0, name='ema ' + n1)
+
+
+def test_dacs_iteration_second_config_matches_oracle(tgt):
+    """configs/fusion/cs2dz_image+raw-isr_b5.py: AttentionFusion (concat) instead of the averaging fusion, no
+    events and no generator -- the event encoder sees the ISR --, three decoder branches, the pseudo-weight's top / bottom rows
+    zeroed (dacs.py:707-710); the student's source + mixed steps still run as one pass (6 BatchNorm groups)"""
+    dacs, ema, outs = run_case(tgt, SMALL['dims'], SMALL['ch'], torch.float32, train_type='cs2dz_image+raw-isr',
+                               fusion='AttentionFusion', generator=False, ignore_top=3, ignore_bottom=9)
+    assert dacs.cyclegan_itrd2en is None
+    w = outs[0][1]['pseudo_weight']
+    assert w.shape[-2:] == (64, 64)
     check_iteration(outs[0], True, 1e-4, 5e-2)
     for (n1, p), (n2, q) in zip(dacs.ema_model.named_parameters(), ema.named_parameters()):
         assert_close(p.data, q.data, 0, name='ema ' + n1)
