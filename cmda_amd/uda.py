@@ -37,6 +37,12 @@ def set_stochastic(model, flag):
             m.stochastic = flag
 
 
+def tgt_shape(tgt):
+    """shape of the target batch's image tensor (key name differs between the train types)"""
+    t = tgt['warp_image'] if 'warp_image' in tgt else tgt['image']
+    return t.shape
+
+
 def log_vars_to_float(log_vars):
     return {k: (v.item() if isinstance(v, torch.Tensor) else v) for k, v in log_vars.items()}
 
@@ -477,7 +483,8 @@ class DACS(nn.Module):
         finally:
             rt.set_concurrency(False)
         torch.cuda.synchronize(dev)
-        self._graph = dict(graph=g, src=st_src, tgt=st_tgt, second=second, out=out, key=(use_events_struct, direction))
+        self._graph = dict(graph=g, src=st_src, tgt=st_tgt, second=second, out=out,
+                           key=(use_events_struct, direction, tuple(src['image'].shape), tuple(tgt_shape(tgt))))
 
     def forward_train(self, **kwargs):
         src, tgt = kwargs['source'], kwargs['target']
@@ -506,7 +513,8 @@ class DACS(nn.Module):
         graph_on = (getattr(self, '_graph_warmup', None) is not None and dev.type == 'cuda'
                     and self.local_iter >= self._graph_warmup)
         if graph_on:
-            if self._graph is None or self._graph['key'] != (struct_events, ndir_key):
+            if self._graph is None or self._graph['key'] != (struct_events, ndir_key, tuple(src['image'].shape), tuple(tgt_shape(tgt))):
+                # (first replay, another launch structure, or another batch shape: the captured launches are shape-specific)
                 self._capture(src, tgt, cb, struct_events, ndir_key)
             G = self._graph
             for k, v in G['src'].items():
