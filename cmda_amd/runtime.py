@@ -177,7 +177,9 @@ def ones1(device):
 # than it hides (GPU_MAX_HW_QUEUES=8: 176), so the default set is {enc}: two queues, everything that can run in pairs does.
 # Also measured: the weight gradients of every transformer block as ONE side-lane entry after the block's dgrad chain
 # (lane_batch('wgrad'): 4 queues, ~200 forks per step): 83.0 against 79.8 ms -- kept as an option, off; and the event
-# encoder's two input sets as separate passes on a second side lane (3 queues, +50 % event-encoder launches): 95.6 against 79.6.
+# encoder's two input sets as separate passes on a second side lane (3 queues, +50 % event-encoder launches): 95.6 against 79.6;
+# the four ASPP branches of the decode head split over the two lanes (HBM-bound stencils / BatchNorm next to the pointwise GEMMs): the
+# branches take twice as long side by side -- no gain, and the generator loses its slot next to the teacher's decoder.
 _conc = {'on': False, 'streams': {}, 'stack': ['main'], 'sstack': [], 'used': {}, 'keep': {}, 'enabled': {'enc'}, 'seg': None, 'seen': set()}
 
 
@@ -226,13 +228,21 @@ class SegmentedCapture:
         self.program.append(('call', fn, stream))
         self.begin(stream)
 
-    def replay(self):
+    def replay(self, timeline=None):
+        """timeline: a list to receive (program index, stream id, start event, end event) per segment (tools/lanes_timeline.py)"""
         cur = torch.cuda.current_stream(self.device)
         self.main.wait_stream(cur)
-        for op, a, b in self.program:
+        for i, (op, a, b) in enumerate(self.program):
             if op == 'replay':
                 with torch.cuda.stream(b):
-                    a.replay()
+                    if timeline is not None:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        a.replay()
+                        e1.record()
+                        timeline.append((i, id(b), e0, e1))
+                    else:
+                        a.replay()
             elif op == 'call':
                 with torch.cuda.stream(b):
                     a()
