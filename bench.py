@@ -512,6 +512,9 @@ def main():
 
     import cmda_amd.runtime as rt
     rt.set_compute_dtype(torch.bfloat16 if args.dtype == 'bf16' else torch.float32)
+    if os.environ.get('CMDA_BENCH_GEMM_HINT'):   # tuning A/B (tools/gpu): cmda_gemm_params_t.tile_hint for every GEMM of the run
+        from cmda_amd import ops
+        ops.GEMM_TILE_HINT = int(os.environ['CMDA_BENCH_GEMM_HINT'])
     if args.workload == 'dacs':
         return run_dacs(args, rank, world, dev, dist)
     return run_supervised(args, rank, world, dev, dist)
