@@ -61,6 +61,17 @@ int launch_dtype(GemmParams& p, void* stream) {
     else if (p.N > 64 && blocks(128, 128) * sp >= 256) tile = 0;
     else if (blocks(128, 64) * sp >= 2048) tile = 1;
     else tile = 2;
+    // Small grids (at most ~two waves of 128x128 tiles: the UDA step's encoder Linears, M = 2048...8192 rows): the kernel time is
+    // (waves of resident blocks) x (time of one block), so pick the tile by that product.  Block time ~ c0 + c1 * k-tiles, fitted to
+    // tools/gemm_sweep.py (profiles/r02_gemm_sweep.txt): 128x128 4 + 0.9 nkt us (2 blocks per CU), 128x64 3 + 0.75 nkt (3 per CU),
+    // 64x64 2.5 + 0.6 nkt (4 per CU).  8192x1280x320: 128x128 26.1 -> 128x64 20.9 us; 8192x320x1280 stays on 64x64.
+    if (tile != 3 && blocks(128, 128) * sp < 1024 && p.M > 64 && p.N > 64) {
+      const double nk = (double)nkt;
+      const double cost0 = (double)((blocks(128, 128) * sp + 511) / 512) * (4.0 + 0.9 * nk);
+      const double cost1 = (double)((blocks(128, 64) * sp + 767) / 768) * (3.0 + 0.75 * nk);
+      const double cost2 = (double)((blocks(64, 64) * sp + 1023) / 1024) * (2.5 + 0.6 * nk);
+      tile = cost0 <= cost1 && cost0 <= cost2 ? 0 : cost1 <= cost2 ? 1 : 2;
+    }
   }
   if ((p.tile_hint & 15) >= 1 && (p.tile_hint & 15) <= 4 && p.tile_hint > 0) tile = (p.tile_hint & 15) - 1;  // caller's explicit tile choice (tuning sweeps, tests)
   if constexpr (sizeof(T) == 2) {
