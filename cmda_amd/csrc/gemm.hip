@@ -22,7 +22,8 @@ int launch_dtype(GemmParams& p, void* stream) {
       // (the im2col-view weight gradient spills on the 256x256 tile: 11.7 ms against 9.6 ms on 128x128 at batch 64)
       if (sizeof(T) == 2 && p.M >= 256 && p.N >= 256 && blocks(256, 256) >= 32 && p.B.conv != 1) tile = 3;
       else if (blocks(128, 128) >= 64 || (blocks(128, 128) >= 16 && nkt >= 1024)) tile = 0;  // very deep K: split further
-      else if (blocks(128, 64) >= 48) tile = 1;  // e.g. the 320x1280 MixFFN weight gradients (57 vs 72 us on 64x64 tiles)
+      else if (blocks(128, 64) >= 48 && nkt >= 256) tile = 1;  // e.g. the 320x1280 MixFFN weight gradients at K >= 16 k rows (57 vs 72 us on
+                                                               // 64x64 tiles); at the UDA step's K = 8192 the 64x64 tile is ahead (30.0 vs 32.5 us)
     }
     const long b = tile == 3 ? blocks(256, 256) : tile == 0 ? blocks(128, 128) : tile == 1 ? blocks(128, 64) : blocks(64, 64);
     // im2col weight gradients (very deep K, output of a few MB): let the wave-quantisation search below look as far as two

@@ -1,6 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out/tileab
-timeout 600 python tools/gemm_sweep.py > gpurun_out/tileab/sweep.txt 2> gpurun_out/tileab/err; cut -c1-60 gpurun_out/tileab/sweep.txt | head -40
+timeout 600 python tools/gemm_sweep.py > gpurun_out/tileab/sweep.txt 2> gpurun_out/tileab/err; grep " 1 1 1 " gpurun_out/tileab/sweep.txt | cut -c1-60
 for i in 1 2; do
 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/tileab/bench_$i.json 2> gpurun_out/tileab/err_$i
 python -c "
