@@ -908,7 +908,7 @@ int launch_glds(const GemmParams& p, void* stream) {
   dim3 grid((unsigned)tiles, 1, (unsigned)zz);
   if constexpr (NW == 4) {
     // latency configuration: the whole grid is resident at once even at 4 stages (64x64: 64 KiB -> 2 blocks per CU; the wider
-    // tiles: 96 / 128 KiB -> 1 block per CU) and every block runs >= 3 k-tiles
+    // tiles: 96 / 128 KiB -> 1 block per CU) and every block runs >= 12 k-tiles (K >= 768)
     constexpr long kStage = (long)(BM + BN) * 128;
     const long resident = 256L * (4 * kStage <= 65536 ? 2 : 1);
     const long nkt = ((long)p.K + 63) / 64 / (p.splits > 0 ? p.splits : 1);
@@ -916,7 +916,9 @@ int launch_glds(const GemmParams& p, void* stream) {
     if (force) return force == 4 ? launch_glds_ns<TM, TN, NW, 4>(p, grid, stream) : launch_glds_ns<TM, TN, NW, 0>(p, grid, stream);
     // (deeper than 4 -- 8 x 16 KiB on the 64x64 tile, 6 x 24 KiB on 128x64, one block per CU -- measured slower on every shape
     // of the step: profiles/r02_gemm_sweep.txt)
-    if (tiles * zz <= resident && nkt >= 3) return launch_glds_ns<TM, TN, NW, 4>(p, grid, stream);
+    const int min_nkt = (p.tile_hint > 0 && (p.tile_hint >> 12)) ? (p.tile_hint >> 12) : 12;   // (bits 12..: tuning sweeps; in the step 12 k-tiles measured
+                                                                                                // 77.5-78.1 ms against 78.0-78.2 at 3 and 78.2-79.2 at 40)
+    if (tiles * zz <= resident && nkt >= min_nkt) return launch_glds_ns<TM, TN, NW, 4>(p, grid, stream);
   }
   return launch_glds_ns<TM, TN, NW, 0>(p, grid, stream);
 }
