@@ -75,25 +75,40 @@ __global__ void permute4_batch_kernel(const PermuteDesc* __restrict__ desc, cons
   const int e1 = D.d[D.p[1]], e2 = D.d[D.p[2]], e3 = D.d[D.p[3]];
   const long base = (long)bk_y * 1024;
   if (D.dst_bf16 == 2) {
-    // drain mode (conv weight gradients accumulated in the GEMM's own [Co][KH][KW][Ci] order): walk the SOURCE in order,
-    // dst (fp32, permuted layout) += src, src = 0 -- the shadow is left zeroed for the next backward pass
-    const long es[4] = {(long)e1 * e2 * e3, (long)e2 * e3, (long)e3, 1};   // dst strides
-    long dstr[4] = {0, 0, 0, 0};                                              // dst stride of SOURCE axis ax
-#pragma unroll
-    for (int a = 0; a < 4; ++a) dstr[D.p[a]] = es[a];
+    // drain mode (conv weight gradients accumulated in the GEMM's own [Co][KH][KW][Ci] order): dst (fp32, [Co][Ci][KH][KW]) += src,
+    // src = 0 -- the shadow is left zeroed for the next backward pass.  The chunk is walked in DST order, 4 consecutive elements
+    // per thread: the read-modify-write of the gradient is one 16-byte access per lane (fully coalesced), the shadow is read
+    // (and cleared) at (cell, ci) with ci advancing along the lanes -- whole sectors per cell row.  (Walking the source in order
+    // made every gradient access a 4-byte scatter at stride KH*KW*4 bytes: 0.7 ms per step.)
+    const int Ci = D.d[3], cells = D.d[1] * D.d[2];   // source dims (Co, KH, KW, Ci), p = (0, 3, 1, 2)
     float* src = const_cast<float*>(D.src);
     float* dst = reinterpret_cast<float*>(D.dst);
-    for (int k = threadIdx.x; k < 1024; k += blockDim.x) {
-      const long i = base + k;
-      if (i >= D.total) break;
-      const float v = src[i];
-      if (v == 0.f) continue;
-      long t = i;
-      const int i3 = (int)(t % D.d[3]); t /= D.d[3];
-      const int i2 = (int)(t % D.d[2]); t /= D.d[2];
-      const int i1 = (int)(t % D.d[1]); t /= D.d[1];
-      dst[t * dstr[0] + i1 * dstr[1] + i2 * dstr[2] + i3 * dstr[3]] += v;
-      src[i] = 0.f;
+    const long i0 = base + 4L * threadIdx.x;
+    if (i0 >= D.total) return;
+    float add[4];
+    bool any = false;
+    const int n = (int)min(4L, D.total - i0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      add[e] = 0.f;
+      if (e < n) {
+        const long i = i0 + e;
+        const long pair = i / cells;                 // co * Ci + ci
+        const int cell = (int)(i - pair * cells);
+        const long co = pair / Ci;
+        const int ci = (int)(pair - co * Ci);
+        float* sp = src + (co * cells + cell) * Ci + ci;
+        add[e] = *sp;
+        if (add[e] != 0.f) { *sp = 0.f; any = true; }
+      }
+    }
+    if (!any) return;
+    if (n == 4 && (i0 & 3) == 0) {
+      float4 g = *reinterpret_cast<float4*>(dst + i0);
+      g.x += add[0]; g.y += add[1]; g.z += add[2]; g.w += add[3];
+      *reinterpret_cast<float4*>(dst + i0) = g;
+    } else {
+      for (int e = 0; e < n; ++e) dst[i0 + e] += add[e];
     }
     return;
   }

@@ -191,8 +191,8 @@ typedef struct cmda_permute_desc_t {
   int32_t d[4];       /* source dims */
   int32_t p[4];       /* dst axis a = source axis p[a] */
   int32_t flipmask;   /* bit ax set: source axis ax reversed */
-  int32_t dst_bf16;   /* 1: dst is bf16, 0: fp32; 2: DRAIN -- dst (fp32) += src and src = 0, walking the source in order (the
-                         conv weight-gradient shadows in GEMM order -> the parameter's own layout) */
+  int32_t dst_bf16;   /* 1: dst is bf16, 0: fp32; 2: DRAIN -- dst (fp32) += src and src = 0 for d = (Co,KH,KW,Ci), p = (0,3,1,2): the conv
+                         weight-gradient shadows in GEMM order -> the parameter's own [Co][Ci][KH][KW] layout */
   int64_t total;      /* d[0]*d[1]*d[2]*d[3] */
 } cmda_permute_desc_t;
 /* dst (activation dtype) = src; src (fp32, n % 4 == 0) = 0: drains a persistent accumulation workspace and leaves it zeroed */
