@@ -112,6 +112,29 @@ __global__ void permute4_batch_kernel(const PermuteDesc* __restrict__ desc, cons
     }
     return;
   }
+  if (D.p[0] == 0 && D.p[1] == 2 && D.p[2] == 3 && D.p[3] == 1 && D.flipmask == 0 && (D.total & 3) == 0 &&
+      (reinterpret_cast<uintptr_t>(D.src) & 15) == 0) {
+    // [Co][Ci][KH][KW] -> [Co][KH][KW][Ci] (the implicit-GEMM weight layout: most of the bytes of a refresh): walk the SOURCE in order,
+    // one 16-byte load per lane; the stores of one (kh,kw) cell then run along ci across the lanes (whole sectors) instead of every
+    // load being a 4-byte gather at stride KH*KW*4 bytes
+    const int Ci = D.d[1], cells = D.d[2] * D.d[3];
+    const long i0 = base + 4L * threadIdx.x;
+    if (i0 >= D.total) return;
+    float v[4];
+    ld4(D.src + i0, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long i = i0 + e;
+      const long pair = i / cells;                  // co * Ci + ci
+      const int cell = (int)(i - pair * cells);
+      const long co = pair / Ci;
+      const int ci = (int)(pair - co * Ci);
+      const long o = (co * cells + cell) * Ci + ci;
+      if (D.dst_bf16) stf(reinterpret_cast<bf16_t*>(D.dst) + o, v[e]);
+      else reinterpret_cast<float*>(D.dst)[o] = v[e];
+    }
+    return;
+  }
   for (int k = threadIdx.x; k < 1024; k += blockDim.x) {
     const long i = base + k;
     if (i >= D.total) break;
