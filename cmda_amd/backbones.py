@@ -133,6 +133,24 @@ class OverlapPatchEmbed(nn.Module):
                           need_dx=need_dx)
 
 
+def draw_drop_path(owner, blocks, B, device):
+    """Stochastic depth (mix_transformer.py:147-152, DropPath per residual branch) for a run of blocks that is about to execute: all
+    of their per-sample keep masks come from ONE torch.rand call (4 launches per pass instead of 4 per mask); block i takes rows
+    2i (attention branch) and 2i+1 (MLP branch).  `owner` caches the per-row keep probabilities."""
+    live = [blk for blk in blocks if blk.training and blk.drop_path_rate > 0. and getattr(blk, 'stochastic', True)]
+    if not live:
+        return
+    rates = tuple(blk.drop_path_rate for blk in live)
+    cached = getattr(owner, '_dp_keep', None)
+    if cached is None or cached[0] != (rates, str(device)):
+        keep = torch.tensor([1.0 - r for r in rates for _ in range(2)], dtype=torch.float32).to(device).unsqueeze(1)
+        owner._dp_keep = cached = ((rates, str(device)), keep)
+    keep = cached[1]
+    masks = (keep + torch.rand(2 * len(live), B, device=device)).floor_().div_(keep)
+    for i, blk in enumerate(live):
+        blk._dp_pool = [masks, 2 * i]
+
+
 @BACKBONES.register_module()
 class MixVisionTransformer(nn.Module):
     def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dims=[64, 128, 256, 512],
@@ -199,21 +217,7 @@ class MixVisionTransformer(nn.Module):
 
     # -- hand-scheduled passes ------------------------------------------------------------------------------
     def _draw_drop_path(self, B, device):
-        """Stochastic depth (mix_transformer.py:147-152, DropPath per residual branch): all of a pass's per-sample keep
-        masks come from ONE torch.rand call; block i takes rows 2i (attention branch) and 2i+1 (MLP branch)."""
-        blocks = [blk for s in range(1, 5) for blk in getattr(self, f'block{s}')]
-        live = [blk for blk in blocks if blk.training and blk.drop_path_rate > 0. and getattr(blk, 'stochastic', True)]
-        if not live:
-            return
-        rates = tuple(blk.drop_path_rate for blk in live)
-        cached = getattr(self, '_dp_keep', None)
-        if cached is None or cached[0] != (rates, str(device)):
-            keep = torch.tensor([1.0 - r for r in rates for _ in range(2)], dtype=torch.float32).to(device).unsqueeze(1)
-            self._dp_keep = cached = ((rates, str(device)), keep)
-        keep = cached[1]
-        masks = (keep + torch.rand(2 * len(live), B, device=device)).floor_().div_(keep)
-        for i, blk in enumerate(live):
-            blk._dp_pool = [masks, 2 * i]
+        draw_drop_path(self, [blk for s in range(1, 5) for blk in getattr(self, f'block{s}')], B, device)
 
     def feature_shapes(self, H, W):
         """(H_s, W_s) of the four stage outputs for an H x W input (patch embeds: k7 s4 p3, then k3 s2 p1)"""

@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from . import ops
 from . import runtime as rt
-from .backbones import Block, Mlp
+from .backbones import Block, Mlp, draw_drop_path
 from .registry import FUSION
 
 _LN6 = partial(nn.LayerNorm, eps=1e-6)
@@ -34,9 +34,11 @@ class AttentionAvgFusion(nn.Module):
     def fwd(self, feats_i, feats_e, B, save=True, into=None):
         """into: optional list of 4 pre-allocated tensors the fused maps are written into"""
         outs, saved = [], []
+        draw_drop_path(self, list(self.basic_block), B, feats_i[0][0].device)   # one RNG call for the eight blocks
         for i, ((xi, H, W), (xe, _, _)) in enumerate(zip(feats_i, feats_e)):
             yi, si = self.basic_block[2 * i].fwd(xi, B, H, W, save=save)
             ye, se = self.basic_block[2 * i + 1].fwd(xe, B, H, W, save=save)
+            self.basic_block[2 * i]._dp_pool = self.basic_block[2 * i + 1]._dp_pool = None
             outs.append((ops.axpby(yi, ye, 0.5, 0.5, out=into[i] if into is not None else None), H, W))
             saved.append((si, se, H, W))
         return outs, saved
@@ -81,12 +83,14 @@ class AttentionFusion(nn.Module):
 
     def fwd(self, feats_i, feats_e, B, save=True, into=None):
         outs, saved = [], []
+        draw_drop_path(self, list(self.basic_block), B, feats_i[0][0].device)
         for i, ((xi, H, W), (xe, _, _)) in enumerate(zip(feats_i, feats_e)):
             C, M = self.in_channels[i], B * H * W
             cat = torch.empty(M, 2 * C, dtype=rt.compute_dtype(), device=xi.device)
             ops.copy2d(xi, cat, M, C, C, 2 * C)
             ops.copy2d(xe, cat, M, C, C, 2 * C, dst_off=C)
             y, sb = self.basic_block[i].fwd(cat, B, H, W, save=save)
+            self.basic_block[i]._dp_pool = None
             z, sm = self.linear_block[i].fwd(y, B, H, W)
             if into is not None:
                 z = ops.copy2d(z, into[i], M, C, C, C)
