@@ -512,12 +512,14 @@ def bn_train_bwd(dy, x, mean, rstd, gamma, beta, dgamma, dbeta, M, C, relu, lddy
     return dx
 
 
-def ce_upsample_fwd(logits, label, weight, H, W, ignore_index=255):
-    """logits fp32 NHWC [B,h,w,nc]; returns (acc[2] = (sum w*nll, #correct), lse[B,H,W])."""
-    check_dev(logits, label, weight)
+def ce_upsample_fwd(logits, label, weight, H, W, ignore_index=255, acc=None):
+    """logits fp32 NHWC [B,h,w,nc]; returns (acc[2] = (sum w*nll, #correct), lse[B,H,W]).  acc: optional ZEROED fp32 [2] to
+    accumulate into (a slice of one buffer shared by the loss terms of a pass)"""
+    check_dev(logits, label, weight, acc)
     B, h, w, nc = logits.shape
     lse = torch.empty(B, H, W, dtype=torch.float32, device=logits.device)
-    acc = torch.zeros(2, dtype=torch.float32, device=logits.device)
+    if acc is None:
+        acc = torch.zeros(2, dtype=torch.float32, device=logits.device)
     call('cmda_ce_upsample_fwd', ptr(logits), ptr(label), ptr(weight), ptr(lse), ptr(acc), c_i32(B), c_i32(h), c_i32(w),
          c_i32(H), c_i32(W), c_i32(nc), c_i32(ignore_index), stream_of(logits))
     return acc, lse
