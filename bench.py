@@ -259,6 +259,23 @@ def profile_json(name):
         return None
 
 
+def rocprof_gemm_stats(workload):
+    """GEMM-family launches / average duration in the committed rocprofv3 --kernel-trace --stats summary of this command's eager
+    launch sequence (profiles/r02_<workload>_eager_kernel_stats.csv), for the cross-check against the live HIP-event figure"""
+    import csv
+    path = os.path.join(ROOT, 'profiles', f'r02_{workload}_eager_kernel_stats.csv')
+    try:
+        calls = ns = 0
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                if 'gemm' in r['Name']:
+                    calls += int(r['Calls'])
+                    ns += int(r['TotalDurationNs'])
+        return {'file': os.path.relpath(path, ROOT), 'launches': calls, 'avg_launch_us': round(ns / max(calls, 1) / 1e3, 2)} if calls else None
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def gemm_roofline(step, workload):
     """One more (eager) step with every GEMM launch bracketed by HIP events on the launch stream."""
     from cmda_amd import ops
@@ -295,6 +312,9 @@ def gemm_roofline(step, workload):
     micro = profile_json('micro_peaks')
     if micro:
         roof['peak_measured'] = micro
+    rp = rocprof_gemm_stats(workload)
+    if rp:   # kernel durations alone; the live event pairs also bracket the ~2-3 us dependent-launch gap
+        roof['rocprof'] = rp
     return roof
 
 
