@@ -86,7 +86,7 @@ def oracle_draws(d):
     return out
 
 
-def run_case(tgt, dims, ch, dtype, B=2, H=64, W=64, iters=1, graph=False, shift_type='random', **variant):
+def run_case(tgt, dims, ch, dtype, B=2, H=64, W=64, iters=1, graph=False, shift_type='random', lanes=None, **variant):
     """variant: train_type / fusion / ignore_top / ignore_bottom / generator of the second reference config (cs2dz_image+raw-isr)"""
     rt.set_compute_dtype(dtype)
     dacs = build_train_model(make_cfg(dims, ch, shift_type=shift_type, **variant))
@@ -105,6 +105,8 @@ def run_case(tgt, dims, ch, dtype, B=2, H=64, W=64, iters=1, graph=False, shift_
     torch.manual_seed(11), random.seed(11), np.random.seed(11)
     if graph:
         dacs.enable_graph(warmup_iters=1)
+        if lanes is not None:
+            dacs.graph_lane_set = set(lanes)
     outs = []
     for it in range(iters):
         for p in dacs.model.parameters():
@@ -199,16 +201,18 @@ def test_dacs_iteration_full_width_gpu(mode):
 
 
 @pytest.mark.gpu
-def test_dacs_graph_replay_matches_oracle():
-    """iteration 0 eager (warm-up), iterations 1-2 captured / replayed as one hipGraph: each must still match the oracle's
-    iteration with the same draws (different draws per iteration: the gates and parameters travel through the control block)"""
+@pytest.mark.parametrize('lanes', [None, ('enc', 'wgrad'), ()])
+def test_dacs_graph_replay_matches_oracle(lanes):
+    """iteration 0 eager (warm-up), iterations 1-2 captured / replayed as hipGraph segments: each must still match the oracle's
+    iteration with the same draws (different draws per iteration: the gates and parameters travel through the control block).
+    lanes: the default side lane; + the block-level weight-gradient lane (runtime.lane_batch); no side lane at all."""
     from conftest import Target
     from cmda_amd import _lib
     _lib._unbind_for_tests()
     if not torch.cuda.is_available():
         pytest.skip('no GPU on this machine')
     tgt = Target('gpu')
-    dacs, ema, outs = run_case(tgt, SMALL['dims'], SMALL['ch'], torch.float32, iters=3, graph=True)
+    dacs, ema, outs = run_case(tgt, SMALL['dims'], SMALL['ch'], torch.float32, iters=3, graph=True, lanes=lanes)
     assert dacs._graph is not None, 'the iteration was not captured'
     for it, out in enumerate(outs):
         print(f'iteration {it}: source loss {out[0]["decode.loss_seg"].item():.6f} vs {out[3]["decode.loss_seg"].item():.6f}, mix loss '
