@@ -204,6 +204,7 @@ struct AttnBwdParams {
   const bf16_t* d_o;
   bf16_t* dq;
   float* dkv32;
+  bf16_t* dkv16;  // direct mode (one query span per key slice): dK | dV stored as bf16, no atomics, no workspace
   float* stats;  // [B, heads, N, 2] = (lse, D)
   int B, N, Nk, heads, C, q_per_block;
   float scale;
@@ -402,6 +403,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
     }
     __syncthreads();
   }
+  if (p.dkv16) {  // this block saw every query of its (batch, head, key slice): the sums are final
+    bf16_t* ob = p.dkv16 + ((long)b * p.Nk + key0) * 2 * p.C + h * kHD;
+    for (int e = tid; e < kKS * kHD; e += 256) {
+      const int kl = e >> 6, d = e & 63;
+      if (kl < nkeys) {
+        stf(ob + (long)kl * 2 * p.C + d, red[kl * kRedPitch + d]);
+        stf(ob + (long)kl * 2 * p.C + p.C + d, red[(kKS + kl) * kRedPitch + d]);
+      }
+    }
+    return;
+  }
   float* ob = p.dkv32 + ((long)b * p.Nk + key0) * 2 * p.C + h * kHD;
   for (int e = tid; e < kKS * kHD; e += 256) {
     const int kl = e >> 6, d = e & 63;
@@ -434,23 +446,34 @@ extern "C" int cmda_attention_fwd(const void* q, const void* kv, void* o, int B,
 // stats: scratch of cmda_attention_bwd_ws_floats(B, N, heads) floats.
 extern "C" int64_t cmda_attention_bwd_ws_floats(int B, int N, int heads) { return (int64_t)B * N * heads * 2; }
 
-extern "C" int cmda_attention_bwd(const void* q, const void* kv, const void* d_o, void* dq, float* dkv32, float* stats,
-                                  int B, int N, int Nk, int heads, int C, float scale, int dtype, void* stream) {
+// direct mode: with at most 1024 queries per (batch, head) ONE block per 64-key slice walks all of them, so dK | dV need no
+// cross-block accumulation: they are stored as bf16 into dkv16 (no fp32 workspace, no atomics -- ~12 of the kernel's ~24 us at the
+// stage-3 shape -- and no cast pass afterwards).  1 = cmda_attention_bwd will take dkv16 for these sizes.
+extern "C" int cmda_attention_bwd_direct(int B, int N, int Nk, int heads) {
+  (void)B; (void)heads;
+  return N <= 1024 && Nk <= kMaxK ? 1 : 0;
+}
+
+extern "C" int cmda_attention_bwd(const void* q, const void* kv, const void* d_o, void* dq, float* dkv32, void* dkv16,
+                                  float* stats, int B, int N, int Nk, int heads, int C, float scale, int dtype, void* stream) {
   if (B <= 0 || N <= 0) return CMDA_OK;
   if (dtype != CMDA_BF16) return CMDA_ERR_DTYPE;
   if (heads <= 0 || C != heads * kHD || Nk <= 0 || Nk > kMaxK) return CMDA_ERR_UNSUPPORTED;
   if (heads * 4 > 65535 || B > 65535) return CMDA_ERR_SHAPE;
+  const bool direct = cmda_attention_bwd_direct(B, N, Nk, heads) != 0 && dkv16 != nullptr;
+  if (!direct && dkv32 == nullptr) return CMDA_ERR_SHAPE;
   const int fqpb = fwd_queries_per_block(B, N, heads);
-  AttnBwdParams p{(const bf16_t*)q, (const bf16_t*)kv, (const bf16_t*)d_o, (bf16_t*)dq, dkv32, stats, B, N, Nk, heads, C, 0, scale, fqpb};
+  AttnBwdParams p{(const bf16_t*)q, (const bf16_t*)kv, (const bf16_t*)d_o, (bf16_t*)dq, dkv32, direct ? (bf16_t*)dkv16 : nullptr, stats,
+                  B, N, Nk, heads, C, 0, scale, fqpb};
   const long nblk1 = (long)((N + fqpb - 1) / fqpb) * heads * B;
   if (nblk1 > 0x7fffffffL) return CMDA_ERR_SHAPE;
   dim3 g1((unsigned)nblk1);
   CMDA_LAUNCH(attn_bwd_dq_kernel, g1, dim3(256), 0, stream, p);
   // dK/dV: (batch, head, key slice) x query spans, spans a multiple of 128 queries.  Every span costs one fp32 atomic per
   // dK/dV element (~1.3 TB/s chip-wide: 1280 blocks of the stage-3 shape spent 31 of their 61 us there), so only as many
-  // spans as it takes to reach ~2 blocks per CU.
+  // spans as it takes to reach ~2 blocks per CU -- and a single span (direct mode) when the queries are few.
   const long slices = (long)B * heads * ((Nk + kKS - 1) / kKS);
-  long spans = std::max<long>(1, 512 / slices);
+  long spans = direct ? 1 : std::max<long>(1, 512 / slices);
   long qpb = ((N + spans - 1) / spans + 127) / 128 * 128;
   spans = (N + qpb - 1) / qpb;
   p.q_per_block = (int)qpb;

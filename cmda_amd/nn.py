@@ -124,7 +124,12 @@ def attention_bwd(do, q, kv, P, B, N, Nk, heads, C, scale):
     hd = C // heads
     dev = do.device
     tag = rt.tag()
-    if P is None:  # fused forward ran (bf16): dK|dV accumulate in the persistent zeroed workspace, drained by one cast+clear
+    if P is None:  # fused forward ran (bf16)
+        if ops.attention_bwd_direct(B, N, Nk, heads):   # few queries: dK | dV come out final, as bf16, from one block per key slice
+            dkv = torch.empty(B * Nk, 2 * C, dtype=rt.compute_dtype(), device=dev)
+            dq = ops.attention_fused_bwd(q, kv, do, None, B, N, Nk, heads, C, scale, dkv16=dkv)
+            return dq, dkv
+        # otherwise dK | dV accumulate in the persistent zeroed workspace, drained by one cast+clear
         dkv32 = ops.zero_ws(dev, B * Nk * 2 * C).view(B * Nk, 2 * C)
         dq = ops.attention_fused_bwd(q, kv, do, dkv32, B, N, Nk, heads, C, scale)
         return dq, ops.cast_clear(dkv32, rt.compute_dtype())

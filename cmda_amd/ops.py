@@ -420,13 +420,18 @@ def attention_fused_fwd(q, kv, B, N, Nk, heads, C, scale):
     return o
 
 
-def attention_fused_bwd(q, kv, do, dkv32, B, N, Nk, heads, C, scale):
-    """returns dq; accumulates dK | dV into dkv32 (fp32 [B*Nk, 2C])"""
-    check_dev(q, kv, do, dkv32)
+def attention_bwd_direct(B, N, Nk, heads):
+    """True: the fused backward stores dK | dV straight as bf16 (few queries: one block per key slice walks them all)"""
+    return bool(L.lib().cmda_attention_bwd_direct(int(B), int(N), int(Nk), int(heads)))
+
+
+def attention_fused_bwd(q, kv, do, dkv32, B, N, Nk, heads, C, scale, dkv16=None):
+    """returns dq; dK | dV accumulate into dkv32 (fp32 [B*Nk, 2C], zero on entry) or -- direct mode -- are stored into dkv16 (bf16)"""
+    check_dev(q, kv, do, dkv32, dkv16)
     dq = torch.empty(B * N, C, dtype=q.dtype, device=q.device)
     stats = torch.empty(B * N * heads * 2, dtype=torch.float32, device=q.device)
-    call('cmda_attention_bwd', ptr(q), ptr(kv), ptr(do), ptr(dq), ptr(dkv32), ptr(stats), c_i32(B), c_i32(N), c_i32(Nk),
-         c_i32(heads), c_i32(C), c_f32(scale), dtype_tag(q), stream_of(q))
+    call('cmda_attention_bwd', ptr(q), ptr(kv), ptr(do), ptr(dq), ptr(dkv32), ptr(dkv16), ptr(stats), c_i32(B), c_i32(N),
+         c_i32(Nk), c_i32(heads), c_i32(C), c_f32(scale), dtype_tag(q), stream_of(q))
     return dq
 
 

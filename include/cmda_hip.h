@@ -119,8 +119,11 @@ int cmda_softmax_bwd(const void* p, void* dp, int64_t rows, int L, float alpha, 
 int cmda_attention_fwd(const void* q, const void* kv, void* o, int B, int N, int Nk, int heads, int C, float scale,
     int dtype, void* stream);
 int64_t cmda_attention_bwd_ws_floats(int B, int N, int heads);   /* size of `stats` (per-query log-sum-exp and D) */
-int cmda_attention_bwd(const void* q, const void* kv, const void* d_o, void* dq, float* dkv32, float* stats, int B, int N,
-    int Nk, int heads, int C, float scale, int dtype, void* stream);
+/* dK | dV: accumulated into dkv32 (fp32 [B*Nk, 2C], zero on entry) -- or, when cmda_attention_bwd_direct(...) is 1 and dkv16 is
+ * given, stored as bf16 [B*Nk, 2C] into dkv16 by one block per key slice (no workspace, no atomics; dkv32 may then be NULL). */
+int cmda_attention_bwd_direct(int B, int N, int Nk, int heads);
+int cmda_attention_bwd(const void* q, const void* kv, const void* d_o, void* dq, float* dkv32, void* dkv16, float* stats, int B,
+    int N, int Nk, int heads, int C, float scale, int dtype, void* stream);
 
 /* ---- Depthwise 3x3 convolution, NHWC -- DWConv(+GELU) of MixFFN mix_transformer.py:37-44,443-455 and the dilated depthwise
  * half of the sep-ASPP decode_heads/sep_aspp_head.py:18-27.  `w` is tap-major fp32 [9][C]; dw (gradient) is [C][9]. */

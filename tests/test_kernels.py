@@ -314,6 +314,12 @@ def test_fused_attention(tgt, B, N, Nk, heads):
     o = ops.attention_fused_fwd(qd, kvd, B, N, Nk, heads, C, scale)
     assert_close(o, ref.detach(), 1.6e-2, name='attention o')
     dkv = torch.zeros(B * Nk, 2 * C, device=tgt.device)
-    dq = ops.attention_fused_bwd(qd, kvd, dod, dkv, B, N, Nk, heads, C, scale)
+    dq = ops.attention_fused_bwd(qd, kvd, dod, dkv, B, N, Nk, heads, C, scale)   # accumulating form: fp32 workspace + atomics
     assert_close(dq, qr.grad, 2e-2, name='attention dq')
     assert_close(dkv, kvr.grad, 2e-2, name='attention dkv')
+    assert ops.attention_bwd_direct(B, N, Nk, heads) == (N <= 1024)
+    if ops.attention_bwd_direct(B, N, Nk, heads):   # few queries: one block per key slice, dK | dV stored straight as bf16
+        dkv16 = torch.full((B * Nk, 2 * C), float('nan'), dtype=torch.bfloat16, device=tgt.device)
+        dq2 = ops.attention_fused_bwd(qd, kvd, dod, None, B, N, Nk, heads, C, scale, dkv16=dkv16)
+        assert_close(dq2, qr.grad, 2e-2, name='attention dq (direct)')
+        assert_close(dkv16, kvr.grad, 2e-2, name='attention dkv (direct)')
