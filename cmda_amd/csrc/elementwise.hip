@@ -261,7 +261,7 @@ __global__ void copy2d_kernel(const T* __restrict__ src, T* __restrict__ dst, lo
   }
 }
 
-__global__ void ema_kernel(float* __restrict__ ema, const float* __restrict__ p, float alpha, long n) {
+__global__ void ema_kernel(float* __restrict__ ema, const float* __restrict__ p, float alpha, long n, bf16_t* __restrict__ mirror) {
   for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
     if (i + 4 <= n) {
       float e[4], v[4];
@@ -270,8 +270,12 @@ __global__ void ema_kernel(float* __restrict__ ema, const float* __restrict__ p,
 #pragma unroll
       for (int j = 0; j < 4; ++j) e[j] = alpha * e[j] + (1.f - alpha) * v[j];
       st4(ema + i, e);
+      if (mirror) st4(mirror + i, e);   // the teacher's bf16 compute copy, written in the same pass (was a separate cast launch)
     } else {
-      for (long j = i; j < n; ++j) ema[j] = alpha * ema[j] + (1.f - alpha) * p[j];
+      for (long j = i; j < n; ++j) {
+        ema[j] = alpha * ema[j] + (1.f - alpha) * p[j];
+        if (mirror) stf(mirror + j, ema[j]);
+      }
     }
   }
 }
@@ -429,9 +433,9 @@ extern "C" int cmda_copy2d(const void* src, void* dst, int64_t rows, int cols, i
   CMDA_CHECK_LAUNCH();
 }
 
-extern "C" int cmda_ema_update(float* ema, const float* param, float alpha, int64_t n, void* stream) {
+extern "C" int cmda_ema_update(float* ema, const float* param, float alpha, int64_t n, void* ema_bf16, void* stream) {
   if (n <= 0) return CMDA_OK;
-  CMDA_LAUNCH(ema_kernel, dim3(grid_for(n, 4)), dim3(256), 0, stream, ema, param, alpha, (long)n);
+  CMDA_LAUNCH(ema_kernel, dim3(grid_for(n, 4)), dim3(256), 0, stream, ema, param, alpha, (long)n, (bf16_t*)ema_bf16);
   CMDA_CHECK_LAUNCH();
 }
 

@@ -364,9 +364,10 @@ def axpby(x, y, a, b, out=None):
     return out
 
 
-def ema_update(ema, param, alpha):
-    check_dev(ema, param)
-    call('cmda_ema_update', ptr(ema), ptr(param), c_f32(alpha), c_i64(ema.numel()), stream_of(ema))
+def ema_update(ema, param, alpha, mirror=None):
+    """ema = alpha * ema + (1 - alpha) * param; mirror: optional bf16 tensor of the same length that receives the result too"""
+    check_dev(ema, param, mirror)
+    call('cmda_ema_update', ptr(ema), ptr(param), c_f32(alpha), c_i64(ema.numel()), ptr(mirror), stream_of(ema))
 
 
 def adamw_step(p, g, m, v, lr, beta1, beta2, eps, wd, step, p_bf16=None):

@@ -162,8 +162,7 @@ class DACS(nn.Module):
 
     def _init_ema_weights(self):
         if self._flat is not None:
-            ops.ema_update(self._flat[1], self._flat[0], 0.0)
-            self._sync_ema_bf16()
+            ops.ema_update(self._flat[1], self._flat[0], 0.0, mirror=getattr(self, '_ema_bf16', None))
         else:
             for e, p in zip(self.ema_model.parameters(), self.model.parameters()):
                 ops.ema_update(e.data.view(-1), p.data.view(-1), 0.0)
@@ -172,8 +171,7 @@ class DACS(nn.Module):
     def _update_ema(self, it):
         alpha_teacher = min(1 - 1 / (it + 1), self.alpha)
         if self._flat is not None:
-            ops.ema_update(self._flat[1], self._flat[0], alpha_teacher)
-            self._sync_ema_bf16()
+            ops.ema_update(self._flat[1], self._flat[0], alpha_teacher, mirror=getattr(self, '_ema_bf16', None))
         else:
             for e, p in zip(self.ema_model.parameters(), self.model.parameters()):
                 ops.ema_update(e.data.view(-1), p.data.view(-1), alpha_teacher)

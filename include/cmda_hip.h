@@ -211,7 +211,8 @@ int cmda_copy2d(const void* src, void* dst, int64_t rows, int cols, int64_t src_
 /* ---- Self-training state -- EMA teacher update uda/dacs.py:261-272; fused AdamW (torch.optim.AdamW semantics,
  * configs/_base_/schedules/adamw.py; optional bf16 copy of the updated weights); ClassMix of image/events/weight and of
  * labels, models/utils/dacs_transforms.py:101-131 (classes: int64 [B,max_classes] padded with -1). */
-int cmda_ema_update(float* ema, const float* param, float alpha, int64_t n, void* stream);
+int cmda_ema_update(float* ema, const float* param, float alpha, int64_t n, void* ema_bf16 /* optional bf16 copy of the result */,
+    void* stream);
 int cmda_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,
     float beta2, float eps, float weight_decay, int step, void* stream);
 int cmda_class_mix(const void* src, const void* tgt, void* out, const int64_t* src_label, const int64_t* classes, int
