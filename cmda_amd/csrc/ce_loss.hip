@@ -32,22 +32,77 @@ static __device__ __forceinline__ void upsample_scores(const float* __restrict__
     if (c < nc) s[c] = bilin_mix(p00[c], p01[c], p10[c], p11[c], tx.l0, tx.l1, ty.l0, ty.l1);
 }
 
+// Tiled form of the per-pixel kernels: a block owns kTW x kTH full-resolution pixels of one image and first copies the low-resolution
+// logits its pixels can touch (a (kTW/scale + 2) x (kTH/scale + 2) patch, 19 floats each: ~4 KB at scale 4) into LDS with coalesced
+// loads; the 4 x 19 reads per pixel then come from LDS.  (Straight from global memory every wave-load touched ~16 different
+// 76-byte-strided lines: the forward took 62 us for 10 MB, staged 37 us; the pseudo-label kernel 40 -> 23 us; 32-row tiles -- a quarter
+// of the same-address atomics -- change nothing.)  Same bilin_mix on the same values: bit-identical scores.
+constexpr int kTW = 64, kTH = 8, kPatchFloats = 6144;
+
+struct ScoreTile {
+  int X0, Y0, b, tx0, ty0, ncols;
+  bool staged;
+};
+
+static __device__ __forceinline__ ScoreTile stage_patch(const float* __restrict__ lg, float* __restrict__ patch, int h, int w, int H,
+                                                        int W, int nc, float sh, float sw) {
+  ScoreTile t;
+  const int tiles_x = (W + kTW - 1) / kTW, tiles_y = (H + kTH - 1) / kTH;
+  const int bt = blockIdx.x;
+  t.b = bt / (tiles_x * tiles_y);
+  const int r = bt - t.b * tiles_x * tiles_y;
+  t.Y0 = (r / tiles_x) * kTH;
+  t.X0 = (r % tiles_x) * kTW;
+  const int X1 = min(t.X0 + kTW, W) - 1, Y1 = min(t.Y0 + kTH, H) - 1;
+  t.tx0 = bilin_tap(t.X0, w, W, sw).i0;
+  t.ty0 = bilin_tap(t.Y0, h, H, sh).i0;
+  const int tx1 = bilin_tap(X1, w, W, sw).i1, ty1 = bilin_tap(Y1, h, H, sh).i1;
+  t.ncols = tx1 - t.tx0 + 1;
+  const int nrows = ty1 - t.ty0 + 1, rowf = t.ncols * nc;
+  t.staged = rowf * nrows <= kPatchFloats;
+  if (t.staged) {
+    for (int rr = 0; rr < nrows; ++rr) {
+      const float* src = lg + ((long)(t.b * h + t.ty0 + rr) * w + t.tx0) * nc;
+      for (int k = threadIdx.x; k < rowf; k += blockDim.x) patch[rr * rowf + k] = src[k];
+    }
+  }
+  __syncthreads();
+  return t;
+}
+
+template <int NC_MAX>
+static __device__ __forceinline__ void tile_scores(const ScoreTile& t, const float* __restrict__ lg, const float* __restrict__ patch,
+                                                   int h, int w, int nc, const BilinTap& ty, const BilinTap& tx, float (&s)[NC_MAX]) {
+  if (!t.staged) {
+    upsample_scores<NC_MAX>(lg, t.b, h, w, nc, ty, tx, s);
+    return;
+  }
+  const float* p00 = patch + ((ty.i0 - t.ty0) * t.ncols + (tx.i0 - t.tx0)) * nc;
+  const float* p01 = patch + ((ty.i0 - t.ty0) * t.ncols + (tx.i1 - t.tx0)) * nc;
+  const float* p10 = patch + ((ty.i1 - t.ty0) * t.ncols + (tx.i0 - t.tx0)) * nc;
+  const float* p11 = patch + ((ty.i1 - t.ty0) * t.ncols + (tx.i1 - t.tx0)) * nc;
+#pragma unroll
+  for (int c = 0; c < NC_MAX; ++c)
+    if (c < nc) s[c] = bilin_mix(p00[c], p01[c], p10[c], p11[c], tx.l0, tx.l1, ty.l0, ty.l1);
+}
+
 // acc[0] += sum_pix weight*nll ; acc[1] += #correct ; lse[pix] saved for the backward
-__global__ void ce_fwd_kernel(const float* __restrict__ logits, const long long* __restrict__ label,
-                              const float* __restrict__ weight, float* __restrict__ lse_out, float* __restrict__ acc,
-                              int B, int h, int w, int H, int W, int nc, int ignore_index) {
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, const long long* __restrict__ label,
+                                                      const float* __restrict__ weight, float* __restrict__ lse_out,
+                                                      float* __restrict__ acc, int B, int h, int w, int H, int W, int nc,
+                                                      int ignore_index) {
   __shared__ float red[2][4];
+  __shared__ float patch[kPatchFloats];
   const float sh = (float)h / (float)H, sw = (float)w / (float)W;
-  const long total = (long)B * H * W;
+  const ScoreTile t = stage_patch(logits, patch, h, w, H, W, nc, sh, sw);
   float lsum = 0.f, csum = 0.f;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int X = (int)(i % W);
-    const long t = i / W;
-    const int Y = (int)(t % H);
-    const int b = (int)(t / H);
+  const int X = t.X0 + (threadIdx.x & (kTW - 1));
+  for (int Y = t.Y0 + (threadIdx.x / kTW); Y < min(t.Y0 + kTH, H); Y += 256 / kTW) {
+    if (X >= W) break;
+    const long i = ((long)t.b * H + Y) * W + X;
     const BilinTap ty = bilin_tap(Y, h, H, sh), tx = bilin_tap(X, w, W, sw);
     float s[kMaxClasses];
-    upsample_scores<kMaxClasses>(logits, b, h, w, nc, ty, tx, s);
+    tile_scores<kMaxClasses>(t, logits, patch, h, w, nc, ty, tx, s);
     float mx = -INFINITY;
     int am = 0;
 #pragma unroll
@@ -216,21 +271,21 @@ __global__ __launch_bounds__(256) void ce_bwd_gather_kernel(const float* __restr
 }
 
 // label = first arg-max of the up-sampled scores; prob = 1 / sum exp(s - max); count += (prob >= thr)
-__global__ void pseudo_label_kernel(const float* __restrict__ logits, long long* __restrict__ label_out,
-                                    float* __restrict__ prob_out, int* __restrict__ count, int B, int h, int w, int H,
-                                    int W, int nc, float thr) {
+__global__ __launch_bounds__(256) void pseudo_label_kernel(const float* __restrict__ logits, long long* __restrict__ label_out,
+                                                            float* __restrict__ prob_out, int* __restrict__ count, int B, int h, int w,
+                                                            int H, int W, int nc, float thr) {
   __shared__ int red[4];
+  __shared__ float patch[kPatchFloats];
   const float sh = (float)h / (float)H, sw = (float)w / (float)W;
-  const long total = (long)B * H * W;
+  const ScoreTile t = stage_patch(logits, patch, h, w, H, W, nc, sh, sw);
   int cnt = 0;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int X = (int)(i % W);
-    const long t = i / W;
-    const int Y = (int)(t % H);
-    const int b = (int)(t / H);
+  const int X = t.X0 + (threadIdx.x & (kTW - 1));
+  for (int Y = t.Y0 + (threadIdx.x / kTW); Y < min(t.Y0 + kTH, H); Y += 256 / kTW) {
+    if (X >= W) break;
+    const long i = ((long)t.b * H + Y) * W + X;
     const BilinTap ty = bilin_tap(Y, h, H, sh), tx = bilin_tap(X, w, W, sw);
     float s[kMaxClasses];
-    upsample_scores<kMaxClasses>(logits, b, h, w, nc, ty, tx, s);
+    tile_scores<kMaxClasses>(t, logits, patch, h, w, nc, ty, tx, s);
     float mx = -INFINITY;
     int am = 0;
 #pragma unroll
@@ -292,8 +347,10 @@ extern "C" int cmda_ce_upsample_fwd(const float* logits, const int64_t* label, c
                                     void* stream) {
   if ((long)B * H * W <= 0) return CMDA_OK;
   if (nc <= 0 || nc > kMaxClasses) return CMDA_ERR_SHAPE;
-  CMDA_LAUNCH(ce_fwd_kernel, dim3(grid_for((long)B * H * W)), dim3(256), 0, stream, logits, (const long long*)label,
-              weight, lse_out, acc, B, h, w, H, W, nc, ignore_index);
+  const long tiles = (long)B * ((W + kTW - 1) / kTW) * ((H + kTH - 1) / kTH);
+  if (tiles > 0x7fffffffL) return CMDA_ERR_SHAPE;
+  CMDA_LAUNCH(ce_fwd_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, logits, (const long long*)label, weight, lse_out, acc, B, h,
+              w, H, W, nc, ignore_index);
   CMDA_CHECK_LAUNCH();
 }
 
@@ -322,8 +379,10 @@ extern "C" int cmda_pseudo_label(const float* logits, int64_t* label_out, float*
                                  int w, int H, int W, int nc, float thr, void* stream) {
   if ((long)B * H * W <= 0) return CMDA_OK;
   if (nc <= 0 || nc > kMaxClasses) return CMDA_ERR_SHAPE;
-  CMDA_LAUNCH(pseudo_label_kernel, dim3(grid_for((long)B * H * W)), dim3(256), 0, stream, logits,
-              (long long*)label_out, prob_out, count, B, h, w, H, W, nc, thr);
+  const long tiles = (long)B * ((W + kTW - 1) / kTW) * ((H + kTH - 1) / kTH);
+  if (tiles > 0x7fffffffL) return CMDA_ERR_SHAPE;
+  CMDA_LAUNCH(pseudo_label_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, logits, (long long*)label_out, prob_out, count, B, h,
+              w, H, W, nc, thr);
   CMDA_CHECK_LAUNCH();
 }
 
