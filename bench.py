@@ -160,7 +160,9 @@ def synthetic_pairs(B, S, seed, dev, n_events=500000):
     from cmda_amd import ops
     g = torch.Generator().manual_seed(seed)
     image = torch.randn(B, 3, S, S, generator=g).to(dev)
-    label = synthetic_labels(B, S, g).to(dev)
+    label_host = synthetic_labels(B, S, g)
+    label = label_host.to(dev)
+    label._cmda_classes = torch.unique(label_host)   # the class set ClassMix draws from, taken on the host like the loader does
     itr = (torch.rand(B, 1, S, S, generator=g) * 2 - 1) * (torch.rand(B, 1, S, S, generator=g) < 0.1)
     itr = itr.repeat(1, 3, 1, 1).to(dev)
     warp = torch.randn(B, 3, S, S, generator=g).to(dev)
@@ -490,6 +492,59 @@ def run_supervised(args, rank, world, dev, dist):
         dist.destroy_process_group()
 
 
+def self_launch(n):
+    """one child process per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, as `python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node n --master-addr 127.0.0.1` would (tools/train.py:104 of the reference delegates this to its
+    launcher); the children are FRESH interpreters (never fork / exec a process that has initialised the GPU)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        for p in procs:
+            p.wait()
+            rc = rc or p.returncode
+    finally:
+        for p in procs:          # a rank died: do not leave its peers waiting in a collective
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def dry_run(args, rank, world):
+    """`--dry-run`: the launch / rendezvous / max-over-ranks / one-JSON-line plumbing with gloo on the host and no GPU work --
+    what the CPU test-suite can check of the N > 1 path (tests/test_parallel.py)."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    from cmda_amd.parallel import shard_range
+    lo, hi = shard_range(2 * world, rank, world)       # rank r owns pairs [2r, 2r+1] of the global batch
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if world > 1:
+            dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0 + 1e-9])
+    pairs = torch.tensor([float(hi - lo)])
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(pairs)
+    if rank == 0:
+        print(json.dumps({'metric': 'training images/sec (512x512 image+event, MiT-B5)', 'value': None, 'unit': 'img/s',
+                          'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'dry_run': True, 'scaling': 'weak',
+                          'config': {'global_batch': f'{int(pairs.item())} + {int(pairs.item())}', 'parallelism': f'dp{world}',
+                                     'ranks': dist.get_world_size() if world > 1 else 1, 'backend': 'gloo (dry run, no GPU work)'}}),
+              flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -507,19 +562,26 @@ def main():
                     help="dacs = BASELINE.json configs[3]/[4] (the bench line the driver reads): one full CMDA UDA iteration per "
                          "step; supervised = configs[1] (MiT-B5 + DAFormer head fwd/bwd)")
     ap.add_argument('--no-graph', action='store_true', help='dacs: launch every kernel from Python instead of replaying the hipGraph')
+    ap.add_argument('--dry-run', action='store_true', help='launch / rendezvous plumbing only (gloo, no GPU work): CPU tests')
     ap.add_argument('--force-reducer', action='store_true',
                     help='testing: run the gradient all-reduce path (RCCL, side stream, staged ranges) even with one rank')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher.  This process has not touched the GPU (no HIP call,
+        # no torch.cuda.* so far) and never will: it starts N fresh children (one rank per GPU, the env torchrun would set),
+        # waits, and exits with the worst return code; rank 0 prints the JSON line.
+        return sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     if args.gpus > 1 and world != args.gpus:
-        sys.exit(f'bench.py --gpus {args.gpus} must be started with one process per GPU:\n  python -m torch.distributed.run '
-                 f'--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus '
-                 f'{args.gpus} --steps {args.steps} --warmup {args.warmup}   (WORLD_SIZE is {world})')
+        sys.exit(f'bench.py --gpus {args.gpus}: WORLD_SIZE is {world} (start it plain, or under torch.distributed.run with '
+                 f'--nproc-per-node {args.gpus})')
     if args.gpus == 1 and world != 1:
         sys.exit(f'--gpus 1 but WORLD_SIZE={world}')
+    if args.dry_run:
+        return dry_run(args, rank, world)
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (the HIP path has no CPU fallback)'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)

@@ -55,6 +55,7 @@ def _declare(lib):
     lib.cmda_bn_ws_floats.argtypes = [ctypes.c_int]
     lib.cmda_attention_bwd_ws_floats.restype = ctypes.c_int64
     lib.cmda_layernorm_slots.restype = ctypes.c_int
+    lib.cmda_gemm_grouped_ws_bytes.restype = ctypes.c_int64
     return lib
 
 

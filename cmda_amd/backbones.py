@@ -292,6 +292,7 @@ class MixVisionTransformer(nn.Module):
                 if nxt is not None:
                     dx, dxs = dx
             dnext = getattr(self, f'patch_embed{s}').bwd(sv_pe, dx, B, need_dx=(s > 1))
+            ops.gemm_flush_deferred()   # the stage's queued weight gradients: one grouped launch per (tile, operand mode)
             rt.notify_grads_ready(f'backbone.stage{s}', self)
         return None
 

@@ -47,6 +47,7 @@ def load_state_dict(module, state_dict, strict=False, logger=None):
             if mirror is not None:
                 mirror.copy_(p.data)
     rt.invalidate()
+    rt.refresh_frozen(module)   # compute copies of frozen parameters (the Motion-Extractor generator) are outside invalidate()
     msg = []
     if unexpected:
         msg.append('unexpected key in source state_dict: ' + ', '.join(unexpected))

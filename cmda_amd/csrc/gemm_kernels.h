@@ -685,28 +685,37 @@ template <int TM, int TN> struct GldsStages { static constexpr int value = 2; };
 // blocks deep).  NSV = 4: the LATENCY configuration for grids that fit the chip in one wave anyway (the 2 + 2-sample UDA step:
 // every Linear of an encoder is 160-320 blocks): with 2 stages every k-tile exposes a full load latency (K = 1280: 8.9 us of an
 // 11.4 us kernel, tools/gemm_phase.py), with 4 stages three tiles are in flight and the lone block's k-loop drops ~3x.
-template <int TM, int TN, bool AKS, bool BKS, bool ACONV, bool BCONV, int NW = 4, int NSV = 0>
-__global__ __launch_bounds__(64 * NW, (NW == 8 || NSV * (TM * 16 * (NW / 2) + TN * 32) * 128 > 65536) ? 1 : 2) void gemm_glds_kernel(GemmParams p) {
+template <int TM, int TN, int NW, int NSV>
+struct GldsCfg {
+  static constexpr int WM = NW / 2, NTHR = 64 * NW;
+  static constexpr int BM = 16 * TM * WM, BN = 32 * TN, BK = 64;
+  static constexpr int NS = NSV ? NSV : GldsStages<TM, TN>::value;
+  static constexpr int SZ_A = BM * BK, SZ_B = BN * BK;                       // elements per stage
+  static constexpr int PITCH_C = BN + 4;
+  static constexpr int EPI_ROWS = NW == 8 ? 16 * TM : BM;                    // rows staged per epilogue pass
+  static constexpr size_t STAGE_BYTES = (size_t)NS * (SZ_A + SZ_B) * sizeof(bf16_t);
+  static constexpr size_t EPI_BYTES = (size_t)EPI_ROWS * PITCH_C * sizeof(float);
+  static constexpr size_t LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
+  static constexpr int MIN_WAVES = (NW == 8 || NSV * (TM * 16 * (NW / 2) + TN * 32) * 128 > 65536) ? 1 : 2;
+};
+
+// The kernel body.  (bt_raw, ntile, z) = this workgroup's tile index, the number of tiles of the problem and its (batch, split)
+// index: blockIdx.x / gridDim.x / blockIdx.z of a plain launch, or read from the block map of a GROUPED launch (many problems
+// of the same template instance in one grid -- the deferred weight gradients of a backward pass, gemm_glds_grouped_kernel).
+template <int TM, int TN, bool AKS, bool BKS, bool ACONV, bool BCONV, int NW, int NSV>
+static __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, char* smem, int bt_raw, int ntile_raw, int z_raw, bool xcd_walk) {
   typedef bf16_t T;
-  constexpr int WM = NW / 2, NTHR = 64 * NW;
-  constexpr int BM = 16 * TM * WM, BN = 32 * TN, BK = 64;
-  constexpr int NS = NSV ? NSV : GldsStages<TM, TN>::value;
-  constexpr int SZ_A = BM * BK, SZ_B = BN * BK;                       // elements per stage
-  constexpr int PITCH_C = BN + 4;
-  constexpr int EPI_ROWS = NW == 8 ? 16 * TM : BM;                    // rows staged per epilogue pass
-  constexpr size_t STAGE_BYTES = (size_t)NS * (SZ_A + SZ_B) * sizeof(T);
-  constexpr size_t EPI_BYTES = (size_t)EPI_ROWS * PITCH_C * sizeof(float);
-  constexpr size_t LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
-  __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
+  typedef GldsCfg<TM, TN, NW, NSV> Cfg;
+  constexpr int WM = Cfg::WM, NTHR = Cfg::NTHR, BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, NS = Cfg::NS;
+  constexpr int SZ_A = Cfg::SZ_A, SZ_B = Cfg::SZ_B, PITCH_C = Cfg::PITCH_C, EPI_ROWS = Cfg::EPI_ROWS;
   T* const sAbase = reinterpret_cast<T*>(smem);
   T* const sBbase = sAbase + NS * SZ_A;
-
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1, g = lane >> 4, l15 = lane & 15;
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int ntile = gridDim.x;
-  int bt = blockIdx.x;
-  {
+  const int ntile = ntile_raw;
+  int bt = bt_raw;
+  if (xcd_walk) {
     const int q = ntile / 8, rr = ntile % 8, xcd = bt % 8, loc = bt / 8;
     bt = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
   }
@@ -730,7 +739,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || NSV * (TM * 16 * (NW / 2) + TN
   }
   const long m0 = mt * BM;
   const long n0 = nt * BN;
-  const int z = blockIdx.z;
+  const int z = z_raw;
   const int bz = z / p.splits;
   const int split = z - bz * p.splits;
   const int batch = bz / p.batch2, batch2 = bz - batch * p.batch2;
@@ -885,6 +894,33 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || NSV * (TM * 16 * (NW / 2) + TN
   CMDA_STAMP(5);
 }
 
+template <int TM, int TN, bool AKS, bool BKS, bool ACONV, bool BCONV, int NW = 4, int NSV = 0>
+__global__ __launch_bounds__(64 * NW, (GldsCfg<TM, TN, NW, NSV>::MIN_WAVES)) void gemm_glds_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(1024))) char smem[GldsCfg<TM, TN, NW, NSV>::LDS_BYTES];
+  gemm_glds_body<TM, TN, AKS, BKS, ACONV, BCONV, NW, NSV>(p, smem, blockIdx.x, gridDim.x, blockIdx.z, true);
+}
+
+// GROUPED launch: one grid over MANY problems of this template instance.  `tab` = DEVICE array of parameter blocks (splits already
+// resolved), `blk` = DEVICE array with one {problem, block index inside the problem} pair per workgroup; inside a problem the
+// blocks are numbered z-major (z * tiles + tile).  Used for the DEFERRED weight gradients of a backward pass (ops.gemm_deferral):
+// ~300 latency-bound launches of 100-200 blocks each per encoder stage become one launch of ~50 k blocks that runs at the
+// MFMA / atomic rate.  The XCD-aware tile walk is off (weight-gradient outputs are a few tiles; nothing to share through L2).
+template <int TM, int TN, bool AKS, bool BKS, bool ACONV, bool BCONV, int NW = 4, int NSV = 0>
+__global__ __launch_bounds__(64 * NW, (GldsCfg<TM, TN, NW, NSV>::MIN_WAVES)) void gemm_glds_grouped_kernel(const GemmParams* __restrict__ tab,
+                                                                                                            const int* __restrict__ blk) {
+  __shared__ __attribute__((aligned(1024))) char smem[GldsCfg<TM, TN, NW, NSV>::LDS_BYTES];
+#ifndef CMDA_EMU
+  const int prob = __builtin_amdgcn_readfirstlane(blk[2 * blockIdx.x]), loc = __builtin_amdgcn_readfirstlane(blk[2 * blockIdx.x + 1]);
+#else
+  const int prob = blk[2 * blockIdx.x], loc = blk[2 * blockIdx.x + 1];
+#endif
+  const GemmParams& p = tab[prob];
+  constexpr int BM = GldsCfg<TM, TN, NW, NSV>::BM, BN = GldsCfg<TM, TN, NW, NSV>::BN;
+  const int ntile = (int)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  const int z = loc / ntile;
+  gemm_glds_body<TM, TN, AKS, BKS, ACONV, BCONV, NW, NSV>(p, smem, loc - z * ntile, ntile, z, false);
+}
+
 template <int TM, int TN, int NW, int NSV>
 int launch_glds_ns(const GemmParams& p, const dim3& grid, void* stream) {
   const dim3 blk(64 * NW);
@@ -923,6 +959,17 @@ int launch_glds(const GemmParams& p, void* stream) {
   return launch_glds_ns<TM, TN, NW, 0>(p, grid, stream);
 }
 
+// grouped launch of the weight-gradient operand modes (A and B K-strided; B plain / patch view, or an im2col view)
+template <int TM, int TN>
+int launch_glds_grouped(const GemmParams* tab, const void* blk, int nblocks, int bconv, void* stream) {
+  if (nblocks <= 0) return CMDA_OK;
+  const dim3 grid((unsigned)nblocks), blkdim(256);
+  const int* b = reinterpret_cast<const int*>(blk);
+  if (bconv) CMDA_LAUNCH((gemm_glds_grouped_kernel<TM, TN, true, true, false, true, 4, 0>), grid, blkdim, 0, stream, tab, b);
+  else CMDA_LAUNCH((gemm_glds_grouped_kernel<TM, TN, true, true, false, false, 4, 0>), grid, blkdim, 0, stream, tab, b);
+  CMDA_CHECK_LAUNCH();
+}
+
 template <typename T, int TM, int TN>
 int launch_tile(const GemmParams& p, void* stream) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
@@ -944,6 +991,8 @@ int cmda_gemm_glds_t0_(const cmda_gemm_params_t& p, void* stream);        // gem
 int cmda_gemm_glds_t1_(const cmda_gemm_params_t& p, void* stream);        // gemm_t1.hip: 128x64 tile
 int cmda_gemm_glds_t2_(const cmda_gemm_params_t& p, void* stream);        // gemm_t2.hip: 64x64 tile
 int cmda_gemm_glds_t3_(const cmda_gemm_params_t& p, void* stream);        // gemm_t3.hip: 256x256 tile, 8 waves
+int cmda_gemm_grouped_t2_(const cmda_gemm_params_t* tab, const void* blk, int nblocks, int bconv, void* stream);  // gemm_g2.hip
+int cmda_gemm_grouped_t0_(const cmda_gemm_params_t* tab, const void* blk, int nblocks, int bconv, void* stream);  // gemm_g0.hip
 int cmda_gemm_reg_(const cmda_gemm_params_t& p, int tile, void* stream);  // gemm_reg.hip: register-staged kernels, dispatch
 // gemm_reg_{f32,bf16}_t{0,1,2}.hip: one (dtype, tile) each -- these are the slow units to compile (~50 s apiece)
 int cmda_gemm_reg_f32_t0_(const cmda_gemm_params_t& p, void* stream);

@@ -56,6 +56,25 @@ def _blocky_labels(g, h, w, cell=32, ignore=0.05):
     return lab
 
 
+_WARNED = set()
+
+
+def _warn_synthetic(cls, path):
+    """The registry keys are the reference's, the data is NOT: a config that points at real files must not train on seeded noise
+    silently.  One loud warning per dataset class; CMDA_STRICT_DATA=1 turns it into an error."""
+    if not path:
+        return
+    msg = (f'{cls.__name__}: path {path!r} was given, but cmda_amd has no file-backed reader (PNG / HDF5 decoding is outside the '
+           f'accelerated hot path, SURVEY.md section 2): this dataset produces SEEDED SYNTHETIC frames / labels / events of the real '
+           f'geometry.  Pass dataset_path="" to acknowledge, or feed real tensors to DACS.train_step directly.')
+    if os.environ.get('CMDA_STRICT_DATA') == '1':
+        raise FileNotFoundError(msg)
+    if cls.__name__ not in _WARNED:
+        _WARNED.add(cls.__name__)
+        import warnings
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
+
 class _SyntheticBase:
     CLASSES, PALETTE, ignore_index = CLASSES, PALETTE, 255
 
@@ -82,6 +101,7 @@ class CityscapesICDataset(_SyntheticBase):
                  outputs={'image', 'label'}, isr_noise=False, isr_cow_mask=False, high_resolution_isr=False, random_flare=None,
                  cs_isr_data_type='day', sky_mask=None, shift_3_channel=False, isr_parms='', shift_type='rightdown',
                  synthetic_length=2975, raw_size=(2048, 1024), seed=0, device=None):
+        _warn_synthetic(type(self), dataset_path)
         assert image_crop_size[0] <= image_resize_size[0] and image_crop_size[1] <= image_resize_size[1]
         assert not (isr_noise or isr_cow_mask or high_resolution_isr or shift_3_channel) and random_flare is None and sky_mask is None, \
             'augmentations that are off in configs/fusion/* are not implemented'
@@ -101,16 +121,34 @@ class CityscapesICDataset(_SyntheticBase):
         prev = (now.int() + (torch.randn((H, W, 3), generator=g) * 18).int()).clamp(0, 255).to(torch.uint8)
         return now, prev, _blocky_labels(g, self.image_resize_size[1], self.image_resize_size[0])
 
-    def get_batch(self, indices):
+    def draw_decisions(self):
+        """the loader's random decisions of ONE sample, in the reference's order (cityscapes_ic.py:149-151): (flip, x, y)"""
+        (rw, rh), (cw, ch) = self.image_resize_size, self.image_crop_size
+        return int(random.random() < 0.5), random.randint(0, rw - cw), random.randint(0, rh - ch)
+
+    def label_crop(self, idx, decision):
+        """the cropped / flipped label of sample idx under `decision` (host tensor [ch, cw]): what Rare-Class-Sampling inspects
+        before it accepts a crop (uda_dataset.py:96-107) -- without running the image pipeline for a crop it may reject"""
+        f, x, y = decision
+        cw, ch = self.image_crop_size
+        lab = self.raw_label(idx)[y:y + ch, x:x + cw]
+        return torch.flip(lab, dims=[-1]) if f else lab
+
+    def raw_label(self, idx):
+        g = self._gen(idx)
+        W, H = self.raw_size
+        _blocky_u8(g, H, W, 3)                      # keep the generator stream of raw(): frame, previous-frame noise, label
+        torch.randn((H, W, 3), generator=g)
+        return _blocky_labels(g, self.image_resize_size[1], self.image_resize_size[0])
+
+    def get_batch(self, indices, decisions=None):
+        """decisions: optional per-sample (flip, x, y) drawn by the caller (UDADataset's Rare-Class-Sampling re-crop loop)"""
         dev = self.device
         B = len(indices)
         (rw, rh), (cw, ch) = self.image_resize_size, self.image_crop_size
-        # the loader's random decisions, in the reference's order (cityscapes_ic.py:149-151)
-        flips, xs, ys = [], [], []
-        for _ in indices:
-            flips.append(int(random.random() < 0.5))
-            xs.append(random.randint(0, rw - cw))
-            ys.append(random.randint(0, rh - ch))
+        if decisions is None:
+            decisions = [self.draw_decisions() for _ in indices]
+        flips, xs, ys = [d[0] for d in decisions], [d[1] for d in decisions], [d[2] for d in decisions]
         raws = [self.raw(i) for i in indices]
         now = _stack_dev([r[0] for r in raws], dev)
         out = {}
@@ -125,7 +163,16 @@ class CityscapesICDataset(_SyntheticBase):
             for (_, _, lab), x, y, f in zip(raws, xs, ys, flips):
                 lab = lab[y:y + ch, x:x + cw]
                 labs.append((torch.flip(lab, dims=[-1]) if f else lab)[None])
+            # the class set ClassMix draws from (dacs_transforms.py:103-104: unique over the whole batch), taken HERE on the host
+            # from the cropped labels: the training step then needs no device read at all for it (the reference's
+            # `torch.unique(labels)` + `.cpu()` is a sync; a side-stream read would have to be ordered after the copy below)
+            # (out-of-band attributes of the label tensor: the batch-dict schema stays the reference's)
+            classes = torch.unique(torch.stack(labs))
             out['label'] = _stack_dev(labs, dev)
+            out['label']._cmda_classes = classes
+            if dev.type == 'cuda':
+                out['label']._cmda_ready = torch.cuda.Event()
+                out['label']._cmda_ready.record()
         if 'img_time_res' in self.outputs:
             prev = _stack_dev([r[1] for r in raws], dev)
             tr = pl.time_residual_u8(pl.luma_u8(now), pl.luma_u8(prev))
@@ -163,6 +210,7 @@ class DSECDataset(_SyntheticBase):
                  classes=CLASSES, palette=PALETTE, isr_shift_pixel=4, test_mode=False, events_bins_5_avg_1=False, isr_parms='',
                  isr_type='real_time', enforce_3_channels=True, shift_type='rightdown', synthetic_length=1692,
                  synthetic_events=500000, seed=1, device=None):
+        _warn_synthetic(type(self), dataset_txt_path)
         assert output_num == 1 and not events_bins_5_avg_1 and isr_type == 'real_time'
         assert shift_type in {'all', 'random', 'rightdown'}
         self.outputs = set(outputs)
@@ -258,6 +306,7 @@ class DarkZurichICDataset(_SyntheticBase):
                  classes=CLASSES, palette=PALETTE, outputs={'image', 'night_isr'}, submit_to_website=False, auto_threshold=False,
                  high_resolution_isr=False, isr_parms='', shift_3_channel=False, shift_type='rightdown', synthetic_length=2416,
                  raw_size=(1920, 1080), seed=2, device=None):
+        _warn_synthetic(type(self), dataset_path)
         assert image_resize_size2 is None and not (auto_threshold or high_resolution_isr or shift_3_channel or submit_to_website)
         self.image_resize_size, self.image_crop_size = tuple(image_resize_size), tuple(image_crop_size)
         self.test_mode, self.outputs = test_mode, set(outputs)
@@ -343,7 +392,12 @@ class UDADataset:
             path = os.path.join(root, 'sample_class_stats.json')
             stats = json.load(open(path)) if os.path.exists(path) else source.sample_class_stats()
             self.rcs_classes, self.rcs_classprob = get_rcs_class_probs(stats, self.rcs_class_temp)
-            self.samples_with_class = {c: [s['file'] for s in stats if s.get(str(c), 0) > self.rcs_min_pixels] for c in self.rcs_classes}
+            swc_path = os.path.join(root, 'samples_with_class.json')
+            if os.path.exists(swc_path):   # uda_dataset.py:63-76: {class: [[file, pixels], ...]}
+                swc = {int(k): v for k, v in json.load(open(swc_path)).items()}
+                self.samples_with_class = {c: [f for f, px in swc.get(c, []) if px > self.rcs_min_pixels] for c in self.rcs_classes}
+            else:
+                self.samples_with_class = {c: [s['file'] for s in stats if s.get(str(c), 0) > self.rcs_min_pixels] for c in self.rcs_classes}
             self.rcs_classes = [c for c in self.rcs_classes if self.samples_with_class[c]]
             self.rcs_classprob = np.array([p for c, p in zip(get_rcs_class_probs(stats, self.rcs_class_temp)[0], self.rcs_classprob)
                                            if c in self.rcs_classes])
@@ -351,20 +405,43 @@ class UDADataset:
             self.file_to_idx = {f: i for i, f in enumerate(source.file_path['label'])}
 
     def _source_index(self, idx):
+        """-> (source index, accepted crop decision or None).  Rare-Class-Sampling (uda_dataset.py:89-107): draw a class, a file
+        that holds it, then re-crop that file up to 10 times until the crop shows more than min_pixels * min_crop_ratio pixels of
+        the class (each re-crop = one more `self.source[i1]` in the reference, i.e. one more (flip, x, y) draw)."""
         if not self.rcs_enabled:
-            return idx // len(self.target)
+            return idx // len(self.target), None
         c = np.random.choice(self.rcs_classes, p=self.rcs_classprob)
-        return self.file_to_idx[np.random.choice(self.samples_with_class[c])]
+        i1 = self.file_to_idx[np.random.choice(self.samples_with_class[c])]
+        if not hasattr(self.source, 'draw_decisions'):
+            return i1, None
+        dec = self.source.draw_decisions()
+        if self.rcs_min_crop_ratio > 0:
+            for _ in range(10):
+                n_class = int((self.source.label_crop(i1, dec) == int(c)).sum())
+                if n_class > self.rcs_min_pixels * self.rcs_min_crop_ratio:
+                    break
+                dec = self.source.draw_decisions()
+        return i1, dec
 
     def _target_index(self, idx):
         return int(np.random.choice(range(len(self.target)))) if self.rcs_enabled else idx % len(self.target)
 
     def __getitem__(self, idx):
-        return {'source': self.source[self._source_index(idx)], 'target': self.target[self._target_index(idx)]}
+        b = self.get_batch([idx])
+        pick = lambda d: {k: (v[0] if isinstance(v, (torch.Tensor, list)) else v) for k, v in d.items()}   # noqa: E731
+        return {'source': pick(b['source']), 'target': pick(b['target'])}
 
     def get_batch(self, indices):
-        return {'source': self.source.get_batch([self._source_index(i) for i in indices]),
-                'target': self.target.get_batch([self._target_index(i) for i in indices])}
+        # per sample, in the reference's order (get_rare_class_sample): source draws, then the target index
+        src, tgt = [], []
+        for i in indices:
+            src.append(self._source_index(i))
+            tgt.append(self._target_index(i))
+        if all(d is None for _, d in src):
+            source = self.source.get_batch([i for i, _ in src])
+        else:
+            source = self.source.get_batch([i for i, _ in src], decisions=[d for _, d in src])
+        return {'source': source, 'target': self.target.get_batch(tgt)}
 
     def __len__(self):
         return len(self.source) * len(self.target)

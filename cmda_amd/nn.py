@@ -35,7 +35,8 @@ def linear_bwd(dy, x, weight, bias, M, K, *, need_dx=True, dx_out=None, dx_beta=
              and (dy_ld or N) % 8 == 0 and (x_ld or K) % 8 == 0)
     def wgrad():   # off the critical dgrad chain when a block-level batch is open (runtime.lane_batch)
         ops.gemm(dyv_k, xv, rt.grad(weight), N, K, M, a_kstrided=True, b_kstrided=True, dtype=rt.tag(), atomic=True,
-                 splits=0, colsum=rt.grad(bias) if fused else None)  # bias gradient rides along in the wgrad kernel
+                 splits=0, colsum=rt.grad(bias) if fused else None,   # bias gradient rides along in the wgrad kernel
+                 defer=True, keep=(dy, x))   # inside a backward pass: queued, launched in groups (ops.gemm_flush_deferred)
         if bias is not None and not fused:
             ops.colsum(dy, rt.grad(bias), M, N, ld=dy_ld, offset=dy_off)
     rt.side('wgrad', wgrad, dy, x)
@@ -75,7 +76,7 @@ def conv_bwd(dy, x, weight, bias, B, H, W, stride, pad, dil=1, *, need_dx=True, 
         if shadow is not None:   # inside a pass: coalesced atomics into the [Co,KH,KW,Ci] shadow, drained once per pass
             ops.gemm(dyv, conv_view(x, B, H, W, Ci, KH, KW, stride, pad, dil, OH=OH, OW=OW), shadow, Co, K, M,
                      a_kstrided=True, b_kstrided=True, dtype=rt.tag(), atomic=True, splits=0,
-                     colsum=rt.grad(bias) if fused else None)
+                     colsum=rt.grad(bias) if fused else None, defer=True, keep=(dy, x))
         else:
             ops.gemm(dyv, conv_view(x, B, H, W, Ci, KH, KW, stride, pad, dil, OH=OH, OW=OW), rt.grad(weight), Co, K, M,
                      a_kstrided=True, b_kstrided=True, dtype=rt.tag(), atomic=True, splits=0, c_perm=(Ci, KH * KW),

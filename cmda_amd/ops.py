@@ -51,8 +51,11 @@ GEMM_TILE_HINT = 0
 
 def gemm(A, B, out, M, N, K, *, a_kstrided=False, b_kstrided=False, ldc=None, batch=1, c_batch_stride=0,
          batch2=1, c_batch2_stride=0, res_batch2_stride=0, splits=1, alpha=1.0, beta=0.0, bias=None, act=None, res=None, ldres=None, res_batch_stride=0,
-         rowscale=None, rows_per_scale=1, atomic=False, dtype=None, c_offset=0, colsum=None, c_patch=None, c_perm=None):
-    """out[m,n] = epi(alpha * sum_k A(m,k) B(n,k)); A/B are `View`s built by plain_view / conv_view."""
+         rowscale=None, rows_per_scale=1, atomic=False, dtype=None, c_offset=0, colsum=None, c_patch=None, c_perm=None, defer=False, keep=()):
+    """out[m,n] = epi(alpha * sum_k A(m,k) B(n,k)); A/B are `View`s built by plain_view / conv_view.
+    defer=True (weight gradients: nothing reads `out` before the pass ends): inside a deferral scope (`ln_deferral`) the launch is
+    only QUEUED and goes out with the next `gemm_flush_deferred()` as part of a grouped launch; `keep` = the tensors behind the
+    operand views (kept alive until then)."""
     check_dev(out, bias, res, rowscale)
     out_f32 = out.dtype == torch.float32
     p = GemmParams()
@@ -89,6 +92,12 @@ def gemm(A, B, out, M, N, K, *, a_kstrided=False, b_kstrided=False, ldc=None, ba
         assert res is None and batch == 1 and batch2 == 1 and not atomic
         p.c_patch_ow, p.c_patch_kh, p.c_patch_kwci = c_patch
         p.c_vec_ok = int(p.C % 16 == 0 and c_patch[2] % 4 == 0 and (bias is None or bias.data_ptr() % 16 == 0))
+    if defer and _LN_DEFER['depth'] > 0 and GEMM_DEFER:
+        es = 4 if dtype == 0 else 2
+        nb = batch * batch2
+        _GD['queues'].setdefault(LN_LANE, []).append((p, (out, colsum) + tuple(keep), 2.0 * M * N * K * nb,
+                                                      (M * K + N * K) * nb * es + 2 * M * N * nb * 4))
+        return out
     if GEMM_PROFILE is not None and out.is_cuda:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -105,6 +114,67 @@ def gemm(A, B, out, M, N, K, *, a_kstrided=False, b_kstrided=False, ldc=None, ba
         return out
     call('cmda_gemm', ctypes.byref(p), stream_of(out))
     return out
+
+
+# ---- deferred weight gradients: queued by gemm(defer=True) inside a deferral scope, launched in groups (cmda_gemm_grouped) ----------
+import os as _os
+GEMM_DEFER = _os.environ.get('CMDA_GEMM_DEFER', '1') != '0'    # False: defer=True launches in place (A/B switch for tuning, tests of the single-launch path)
+_GD = {'queues': {}, 'plans': {}, 'arena': None, 'pinned_plans': False}
+_GD_ARENA_BYTES = 192 << 20
+
+
+def _gd_arena(dev, nbytes):
+    """slice of the pinned host arena the grouped launches' tables are built in (a plain CPU tensor under the emulator).  Slices
+    are never reused while a plan lives: a captured graph re-runs the upload kernel of its plans on every replay."""
+    nbytes = (nbytes + 255) // 256 * 256
+    a = _GD['arena']
+    if a is None:
+        if dev.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('grouped-GEMM arena: run one eager backward pass before capturing')
+        a = _GD['arena'] = [torch.empty(_GD_ARENA_BYTES, dtype=torch.uint8, pin_memory=(dev.type == 'cuda')), 0]
+    if a[1] + nbytes > a[0].numel():
+        if _GD['pinned_plans'] or (dev.type == 'cuda' and torch.cuda.is_current_stream_capturing()):
+            raise RuntimeError('grouped-GEMM arena exhausted while captured graphs hold plans in it')
+        if dev.type == 'cuda':
+            torch.cuda.synchronize(dev)   # eager plans only: every upload that read the arena has run
+        _GD['plans'].clear()
+        a[1] = 0
+    lo = a[1]
+    a[1] = lo + nbytes
+    return a[0][lo:lo + nbytes]
+
+
+def gemm_flush_deferred(all_lanes=False):
+    """launch what gemm(defer=True) queued since the last flush: the CURRENT concurrency lane's queue by default (another lane's
+    producers may still be running on their stream), every queue with all_lanes (after the lanes were joined)."""
+    lanes = list(_GD['queues']) if all_lanes else [k for k in _GD['queues'] if k == LN_LANE or k.startswith(LN_LANE + '/wgrad')]
+    for lane in lanes:
+        q = _GD['queues'].pop(lane, None)
+        if not q:
+            continue
+        n = len(q)
+        arr = (GemmParams * n)(*[e[0] for e in q])
+        out0 = q[0][1][0]
+        dev = out0.device
+        key = (str(dev), bytes(arr))
+        plan = _GD['plans'].get(key)
+        upload = 0
+        if plan is None:
+            nbytes = int(L.lib().cmda_gemm_grouped_ws_bytes(arr, c_i32(n)))
+            host = _gd_arena(dev, max(nbytes, 16))
+            plan = _GD['plans'][key] = (host, torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev), nbytes)
+            upload = 1
+        if dev.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+            _GD['pinned_plans'] = True
+        host, devbuf, nbytes = plan
+        prof = GEMM_PROFILE is not None and out0.is_cuda
+        if prof:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        call('cmda_gemm_grouped', arr, c_i32(n), ptr(host), ptr(devbuf), c_i64(nbytes), c_i32(upload), stream_of(out0))
+        if prof:
+            e1.record()
+            GEMM_PROFILE.append((sum(e[2] for e in q), e0, e1, sum(e[3] for e in q), ('grouped', n, 0, 0, 0, False, True, True, True, True)))
 
 
 def layernorm_fwd(x, gamma, beta, eps, save_stats=True, out=None):
@@ -184,9 +254,27 @@ class ln_deferral:
 
     def __exit__(self, *exc):
         _LN_DEFER['depth'] -= 1
-        if _LN_DEFER['depth'] == 0 and exc[0] is None:
-            ln_fold_deferred(all_lanes=True)
+        if _LN_DEFER['depth'] == 0:
+            if exc[0] is None:
+                ln_fold_deferred(all_lanes=True)
+            else:   # the pass died half way: drop what it queued / touched instead of folding it into the next pass
+                _LN_DEFER['touched'] = {}
+                _CG['touched'] = {}
+                _GD['queues'].clear()
         return False
+
+
+def _take_lanes(store, all_lanes):
+    """pop the entries of the CURRENT lane and of the lanes forked below it that were joined back (`<lane>/wgrad...`: the
+    batched weight-gradient closures of runtime.lane_batch register their work there) -- or of every lane"""
+    if all_lanes:
+        keys = list(store)
+    else:
+        keys = [k for k in store if k == LN_LANE or k.startswith(LN_LANE + '/wgrad')]
+    out = {}
+    for k in keys:
+        out.update(store.pop(k))
+    return out
 
 
 def _ln_region(dgamma, dbeta, C):
@@ -203,14 +291,9 @@ def ln_fold_deferred(all_lanes=False):
     """fold every workspace touched since the last fold into its dgamma / dbeta: one launch per device.  Only the CURRENT
     concurrency lane's workspaces by default (another lane's LayerNorm backward kernels may still be running on their stream);
     the end of the scope, which follows the lanes' joins, folds them all."""
+    gemm_flush_deferred(all_lanes)   # queued weight gradients first: the convolution ones land in the shadows drained next
     conv_grad_drain(all_lanes)
-    if all_lanes:
-        touched = {}
-        for d in _LN_DEFER['touched'].values():
-            touched.update(d)
-        _LN_DEFER['touched'] = {}
-    else:
-        touched = _LN_DEFER['touched'].pop(LN_LANE, {})
+    touched = _take_lanes(_LN_DEFER['touched'], all_lanes)
     if not touched:
         return
     import numpy as np
@@ -251,13 +334,7 @@ def conv_grad_shadow(grad):
 
 
 def conv_grad_drain(all_lanes=False):
-    if all_lanes:
-        touched = {}
-        for d in _CG['touched'].values():
-            touched.update(d)
-        _CG['touched'] = {}
-    else:
-        touched = _CG['touched'].pop(LN_LANE, {})
+    touched = _take_lanes(_CG['touched'], all_lanes)
     if not touched:
         return
     import numpy as np

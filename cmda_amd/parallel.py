@@ -40,6 +40,29 @@ def shard_range(total, rank, world):
     return rank * per, (rank + 1) * per
 
 
+def reduce_log_vars(log_vars, group=None):
+    """`_parse_losses`' distributed tail (mmseg/models/segmentors/base.py:736-741): every log scalar becomes its MEAN over the
+    ranks (`dist.all_reduce(loss_value.div_(world))`).  The reference issues one all-reduce per scalar with a host sync each;
+    here the scalars of a step travel as ONE small fp32 vector (the tail of the gradient exchange) and stay
+    device tensors.  No-op (same dict) without an initialised process group or at world size 1.  Every rank must pass the same
+    keys in the same order (it does: the keys are a function of the configuration)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return log_vars
+    world = dist.get_world_size(group)
+    if world <= 1 or not log_vars:
+        return log_vars
+    keys = list(log_vars.keys())
+    vals = [log_vars[k] if isinstance(log_vars[k], torch.Tensor) else torch.tensor(float(log_vars[k])) for k in keys]
+    dev = next((v.device for v in vals if v.is_cuda), vals[0].device)
+    vec = torch.stack([v.detach().float().reshape(-1)[0].to(dev) for v in vals])
+    vec.div_(world)
+    dist.all_reduce(vec, group=group)
+    out = type(log_vars)()
+    for i, k in enumerate(keys):
+        out[k] = vec[i].reshape(vals[i].shape) if vals[i].dim() else vec[i]
+    return out
+
+
 class GradAllReducer:
     """Mean all-reduce of a flat gradient buffer in large buckets.
 

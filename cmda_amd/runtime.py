@@ -74,9 +74,14 @@ def _refresh():
     for e in live:
         by_dev.setdefault(e.dst.device, []).append(e)
     for dev, entries in by_dev.items():
-        key = (dev, tuple((id(e), e.ref().data.data_ptr()) for e in entries))
-        plan = _plans.get(dev)
-        if plan is None or plan['key'] != key:
+        # the plan of an entry set: descriptor / block tables on the device.  Keyed by what the tables hold (source and
+        # destination ADDRESSES and the geometry) -- not by object ids, which CPython reuses -- and kept per key: switching between
+        # two entry sets (training / evaluation model) does not rebuild, and a plan whose launch was CAPTURED into a hipGraph is
+        # never dropped (`_pinned`: the graph bakes in the table pointers; the plan also holds the copies' and the masters'
+        # storage, so a replay never reads or writes recycled memory even if a module of that set died meanwhile).
+        key = (dev, tuple((e.ref().data.data_ptr(), e.dst.data_ptr(), tuple(e.dims), tuple(e.perm), e.flip) for e in entries))
+        plan = _plans.get(key)
+        if plan is None:
             import numpy as np
             desc = np.zeros(len(entries), dtype=[('src', '<u8'), ('dst', '<u8'), ('d', '<i4', 4), ('p', '<i4', 4), ('flip', '<i4'),
                                                    ('bf16', '<i4'), ('total', '<i8')])
@@ -89,10 +94,34 @@ def _refresh():
                     total *= v
                 desc[t] = (e.ref().data.data_ptr(), e.dst.data_ptr(), d, pm, e.flip, int(e.dst.dtype == torch.bfloat16), total)
                 blocks += [(t, c) for c in range((total + 1023) // 1024)]
-            plan = _plans[dev] = dict(key=key, nblocks=len(blocks),
+            if len(_plans) > 8:   # un-captured plans of entry sets that are gone
+                for k in [k for k, pl in _plans.items() if not pl.get('pinned')]:
+                    del _plans[k]
+            plan = _plans[key] = dict(key=key, nblocks=len(blocks),
                                       desc=torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()).to(dev),
-                                      blocks=torch.tensor(blocks, dtype=torch.int32).to(dev))
+                                      blocks=torch.tensor(blocks, dtype=torch.int32).to(dev),
+                                      hold=[(e.dst, e.ref().data) for e in entries])
+        if dev.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+            plan['pinned'] = True
         ops.permute4_batch(plan['desc'], plan['blocks'], plan['nblocks'])
+
+
+def refresh_frozen(module=None):
+    """rewrite the compute copies of FROZEN parameters (`_cmda_frozen`: the Motion-Extractor generator) from their masters --
+    they are outside invalidate() / refresh(), so a checkpoint load that restores `cyclegan_itrd2en.*` after a forward pass must
+    call this (checkpoint.load_state_dict does).  module: only that module's parameters (default: all)."""
+    ids = None if module is None else {id(p) for p in module.parameters()}
+    for (pid, _kind), e in list(_frozen.items()):
+        prm = e.ref()
+        if prm is None:
+            del _frozen[(pid, _kind)]
+            continue
+        if ids is not None and pid not in ids:
+            continue
+        if e.dst.device != prm.device:
+            del _frozen[(pid, _kind)]
+            continue
+        ops.permute4(prm.data, e.dst, e.dims, e.perm, flipmask=e.flip)
 
 
 _plans = {}

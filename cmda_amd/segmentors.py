@@ -285,6 +285,7 @@ class FusionEncoderDecoder(nn.Module):
         d = [dJ.get(i) for i in range(4)]
         d_fus = [(t[m:2 * m] if t is not None else None) for t, m in zip(d, n)]
         di, de = self.fusion_module.bwd(sv_f, d_fus, B)
+        ops.gemm_flush_deferred()       # the fusion blocks' queued weight gradients
         d_img, d_ev = [], []
         for t, m, a, b in zip(d, n, di, de):
             if t is None:
@@ -335,6 +336,7 @@ class FusionEncoderDecoder(nn.Module):
                 _, sv, sv_h, B = saved[:4]
                 P = saved[4] if len(saved) > 4 else 1
                 dJ = self.decode_head.bwd_train_joint(sv_h, B // P, gscale)
+                ops.gemm_flush_deferred()   # the decode head's queued weight gradients
                 rt.notify_grads_ready('decode_head', self.decode_head)
                 self._extract_joint_bwd(sv, dJ, B)
                 return

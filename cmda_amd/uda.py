@@ -24,6 +24,7 @@ import torch.nn as nn
 from . import ops
 from . import runtime as rt
 from .cyclegan import define_G
+from .parallel import reduce_log_vars
 from .registry import UDA, build_segmentor
 from .segmentors import add_prefix, parse_losses
 
@@ -104,7 +105,7 @@ class DACS(nn.Module):
         lfc = cfg.get('lambda_feature_consistency', -1)
         self.forward_cfg['lambda_feature_consistency'] = lfc if lfc != -1 else 0.25
         self._flat = None
-        self._graph = None
+        self._graph, self._graphs = None, {}
         self._graph_warmup = None
         for p in self.ema_model.parameters():
             p.requires_grad_(False)
@@ -182,6 +183,8 @@ class DACS(nn.Module):
         optimizer.zero_grad()
         log_vars = self(**data_batch)
         optimizer.step()
+        # base.py:736-741: under data parallelism every logged scalar is its mean over the ranks (one small all-reduce)
+        log_vars = reduce_log_vars(log_vars)
         log_vars.pop('loss', None)
         src = data_batch['source']
         n = src['image'].shape[0] if 'image' in src else data_batch['target']['warp_image'].shape[0]
@@ -194,13 +197,26 @@ class DACS(nn.Module):
         """get_class_masks (dacs_transforms.py:101-112): classes = unique over the WHOLE batch, ceil(n/2) drawn per
         sample with np.random.choice.  One small device->host read (<= 20 class ids), as in the reference.  Returns a CPU
         int64 [B, Kmax] tensor padded with -1 (Kmax fixed by num_classes, so the launch shapes never change)."""
-        if labels.is_cuda and getattr(self, '_graph_warmup', None) is not None:
-            # graph mode: the host runs far ahead of the GPU, so the read goes through a side stream instead of draining the
-            # main one (the label tensor is an input of the step: complete before train_step is called)
+        host = getattr(labels, '_cmda_classes', None)
+        if host is not None:
+            # the loader took the class set on the host from the cropped labels before the H2D copy (datasets.CityscapesICDataset):
+            # no device read, no sync, nothing to order
+            classes = host
+        elif labels.is_cuda and getattr(self, '_graph_warmup', None) is not None:
+            # graph mode: the host runs an iteration ahead of the GPU, so the read goes through a side stream instead of draining
+            # the main one -- ORDERED after the label's producer: the event the loader recorded behind its copy (`_cmda_ready`),
+            # else everything enqueued so far on the current stream (safe for any producer; costs the run-ahead).  record_stream
+            # keeps the caching allocator from recycling the buffer under the reader.
             side = getattr(self, '_side_stream', None) or torch.cuda.Stream(labels.device)
             self._side_stream = side
+            ready = getattr(labels, '_cmda_ready', None)
+            if ready is not None:
+                side.wait_event(ready)
+            else:
+                side.wait_stream(torch.cuda.current_stream(labels.device))
             with torch.cuda.stream(side):
                 classes = torch.unique(labels).cpu()
+            labels.record_stream(side)
         else:
             classes = torch.unique(labels).cpu()
         n = classes.shape[0]
@@ -451,11 +467,11 @@ class DACS(nn.Module):
         GPU the eager step is bound by the host's launch rate, not by the GPU.  Only the EMA update, the control-block copy and
         the optimizer step stay outside."""
         self._graph_warmup = warmup_iters
-        self._graph = None
+        self._graph, self._graphs = None, {}
 
     def disable_graph(self):
         self._graph_warmup = None
-        self._graph = None
+        self._graph, self._graphs = None, {}
 
     def _capture(self, src, tgt, cb, use_events_struct, direction):
         dev = src['image'].device
@@ -481,8 +497,10 @@ class DACS(nn.Module):
         finally:
             rt.set_concurrency(False)
         torch.cuda.synchronize(dev)
-        self._graph = dict(graph=g, src=st_src, tgt=st_tgt, second=second, out=out,
-                           key=(use_events_struct, direction, tuple(src['image'].shape), tuple(tgt_shape(tgt))))
+        key = (use_events_struct, direction, tuple(src['image'].shape), tuple(tgt_shape(tgt)))
+        # one captured iteration per launch structure / batch shape, all kept: configurations whose structure follows a
+        # per-iteration random choice ('cs2dsec_image+events', isr_another_fusion) alternate between two of them
+        self._graphs[key] = self._graph = dict(graph=g, src=st_src, tgt=st_tgt, second=second, out=out, key=key)
 
     def forward_train(self, **kwargs):
         src, tgt = kwargs['source'], kwargs['target']
@@ -511,10 +529,13 @@ class DACS(nn.Module):
         graph_on = (getattr(self, '_graph_warmup', None) is not None and dev.type == 'cuda'
                     and self.local_iter >= self._graph_warmup)
         if graph_on:
-            if self._graph is None or self._graph['key'] != (struct_events, ndir_key, tuple(src['image'].shape), tuple(tgt_shape(tgt))):
+            key = (struct_events, ndir_key, tuple(src['image'].shape), tuple(tgt_shape(tgt)))
+            if not hasattr(self, '_graphs'):
+                self._graphs = {}
+            if key not in self._graphs:
                 # (first replay, another launch structure, or another batch shape: the captured launches are shape-specific)
                 self._capture(src, tgt, cb, struct_events, ndir_key)
-            G = self._graph
+            G = self._graph = self._graphs[key]
             for k, v in G['src'].items():
                 if v.data_ptr() != src[k].data_ptr():
                     v.copy_(src[k])

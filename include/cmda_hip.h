@@ -88,6 +88,18 @@ typedef struct cmda_gemm_params_t {
 
 int cmda_gemm(const cmda_gemm_params_t* p, void* stream);
 
+/* GROUPED launch of n GEMMs in list order semantics-wise independent of each other (no problem reads another's output): the
+ * DEFERRED weight gradients of a backward pass -- `dW += dY^T X` of every nn.Linear / nn.Conv2d the pass walked
+ * (mix_transformer.py:31-44,62-76,169-173; decode_heads/segformer_head.py:25-28 under torch autograd) -- as ONE grid per (tile,
+ * operand mode) instead of n latency-bound launches.  Problems in weight-gradient form (bf16, atomic fp32 output, both operands
+ * K-strided, splits <= 0, LDS-DMA-able views) are grouped; every other problem is launched by itself through cmda_gemm.
+ * ws_host: PINNED host memory, ws_dev: device memory, both >= cmda_gemm_grouped_ws_bytes(params, n) bytes, 16-byte aligned, owned
+ * by the caller.  upload != 0: the parameter table / block map are (re)built in ws_host and copied to ws_dev by a kernel on
+ * `stream` (ws_host must stay untouched until that kernel has run -- for as long as a captured graph replays it); upload == 0:
+ * ws_dev still holds the table of an earlier call with IDENTICAL params. */
+int64_t cmda_gemm_grouped_ws_bytes(const cmda_gemm_params_t* params, int n);
+int cmda_gemm_grouped(const cmda_gemm_params_t* params, int n, void* ws_host, void* ws_dev, int64_t ws_bytes, int upload, void* stream);
+
 /* ---- LayerNorm -- nn.LayerNorm at mmseg/models/backbones/mix_transformer.py:76 (sr norm, eps 1e-5), :123,:136 (Block, 1e-6),
  * :175 (patch embed, 1e-5), :270-318 (stage norms).  bwd: dx = [dres +] LN'(dy); dgamma/dbeta accumulated.
  * ws: cmda_layernorm_bwd_ws_floats() floats, ZERO on entry; the call leaves it zeroed again (reusable without a memset). */

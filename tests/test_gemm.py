@@ -165,3 +165,69 @@ def test_gemm_grouped_tile_walk(tgt, hint, M, N):
         assert torch.equal(out.cpu(), out2.cpu())
     finally:
         ops.GEMM_TILE_HINT = 0
+
+
+@pytest.mark.parametrize('dt,tag', [(torch.bfloat16, 1), (torch.float32, 0)])
+def test_gemm_deferred_grouped_weight_gradients(tgt, dt, tag):
+    """ops.gemm(defer=True) inside a deferral scope queues the weight gradients of a backward pass and gemm_flush_deferred()
+    launches them as grouped grids (cmda_gemm_grouped: 64x64 and 128x128 tiles, plain / patch / im2col B views, fused bias
+    gradient, accumulation into non-zero gradients, deep contractions split by the planner); the fp32 parity mode and forced
+    tiles fall back to single launches inside the same call.  Result == the same GEMMs launched one by one."""
+    import torch.nn.functional as Fn
+    from cmda_amd import nn as K
+    import cmda_amd.runtime as rt
+    torch.manual_seed(5)
+    rt.set_compute_dtype(dt)
+    try:
+        shapes = [(520, 64, 64), (4200, 320, 128), (3300, 128, 256), (700, 72, 40), (130, 256, 128), (64, 8, 24)]   # (rows M, out N, in K)
+        lins = []
+        for rows, n, k in shapes:
+            lins.append((torch.randn(rows, n).to(dt), torch.randn(rows, k).to(dt), torch.nn.Parameter(torch.randn(n, k)),
+                         torch.nn.Parameter(torch.randn(n))))
+        # a spatial-reduction conv (patch view) and a 3x3 conv (im2col view)
+        convs = [(2, 16, 16, 32, 24, 2, 2, 0), (1, 12, 20, 16, 16, 3, 1, 1)]
+        cvs = []
+        for Bc, H, W, Ci, Co, k, st, pd in convs:
+            OH, OW = K.conv_out_size(H, W, k, st, pd)
+            cvs.append((torch.randn(Bc * OH * OW, Co).to(dt), torch.randn(Bc, H, W, Ci).to(dt), torch.nn.Parameter(torch.randn(Co, Ci, k, k)),
+                        torch.nn.Parameter(torch.randn(Co)), (Bc, H, W, st, pd)))
+
+        def run(defer):
+            ops.GEMM_DEFER = defer
+            grads = []
+            for _, _, w, b in lins:
+                w.grad, b.grad = tgt.to(torch.full_like(w.data, 0.5)), tgt.to(torch.full_like(b.data, -1.0))
+            for _, _, w, b, _ in cvs:
+                w.grad, b.grad = tgt.to(torch.zeros_like(w.data)), tgt.to(torch.zeros_like(b.data))
+            with ops.ln_deferral():
+                for dy, x, w, b in lins:
+                    K.linear_bwd(tgt.to(dy), tgt.to(x), w, b, dy.shape[0], x.shape[1], need_dx=False)
+                for dy, x, w, b, (Bc, H, W, st, pd) in cvs:
+                    K.conv_bwd(tgt.to(dy), tgt.to(x.reshape(-1, x.shape[-1])), w, b, Bc, H, W, st, pd, need_dx=False)
+                assert bool(ops._GD['queues']) == bool(defer)
+            assert not ops._GD['queues']
+            for _, _, w, b in lins:
+                grads += [w.grad.cpu().clone(), b.grad.cpu().clone()]
+            for _, _, w, b, _ in cvs:
+                grads += [w.grad.cpu().clone(), b.grad.cpu().clone()]
+            return grads
+        try:
+            single, grouped = run(False), run(True)
+        finally:
+            ops.GEMM_DEFER = True
+        tol = 2e-2 if dt == torch.bfloat16 else 1e-4
+        for i, (a, b) in enumerate(zip(single, grouped)):
+            assert_close(b, a, 1e-5, name=f'grouped vs single {i}')
+        # and against torch
+        for j, (dy, x, w, b) in enumerate(lins):
+            assert_close(grouped[2 * j], dy.float().t() @ x.float() + 0.5, tol, name=f'dW {j}')
+            assert_close(grouped[2 * j + 1], dy.float().sum(0) - 1.0, tol, name=f'db {j}')
+        for j, (dy, x, w, b, (Bc, H, W, st, pd)) in enumerate(cvs):
+            xr = x.float().permute(0, 3, 1, 2)
+            wr = w.data.clone().requires_grad_(True)
+            y = Fn.conv2d(xr, wr, None, st, pd)
+            g = dy.float().view(Bc, y.shape[2], y.shape[3], -1).permute(0, 3, 1, 2)
+            y.backward(g)
+            assert_close(grouped[2 * len(lins) + 2 * j], wr.grad, tol, name=f'conv dW {j}')
+    finally:
+        rt.set_compute_dtype(torch.float32)

@@ -317,8 +317,16 @@ def _dacs_worker(rank, world, port, out):
             started.append((lo, hi))
     dacs.final_pass_grad_hook = hook
     opt.zero_grad()
-    dacs(source=src, target=tg)
+    lv = dacs(source=src, target=tg)
     reducer.finish()
+    # K19 (base.py:736-741): the step's log scalars, mean-reduced over the ranks in one small exchange
+    from cmda_amd.parallel import reduce_log_vars
+    mine_lv = {k: float(v.reshape(-1)[0]) for k, v in lv.items()}
+    red_lv = {k: float(v.reshape(-1)[0]) for k, v in reduce_log_vars(lv).items()}
+    all_lv = [None] * world
+    dist.all_gather_object(all_lv, mine_lv)
+    lv_err = max(abs(red_lv[k] - sum(d[k] for d in all_lv) / world) for k in mine_lv)
+    lv_spread = max(abs(all_lv[0][k] - all_lv[1][k]) for k in mine_lv)
     o = dacs_iter.dacs_iteration(ref, ema, None, src, tg, local_iter=0, forward_cfg=T.FCFG, isr_parms=T.ISR, shift_type='random',
                                  draws=T.oracle_draws(dacs.last_draws))
     del o
@@ -332,7 +340,7 @@ def _dacs_worker(rank, world, port, out):
         worst = max(worst, ((p.grad - gq).abs().max() / (gq.abs().max() + 1e-12)).item())
         n_checked += 1
     out[rank] = dict(worst=worst, n=n_checked, staged=len(started), staged_elems=sum(hi - lo for lo, hi in started),
-                     total=opt.flat_g.numel())
+                     total=opt.flat_g.numel(), lv_err=lv_err, lv_spread=lv_spread, lv_keys=sorted(mine_lv))
     dist.destroy_process_group()
 
 
@@ -347,3 +355,57 @@ def test_dacs_data_parallel_world2_matches_mean_of_oracle_steps():
             assert out[r]['worst'] < 5e-2, out[r]
             assert out[r]['staged'] >= 9 and out[r]['staged_elems'] > 0.5 * out[r]['total'], out[r]   # most bytes start inside the last pass
             assert out[r]['n'] > 100
+            assert out[r]['lv_err'] < 1e-5 and out[r]['lv_spread'] > 1e-4, out[r]   # reduced == mean of different rank-local values
+            assert 'decode.loss_seg' in out[r]['lv_keys'] and 'mix.decode.loss_seg' in out[r]['lv_keys']
+
+
+def _logvar_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from collections import OrderedDict
+    from cmda_amd.parallel import reduce_log_vars
+    lv = OrderedDict([('decode.loss_seg', torch.tensor(1.0 + rank)), ('decode.acc_seg', torch.tensor([10.0 * (rank + 1)])),
+                      ('mix.decode.loss_seg', torch.tensor(0.25 * (rank + 1))), ('loss', torch.tensor(3.0 - rank))])
+    red = reduce_log_vars(lv)
+    out[rank] = {k: (v.tolist() if v.dim() else v.item()) for k, v in red.items()}
+    out[f'keys{rank}'] = list(red.keys())
+    dist.destroy_process_group()
+
+
+def test_log_vars_are_mean_reduced_world2():
+    """K19 / mmseg/models/segmentors/base.py:736-741: under data parallelism every logged scalar is its mean over the ranks;
+    shapes ([] and [1]) and key order survive; without a process group the dict comes back untouched."""
+    from cmda_amd.parallel import reduce_log_vars
+    lv = {'a': torch.tensor(1.0)}
+    assert reduce_log_vars(lv) is lv
+    world = 2
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_logvar_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        for r in range(world):
+            assert out[f'keys{r}'] == ['decode.loss_seg', 'decode.acc_seg', 'mix.decode.loss_seg', 'loss']
+            assert out[r]['decode.loss_seg'] == pytest.approx(1.5)
+            assert out[r]['decode.acc_seg'] == pytest.approx([15.0])
+            assert out[r]['mix.decode.loss_seg'] == pytest.approx(0.375)
+            assert out[r]['loss'] == pytest.approx(2.5)
+
+
+def test_bench_gpus_2_launches_itself():
+    """`python bench.py --gpus 2` with no launcher forks one fresh rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as
+    torchrun sets them), rank 0 prints the line, the return code is the ranks' -- checked through --dry-run (gloo, no GPU)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--dry-run', '--steps', '2'], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['config']['ranks'] == 2 and out['config']['global_batch'] == '4 + 4'
+    # a mismatching launcher environment is an error, not a silent single-rank run
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--dry-run'], env=dict(env, WORLD_SIZE='1', RANK='0'),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
