@@ -15,10 +15,16 @@
 
 namespace {
 
+// tile kinds of the grouped kernels: {BM, BN, resident blocks per CU (LDS 2 stages x (BM + BN) x 128 B)}
+constexpr int kTileBM[4] = {64, 128, 64, 128}, kTileBN[4] = {64, 64, 128, 128}, kTileRes[4] = {4, 3, 3, 2};
+constexpr int kBuckets = 8;   // bucket = tile kind * 2 + (B is an im2col view)
+
 struct Plan {
-  int bucket;       // 0..3 = (tile 64x64 | 128x128) x (B plain / patch | B im2col view); -1 = single launch
+  int bucket;       // -1 = single launch through cmda_gemm
   int splits;
-  long blocks;
+  int tiles;        // output tiles of one (batch, split)
+  int nkt;          // 64-deep k-tiles of the whole contraction
+  long blocks;      // tiles * splits * batch * batch2
 };
 
 static bool dma_view_ok(const GemmView& v) {
@@ -28,24 +34,23 @@ static bool dma_view_ok(const GemmView& v) {
                           v.H == v.OH * v.stride && v.W == v.OW * v.stride));
 }
 
-// kt_target: k-tiles (64 deep) one block should run: bounds a block's time (load balance inside the big grid) while keeping the
-// atomic traffic (one fp32 atomic per output element per split) low
-static Plan plan_one(const GemmParams& p, int kt_target) {
-  Plan pl{-1, 1, 0};
+// which problems the grouped kernels take, and on which tile: the largest tile that divides the output evenly (a 64x64 tile moves
+// 16 KB through L2 -> LDS per 0.5 MFLOP, 128x128 32 KB per 2.1 MFLOP: the k-loop is bound by that per-CU rate)
+static Plan classify(const GemmParams& p) {
+  Plan pl{-1, 1, 0, 0, 0};
   const bool ok = p.dtype == CMDA_BF16 && p.atomic && p.out_f32 && p.a_kstrided && p.b_kstrided && p.A.conv != 1 && p.batch >= 1 &&
                   p.M > 0 && p.N > 0 && p.K > 0 && dma_view_ok(p.A) && dma_view_ok(p.B) && p.tile_hint == 0 && p.splits <= 0 &&
                   !p.bias && !p.act && !p.res && !p.rowscale && p.c_patch_ow == 0;
   if (!ok) return pl;
-  const int b2 = p.batch2 > 0 ? p.batch2 : 1;
-  const bool big = (p.M % 128 == 0) && (p.N % 128 == 0);
-  const int bm = big ? 128 : 64;
-  const long tiles = (long)((p.M + bm - 1) / bm) * ((p.N + bm - 1) / bm);
-  const int nkt = (p.K + 63) / 64;
-  long s = (nkt + kt_target - 1) / kt_target;
-  s = std::max<long>(1, std::min<long>(s, 256));
-  pl.bucket = (big ? 2 : 0) + (p.B.conv == 1 ? 1 : 0);
-  pl.splits = (int)s;
-  pl.blocks = tiles * s * p.batch * b2;
+  // a problem that fills the chip by itself (the decode head's weight gradients over 262144 rows: 0.14 - 1.2 TFLOP each) keeps
+  // its own launch and the single-launch heuristics (256x256 / 128x128 tiles, wave-quantised split-K): grouped, its >= 144 tiles
+  // per split no longer run side by side on one XCD and re-stream their K slice (measured 5.3 against 2.9 ms)
+  const int b2c = p.batch2 > 0 ? p.batch2 : 1;
+  if (2.0 * p.M * p.N * (double)p.K * p.batch * b2c > 30e9) return pl;
+  const int kind = (p.M % 128 == 0 ? 1 : 0) + (p.N % 128 == 0 ? 2 : 0);
+  pl.bucket = kind * 2 + (p.B.conv == 1 ? 1 : 0);
+  pl.tiles = ((p.M + kTileBM[kind] - 1) / kTileBM[kind]) * ((p.N + kTileBN[kind] - 1) / kTileBN[kind]);
+  pl.nkt = (p.K + 63) / 64;
   return pl;
 }
 
@@ -53,59 +58,125 @@ __global__ void upload_kernel(const uint4* __restrict__ src, uint4* __restrict__
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
-static long plan_all(const GemmParams* params, int n, std::vector<Plan>& plans) {
-  plans.resize(n);
-  long total = 0;
-  // fewer k-tiles per block while the whole group would not fill the chip a few times over
-  for (int kt_target : {48, 24, 12, 8}) {
-    total = 0;
-    for (int i = 0; i < n; ++i) {
-      plans[i] = plan_one(params[i], kt_target);
-      if (plans[i].bucket >= 0) total += plans[i].blocks;
-    }
-    if (total >= 4096) break;
+struct Unit { int prob, z, tiles, len; };   // one (batch, split) of a problem: `tiles` workgroups running `len` k-tiles each
+
+// Split choice + block map of one bucket.  A unit's workgroups read the same K slice of both operands, so a unit goes to ONE XCD
+// (workgroups b, b + 8, ... of the grid): there its tiles run side by side and share the slice through that XCD's L2 -- dealt
+// round-robin over the XCDs instead, every XCD streams every operand (measured: 18 GB through the memory side for 1.9 GB of
+// operands on an encoder stage's group).  Units are placed longest-first on the least loaded XCD (LPT), and run longest-first
+// inside an XCD.  Splits: a block should run ~1/3 of the bucket's ideal time at most (tail), never fewer than 16 k-tiles (one
+// fp32 atomic per output element per split: ~1.3 TB/s chip-wide).
+struct BucketPlan {
+  std::vector<Unit> xcd[8];
+  long rows = 0;   // workgroups per XCD after padding: the grid is 8 * rows
+};
+
+static void plan_bucket(const GemmParams* params, std::vector<Plan>& plans, const std::vector<int>& members, int kind, BucketPlan& bp) {
+  double work = 0;
+  for (int i : members) {
+    const GemmParams& p = params[i];
+    const int b2 = p.batch2 > 0 ? p.batch2 : 1;
+    work += (double)plans[i].tiles * plans[i].nkt * p.batch * b2;
   }
-  return total;
+  const double slots = 256.0 * kTileRes[kind];
+  const int len_target = (int)std::max(16.0, std::min(4096.0, work / slots / 3.0));
+  std::vector<Unit> units;
+  for (int i : members) {
+    const GemmParams& p = params[i];
+    const int b2 = p.batch2 > 0 ? p.batch2 : 1;
+    Plan& pl = plans[i];
+    int s = (pl.nkt + len_target - 1) / len_target;
+    s = std::max(1, std::min(s, std::max(1, pl.nkt / 8)));
+    s = std::min(s, 4096);
+    pl.splits = s;
+    pl.blocks = (long)pl.tiles * s * p.batch * b2;
+    const int per = (pl.nkt + s - 1) / s;
+    for (int z = 0; z < s * p.batch * b2; ++z) units.push_back(Unit{i, z, pl.tiles, per});
+  }
+  std::stable_sort(units.begin(), units.end(), [](const Unit& a, const Unit& b) { return (long)a.len * a.tiles > (long)b.len * b.tiles; });
+  double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (const Unit& u : units) {
+    int best = 0;
+    for (int x = 1; x < 8; ++x)
+      if (load[x] < load[best]) best = x;
+    bp.xcd[best].push_back(u);
+    load[best] += (double)u.len * u.tiles;
+  }
+  bp.rows = 0;
+  for (int x = 0; x < 8; ++x) {
+    std::stable_sort(bp.xcd[x].begin(), bp.xcd[x].end(), [](const Unit& a, const Unit& b) { return a.len > b.len; });
+    long r = 0;
+    for (const Unit& u : bp.xcd[x]) r += u.tiles;
+    bp.rows = std::max(bp.rows, r);
+  }
+}
+
+struct GroupPlan {
+  std::vector<Plan> plans;
+  BucketPlan buckets[kBuckets];
+  long start[kBuckets], total = 0;   // first entry of each bucket in the block map, entries overall
+};
+
+static void plan_all(const GemmParams* params, int n, GroupPlan& g) {
+  g.plans.resize(n);
+  std::vector<int> members[kBuckets];
+  for (int i = 0; i < n; ++i) {
+    g.plans[i] = classify(params[i]);
+    if (g.plans[i].bucket >= 0) members[g.plans[i].bucket].push_back(i);
+  }
+  g.total = 0;
+  for (int b = 0; b < kBuckets; ++b) {
+    g.start[b] = g.total;
+    if (members[b].empty()) continue;
+    plan_bucket(params, g.plans, members[b], b >> 1, g.buckets[b]);
+    g.total += g.buckets[b].rows * 8;
+  }
 }
 
 }  // namespace
 
 extern "C" int64_t cmda_gemm_grouped_ws_bytes(const cmda_gemm_params_t* params, int n) {
   if (!params || n <= 0) return 0;
-  std::vector<Plan> plans;
-  const long total = plan_all(params, n, plans);
+  GroupPlan g;
+  plan_all(params, n, g);
   const long tab = ((long)n * (long)sizeof(GemmParams) + 15) / 16 * 16;
-  return tab + (total * 8 + 15) / 16 * 16;
+  return tab + (g.total * 8 + 15) / 16 * 16;
 }
 
 extern "C" int cmda_gemm_grouped(const cmda_gemm_params_t* params, int n, void* ws_host, void* ws_dev, int64_t ws_bytes, int upload,
                                  void* stream) {
   if (n <= 0) return CMDA_OK;
   if (!params) return CMDA_ERR_SHAPE;
-  std::vector<Plan> plans;
-  const long total = plan_all(params, n, plans);
+  GroupPlan g;
+  plan_all(params, n, g);
   const long tab_bytes = ((long)n * (long)sizeof(GemmParams) + 15) / 16 * 16;
-  const long need = tab_bytes + (total * 8 + 15) / 16 * 16;
-  long start[4] = {0, 0, 0, 0}, count[4] = {0, 0, 0, 0};
-  for (int i = 0; i < n; ++i)
-    if (plans[i].bucket >= 0) count[plans[i].bucket] += plans[i].blocks;
-  for (int b = 1; b < 4; ++b) start[b] = start[b - 1] + count[b - 1];
-  if (total > 0) {
+  const long need = tab_bytes + (g.total * 8 + 15) / 16 * 16;
+  if (g.total > 0) {
     if (!ws_host || !ws_dev || ws_bytes < need) return CMDA_ERR_SHAPE;
-    if (total > 0x7fffffffL) return CMDA_ERR_SHAPE;
+    if (g.total > 0x7fffffffL) return CMDA_ERR_SHAPE;
     if (upload) {
       GemmParams* tab = reinterpret_cast<GemmParams*>(ws_host);
       int* blk = reinterpret_cast<int*>(reinterpret_cast<char*>(ws_host) + tab_bytes);
-      long fill[4] = {start[0], start[1], start[2], start[3]};
       for (int i = 0; i < n; ++i) {
         tab[i] = params[i];
         if (tab[i].batch2 <= 0) tab[i].batch2 = 1;
-        if (plans[i].bucket < 0) continue;
-        tab[i].splits = plans[i].splits;
-        long& f = fill[plans[i].bucket];
-        for (long k = 0; k < plans[i].blocks; ++k, ++f) {
-          blk[2 * f] = i;
-          blk[2 * f + 1] = (int)k;
+        if (g.plans[i].bucket >= 0) tab[i].splits = g.plans[i].splits;
+      }
+      for (int b = 0; b < kBuckets; ++b) {
+        const BucketPlan& bp = g.buckets[b];
+        if (!bp.rows) continue;
+        int* base = blk + 2 * g.start[b];
+        for (int x = 0; x < 8; ++x) {
+          long r = 0;
+          for (const Unit& u : bp.xcd[x])
+            for (int t = 0; t < u.tiles; ++t, ++r) {
+              base[2 * (r * 8 + x)] = u.prob;
+              base[2 * (r * 8 + x) + 1] = u.z * u.tiles + t;
+            }
+          for (; r < bp.rows; ++r) {
+            base[2 * (r * 8 + x)] = -1;
+            base[2 * (r * 8 + x) + 1] = 0;
+          }
         }
       }
       const long n16 = need / 16;
@@ -114,15 +185,20 @@ extern "C" int cmda_gemm_grouped(const cmda_gemm_params_t* params, int n, void* 
     }
     const GemmParams* dtab = reinterpret_cast<const GemmParams*>(ws_dev);
     const char* dblk = reinterpret_cast<const char*>(ws_dev) + tab_bytes;
-    for (int b = 0; b < 4; ++b) {
-      if (!count[b]) continue;
-      const void* bp = dblk + start[b] * 8;
-      const int rc = (b & 2) ? cmda_gemm_grouped_t0_(dtab, bp, (int)count[b], b & 1, stream) : cmda_gemm_grouped_t2_(dtab, bp, (int)count[b], b & 1, stream);
+    for (int b = 0; b < kBuckets; ++b) {
+      const long cnt = g.buckets[b].rows * 8;
+      if (!cnt) continue;
+      const void* bptr = dblk + g.start[b] * 8;
+      const int kind = b >> 1, bc = b & 1;
+      const int rc = kind == 0 ? cmda_gemm_grouped_t2_(dtab, bptr, (int)cnt, bc, stream)
+                   : kind == 1 ? cmda_gemm_grouped_t1_(dtab, bptr, (int)cnt, bc, stream)
+                   : kind == 2 ? cmda_gemm_grouped_t3_(dtab, bptr, (int)cnt, bc, stream)
+                               : cmda_gemm_grouped_t0_(dtab, bptr, (int)cnt, bc, stream);
       if (rc != CMDA_OK) return rc;
     }
   }
   for (int i = 0; i < n; ++i)
-    if (plans[i].bucket < 0) {
+    if (g.plans[i].bucket < 0) {
       const int rc = cmda_gemm(&params[i], stream);
       if (rc != CMDA_OK) return rc;
     }

@@ -901,8 +901,10 @@ __global__ __launch_bounds__(64 * NW, (GldsCfg<TM, TN, NW, NSV>::MIN_WAVES)) voi
 }
 
 // GROUPED launch: one grid over MANY problems of this template instance.  `tab` = DEVICE array of parameter blocks (splits already
-// resolved), `blk` = DEVICE array with one {problem, block index inside the problem} pair per workgroup; inside a problem the
-// blocks are numbered z-major (z * tiles + tile).  Used for the DEFERRED weight gradients of a backward pass (ops.gemm_deferral):
+// resolved), `blk` = DEVICE array with one {problem, block index inside the problem} pair per workgroup (problem < 0: padding,
+// the workgroup exits); inside a problem the blocks are numbered z-major (z * tiles + tile).  The planner (gemm_grouped.hip)
+// lays the map out so that the workgroups an XCD receives (b, b + 8, b + 16, ...) walk whole (problem, split) units: their
+// tiles read the same K slice of both operands through that XCD's L2.  Used for the DEFERRED weight gradients of a backward pass (ops.gemm_deferral):
 // ~300 latency-bound launches of 100-200 blocks each per encoder stage become one launch of ~50 k blocks that runs at the
 // MFMA / atomic rate.  The XCD-aware tile walk is off (weight-gradient outputs are a few tiles; nothing to share through L2).
 template <int TM, int TN, bool AKS, bool BKS, bool ACONV, bool BCONV, int NW = 4, int NSV = 0>
@@ -914,6 +916,7 @@ __global__ __launch_bounds__(64 * NW, (GldsCfg<TM, TN, NW, NSV>::MIN_WAVES)) voi
 #else
   const int prob = blk[2 * blockIdx.x], loc = blk[2 * blockIdx.x + 1];
 #endif
+  if (prob < 0) return;   // padding entry of the XCD-interleaved block map
   const GemmParams& p = tab[prob];
   constexpr int BM = GldsCfg<TM, TN, NW, NSV>::BM, BN = GldsCfg<TM, TN, NW, NSV>::BN;
   const int ntile = (int)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
@@ -991,8 +994,10 @@ int cmda_gemm_glds_t0_(const cmda_gemm_params_t& p, void* stream);        // gem
 int cmda_gemm_glds_t1_(const cmda_gemm_params_t& p, void* stream);        // gemm_t1.hip: 128x64 tile
 int cmda_gemm_glds_t2_(const cmda_gemm_params_t& p, void* stream);        // gemm_t2.hip: 64x64 tile
 int cmda_gemm_glds_t3_(const cmda_gemm_params_t& p, void* stream);        // gemm_t3.hip: 256x256 tile, 8 waves
-int cmda_gemm_grouped_t2_(const cmda_gemm_params_t* tab, const void* blk, int nblocks, int bconv, void* stream);  // gemm_g2.hip
-int cmda_gemm_grouped_t0_(const cmda_gemm_params_t* tab, const void* blk, int nblocks, int bconv, void* stream);  // gemm_g0.hip
+int cmda_gemm_grouped_t2_(const cmda_gemm_params_t* tab, const void* blk, int nblocks, int bconv, void* stream);  // gemm_g2.hip: 64x64
+int cmda_gemm_grouped_t0_(const cmda_gemm_params_t* tab, const void* blk, int nblocks, int bconv, void* stream);  // gemm_g0.hip: 128x128
+int cmda_gemm_grouped_t1_(const cmda_gemm_params_t* tab, const void* blk, int nblocks, int bconv, void* stream);  // gemm_g1.hip: 128x64
+int cmda_gemm_grouped_t3_(const cmda_gemm_params_t* tab, const void* blk, int nblocks, int bconv, void* stream);  // gemm_g3.hip: 64x128
 int cmda_gemm_reg_(const cmda_gemm_params_t& p, int tile, void* stream);  // gemm_reg.hip: register-staged kernels, dispatch
 // gemm_reg_{f32,bf16}_t{0,1,2}.hip: one (dtype, tile) each -- these are the slow units to compile (~50 s apiece)
 int cmda_gemm_reg_f32_t0_(const cmda_gemm_params_t& p, void* stream);

@@ -179,26 +179,26 @@ def test_gemm_deferred_grouped_weight_gradients(tgt, dt, tag):
     torch.manual_seed(5)
     rt.set_compute_dtype(dt)
     try:
-        shapes = [(520, 64, 64), (4200, 320, 128), (3300, 128, 256), (700, 72, 40), (130, 256, 128), (64, 8, 24)]   # (rows M, out N, in K)
+        shapes = [(520, 64, 64), (4200, 320, 128), (3300, 128, 256), (700, 72, 40), (130, 256, 128), (64, 8, 24), (2000, 256, 64), (9000, 128, 320)]   # (rows M, out N, in K)
         lins = []
         for rows, n, k in shapes:
-            lins.append((torch.randn(rows, n).to(dt), torch.randn(rows, k).to(dt), torch.nn.Parameter(torch.randn(n, k)),
-                         torch.nn.Parameter(torch.randn(n))))
+            lins.append((torch.randn(rows, n).to(dt), torch.randn(rows, k).to(dt), torch.nn.Parameter(tgt.to(torch.randn(n, k))),
+                         torch.nn.Parameter(tgt.to(torch.randn(n)))))
         # a spatial-reduction conv (patch view) and a 3x3 conv (im2col view)
         convs = [(2, 16, 16, 32, 24, 2, 2, 0), (1, 12, 20, 16, 16, 3, 1, 1)]
         cvs = []
         for Bc, H, W, Ci, Co, k, st, pd in convs:
             OH, OW = K.conv_out_size(H, W, k, st, pd)
-            cvs.append((torch.randn(Bc * OH * OW, Co).to(dt), torch.randn(Bc, H, W, Ci).to(dt), torch.nn.Parameter(torch.randn(Co, Ci, k, k)),
-                        torch.nn.Parameter(torch.randn(Co)), (Bc, H, W, st, pd)))
+            cvs.append((torch.randn(Bc * OH * OW, Co).to(dt), torch.randn(Bc, H, W, Ci).to(dt), torch.nn.Parameter(tgt.to(torch.randn(Co, Ci, k, k))),
+                        torch.nn.Parameter(tgt.to(torch.randn(Co))), (Bc, H, W, st, pd)))
 
         def run(defer):
             ops.GEMM_DEFER = defer
             grads = []
             for _, _, w, b in lins:
-                w.grad, b.grad = tgt.to(torch.full_like(w.data, 0.5)), tgt.to(torch.full_like(b.data, -1.0))
+                w.grad, b.grad = torch.full_like(w.data, 0.5), torch.full_like(b.data, -1.0)
             for _, _, w, b, _ in cvs:
-                w.grad, b.grad = tgt.to(torch.zeros_like(w.data)), tgt.to(torch.zeros_like(b.data))
+                w.grad, b.grad = torch.zeros_like(w.data), torch.zeros_like(b.data)
             with ops.ln_deferral():
                 for dy, x, w, b in lins:
                     K.linear_bwd(tgt.to(dy), tgt.to(x), w, b, dy.shape[0], x.shape[1], need_dx=False)
@@ -224,7 +224,7 @@ def test_gemm_deferred_grouped_weight_gradients(tgt, dt, tag):
             assert_close(grouped[2 * j + 1], dy.float().sum(0) - 1.0, tol, name=f'db {j}')
         for j, (dy, x, w, b, (Bc, H, W, st, pd)) in enumerate(cvs):
             xr = x.float().permute(0, 3, 1, 2)
-            wr = w.data.clone().requires_grad_(True)
+            wr = w.data.cpu().clone().requires_grad_(True)
             y = Fn.conv2d(xr, wr, None, st, pd)
             g = dy.float().view(Bc, y.shape[2], y.shape[3], -1).permute(0, 3, 1, 2)
             y.backward(g)
