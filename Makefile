@@ -40,6 +40,13 @@ build/hip_timing/gemm.o: $(CSRC)/gemm.hip $(wildcard $(CSRC)/gemm_*.hip) $(HDRS)
 timing: build/hip_timing/gemm.o $(HIP_OBJS)
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o build/libcmda_hip_timing.so build/hip_timing/gemm.o $(filter-out build/hip/gemm.o build/hip/gemm_t%.o build/hip/gemm_reg%.o,$(HIP_OBJS))
 
+# tuning build of the ping-pong GEMM with per-segment s_memtime stamps (tools/dbg/pp_phase.py)
+build/hip_pptiming/gemm_pp.o: $(CSRC)/gemm_pp.hip $(HDRS)
+	@mkdir -p build/hip_pptiming
+	$(HIPCC) $(HIPFLAGS) -DCMDA_PP_TIMING -c $< -o $@
+pptiming: build/hip_pptiming/gemm_pp.o $(HIP_OBJS)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o build/libcmda_hip_pptiming.so build/hip_pptiming/gemm_pp.o $(filter-out build/hip/gemm_pp.o,$(HIP_OBJS))
+
 clean:
 	rm -rf build cmda_amd/libcmda_hip.so tests/emu/libcmda_emu.so
-.PHONY: all hip emu timing clean
+.PHONY: all hip emu timing pptiming clean

@@ -90,6 +90,16 @@ int launch_dtype(GemmParams& p, void* stream) {
     const bool nt_plain = kind_ok && dma_ok(p.A) && dma_ok(p.B);
     if (p.colsum && !(nt_plain && !no_glds && aks)) return CMDA_ERR_UNSUPPORTED;
     if (nt_plain && !no_glds) {
+      // the 256x256 tile has two kernels: the ping-pong kernel (gemm_pp.hip: 32x32x16 MFMA, two wave groups alternating LDS reads and
+      // MFMAs, bf16 epilogue image) for plain epilogues, gemm_glds_kernel for the rest (tile_hint bit 9: force the latter, tuning A/B)
+      // Measured (profiles/r03_gemm_big.txt): the ping-pong kernel wins where the epilogue / short contraction dominates (K <= 1024:
+      // 65536x1280x320 96 against 113 us, the head's pointwise data gradient 262144x1024x256 300 against 392 us) and on K-strided B
+      // (8192^3 NN 863 against 778-837 TFLOP/s); long K-contiguous contractions and im2col views stay on gemm_glds_kernel (8192^3 NT
+      // 1086 against 1024, the 3x3 bottleneck 1405 against 1776 us: the per-lane im2col address arithmetic sits in the LOAD segments)
+      const bool pp_shape = (p.tile_hint > 0 && (p.tile_hint & 1024)) || (!ac && (p.K <= 1024 || bks));
+      if (tile == 3 && pp_shape && !(p.tile_hint > 0 && (p.tile_hint & 512)) && !aks && !bc && !p.atomic && p.splits == 1 && !p.res &&
+          !p.rowscale && p.beta == 0.f && !p.out_f32 && p.c_patch_ow == 0 && !p.colsum)
+        return cmda_gemm_pp_(p, stream);
       if (tile == 3) return cmda_gemm_glds_t3_(p, stream);
       if (tile == 0) return cmda_gemm_glds_t0_(p, stream);
       if (tile == 1) return cmda_gemm_glds_t1_(p, stream);

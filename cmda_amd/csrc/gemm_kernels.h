@@ -525,7 +525,10 @@ __device__ unsigned long long g_stamps[256 * 8];
 #define CMDA_STAMP(i) do { } while (0)
 #endif
 
-template <bool KS, int TILE, bool CONV, int NW = 4>
+// SWZ = 1 (K-contiguous tiles only): slot = chunk ^ ((line >> 1) & 7) -- conflict-free for ds_read_b128 fragments of 32 consecutive
+// lines (the 32x32x16 operand map of gemm_pp.hip: the 16-lane service groups of ds_read_b128 then touch 16 distinct 16-byte positions of
+// the 256-byte bank row; with (line & 7) lines r and r + 8 share one)
+template <bool KS, int TILE, bool CONV, int NW = 4, int SWZ = 0>
 struct DmaSrc {
   static constexpr int BK = 64;
   static constexpr int J = TILE / (8 * NW);                         // DMA instructions per wave per stage
@@ -548,7 +551,7 @@ struct DmaSrc {
       const int ln = (wid * J + j) * LPI + lane / CPL;              // K-contig: tile row; K-strided: k row
       const int slot = lane % CPL;
       line[j] = ln;
-      chunk[j] = slot ^ (ln & 7);
+      chunk[j] = slot ^ ((SWZ && !KS) ? ((ln >> 1) & 7) : (ln & 7));
       ca[j] = cbc[j] = 0;
       s0[j] = s1[j] = s2[j] = 0;
       ptr[j] = nullptr;
@@ -998,6 +1001,7 @@ int cmda_gemm_grouped_t2_(const cmda_gemm_params_t* tab, const void* blk, int nb
 int cmda_gemm_grouped_t0_(const cmda_gemm_params_t* tab, const void* blk, int nblocks, int bconv, void* stream);  // gemm_g0.hip: 128x128
 int cmda_gemm_grouped_t1_(const cmda_gemm_params_t* tab, const void* blk, int nblocks, int bconv, void* stream);  // gemm_g1.hip: 128x64
 int cmda_gemm_grouped_t3_(const cmda_gemm_params_t* tab, const void* blk, int nblocks, int bconv, void* stream);  // gemm_g3.hip: 64x128
+int cmda_gemm_pp_(const cmda_gemm_params_t& p, void* stream);             // gemm_pp.hip: 256x256 ping-pong kernel (32x32x16 MFMA)
 int cmda_gemm_reg_(const cmda_gemm_params_t& p, int tile, void* stream);  // gemm_reg.hip: register-staged kernels, dispatch
 // gemm_reg_{f32,bf16}_t{0,1,2}.hip: one (dtype, tile) each -- these are the slow units to compile (~50 s apiece)
 int cmda_gemm_reg_f32_t0_(const cmda_gemm_params_t& p, void* stream);

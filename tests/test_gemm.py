@@ -107,11 +107,13 @@ def _run_forced_tile(marker):
     import os
     import subprocess
     import sys
-    env = dict(os.environ, CMDA_TEST_GEMM_TILE='4')
     here = os.path.abspath(__file__)
-    r = subprocess.run([sys.executable, '-m', 'pytest', here, '-q', '-x', '-m', marker, '-k', 'not forced_tile', '-p', 'no:cacheprovider'],
-                       env=env, capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    # 4 | 1024: the ping-pong kernel (gemm_pp.hip) wherever its epilogue / operand modes allow; 4 | 512: gemm_glds_kernel's 8-wave tile
+    for hint in ('1028', '516'):
+        env = dict(os.environ, CMDA_TEST_GEMM_TILE=hint)
+        r = subprocess.run([sys.executable, '-m', 'pytest', here, '-q', '-x', '-m', marker, '-k', 'not forced_tile', '-p', 'no:cacheprovider'],
+                           env=env, capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, f'tile_hint {hint}: ' + r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_forced_tile_256_emu():

@@ -59,7 +59,7 @@ def main():
         rows.append((name + ' wgrad', 2.0 * M * Co * K, timeit(lambda: ops.gemm(ops.plain_view(dy, M, Co), ops.conv_view(x, B, H, W, Ci, k, k, 1, k // 2), dw, Co, K, M, a_kstrided=True, b_kstrided=True, dtype=tag, atomic=True, splits=0), 10)))
 
     if args.big:
-        for hint, tag_ in ((0, 'grouped walk'), (256 | 4, 'row-major 256^2'), (4, 'grouped 256^2'), (1, 'grouped 128^2'), (256 | 1, 'row-major 128^2')):
+        for hint, tag_ in ((0, 'library heuristics'), (1024 | 4, 'ping-pong 256^2 (gemm_pp.hip) forced'), (512 | 4, 'gemm_glds_kernel 256^2 forced'), (3, '128^2')):
             ops.GEMM_TILE_HINT = hint
             rows.append((f'--- {tag_} (tile_hint {hint})', 0.0, 1.0))
             nt('NT 8192x8192x8192', 8192, 8192, 8192)
@@ -68,6 +68,9 @@ def main():
             nn('NN 8192x8192x8192', 8192, 8192, 8192)
             nt('NT 65536x1280x320', 65536, 1280, 320)
             nt('NT 65536x2048x512', 65536, 2048, 512)
+            nt('NT 262144x256x1024 (head pw)', 262144, 256, 1024)
+            nn('NN 262144x1024x256 (head dpw)', 262144, 1024, 256)
+            conv('head bottleneck 3x3 1024->256 B16', 16, 128, 128, 1024, 256, 3)
         ops.GEMM_TILE_HINT = 0
         for name, fl, us in rows:
             print(f'{name:38s} {us:10.1f} us  {fl / us / 1e6:8.1f} TFLOP/s')
