@@ -147,6 +147,7 @@ def draw_drop_path(owner, blocks, B, device):
         owner._dp_keep = cached = ((rates, str(device)), keep)
     keep = cached[1]
     masks = (keep + torch.rand(2 * len(live), B, device=device)).floor_().div_(keep)
+    rt.tap(('drop_path', getattr(owner, '_tap_name', type(owner).__name__)), masks)
     for i, blk in enumerate(live):
         blk._dp_pool = [masks, 2 * i]
 

@@ -263,6 +263,7 @@ class _HeadBase(nn.Module):
             forced = getattr(self, 'inject_dropout_mask', None)   # tests: the oracle's Dropout2d mask [drop_B or B, Ch] of 0/1
             nb = B if drop_B is None else drop_B
             m = (torch.rand(nb, Ch, device=feat.device) < keep).float() if forced is None else forced.to(feat.device).float()
+            rt.tap(('dropout2d', getattr(self, '_tap_name', type(self).__name__)), m)
             m = m / keep
             if nb < B:
                 mask = torch.ones(B, Ch, dtype=torch.float32, device=feat.device)

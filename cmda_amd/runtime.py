@@ -176,6 +176,18 @@ def act_empty(*shape, device):
     return torch.empty(*shape, dtype=_state['dtype'], device=device)
 
 
+# Test taps: when a dict is installed here, the stochastic decisions of a pass drawn ON THE DEVICE (DropPath keep masks,
+# Dropout2d masks) are published under a name -- the dict then holds the very tensors the kernels read, so after a hipGraph
+# replay it shows that replay's draws (tests/test_dacs.py: replayed segments must draw fresh masks, and the oracle fed the same
+# masks must reproduce the replayed iteration).  None (the default): nothing is kept.
+taps = None
+
+
+def tap(name, tensor):
+    if taps is not None:
+        taps[name] = tensor
+
+
 _ones = {}
 
 

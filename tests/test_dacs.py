@@ -34,12 +34,13 @@ FCFG = dict(loss_weight={'image': 0.5, 'events': 0.5, 'fusion': 0.5, 'img_self_r
 
 
 def make_cfg(dims, ch, generator=True, blur=True, jitter_p=0.2, shift_type='random', train_type='cs2dsec_image+events_together',
-             fusion='AttentionAvgFusion', ignore_top=0, ignore_bottom=0):
+             fusion='AttentionAvgFusion', ignore_top=0, ignore_bottom=0, depths=None, drop_path_rate=0.0, fusion_drop_path=0.0,
+             dropout_ratio=0.0):
     bb = dict(type='MixVisionTransformer', embed_dims=dims, num_heads=[1, 2, 5, 8], qkv_bias=True,
-              depths=DEPTHS, sr_ratios=[8, 4, 2, 1], drop_path_rate=0.0,
+              depths=depths or DEPTHS, sr_ratios=[8, 4, 2, 1], drop_path_rate=drop_path_rate,
               norm_layer=functools.partial(torch.nn.LayerNorm, eps=1e-6))
     head = dict(type='DAFormerHeadFusion', in_channels=dims, in_index=[0, 1, 2, 3], channels=ch,
-                dropout_ratio=0.0, num_classes=19, norm_cfg=dict(type='BN', requires_grad=True), align_corners=False,
+                dropout_ratio=dropout_ratio, num_classes=19, norm_cfg=dict(type='BN', requires_grad=True), align_corners=False,
                 decoder_params=dict(embed_dims=ch, embed_cfg=dict(type='mlp', act_cfg=None, norm_cfg=None),
                                     embed_neck_cfg=dict(type='mlp', act_cfg=None, norm_cfg=None),
                                     fusion_cfg=dict(type='aspp', sep=True, dilations=(1, 6, 12, 18), pool=False,
@@ -47,7 +48,7 @@ def make_cfg(dims, ch, generator=True, blur=True, jitter_p=0.2, shift_type='rand
                                     train_type=train_type, share_decoder=True),
                 loss_decode=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0))
     model = dict(type='FusionEncoderDecoder', backbone_image=dict(bb), backbone_events=dict(bb),
-                 fusion_module=dict(type=fusion, in_channels=dims, drop_path_rate=0.0), decode_head=head,
+                 fusion_module=dict(type=fusion, in_channels=dims, drop_path_rate=fusion_drop_path), decode_head=head,
                  train_type=train_type, train_cfg=dict(), test_cfg=dict(mode='whole'))
     uda = dict(type='DACS', alpha=0.999, pseudo_threshold=0.968, pseudo_weight_ignore_top=ignore_top,
                pseudo_weight_ignore_bottom=ignore_bottom,
@@ -59,12 +60,13 @@ def make_cfg(dims, ch, generator=True, blur=True, jitter_p=0.2, shift_type='rand
     return dict(model=model, uda=uda, runner=dict(type='IterBasedRunner', max_iters=40000))
 
 
-def oracle_student(dims, ch, fusion='AttentionAvgFusion'):
-    return oseg.FusionEncoderDecoder(backbone_image=omit.MixVisionTransformer(embed_dims=dims, depths=DEPTHS, drop_path_rate=0.0),
-                                     backbone_events=omit.MixVisionTransformer(embed_dims=dims, depths=DEPTHS, drop_path_rate=0.0),
-                                     fusion_module=getattr(ofu, fusion)(in_channels=dims, drop_path_rate=0.0),
+def oracle_student(dims, ch, fusion='AttentionAvgFusion', depths=None, drop_path_rate=0.0, fusion_drop_path=0.0, dropout_ratio=0.0):
+    depths = depths or DEPTHS
+    return oseg.FusionEncoderDecoder(backbone_image=omit.MixVisionTransformer(embed_dims=dims, depths=depths, drop_path_rate=drop_path_rate),
+                                     backbone_events=omit.MixVisionTransformer(embed_dims=dims, depths=depths, drop_path_rate=drop_path_rate),
+                                     fusion_module=getattr(ofu, fusion)(in_channels=dims, drop_path_rate=fusion_drop_path),
                                      decode_head=ohd.DAFormerHeadFusion(in_channels=dims, channels=ch, embed_dims=ch,
-                                                                        dropout_ratio=0.0, share_decoder=True))
+                                                                        dropout_ratio=dropout_ratio, share_decoder=True))
 
 
 def make_batch(B, H, W):
@@ -221,3 +223,190 @@ def test_dacs_graph_replay_matches_oracle(lanes):
         check_iteration(out, True, 1e-4, 5e-2)
     for (n1, p), (n2, q) in zip(dacs.ema_model.named_parameters(), ema.named_parameters()):
         assert_close(p.data, q.data, 1e-6, name='ema ' + n1)
+
+
+def _upsampled(logits_nhwc, H, W):
+    from cmda_amd import ops
+    return ops.upsample_logits_nchw(logits_nhwc.contiguous(), H, W).cpu()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+def test_dacs_iteration_full_depth_512_gpu(mode):
+    """THE BENCH'S CONFIGURATION against the oracle (VERDICT r02 #4a): full-depth MiT-B5 encoders (3, 6, 40, 3), 512 x 512, 2 source
+    + 2 target samples, generator + colour jitter + blur + random ISR direction ON, DropPath / Dropout2d OFF (the draws that remain
+    are injected from the HIP run).  fp32: source / mixed loss 1e-4, teacher logits 1e-3 of their range, pseudo-labels equal up to
+    numerical ties (>= 99.99 %), mixed inputs equal; bf16 (the speed mode the bench line runs): reported and bounded.
+    CMDA_TEST_FULL_B: samples per domain (default 2; the CPU oracle holds every activation of 3 + 3 encoder passes)."""
+    import time
+    from conftest import Target
+    from cmda_amd import _lib
+    _lib._unbind_for_tests()
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU on this machine')
+    tgt = Target('gpu')
+    depths = [3, 6, 40, 3]
+    B, S = int(os.environ.get('CMDA_TEST_FULL_B', 2)), 512
+    dt = torch.float32 if mode == 'f32' else torch.bfloat16
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    rt.set_compute_dtype(dt)
+    try:
+        dacs = build_train_model(make_cfg(FULLW['dims'], FULLW['ch'], depths=depths))
+        seeded_fill(dacs.model, 7)
+        seeded_fill(dacs.ema_model, 8)
+        seeded_fill(dacs.cyclegan_itrd2en, 9)
+        dacs.to(tgt.device).train()
+        src, tg = make_batch(B, S, S)
+        batch = dict(source={k: tgt.to(v) for k, v in src.items()}, target={k: tgt.to(v) for k, v in tg.items()})
+        torch.manual_seed(11), random.seed(11), np.random.seed(11)
+        log_vars = dacs(**batch)
+        torch.cuda.synchronize()
+        mix = dacs.last_mix
+        ref, ema, G = (oracle_student(FULLW['dims'], FULLW['ch'], depths=depths), oracle_student(FULLW['dims'], FULLW['ch'], depths=depths),
+                       ocg.ResnetGenerator().eval())
+        seeded_fill(ref, 7).train()
+        seeded_fill(ema, 8).train()
+        seeded_fill(G, 9)
+        t0 = time.time()
+        o = dacs_iter.dacs_iteration(ref, ema, G, src, tg, local_iter=0, forward_cfg=FCFG, isr_parms=ISR, shift_type='random',
+                                     draws=oracle_draws(dacs.last_draws))
+        t_oracle = time.time() - t0
+        # teacher logits (fusion branch), at full resolution, relative to their range
+        tl = _upsampled(mix['teacher_logits']['fusion_output'], S, S)
+        rl = o['teacher_logits']['fusion_output']
+        logit_err = ((tl - rl).abs().max() / rl.abs().max()).item()
+        agree = (mix['pseudo_label'].cpu() == o['pseudo_label']).float().mean().item()
+        lbl_same = (mix['mixed_lbl'].cpu() == o['mixed_lbl']).float().mean().item()
+        ls, lm = log_vars['decode.loss_seg'].item(), log_vars['mix.decode.loss_seg'].item()
+        rs, rm = o['decode.loss_seg'].item(), o['mix.decode.loss_seg'].item()
+        worst, errs = 0.0, []
+        grads = {n: p.grad.detach().cpu() for n, p in dacs.model.named_parameters()}
+        for n, q in ref.named_parameters():
+            e = (grads[n] - q.grad).abs().max().item() / (q.grad.abs().max().item() + 1e-12)
+            errs.append(e)
+        errs.sort()
+        print(f'[{mode}] full-depth 512x512 B={B}+{B}: oracle {t_oracle:.0f} s; teacher logits rel err {logit_err:.2e}; pseudo-label '
+              f'agreement {agree:.6f}; mixed-label agreement {lbl_same:.6f}; source loss {ls:.6f} vs {rs:.6f}; mixed loss {lm:.6f} vs '
+              f'{rm:.6f}; gradient rel err median {errs[len(errs) // 2]:.2e}, 90th pct {errs[int(len(errs) * 0.9)]:.2e}, worst {errs[-1]:.2e}')
+        if mode == 'f32':
+            assert logit_err < 1e-3
+            assert agree >= 0.9999 and lbl_same >= 0.9999
+            assert abs(ls - rs) < 1e-4 * max(1.0, abs(rs)) and abs(lm - rm) < 2e-3 * max(1.0, abs(rm))
+            assert_close(mix['mixed_img'], o['mixed_img'], 1e-4, atol=2e-4, name='mixed image', outlier_frac=1e-3, outlier_rtol=2.0)
+            assert errs[int(len(errs) * 0.9)] < 2e-2, 'bulk of the accumulated parameter gradients'
+        else:
+            assert logit_err < 6e-2 and agree > float(os.environ.get('CMDA_TEST_BF16_LABEL_AGREE', 0.95))
+            assert abs(ls - rs) < 2e-2 * max(1.0, abs(rs)) and abs(lm - rm) < 0.1 * max(1.0, abs(rm))
+    finally:
+        rt.set_compute_dtype(torch.float32)
+
+
+class _MaskFeed(torch.nn.Module):
+    """stands in for an oracle DropPath: pops the next per-sample keep factors (already divided by keep)"""
+
+    def __init__(self, queue):
+        super().__init__()
+        self.queue = queue
+
+    def forward(self, x):
+        m = self.queue.pop(0)
+        return x * m.view(-1, *([1] * (x.dim() - 1))).to(x.dtype)
+
+
+class _Dropout2dFeed(torch.nn.Module):
+    def __init__(self, queue, keep):
+        super().__init__()
+        self.queue, self.keep = queue, keep
+
+    def forward(self, x):
+        return x * (self.queue.pop(0) / self.keep)[:, :, None, None]
+
+
+def _feed_oracle_masks(ref, taps, B, keep):
+    """Route the masks one HIP pass drew (taps: rows 2i / 2i+1 = attention / MLP branch of live block i, columns = the samples of
+    the joint pass) to the oracle's modules in the order its two forward_train calls consume them.  Image encoder / fusion
+    blocks / Dropout2d: columns [source | mixed]; event encoder (one 4B batch on the GPU): [source events | mixed events | source
+    ISR | mixed ISR], while the oracle runs events then ISR inside the source step, then again inside the mixed step."""
+    def live(blocks):
+        return [b for b in blocks if not isinstance(b.drop_path, torch.nn.Identity)]
+
+    def wire(blocks, masks, col_sets):
+        for i, blk in enumerate(live(blocks)):
+            q = []
+            for cols in col_sets:
+                q += [masks[2 * i][cols].cpu(), masks[2 * i + 1][cols].cpu()]
+            blk.drop_path = _MaskFeed(q)
+    s = lambda k: slice(k * B, (k + 1) * B)  # noqa: E731
+    enc = lambda m: [b for st in range(1, 5) for b in getattr(m, f'block{st}')]  # noqa: E731
+    wire(enc(ref.backbone_image), taps[('drop_path', 'image')], [s(0), s(1)])
+    wire(enc(ref.backbone_events), taps[('drop_path', 'events')], [s(0), s(2), s(1), s(3)])
+    wire(list(ref.fusion_module.basic_block), taps[('drop_path', 'fusion')], [s(0), s(1)])
+    d = taps[('dropout2d', 'head')].cpu()
+    ref.decode_head.dropout = _Dropout2dFeed([d[s(0)], d[s(1)]], keep)
+
+
+@pytest.mark.gpu
+def test_dacs_graph_replay_draws_fresh_masks_and_matches_oracle():
+    """VERDICT r02 #4b: with DropPath / Dropout2d ON (rates well above the recipe's so that every replay drops something), the
+    segmented hipGraph replay must draw FRESH masks per replay (torch's philox bookkeeping across 13 separately captured
+    segments) and the replayed iteration must equal the oracle's iteration fed the very masks that replay drew (read back from
+    the tensors the kernels consumed, runtime.taps)."""
+    from conftest import Target
+    from cmda_amd import _lib
+    _lib._unbind_for_tests()
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU on this machine')
+    tgt = Target('gpu')
+    rt.set_compute_dtype(torch.float32)
+    dims, ch, B, S = SMALL['dims'], SMALL['ch'], 2, 64
+    dpr, fdp, drop = 0.4, 0.3, 0.3
+    kw = dict(drop_path_rate=dpr, fusion_drop_path=fdp, dropout_ratio=drop)
+    dacs = build_train_model(make_cfg(dims, ch, **kw))
+    seeded_fill(dacs.model, 7)
+    seeded_fill(dacs.ema_model, 8)
+    seeded_fill(dacs.cyclegan_itrd2en, 9)
+    dacs.to(tgt.device).train()
+    st = dacs.model
+    st.backbone_image._tap_name, st.backbone_events._tap_name, st.fusion_module._tap_name, st.decode_head._tap_name = 'image', 'events', 'fusion', 'head'
+    src, tg = make_batch(B, S, S)
+    batch = dict(source={k: tgt.to(v) for k, v in src.items()}, target={k: tgt.to(v) for k, v in tg.items()})
+    ref, ema, G = oracle_student(dims, ch, **kw), oracle_student(dims, ch), ocg.ResnetGenerator().eval()
+    seeded_fill(ref, 7).train()
+    seeded_fill(ema, 8).train()
+    seeded_fill(G, 9)
+    torch.manual_seed(11), random.seed(11), np.random.seed(11)
+    dacs.enable_graph(warmup_iters=1)
+    rt.taps = {}
+    try:
+        seen = []
+        for it in range(4):
+            for p in dacs.model.parameters():
+                if p.grad is not None:
+                    p.grad.zero_()
+            log_vars = dacs(**batch)
+            torch.cuda.synchronize()
+            assert (dacs._graph is not None) == (it >= 1)
+            # the student tensors only (the teacher passes run with the stochastic layers off and publish nothing)
+            taps = {k: v.detach().clone() for k, v in rt.taps.items()}
+            assert set(taps) == {('drop_path', 'image'), ('drop_path', 'events'), ('drop_path', 'fusion'), ('dropout2d', 'head')}
+            assert taps[('drop_path', 'image')].shape[1] == 2 * B and taps[('drop_path', 'events')].shape[1] == 4 * B
+            seen.append(taps)
+            grads = {n: p.grad.detach().cpu().clone() for n, p in dacs.model.named_parameters()}
+            for p in ref.parameters():
+                p.grad = None
+            _feed_oracle_masks(ref, taps, B, 1 - drop)
+            o = dacs_iter.dacs_iteration(ref, ema, G, src, tg, local_iter=it, forward_cfg=FCFG, isr_parms=ISR, shift_type='random',
+                                         draws=oracle_draws(dacs.last_draws))
+            for blk in [b for m in (ref.backbone_image, ref.backbone_events) for s_ in range(1, 5) for b in getattr(m, f'block{s_}')]:
+                assert isinstance(blk.drop_path, torch.nn.Identity) or not blk.drop_path.queue, 'oracle left injected masks unused'
+            out = ({k: v.detach().clone() for k, v in log_vars.items()}, dacs.last_mix, grads, o, {n: q.grad.clone() for n, q in ref.named_parameters()})
+            check_iteration(out, True, 1e-4, 5e-2)
+            print(f'iteration {it} ({"replay" if it >= 1 and dacs._graph is not None else "eager"}): source loss '
+                  f'{log_vars["decode.loss_seg"].item():.6f} vs {o["decode.loss_seg"].item():.6f}; dropped entries '
+                  f'{int((taps[("drop_path", "events")] == 0).sum())} / {taps[("drop_path", "events")].numel()}')
+        # replays 2 and 3 re-run the captured launches of iteration 1: their masks must differ from it and from each other
+        for k in seen[1]:
+            assert not torch.equal(seen[1][k], seen[2][k]) and not torch.equal(seen[2][k], seen[3][k]), f'{k}: the replay repeated its masks'
+            assert (seen[2][k] == 0).any() and (seen[2][k] > 0).any()
+    finally:
+        rt.taps = None

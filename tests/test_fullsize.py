@@ -66,6 +66,60 @@ def grad_errors(model, ref):
     return sorted(errs)
 
 
+class ReluFlipProbe:
+    """Makes the 'a train-mode BatchNorm + ReLU pre-activation within round-off of zero may flip its mask' caveat CHECKABLE
+    (VERDICT r02 #4d): hooks every BatchNorm2d of the oracle's decode head (each feeds a ReLU) and records, per layer, the channels
+    that hold a pre-activation within `tau` of zero -- the only places where a different fp32 summation order of the batch
+    statistics can change the ReLU mask.  `masked_errors` then compares every parameter gradient with those channels of THAT
+    layer's BatchNorm affine and of the convolution feeding it left out; everything else must agree tightly."""
+
+    def __init__(self, head, tau=4e-6):
+        self.tau, self.suspect, self.total = tau, {}, 0
+        for name, m in head.named_modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.register_forward_hook(self._hook(name))
+
+    def _hook(self, name):
+        def fn(mod, inp, out):
+            y = out.detach()
+            near = (y.abs() < self.tau * max(1.0, y.abs().max().item() / 4.0))
+            ch = near.any(dim=0).any(dim=-1).any(dim=-1).nonzero().flatten().tolist()
+            self.suspect.setdefault(name, set()).update(ch)
+            self.total += int(near.sum())
+        return fn
+
+    def mask_for(self, pname, tensor, prefix='decode_head.'):
+        """boolean keep-mask over dim 0 of a parameter gradient (None = keep everything)"""
+        if not pname.startswith(prefix):
+            return None
+        rel_name = pname[len(prefix):]
+        for bn_name, chans in self.suspect.items():
+            owner = bn_name[:-len('.bn')] if bn_name.endswith('.bn') else None
+            if owner is None or not chans:
+                continue
+            if rel_name in (owner + '.bn.weight', owner + '.bn.bias', owner + '.conv.weight'):
+                keep = torch.ones(tensor.shape[0], dtype=torch.bool)
+                keep[sorted(chans)] = False
+                return keep
+        return None
+
+    def masked_errors(self, model, ref, prefix='decode_head.'):
+        out = []
+        for (n1, p), (n2, q) in zip(model.named_parameters(), ref.named_parameters()):
+            assert n1 == n2
+            if q.grad is None:
+                continue
+            g, r = p.grad.detach().cpu().float(), q.grad.float()
+            raw = ((g - r).abs().max() / (r.abs().max() + 1e-12)).item()
+            keep = self.mask_for(n1, r, prefix)
+            if keep is not None and keep.any():
+                m = ((g[keep] - r[keep]).abs().max() / (r[keep].abs().max() + 1e-12)).item()
+            else:
+                m = raw
+            out.append((m, raw, n1, 0 if keep is None else int((~keep).sum())))
+        return sorted(out, reverse=True)
+
+
 def grad_report(model, ref):
     """worst max-norm relative error over the parameter gradients + the fraction of tensors within 2e-2"""
     errs = grad_errors(model, ref)
@@ -87,6 +141,7 @@ def test_mit_b5_daformer_512_vs_oracle(mode):
     ref.load_state_dict(model.state_dict())
     model.to(tgt.device).train()
     ref.train()
+    probe = ReluFlipProbe(ref.decode_head)
     img, gt = seeded_randn((1, 3, 512, 512), 5, 'img'), labels(1, 512, 5)
     losses, logits = model.forward_train(tgt.to(img), None, tgt.to(gt))
     losses['decode.loss_seg'].backward()
@@ -102,7 +157,14 @@ def test_mit_b5_daformer_512_vs_oracle(mode):
     if mode == 'f32':
         assert e_log < 1e-3, f'fp32 logits rel err {e_log}'
         assert_close(losses['decode.loss_seg'], rl['decode.loss_seg'], 1e-4, name='loss')
-        assert within > 0.97 and worst < 0.2
+        # gradients: every tensor within 2e-2 once the channels whose BatchNorm + ReLU pre-activation sits within round-off of zero
+        # (a flipped mask bit moves that channel's gradient) are left out of THEIR layer's comparison -- no blanket 0.2 bound
+        me = probe.masked_errors(model, ref)
+        nsus = sum(len(v) for v in probe.suspect.values())
+        print(f'[{mode}] {probe.total} pre-activations within round-off of zero in {nsus} (layer, channel) pairs; worst masked gradient errors: '
+              + '; '.join(f'{n} {m:.2e} (raw {r:.2e}, {k} channels out)' for m, r, n, k in me[:6]))
+        assert me[0][0] < 2e-2, me[:6]
+        assert nsus < 0.25 * sum(m.num_features for m in ref.decode_head.modules() if isinstance(m, nn.BatchNorm2d)), 'probe masks too much'
     else:
         assert e_log < 6e-2, f'bf16 logits rel err {e_log}'
         assert agree > 0.97
