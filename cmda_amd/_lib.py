@@ -34,7 +34,8 @@ class GemmParams(ctypes.Structure):
                 ('act', c_i32), ('res', c_vp), ('ldres', c_i64), ('res_batch_stride', c_i64), ('res_batch2_stride', c_i64),
                 ('rowscale', c_vp), ('rows_per_scale', c_i32), ('out_f32', c_i32), ('atomic', c_i32),
                 ('dtype', c_i32), ('c_vec_ok', c_i32), ('colsum', c_vp),
-                ('c_patch_ow', c_i32), ('c_patch_kh', c_i32), ('c_patch_kwci', c_i32), ('tile_hint', c_i32), ('c_perm_ci', c_i32), ('c_perm_cells', c_i32)]
+                ('c_patch_ow', c_i32), ('c_patch_kh', c_i32), ('c_patch_kwci', c_i32), ('tile_hint', c_i32), ('c_perm_ci', c_i32), ('c_perm_cells', c_i32),
+                ('res_f32', c_i32), ('reserved_', c_i32)]
 
 
 class CmdaError(RuntimeError):
@@ -69,7 +70,7 @@ def _load():
             '(python -c "import __graft_entry__ as g; g.build()" or `make hip`). '
             'cmda_amd has no CPU fallback.')
     _lib = _declare(ctypes.CDLL(_LIB_PATH))
-    if _lib.cmda_abi_version() != 2:
+    if _lib.cmda_abi_version() != 3:
         raise CmdaError('libcmda_hip.so ABI version mismatch')
     return _lib
 

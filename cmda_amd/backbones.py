@@ -123,7 +123,8 @@ class OverlapPatchEmbed(nn.Module):
 
     def fwd(self, x, B, H, W):
         y, OH, OW = K.conv_fwd(x, self.proj.weight, self.proj.bias, B, H, W, self.stride, self.patch_size // 2)
-        yn, m, r = ops.layernorm_fwd(y, self.norm.weight, self.norm.bias, 1e-5)
+        # the norm's output opens the stage's residual stream: fp32 storage in the bf16 mode (runtime.residual_fp32)
+        yn, m, r = ops.layernorm_fwd(y, self.norm.weight, self.norm.bias, 1e-5, out_dtype=rt.stream_dtype())
         return yn, OH, OW, (x, y, m, r, H, W)
 
     def bwd(self, saved, dyn, B, need_dx=True):
@@ -256,7 +257,8 @@ class MixVisionTransformer(nn.Module):
                 sv_blocks.append(sv)
             nrm = getattr(self, f'norm{s}')
             xin = x
-            x, m, r = ops.layernorm_fwd(xin, nrm.weight, nrm.bias, self.eps, out=out_feats[s - 1] if out_feats is not None else None)
+            x, m, r = ops.layernorm_fwd(xin, nrm.weight, nrm.bias, self.eps, out=out_feats[s - 1] if out_feats is not None else None,
+                                        out_dtype=rt.compute_dtype())   # stage output: back to the compute dtype
             feats.append((x, H, W))
             saved.append((sv_pe, sv_blocks, (xin, m, r), H, W))
         return feats, (saved, B) if save else None

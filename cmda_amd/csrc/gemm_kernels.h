@@ -221,6 +221,7 @@ static __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const 
                                                      int q4, int r0, long cb, long rb_off, bool full, const float (&bv)[4]) {
   constexpr int QPR = BN / 4, RSTEP = NT / QPR, NIT = BM / RSTEP;
   const bool has_res = p.res != nullptr, has_beta = p.beta != 0.f, has_rs = p.rowscale != nullptr, f32o = p.out_f32 != 0;
+  const bool res32 = p.res_f32 != 0;
   const float alpha = p.alpha, beta = p.beta;
   const int patch_ow = p.c_patch_ow;
   const long patch_kh = patch_ow > 0 ? n / p.c_patch_kwci : 0, patch_rest = patch_ow > 0 ? n - patch_kh * p.c_patch_kwci : 0;
@@ -242,7 +243,10 @@ static __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const 
     float rs = 1.f;
     if (has_rs) rs = p.rowscale[m / p.rows_per_scale];
     if (full) {
-      if (has_res) ld4(reinterpret_cast<const T*>(p.res) + ri, rv);
+      if (has_res) {
+        if (res32) ld4(reinterpret_cast<const float*>(p.res) + ri, rv);
+        else ld4(reinterpret_cast<const T*>(p.res) + ri, rv);
+      }
       if (has_beta) {
         if (f32o) ld4(reinterpret_cast<const float*>(p.C) + ci, ov);
         else ld4(reinterpret_cast<const T*>(p.C) + ci, ov);
@@ -251,7 +255,7 @@ static __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const 
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         if (n + e >= p.N) continue;
-        if (has_res) rv[e] = ldf(reinterpret_cast<const T*>(p.res) + ri + e);
+        if (has_res) rv[e] = res32 ? reinterpret_cast<const float*>(p.res)[ri + e] : ldf(reinterpret_cast<const T*>(p.res) + ri + e);
         if (has_beta) ov[e] = f32o ? reinterpret_cast<const float*>(p.C)[ci + e] : ldf(reinterpret_cast<const T*>(p.C) + ci + e);
       }
     }

@@ -27,9 +27,12 @@ static __device__ __forceinline__ float group_sum(float v, int lpr) {
   return v;
 }
 
-template <typename T, int NV>
-__global__ void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-                              T* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out, long rows,
+// TX / TY: storage types of the input and the output.  They differ on the fp32 RESIDUAL STREAM of the bf16 mode (runtime.py
+// residual_fp32: the block input x stays fp32 across the 52 residual additions of an encoder, every LayerNorm reads it and hands
+// bf16 to the GEMM behind it; the patch-embed norm turns the bf16 convolution output into the fp32 stream).
+template <typename TX, typename TY, int NV>
+__global__ void ln_fwd_kernel(const TX* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                              TY* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out, long rows,
                               int C, float eps, int lpr) {
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
@@ -40,7 +43,7 @@ __global__ void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__
   for (long row0 = ((long)blockIdx.x * wpb + wid) * rpw; row0 < rows; row0 += (long)gridDim.x * wpb * rpw) {
     const long row = row0 + grp;
     const bool live = row < rows;
-    const T* xr = x + row * C;
+    const TX* xr = x + row * C;
     float v[NV][4];
     float s = 0.f;
 #pragma unroll
@@ -98,8 +101,8 @@ __global__ void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__
 // out_scale / dx_scaled (optional): a second output dx * out_scale[row / rows_per_scale] -- the per-sample DropPath factor of the
 // residual branch that consumes this gradient next (timm DropPath, mix_transformer.py:145-146), so that no separate scaling
 // kernel runs.
-template <typename T, int NV>
-__global__ void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
+template <typename T, typename TX, int NV>
+__global__ void ln_bwd_kernel(const T* __restrict__ dy, const TX* __restrict__ x, const float* __restrict__ gamma,
                               const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                               const T* __restrict__ dres, T* __restrict__ dx, float* __restrict__ ws, long rows,
                               int C, int lpr, const float* __restrict__ out_scale, long rows_per_scale,
@@ -247,22 +250,36 @@ __global__ void ln_fold_batch_kernel(const LnFoldDesc* __restrict__ desc) {
 
 }  // namespace
 
-extern "C" int cmda_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
-                                  float* rstd, int64_t rows, int C, float eps, int dtype, void* stream) {
+extern "C" int cmda_layernorm_fwd2(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype, float* mean,
+                                   float* rstd, int64_t rows, int C, float eps, void* stream) {
   if (rows <= 0) return CMDA_OK;
   if (C <= 0 || (C & 3) || C > kMaxVec * 256) return CMDA_ERR_SHAPE;
   const int wpb = 4, lpr = lanes_per_row(C);
   const long rpb = wpb * (64 / lpr);
   const int grid = (int)std::min<long>((rows + rpb - 1) / rpb, 8192);
   const int nv = ((C >> 2) + lpr - 1) / lpr;
-#define CMDA_LN_FWD(NVV)                                                                                                      \
-  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((ln_fwd_kernel<T, NVV>), dim3(grid), dim3(64 * wpb), 0, stream, (const T*)x, gamma, \
-                                         beta, (T*)y, mean, rstd, (long)rows, C, eps, lpr))
+#define CMDA_LN_FWD_T(TX, TY, NVV)                                                                                          \
+  CMDA_LAUNCH((ln_fwd_kernel<TX, TY, NVV>), dim3(grid), dim3(64 * wpb), 0, stream, (const TX*)x, gamma, beta, (TY*)y, mean, \
+              rstd, (long)rows, C, eps, lpr)
+#define CMDA_LN_FWD(NVV)                                                                         \
+  do {                                                                                           \
+    if (x_dtype == CMDA_F32 && y_dtype == CMDA_F32) CMDA_LN_FWD_T(float, float, NVV);            \
+    else if (x_dtype == CMDA_BF16 && y_dtype == CMDA_BF16) CMDA_LN_FWD_T(bf16_t, bf16_t, NVV);   \
+    else if (x_dtype == CMDA_F32 && y_dtype == CMDA_BF16) CMDA_LN_FWD_T(float, bf16_t, NVV);     \
+    else if (x_dtype == CMDA_BF16 && y_dtype == CMDA_F32) CMDA_LN_FWD_T(bf16_t, float, NVV);     \
+    else return CMDA_ERR_DTYPE;                                                                  \
+  } while (0)
   if (nv <= 1) { CMDA_LN_FWD(1); }
   else if (nv == 2) { CMDA_LN_FWD(2); }
   else { CMDA_LN_FWD(4); }
 #undef CMDA_LN_FWD
+#undef CMDA_LN_FWD_T
   CMDA_CHECK_LAUNCH();
+}
+
+extern "C" int cmda_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                                  float* rstd, int64_t rows, int C, float eps, int dtype, void* stream) {
+  return cmda_layernorm_fwd2(x, dtype, gamma, beta, y, dtype, mean, rstd, rows, C, eps, stream);
 }
 
 static inline long ln_bwd_grid(long rows, int C) {
@@ -278,27 +295,42 @@ static inline long ln_bwd_grid(long rows, int C) {
 // finalize pass clears what it consumed), so one persistent buffer serves every call on a stream without a memset.
 extern "C" int64_t cmda_layernorm_bwd_ws_floats(int64_t rows, int C) { (void)rows; return (int64_t)kSlots * 2 * C; }
 
-extern "C" int cmda_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
-                                  const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, float* ws,
-                                  int64_t rows, int C, const float* out_scale, int64_t rows_per_scale, void* dx_scaled,
-                                  int dtype, void* stream) {
+extern "C" int cmda_layernorm_bwd2(const void* dy, const void* x, int x_dtype, const float* gamma, const float* mean,
+                                   const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, float* ws,
+                                   int64_t rows, int C, const float* out_scale, int64_t rows_per_scale, void* dx_scaled,
+                                   int dtype, void* stream) {
   if (rows <= 0) return CMDA_OK;
   if (C <= 0 || (C & 3) || C > kMaxVec * 256 || (dx_scaled && (!out_scale || rows_per_scale <= 0))) return CMDA_ERR_SHAPE;
   const int wpb = 4, lpr = lanes_per_row(C);
   int grid = (int)ln_bwd_grid(rows, C);
   const int nv = ((C >> 2) + lpr - 1) / lpr;
-#define CMDA_LN_BWD(NVV)                                                                                                 \
-  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((ln_bwd_kernel<T, NVV>), dim3(grid), dim3(64 * wpb), 0, stream, (const T*)dy, \
-                                         (const T*)x, gamma, mean, rstd, (const T*)dres, (T*)dx, ws, (long)rows, C, lpr, \
-                                         out_scale, (long)rows_per_scale, (T*)dx_scaled))
+#define CMDA_LN_BWD_T(T, TX, NVV)                                                                                             \
+  CMDA_LAUNCH((ln_bwd_kernel<T, TX, NVV>), dim3(grid), dim3(64 * wpb), 0, stream, (const T*)dy, (const TX*)x, gamma, mean, rstd, \
+              (const T*)dres, (T*)dx, ws, (long)rows, C, lpr, out_scale, (long)rows_per_scale, (T*)dx_scaled)
+#define CMDA_LN_BWD(NVV)                                                                      \
+  do {                                                                                        \
+    if (dtype == CMDA_F32 && x_dtype == CMDA_F32) CMDA_LN_BWD_T(float, float, NVV);           \
+    else if (dtype == CMDA_BF16 && x_dtype == CMDA_BF16) CMDA_LN_BWD_T(bf16_t, bf16_t, NVV);  \
+    else if (dtype == CMDA_BF16 && x_dtype == CMDA_F32) CMDA_LN_BWD_T(bf16_t, float, NVV);    \
+    else return CMDA_ERR_DTYPE;                                                               \
+  } while (0)
   if (nv <= 1) { CMDA_LN_BWD(1); }
   else if (nv == 2) { CMDA_LN_BWD(2); }
   else { CMDA_LN_BWD(4); }
 #undef CMDA_LN_BWD
+#undef CMDA_LN_BWD_T
   // dgamma == NULL: deferred -- the partial sums stay in `ws` (a workspace owned by this layer) until cmda_layernorm_fold_batch
   if (dgamma)
     CMDA_LAUNCH(ln_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, stream, ws, dgamma, dbeta, std::min(grid, kSlots), C);
   CMDA_CHECK_LAUNCH();
+}
+
+extern "C" int cmda_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                                  const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, float* ws,
+                                  int64_t rows, int C, const float* out_scale, int64_t rows_per_scale, void* dx_scaled,
+                                  int dtype, void* stream) {
+  return cmda_layernorm_bwd2(dy, x, dtype, gamma, mean, rstd, dres, dx, dgamma, dbeta, ws, rows, C, out_scale, rows_per_scale,
+                             dx_scaled, dtype, stream);
 }
 
 // desc: DEVICE array of n records {float* ws; float* dgamma; float* dbeta; int32 C; int32 nslots} (24 bytes + padding to 32):

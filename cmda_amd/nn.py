@@ -167,7 +167,9 @@ def block_fwd(x, p, B, H, W, C, heads, sr, *, eps=1e-6, dp1=None, dp2=None, save
     N = H * W
     M = B * N
     a = p.attn
-    xn, m1, r1 = ops.layernorm_fwd(x, p.norm1.weight, p.norm1.bias, eps)
+    cd = rt.compute_dtype()
+    sd = x.dtype    # residual-stream storage: fp32 in the bf16 mode's fp32-stream option (runtime.residual_fp32), else the compute dtype
+    xn, m1, r1 = ops.layernorm_fwd(x, p.norm1.weight, p.norm1.bias, eps, out_dtype=cd)
     q = linear_fwd(xn, a.q.weight, a.q.bias, M, C)
     if sr > 1:
         xs_pre, OH, OW = conv_fwd(xn, a.sr.weight, a.sr.bias, B, H, W, sr, 0)
@@ -178,15 +180,15 @@ def block_fwd(x, p, B, H, W, C, heads, sr, *, eps=1e-6, dp1=None, dp2=None, save
     kv = linear_fwd(xs, a.kv.weight, a.kv.bias, B * Nk, C)
     hd = C // heads
     o, P = attention_fwd(q, kv, B, N, Nk, heads, C, hd ** -0.5)
-    x1 = linear_fwd(o, a.proj.weight, a.proj.bias, M, C, res=x, rowscale=dp1, rows_per_scale=N)
-    xn2, m2, r2 = ops.layernorm_fwd(x1, p.norm2.weight, p.norm2.bias, eps)
+    x1 = linear_fwd(o, a.proj.weight, a.proj.bias, M, C, res=x, rowscale=dp1, rows_per_scale=N, out_dtype=sd)
+    xn2, m2, r2 = ops.layernorm_fwd(x1, p.norm2.weight, p.norm2.bias, eps, out_dtype=cd)
     hidden = p.mlp.fc1.weight.shape[0]
     h = linear_fwd(xn2, p.mlp.fc1.weight, p.mlp.fc1.bias, M, C)
     dw = p.mlp.dwconv.dwconv
     act = ops.dwconv_fwd(h, rt.wdw(dw.weight), dw.bias, B, H, W, hidden, 1, 'gelu')
     Cout = p.mlp.fc2.weight.shape[0]
     x2 = linear_fwd(act, p.mlp.fc2.weight, p.mlp.fc2.bias, M, hidden, res=x1 if Cout == C else None, rowscale=dp2,
-                    rows_per_scale=N)
+                    rows_per_scale=N, out_dtype=sd if Cout == C else None)
     saved = (x, m1, r1, xn, q, xs_pre, ms, rs, xs, kv, P, o, x1, m2, r2, xn2, h, act, Nk, dp1, dp2) if save else None
     return x2, saved
 

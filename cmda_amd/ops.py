@@ -69,6 +69,7 @@ def gemm(A, B, out, M, N, K, *, a_kstrided=False, b_kstrided=False, ldc=None, ba
     p.bias = bias.data_ptr() if bias is not None else None
     p.act = ACT[act]
     p.res = res.data_ptr() if res is not None else None
+    p.res_f32 = int(res is not None and res.dtype == torch.float32 and dtype != 0)   # fp32 residual stream of the bf16 mode
     p.ldres = (N if ldres is None else ldres)
     p.res_batch_stride, p.res_batch2_stride = res_batch_stride, res_batch2_stride
     p.rowscale = rowscale.data_ptr() if rowscale is not None else None
@@ -177,15 +178,16 @@ def gemm_flush_deferred(all_lanes=False):
             GEMM_PROFILE.append((sum(e[2] for e in q), e0, e1, sum(e[3] for e in q), ('grouped', n, 0, 0, 0, False, True, True, True, True)))
 
 
-def layernorm_fwd(x, gamma, beta, eps, save_stats=True, out=None):
+def layernorm_fwd(x, gamma, beta, eps, save_stats=True, out=None, out_dtype=None):
+    """y = LayerNorm(x); y takes out's dtype, else out_dtype, else x's (x fp32 -> y bf16 and back: the fp32 residual stream)"""
     check_dev(x, gamma, beta, out)
     C = x.shape[-1]
     rows = x.numel() // C
-    y = torch.empty_like(x) if out is None else out
+    y = torch.empty(x.shape, dtype=out_dtype or x.dtype, device=x.device) if out is None else out
     mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
-    call('cmda_layernorm_fwd', ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), c_i64(rows), c_i32(C),
-         c_f32(eps), dtype_tag(x), stream_of(x))
+    call('cmda_layernorm_fwd2', ptr(x), dtype_tag(x), ptr(gamma), ptr(beta), ptr(y), dtype_tag(y), ptr(mean), ptr(rstd), c_i64(rows),
+         c_i32(C), c_f32(eps), stream_of(x))
     return y, mean, rstd
 
 
@@ -364,14 +366,14 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, out_scale=
     check_dev(dy, x, gamma, mean, rstd, dgamma, dbeta, dres, out_scale)
     C = x.shape[-1]
     rows = x.numel() // C
-    dx = torch.empty_like(x)
-    dxs = torch.empty_like(x) if out_scale is not None else None
+    dx = torch.empty_like(dy)       # (x may be the fp32 residual stream while the gradients travel in the compute dtype)
+    dxs = torch.empty_like(dy) if out_scale is not None else None
     if _LN_DEFER['depth'] > 0:
         ws, dg, db = _ln_region(dgamma, dbeta, C), None, None
     else:
         ws, dg, db = _ln_ws(x.device, L.lib().cmda_layernorm_bwd_ws_floats(rows, C)), dgamma, dbeta
-    call('cmda_layernorm_bwd', ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dg),
-         ptr(db), ptr(ws), c_i64(rows), c_i32(C), ptr(out_scale), c_i64(rows_per_scale), ptr(dxs), dtype_tag(x), stream_of(x))
+    call('cmda_layernorm_bwd2', ptr(dy), ptr(x), dtype_tag(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dg),
+         ptr(db), ptr(ws), c_i64(rows), c_i32(C), ptr(out_scale), c_i64(rows_per_scale), ptr(dxs), dtype_tag(dy), stream_of(x))
     return dx if out_scale is None else (dx, dxs)
 
 

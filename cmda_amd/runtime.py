@@ -35,6 +35,22 @@ def compute_dtype():
     return _state['dtype']
 
 
+def set_residual_fp32(flag):
+    """bf16 mode only: keep the encoders' residual stream (the block input x of mix_transformer.py:134,146, summed over up to 52
+    blocks) in fp32 -- every LayerNorm reads fp32 and writes bf16 for the GEMM behind it, proj / fc2 add their fp32 residual in the
+    epilogue.  Costs ~2x the bytes of the (small) stream tensors; buys back most of the bf16 mode's logit error."""
+    _state['res32'] = bool(flag)
+
+
+def residual_fp32():
+    return _state.get('res32', True) and _state['dtype'] == torch.bfloat16
+
+
+def stream_dtype():
+    """storage type of the encoders' residual stream"""
+    return torch.float32 if residual_fp32() else _state['dtype']
+
+
 def tag():
     return 0 if _state['dtype'] == torch.float32 else 1
 

@@ -84,6 +84,10 @@ typedef struct cmda_gemm_params_t {
    * stored at column ci * c_perm_cells + cell -- a convolution's weight gradient accumulated straight into the parameter's
    * [Co][Ci][KH][KW] gradient. */
   int32_t c_perm_ci, c_perm_cells;
+  /* the residual `res` is fp32 whatever `dtype` says (with out_f32: the fp32 residual stream of the bf16 mode, see
+   * cmda_layernorm_fwd2) */
+  int32_t res_f32;
+  int32_t reserved_;
 } cmda_gemm_params_t;
 
 int cmda_gemm(const cmda_gemm_params_t* p, void* stream);
@@ -113,6 +117,14 @@ int cmda_layernorm_bwd(const void* dy, const void* x, const float* gamma, const 
  * layer alone -- until cmda_layernorm_fold_batch folds MANY layers' workspaces into their dgamma / dbeta in one launch
  * (desc: DEVICE array of n 32-byte records {float* ws; float* dgamma; float* dbeta; int32 C; int32 nslots}; nslots =
  * cmda_layernorm_slots(); max_c = largest C).  The workspaces are left zeroed. */
+/* Mixed storage types -- the fp32 RESIDUAL STREAM of the bf16 mode: `x + drop_path(...)` of Block.forward (mix_transformer.py:134,146)
+ * accumulates over up to 52 blocks, so x stays fp32 while everything the GEMMs read is bf16.  fwd2: x in x_dtype -> y in y_dtype
+ * (any of the four combinations); bwd2: dy / dres / dx / dx_scaled in `dtype`, the saved input x in x_dtype (fp32 or `dtype`). */
+int cmda_layernorm_fwd2(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype, float* mean, float* rstd,
+    int64_t rows, int C, float eps, void* stream);
+int cmda_layernorm_bwd2(const void* dy, const void* x, int x_dtype, const float* gamma, const float* mean, const float* rstd,
+    const void* dres, void* dx, float* dgamma, float* dbeta, float* ws, int64_t rows, int C, const float* out_scale,
+    int64_t rows_per_scale, void* dx_scaled, int dtype, void* stream);
 int cmda_layernorm_fold_batch(const void* desc, int n, int max_c, void* stream);
 int cmda_layernorm_slots(void);
 /* out_scale / rows_per_scale / dx_scaled (all or none): second output dx * out_scale[row / rows_per_scale] -- the per-sample
