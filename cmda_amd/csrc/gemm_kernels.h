@@ -532,10 +532,13 @@ __device__ unsigned long long g_stamps[256 * 8];
 // SWZ = 1 (K-contiguous tiles only): slot = chunk ^ ((line >> 1) & 7) -- conflict-free for ds_read_b128 fragments of 32 consecutive
 // lines (the 32x32x16 operand map of gemm_pp.hip: the 16-lane service groups of ds_read_b128 then touch 16 distinct 16-byte positions of
 // the 256-byte bank row; with (line & 7) lines r and r + 8 share one)
-template <bool KS, int TILE, bool CONV, int NW = 4, int SWZ = 0>
+// BKT: depth of a k-tile (64; 32 for K-STRIDED tiles only -- gemm_wg.hip's four half-depth stages: a K-strided stage is BKT whole lines,
+// a K-contiguous one would halve its lines to 64 bytes)
+template <bool KS, int TILE, bool CONV, int NW = 4, int SWZ = 0, int BKT = 64>
 struct DmaSrc {
-  static constexpr int BK = 64;
-  static constexpr int J = TILE / (8 * NW);                         // DMA instructions per wave per stage
+  static constexpr int BK = BKT;
+  static_assert(BKT == 64 || KS, "half-depth k-tiles: K-strided operands only");
+  static constexpr int J = TILE * BKT / (512 * NW);                 // DMA instructions per wave per stage
   static constexpr int CPL = KS ? TILE / 8 : 8;                     // 16-byte chunks per LDS line
   static constexpr int LPI = 64 / CPL;                              // lines per DMA instruction
   const bf16_t* ptr[J];   // plain: address of (line, chunk) for k-tile 0, or nullptr when the fixed index is out of range
@@ -1005,6 +1008,7 @@ int cmda_gemm_grouped_t2_(const cmda_gemm_params_t* tab, const void* blk, int nb
 int cmda_gemm_grouped_t0_(const cmda_gemm_params_t* tab, const void* blk, int nblocks, int bconv, void* stream);  // gemm_g0.hip: 128x128
 int cmda_gemm_grouped_t1_(const cmda_gemm_params_t* tab, const void* blk, int nblocks, int bconv, void* stream);  // gemm_g1.hip: 128x64
 int cmda_gemm_grouped_t3_(const cmda_gemm_params_t* tab, const void* blk, int nblocks, int bconv, void* stream);  // gemm_g3.hip: 64x128
+int cmda_gemm_wg_(const cmda_gemm_params_t& p, void* stream);             // gemm_wg.hip: 256x256 weight-gradient kernel (32x32x16 MFMA, atomics)
 int cmda_gemm_pp_(const cmda_gemm_params_t& p, void* stream);             // gemm_pp.hip: 256x256 ping-pong kernel (32x32x16 MFMA)
 int cmda_gemm_reg_(const cmda_gemm_params_t& p, int tile, void* stream);  // gemm_reg.hip: register-staged kernels, dispatch
 // gemm_reg_{f32,bf16}_t{0,1,2}.hip: one (dtype, tile) each -- these are the slow units to compile (~50 s apiece)

@@ -29,11 +29,13 @@ def main():
     ap.add_argument('--dtype', default='bf16')
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--big', action='store_true', help='only the large square-ish GEMMs, with and without the grouped tile walk')
+    ap.add_argument('--hint', type=int, default=0, help='cmda_gemm_params_t.tile_hint for every launch (e.g. 1028 = force the ping-pong 256x256 kernel)')
     ap.add_argument('--splits', type=int, default=0, help='force the split-K count of the weight-gradient GEMMs')
     args = ap.parse_args()
     dt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     tag = 1 if dt == torch.bfloat16 else 0
     dev = torch.device('cuda:0')
+    ops.GEMM_TILE_HINT = args.hint
     r = lambda *s: torch.randn(*s, device=dev).to(dt)
     rows = []
 
@@ -71,6 +73,7 @@ def main():
             nt('NT 262144x256x1024 (head pw)', 262144, 256, 1024)
             nn('NN 262144x1024x256 (head dpw)', 262144, 1024, 256)
             conv('head bottleneck 3x3 1024->256 B16', 16, 128, 128, 1024, 256, 3)
+            tn('TN 256x1024x262144 (head wpw)', 256, 1024, 262144)
         ops.GEMM_TILE_HINT = 0
         for name, fl, us in rows:
             print(f'{name:38s} {us:10.1f} us  {fl / us / 1e6:8.1f} TFLOP/s')
