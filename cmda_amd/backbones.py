@@ -122,7 +122,9 @@ class OverlapPatchEmbed(nn.Module):
         self.norm = nn.LayerNorm(embed_dim)  # eps 1e-5 (torch default), as in the reference
 
     def fwd(self, x, B, H, W):
-        y, OH, OW = K.conv_fwd(x, self.proj.weight, self.proj.bias, B, H, W, self.stride, self.patch_size // 2)
+        """x [B*H*W, Cin] NHWC rows -- or Cin padded with zero channels (runtime.conv_channel_pad: the 3-channel input)"""
+        cp = x.shape[1] if x.shape[1] > self.proj.weight.shape[1] else 0
+        y, OH, OW = K.conv_fwd(x, self.proj.weight, self.proj.bias, B, H, W, self.stride, self.patch_size // 2, ci_pad=cp)
         # the norm's output opens the stage's residual stream: fp32 storage in the bf16 mode (runtime.residual_fp32)
         yn, m, r = ops.layernorm_fwd(y, self.norm.weight, self.norm.bias, 1e-5, out_dtype=rt.stream_dtype())
         return yn, OH, OW, (x, y, m, r, H, W)
@@ -130,8 +132,9 @@ class OverlapPatchEmbed(nn.Module):
     def bwd(self, saved, dyn, B, need_dx=True):
         x, y, m, r, H, W = saved
         dy = ops.layernorm_bwd(dyn, y, self.norm.weight, m, r, rt.grad(self.norm.weight), rt.grad(self.norm.bias))
+        cp = x.shape[1] if x.shape[1] > self.proj.weight.shape[1] else 0
         return K.conv_bwd(dy, x, self.proj.weight, self.proj.bias, B, H, W, self.stride, self.patch_size // 2,
-                          need_dx=need_dx)
+                          need_dx=need_dx, ci_pad=cp)
 
 
 def draw_drop_path(owner, blocks, B, device):
@@ -239,11 +242,15 @@ class MixVisionTransformer(nn.Module):
         imgs = list(img) if isinstance(img, (list, tuple)) else [img]
         _, Cin, H, W = imgs[0].shape
         B = sum(t.shape[0] for t in imgs)
-        x = torch.empty(B * H * W, Cin, dtype=rt.compute_dtype(), device=imgs[0].device)
+        cp = rt.conv_channel_pad(Cin)
+        x = torch.empty(B * H * W, cp, dtype=rt.compute_dtype(), device=imgs[0].device)
         row = 0
         for t in imgs:
             b = t.shape[0]
-            ops.permute4(t.contiguous(), x[row:row + b * H * W], (b, Cin, H, W), (0, 2, 3, 1))
+            if cp != Cin:
+                ops.nchw_to_nhwc_pad(t.contiguous(), x[row:row + b * H * W], b, Cin, H * W, cp)
+            else:
+                ops.permute4(t.contiguous(), x[row:row + b * H * W], (b, Cin, H, W), (0, 2, 3, 1))
             row += b * H * W
         feats, saved = [], []
         self._draw_drop_path(B, x.device)

@@ -71,7 +71,13 @@ struct PermuteDesc {
 __global__ void permute4_batch_kernel(const PermuteDesc* __restrict__ desc, const int* __restrict__ blocks) {
   const int bk_x = blocks[2 * blockIdx.x], bk_y = blocks[2 * blockIdx.x + 1];
   const PermuteDesc D = desc[bk_x];
-  const long ss[4] = {(long)D.d[1] * D.d[2] * D.d[3], (long)D.d[2] * D.d[3], (long)D.d[3], 1};
+  // channel padding (flipmask bits 8-10 = padded source axis + 1, bits 16.. = its REAL extent): d[] are the padded dims the
+  // destination is laid out with, the source holds only `pad_real` entries along that axis, the rest of the destination is zero
+  // (the 7x7 patch-embed convolution's 3 input channels padded to 8: its im2col rows become 16-byte chunks of the LDS-DMA GEMM)
+  const int pad_ax = ((D.flipmask >> 8) & 7) - 1, pad_real = D.flipmask >> 16;
+  int rd[4] = {D.d[0], D.d[1], D.d[2], D.d[3]};
+  if (pad_ax >= 0) rd[pad_ax] = pad_real;
+  const long ss[4] = {(long)rd[1] * rd[2] * rd[3], (long)rd[2] * rd[3], (long)rd[3], 1};
   const int e1 = D.d[D.p[1]], e2 = D.d[D.p[2]], e3 = D.d[D.p[3]];
   const long base = (long)bk_y * 1024;
   if (D.dst_bf16 == 2) {
@@ -80,7 +86,8 @@ __global__ void permute4_batch_kernel(const PermuteDesc* __restrict__ desc, cons
     // per thread: the read-modify-write of the gradient is one 16-byte access per lane (fully coalesced), the shadow is read
     // (and cleared) at (cell, ci) with ci advancing along the lanes -- whole sectors per cell row.  (Walking the source in order
     // made every gradient access a 4-byte scatter at stride KH*KW*4 bytes: 0.7 ms per step.)
-    const int Ci = D.d[3], cells = D.d[1] * D.d[2];   // source dims (Co, KH, KW, Ci), p = (0, 3, 1, 2)
+    const int CiS = D.d[3], cells = D.d[1] * D.d[2];   // source dims (Co, KH, KW, Ci), p = (0, 3, 1, 2)
+    const int Ci = pad_ax == 3 ? pad_real : CiS;       // (padded shadow: only the real channels exist in the gradient)
     float* src = const_cast<float*>(D.src);
     float* dst = reinterpret_cast<float*>(D.dst);
     const long i0 = base + 4L * threadIdx.x;
@@ -97,7 +104,7 @@ __global__ void permute4_batch_kernel(const PermuteDesc* __restrict__ desc, cons
         const int cell = (int)(i - pair * cells);
         const long co = pair / Ci;
         const int ci = (int)(pair - co * Ci);
-        float* sp = src + (co * cells + cell) * Ci + ci;
+        float* sp = src + (co * cells + cell) * CiS + ci;
         add[e] = *sp;
         if (add[e] != 0.f) { *sp = 0.f; any = true; }
       }
@@ -145,16 +152,31 @@ __global__ void permute4_batch_kernel(const PermuteDesc* __restrict__ desc, cons
     idx[1] = (int)(t % e1); t /= e1;
     idx[0] = (int)t;
     long so = 0;
+    bool in_pad = false;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       int v = idx[a];
       const int ax = D.p[a];
-      if ((D.flipmask >> ax) & 1) v = D.d[ax] - 1 - v;
+      if (ax == pad_ax && v >= pad_real) in_pad = true;
+      if ((D.flipmask >> ax) & 1) v = rd[ax] - 1 - v;
       so += (long)v * ss[ax];
     }
-    const float v = D.src[so];
+    const float v = in_pad ? 0.f : D.src[so];
     if (D.dst_bf16) stf(reinterpret_cast<bf16_t*>(D.dst) + i, v);
     else reinterpret_cast<float*>(D.dst)[i] = v;
+  }
+}
+
+// NCHW fp32 image -> NHWC rows with the channels padded to `cpad` (zeros): the encoder's input layout.  One thread per pixel: the C
+// loads of a lane group run along W (coalesced per channel), the store is one contiguous cpad-element row.
+template <typename TD>
+__global__ void nchw_to_nhwc_pad_kernel(const float* __restrict__ src, TD* __restrict__ dst, int B, int C, long HW, int cpad) {
+  const long total = (long)B * HW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / HW, pix = i - b * HW;
+    const float* s = src + b * C * HW + pix;
+    TD* d = dst + i * cpad;
+    for (int c = 0; c < cpad; ++c) stf(d + c, c < C ? s[(long)c * HW] : 0.f);
   }
 }
 
@@ -387,6 +409,34 @@ extern "C" int cmda_cast_clear(float* src, void* dst, int64_t n, int dst_dtype, 
 
 // desc: DEVICE array of `cmda_permute_desc_t` (include/cmda_hip.h); blocks: DEVICE int32 [nblocks][2] = {tensor index, chunk index}
 // with one entry per 1024 destination elements of every tensor
+// out[r][c] = bias[c] (fp32): seeds the accumulator of a split-K GEMM whose epilogue cannot add the bias (atomic accumulation)
+__global__ void rows_fill_kernel(float* __restrict__ out, const float* __restrict__ bias, long rows, int C) {
+  const long n4 = rows * (long)(C >> 2);
+  const int c4 = C >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4) * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias) ld4(bias + c, v);
+    st4(out + i * 4, v);
+  }
+}
+
+extern "C" int cmda_rows_fill(float* out, const float* bias, int64_t rows, int C, void* stream) {
+  if (rows <= 0) return CMDA_OK;
+  if (C <= 0 || (C & 3)) return CMDA_ERR_SHAPE;
+  CMDA_LAUNCH(rows_fill_kernel, dim3(grid_for(rows * (C >> 2), 1)), dim3(256), 0, stream, out, bias, (long)rows, C);
+  CMDA_CHECK_LAUNCH();
+}
+
+extern "C" int cmda_nchw_to_nhwc_pad(const float* src, void* dst, int B, int C, int64_t HW, int cpad, int dst_dtype, void* stream) {
+  if (B <= 0 || HW <= 0) return CMDA_OK;
+  if (C <= 0 || cpad < C) return CMDA_ERR_SHAPE;
+  const long n = (long)B * HW;
+  CMDA_DISPATCH_DTYPE(dst_dtype, CMDA_LAUNCH((nchw_to_nhwc_pad_kernel<T>), dim3(grid_for(n, 1)), dim3(256), 0, stream, src, (T*)dst, B, C,
+                                              (long)HW, cpad));
+  CMDA_CHECK_LAUNCH();
+}
+
 extern "C" int cmda_permute4_batch(const void* desc, const int* blocks, int nblocks, void* stream) {
   if (nblocks <= 0) return CMDA_OK;
   static_assert(sizeof(PermuteDesc) == 64, "descriptor layout is part of the ABI");

@@ -52,19 +52,31 @@ def conv_out_size(H, W, k, stride, pad, dil=1):
     return (H + 2 * pad - dil * (k - 1) - 1) // stride + 1, (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
 
-def conv_fwd(x, weight, bias, B, H, W, stride, pad, dil=1, *, act=None, out=None, reflect=0):
+def conv_fwd(x, weight, bias, B, H, W, stride, pad, dil=1, *, act=None, out=None, reflect=0, ci_pad=0):
+    """ci_pad > Ci: x carries ci_pad channels per pixel (zeros past Ci) and the weight copy is padded alike (runtime.wconv)"""
     Co, Ci, KH, KW = weight.shape
+    Ci = max(Ci, ci_pad)
     OH, OW = conv_out_size(H, W, KH, stride, pad, dil)
     M, K = B * OH * OW, KH * KW * Ci
     if out is None:
         out = torch.empty(M, Co, dtype=rt.compute_dtype(), device=x.device)
     ops.gemm(conv_view(x, B, H, W, Ci, KH, KW, stride, pad, dil, OH=OH, OW=OW, reflect=reflect),
-             plain_view(rt.wconv(weight), Co, K), out, M, Co, K, dtype=rt.tag(), bias=bias, act=act)
+             plain_view(rt.wconv(weight, ci_pad=ci_pad), Co, K), out, M, Co, K, dtype=rt.tag(), bias=bias, act=act)
     return out, OH, OW
 
 
-def conv_bwd(dy, x, weight, bias, B, H, W, stride, pad, dil=1, *, need_dx=True, dx_out=None, dx_beta=0.0):
+def conv_bwd(dy, x, weight, bias, B, H, W, stride, pad, dil=1, *, need_dx=True, dx_out=None, dx_beta=0.0, ci_pad=0):
     Co, Ci, KH, KW = weight.shape
+    if ci_pad > Ci:   # channel-padded input (the encoder's first convolution): weight gradient through a padded shadow, no dx
+        assert not need_dx
+        with ops.ln_deferral():   # (a scope of its own when called outside a backward pass: the shadow is drained on exit)
+            return _conv_bwd(dy, x, weight, bias, B, H, W, stride, pad, dil, need_dx=False, ci_pad=ci_pad)
+    return _conv_bwd(dy, x, weight, bias, B, H, W, stride, pad, dil, need_dx=need_dx, dx_out=dx_out, dx_beta=dx_beta)
+
+
+def _conv_bwd(dy, x, weight, bias, B, H, W, stride, pad, dil=1, *, need_dx=True, dx_out=None, dx_beta=0.0, ci_pad=0):
+    Co, Ci, KH, KW = weight.shape
+    Ci = max(Ci, ci_pad)
     OH, OW = conv_out_size(H, W, KH, stride, pad, dil)
     M, K = B * OH * OW, KH * KW * Ci
     def wgrad():
@@ -72,7 +84,7 @@ def conv_bwd(dy, x, weight, bias, B, H, W, stride, pad, dil=1, *, need_dx=True, 
         # gradient (c_perm: no staging buffer); the bias gradient rides along in the same kernel when the operands allow
         dyv = plain_view(dy, M, Co)
         fused = (bias is not None and rt.tag() == 1 and dyv.vec_ok and Co % 8 == 0 and K % 8 == 0 and Ci % 8 == 0)
-        shadow = ops.conv_grad_shadow(rt.grad(weight))
+        shadow = ops.conv_grad_shadow(rt.grad(weight), ci_pad)
         if shadow is not None:   # inside a pass: coalesced atomics into the [Co,KH,KW,Ci] shadow, drained once per pass
             ops.gemm(dyv, conv_view(x, B, H, W, Ci, KH, KW, stride, pad, dil, OH=OH, OW=OW), shadow, Co, K, M,
                      a_kstrided=True, b_kstrided=True, dtype=rt.tag(), atomic=True, splits=0,
@@ -172,9 +184,19 @@ def block_fwd(x, p, B, H, W, C, heads, sr, *, eps=1e-6, dp1=None, dp2=None, save
     xn, m1, r1 = ops.layernorm_fwd(x, p.norm1.weight, p.norm1.bias, eps, out_dtype=cd)
     q = linear_fwd(xn, a.q.weight, a.q.bias, M, C)
     if sr > 1:
-        xs_pre, OH, OW = conv_fwd(xn, a.sr.weight, a.sr.bias, B, H, W, sr, 0)
+        OH, OW = conv_out_size(H, W, sr, sr, 0)
+        Ksr = sr * sr * C
+        if rt.tag() == 1 and Ksr >= 1024 and ((B * OH * OW + 63) // 64) * ((C + 63) // 64) <= 64 and C % 4 == 0:
+            # few output tiles, long contraction (stages 1 / 2: B*256 rows x 64 / 128 channels over K = 4096 / 2048): 8 - 32 workgroups
+            # running 32 - 64 k-tiles one after the other (39 / 23 us).  Split K instead: the slices accumulate with fp32 atomics on
+            # top of the bias, and the LayerNorm behind reads the fp32 sums (which it also keeps for its backward pass).
+            xs_pre = ops.rows_fill(torch.empty(B * OH * OW, C, dtype=torch.float32, device=x.device), a.sr.bias)
+            ops.gemm(conv_view(xn, B, H, W, C, sr, sr, sr, 0, 1, OH=OH, OW=OW), plain_view(rt.wconv(a.sr.weight), C, Ksr), xs_pre,
+                     B * OH * OW, C, Ksr, dtype=rt.tag(), atomic=True, splits=0)
+        else:
+            xs_pre, OH, OW = conv_fwd(xn, a.sr.weight, a.sr.bias, B, H, W, sr, 0)
         Nk = OH * OW
-        xs, ms, rs = ops.layernorm_fwd(xs_pre, a.norm.weight, a.norm.bias, 1e-5)
+        xs, ms, rs = ops.layernorm_fwd(xs_pre, a.norm.weight, a.norm.bias, 1e-5, out_dtype=cd)
     else:
         xs_pre, ms, rs, xs, Nk = None, None, None, xn, N
     kv = linear_fwd(xs, a.kv.weight, a.kv.bias, B * Nk, C)

@@ -322,15 +322,17 @@ def ln_fold_deferred(all_lanes=False):
 _CG = {'regions': {}, 'touched': {}, 'plans': {}}
 
 
-def conv_grad_shadow(grad):
-    """grad: fp32 [Co,Ci,KH,KW] parameter gradient -> its [Co, KH*KW*Ci] shadow, or None outside a deferral scope"""
+def conv_grad_shadow(grad, ci_pad=0):
+    """grad: fp32 [Co,Ci,KH,KW] parameter gradient -> its [Co, KH*KW*Ci] shadow, or None outside a deferral scope.  ci_pad > Ci:
+    the shadow carries the padded channels of the GEMM ([Co, KH*KW*ci_pad]); the drain keeps the real ones."""
     if _LN_DEFER['depth'] == 0:
         return None
     key = grad.data_ptr()
     r = _CG['regions'].get(key)
-    if r is None or r[0].device != grad.device:
-        Co, Ci, KH, KW = grad.shape
-        r = _CG['regions'][key] = (torch.zeros(Co, KH * KW * Ci, dtype=torch.float32, device=grad.device), grad)
+    Co, Ci, KH, KW = grad.shape
+    cs = max(Ci, ci_pad)
+    if r is None or r[0].device != grad.device or r[0].shape[1] != KH * KW * cs:
+        r = _CG['regions'][key] = (torch.zeros(Co, KH * KW * cs, dtype=torch.float32, device=grad.device), grad)
     _CG['touched'].setdefault(LN_LANE, {})[key] = r
     return r[0]
 
@@ -353,7 +355,8 @@ def conv_grad_drain(all_lanes=False):
             blocks = []
             for i, (_, (sh, g)) in enumerate(items):
                 Co, Ci, KH, KW = g.shape
-                desc[i] = (sh.data_ptr(), g.data_ptr(), (Co, KH, KW, Ci), (0, 3, 1, 2), 0, 2, g.numel())
+                cs = sh.shape[1] // (KH * KW)   # channels of the shadow (> Ci: padded)
+                desc[i] = (sh.data_ptr(), g.data_ptr(), (Co, KH, KW, cs), (0, 3, 1, 2), ((4 << 8) | (Ci << 16)) if cs != Ci else 0, 2, g.numel())
                 blocks += [(i, b) for b in range((g.numel() + 1023) // 1024)]
             tab = _host_table(torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()), dev)
             blk = _host_table(torch.from_numpy(np.asarray(blocks, dtype=np.int32).reshape(-1).view(np.uint8).copy()), dev)
@@ -384,6 +387,20 @@ def permute4(src, dst, dims, perm, flipmask=0, accumulate=False):
     p = list(perm) + list(range(len(perm), 4))
     call('cmda_permute4', ptr(src), ptr(dst), *[c_i32(v) for v in d], *[c_i32(v) for v in p], c_i32(flipmask),
          c_i32(int(accumulate)), dtype_tag(src), dtype_tag(dst), stream_of(src))
+    return dst
+
+
+def rows_fill(out, bias):
+    """out fp32 [rows, C] = bias[C] broadcast (zeros when bias is None)"""
+    check_dev(out, bias)
+    call('cmda_rows_fill', ptr(out), ptr(bias), c_i64(out.shape[0]), c_i32(out.shape[1]), stream_of(out))
+    return out
+
+
+def nchw_to_nhwc_pad(src, dst, B, C, HW, cpad):
+    """src fp32 NCHW [B,C,H,W] -> dst [B*HW, cpad] (activation dtype), channels >= C zero"""
+    check_dev(src, dst)
+    call('cmda_nchw_to_nhwc_pad', ptr(src), ptr(dst), c_i32(B), c_i32(C), c_i64(HW), c_i32(cpad), dtype_tag(dst), stream_of(src))
     return dst
 
 

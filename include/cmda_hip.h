@@ -217,7 +217,9 @@ typedef struct cmda_permute_desc_t {
   void* dst;
   int32_t d[4];       /* source dims */
   int32_t p[4];       /* dst axis a = source axis p[a] */
-  int32_t flipmask;   /* bit ax set: source axis ax reversed */
+  int32_t flipmask;   /* bit ax set: source axis ax reversed; bits 8-10 = PADDED source axis + 1 and bits 16.. = its real extent: d[] then
+                         holds the padded dims of the destination layout, entries past the real extent are written as zero (drain mode: the
+                         shadow is padded, the gradient is not) */
   int32_t dst_bf16;   /* 1: dst is bf16, 0: fp32; 2: DRAIN -- dst (fp32) += src and src = 0 for d = (Co,KH,KW,Ci), p = (0,3,1,2): the conv
                          weight-gradient shadows in GEMM order -> the parameter's own [Co][Ci][KH][KW] layout */
   int64_t total;      /* d[0]*d[1]*d[2]*d[3] */
@@ -225,6 +227,12 @@ typedef struct cmda_permute_desc_t {
 /* dst (activation dtype) = src; src (fp32, n % 4 == 0) = 0: drains a persistent accumulation workspace and leaves it zeroed */
 int cmda_cast_clear(float* src, void* dst, int64_t n, int dst_dtype, void* stream);
 int cmda_permute4_batch(const void* desc, const int* blocks, int nblocks, void* stream);
+/* out[r][c] = bias[c] (or 0), fp32 [rows, C]: the accumulator of a split-K convolution -- the spatial-reduction convolution of
+ * Attention (mix_transformer.py:73-75: B*256 output rows, K up to 4096) runs as 8 K-slices accumulating with atomics on top of it */
+int cmda_rows_fill(float* out, const float* bias, int64_t rows, int C, void* stream);
+/* NCHW fp32 image -> NHWC rows of `cpad` >= C channels (zeros past C) in the activation dtype: the input of OverlapPatchEmbed
+ * (mix_transformer.py:169-183) with its 3 channels padded to 8, so that the 7x7 / stride-4 convolution runs on the LDS-DMA GEMM path */
+int cmda_nchw_to_nhwc_pad(const float* src, void* dst, int B, int C, int64_t HW, int cpad, int dst_dtype, void* stream);
 int cmda_colsum(const void* x, float* out, int64_t M, int N, int64_t ld, int dtype, void* stream);
 int cmda_axpby(const void* x, const void* y, void* out, float a, float b, int64_t n, int dtype, void* stream);
 int cmda_sample_scale(const void* x, const float* scale, void* out, int B, int64_t per_sample, int C, int per_channel,

@@ -296,3 +296,52 @@ def test_eval_path_440x640_matches_oracle():
         assert agree >= agree_min, f'{dt}: argmax agreement {agree}'
         r = metrics.mean_iou([torch.from_numpy(pred).to(dev)], [want.argmax(1)[0].to(dev)], 19, 255)
         assert r['aAcc'].item() >= agree_min and r['IoU'].device.type == 'cuda'
+
+
+def test_patch_embed_channel_padding(tgt):
+    """bf16 mode: the encoder's 3-channel input is laid out with 8 channels per pixel (zeros) and the 7x7 / stride-4 patch-embed
+    convolution (mix_transformer.py:169-183) runs with a padded weight copy on the LDS-DMA GEMM path; its weight gradient goes
+    through a padded shadow whose drain keeps the 3 real channels.  Output, LayerNorm and every parameter gradient == torch."""
+    import torch.nn.functional as Fn
+    import cmda_amd.runtime as rt_
+    from cmda_amd import ops as ops_
+    from cmda_amd.backbones import OverlapPatchEmbed
+    torch.manual_seed(3)
+    rt_.set_compute_dtype(torch.bfloat16)
+    try:
+        B, H, W = 2, 32, 40
+        pe = OverlapPatchEmbed(patch_size=7, stride=4, in_chans=3, embed_dim=64)
+        with torch.no_grad():
+            pe.proj.weight.copy_(torch.randn_like(pe.proj.weight) * 0.1)
+            pe.proj.bias.copy_(torch.randn(64) * 0.1)
+            pe.norm.weight.copy_(1 + 0.1 * torch.randn(64))
+            pe.norm.bias.copy_(0.1 * torch.randn(64))
+        pe.to(tgt.device)
+        img = torch.randn(B, 3, H, W)
+        cp = rt_.conv_channel_pad(3)
+        assert cp == 8
+        x = torch.empty(B * H * W, cp, dtype=torch.bfloat16, device=tgt.device)
+        ops_.nchw_to_nhwc_pad(tgt.to(img), x, B, 3, H * W, cp)
+        assert torch.equal(x[:, :3].float().cpu().view(B, H, W, 3), img.bfloat16().float().permute(0, 2, 3, 1)) and float(x[:, 3:].abs().sum()) == 0
+        yn, OH, OW, sv = pe.fwd(x, B, H, W)
+        g = torch.randn(B * OH * OW, 64)
+        for p_ in pe.parameters():
+            p_.grad = None
+        pe.bwd(sv, tgt.to(g.bfloat16()), B, need_dx=False)
+        # torch reference on the bf16-rounded operands
+        xr = img.bfloat16().float()
+        w = pe.proj.weight.detach().cpu().bfloat16().float().requires_grad_(True)
+        b = pe.proj.bias.detach().cpu().clone().requires_grad_(True)
+        gw = pe.norm.weight.detach().cpu().clone().requires_grad_(True)
+        gb = pe.norm.bias.detach().cpu().clone().requires_grad_(True)
+        y = Fn.conv2d(xr, w, b, 4, 3)
+        assert y.shape[2:] == (OH, OW)
+        yl = y.permute(0, 2, 3, 1).reshape(-1, 64)
+        ref = Fn.layer_norm(yl.bfloat16().float(), (64,), gw, gb, 1e-5)
+        ref.backward(g.bfloat16().float())
+        assert_close(yn, ref, 3e-2, name='patch embed + LN (padded channels)')
+        assert_close(pe.proj.weight.grad, w.grad, 3e-2, name='dW through the padded shadow')
+        assert_close(pe.proj.bias.grad, b.grad, 3e-2, name='db')
+        assert_close(pe.norm.weight.grad, gw.grad, 3e-2, name='dgamma')
+    finally:
+        rt_.set_compute_dtype(torch.float32)
