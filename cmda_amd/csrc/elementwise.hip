@@ -409,6 +409,26 @@ extern "C" int cmda_cast_clear(float* src, void* dst, int64_t n, int dst_dtype, 
 
 // desc: DEVICE array of `cmda_permute_desc_t` (include/cmda_hip.h); blocks: DEVICE int32 [nblocks][2] = {tensor index, chunk index}
 // with one entry per 1024 destination elements of every tensor
+// dst[r][0..cp) = cast(src[r][0..c)) | 0: fp32 rows of c columns -> activation-dtype rows padded to cp columns (the 19-class logit
+// gradient -> 32 columns: its two GEMMs -- classifier weight gradient and data gradient -- then run on 16-byte chunks)
+template <typename TD>
+__global__ void cast_pad_cols_kernel(const float* __restrict__ src, TD* __restrict__ dst, long rows, int c, int cp) {
+  const long total = rows * cp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cp;
+    const int k = (int)(i - r * cp);
+    stf(dst + i, k < c ? src[r * c + k] : 0.f);
+  }
+}
+
+extern "C" int cmda_cast_pad_cols(const float* src, void* dst, int64_t rows, int c, int cp, int dst_dtype, void* stream) {
+  if (rows <= 0) return CMDA_OK;
+  if (c <= 0 || cp < c) return CMDA_ERR_SHAPE;
+  CMDA_DISPATCH_DTYPE(dst_dtype, CMDA_LAUNCH((cast_pad_cols_kernel<T>), dim3(grid_for(rows * cp, 1)), dim3(256), 0, stream, src, (T*)dst,
+                                              (long)rows, c, cp));
+  CMDA_CHECK_LAUNCH();
+}
+
 // out[r][c] = bias[c] (fp32): seeds the accumulator of a split-K GEMM whose epilogue cannot add the bias (atomic accumulation)
 __global__ void rows_fill_kernel(float* __restrict__ out, const float* __restrict__ bias, long rows, int C) {
   const long n4 = rows * (long)(C >> 2);

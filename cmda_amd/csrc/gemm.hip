@@ -81,10 +81,11 @@ int launch_dtype(GemmParams& p, void* stream) {
   if ((p.tile_hint & 15) >= 1 && (p.tile_hint & 15) <= 4 && p.tile_hint > 0) tile = (p.tile_hint & 15) - 1;  // caller's explicit tile choice (tuning sweeps, tests)
   if constexpr (sizeof(T) == 2) {
     const bool no_glds = p.tile_hint < 0;  // caller asks for the register-staged kernel (tuning sweeps)
-    // LDS-DMA path: every operand mode with aligned 16-byte chunks (reflection padding included); transposed-conv views and operands
+    // LDS-DMA path: every operand mode with aligned 16-byte chunks (reflection padding and zero-inserted inputs included); operands
     // too large for 32-bit tile arithmetic stay on the register-staged kernel
-    auto dma_ok = [](const GemmView& v) {
-      return v.vec_ok && v.in_dil <= 1 && v.R < (1L << 31) && v.Cc < (1L << 31) &&
+    // (zero-inserted inputs, in_dil > 1 -- transposed convolutions, data gradients of strided ones --: K-contiguous im2col operands only)
+    auto dma_ok = [&](const GemmView& v) {
+      return v.vec_ok && (v.in_dil <= 1 || (v.conv == 1 && !v.reflect && &v == &p.A && !p.a_kstrided)) && v.R < (1L << 31) && v.Cc < (1L << 31) &&
              (!v.conv || (v.H < 32768 && v.W < 32768)) && (v.conv || (v.ld % 8) == 0) && (v.Cc % 8) == 0 &&
              (v.conv != 2 || ((v.KW * v.C) % 64 == 0 && v.KH == v.stride && v.KW == v.stride && v.pad == 0 && v.dil == 1 &&
                               v.H == v.OH * v.stride && v.W == v.OW * v.stride));

@@ -640,6 +640,19 @@ struct DmaSrc {
       }
       if (c + 8 > v.Cc) return zero;
       int ih = (cbc[j] >> 16) + kh * v.dil, iw = (int)(short)(cbc[j] & 0xffff) + kw * v.dil;
+      if (v.in_dil > 1) {   // zero-inserted input (transposed convolution / the data gradient of a strided one): taps that fall
+                            // between the real pixels read zero
+        if (ih < 0 || iw < 0) return zero;
+        if (v.in_dil == 2) {
+          if ((ih | iw) & 1) return zero;
+          ih >>= 1;
+          iw >>= 1;
+        } else {
+          if ((ih % v.in_dil) || (iw % v.in_dil)) return zero;
+          ih /= v.in_dil;
+          iw /= v.in_dil;
+        }
+      }
       if (v.reflect) {
         ih = reflect_idx(ih, v.H);
         iw = reflect_idx(iw, v.W);

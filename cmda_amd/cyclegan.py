@@ -85,9 +85,14 @@ class ResnetGenerator(nn.Module):
         """inp fp32 NCHW [B,1,H,W] -> fp32 NCHW [B,1,H,W] (tanh)."""
         B, Cin, H, W = inp.shape
         m = self.model
-        x = torch.empty(B * H * W, Cin, dtype=rt.compute_dtype(), device=inp.device)
-        ops.permute4(inp.contiguous(), x, (B, Cin, H, W), (0, 2, 3, 1))
-        x, H1, W1 = self._conv(x, m[1], B, H, W, 1, 3, 1)
+        cp = rt.conv_channel_pad(Cin)   # bf16 mode: the 1-channel input padded to 8 (16-byte im2col chunks: the LDS-DMA GEMM path)
+        x = torch.empty(B * H * W, cp, dtype=rt.compute_dtype(), device=inp.device)
+        if cp != Cin:
+            ops.nchw_to_nhwc_pad(inp.contiguous(), x, B, Cin, H * W, cp)
+            x, H1, W1 = K.conv_fwd(x, m[1].weight, m[1].bias, B, H, W, 1, 3, 1, reflect=1, ci_pad=cp)
+        else:
+            ops.permute4(inp.contiguous(), x, (B, Cin, H, W), (0, 2, 3, 1))
+            x, H1, W1 = self._conv(x, m[1], B, H, W, 1, 3, 1)
         x = self._inorm(x, B, H1 * W1, m[1].out_channels, True)
         x, H2, W2 = self._conv(x, m[4], B, H1, W1, 2, 1, 0)
         x = self._inorm(x, B, H2 * W2, m[4].out_channels, True)
@@ -107,8 +112,11 @@ class ResnetGenerator(nn.Module):
         x = self._inorm(x, B, H5 * W5, m[k + 3].out_channels, True)
         last = m[k + 7]
         Co = last.out_channels
-        y = torch.empty(B * H5 * W5, Co, dtype=torch.float32, device=inp.device)
         Ci = last.in_channels
+        if Co == 1 and ops.conv_co1_ok(x, Ci, 7, 3):   # one output channel: a stencil kernel, not an N = 1 GEMM
+            y = ops.conv_co1(x, rt.wconv(last.weight), last.bias, B, H5, W5, Ci, 7, 3, True, 'tanh')
+            return y.view(B, 1, H5, W5)
+        y = torch.empty(B * H5 * W5, Co, dtype=torch.float32, device=inp.device)
         ops.gemm(conv_view(x, B, H5, W5, Ci, 7, 7, 1, 3, 1, OH=H5, OW=W5, reflect=1),
                  plain_view(rt.wconv(last.weight), Co, 49 * Ci), y, B * H5 * W5, Co, 49 * Ci, dtype=rt.tag(),
                  bias=last.bias, act='tanh')

@@ -281,8 +281,23 @@ class _HeadBase(nn.Module):
         featd, mask = saved
         M, Ch = B * H * W, self.channels
         dl = dlogits.view(M, self.num_classes)
-        dl = dl if rt.compute_dtype() == torch.float32 else ops.cast(dl, rt.compute_dtype())
-        dfeat = K.linear_bwd(dl, featd, self.conv_seg.weight, self.conv_seg.bias, M, Ch)
+        nc = self.num_classes
+        if rt.compute_dtype() == torch.float32:
+            dfeat = K.linear_bwd(dl, featd, self.conv_seg.weight, self.conv_seg.bias, M, Ch)
+        elif nc % 8 == 0:
+            dfeat = K.linear_bwd(ops.cast(dl, rt.compute_dtype()), featd, self.conv_seg.weight, self.conv_seg.bias, M, Ch)
+        else:
+            # 19 classes: rows of 38 bytes would send both GEMMs to the register-staged kernel (141 + 180 us at 262144 pixels); the
+            # cast that had to run anyway pads the rows to 32 columns of zeros instead, the classifier weight keeps its 19 rows (the
+            # operand views read zero past them)
+            ncp = (nc + 31) // 32 * 32
+            dlp = ops.cast_pad_cols(dl, ncp, rt.compute_dtype())
+            w, b = self.conv_seg.weight, self.conv_seg.bias
+            dlv = ops.plain_view(dlp, M, ncp)
+            ops.gemm(dlv, ops.plain_view(featd, M, Ch), rt.grad(w).view(nc, Ch), nc, Ch, M, a_kstrided=True, b_kstrided=True, dtype=rt.tag(),
+                     atomic=True, splits=0, colsum=rt.grad(b), defer=True, keep=(dlp, featd))
+            dfeat = torch.empty(M, Ch, dtype=rt.compute_dtype(), device=dl.device)
+            ops.gemm(dlv, ops.plain_view(rt.w(w).view(nc, Ch), nc, Ch), dfeat, M, Ch, ncp, b_kstrided=True, dtype=rt.tag())
         if mask is not None:
             dfeat = ops.sample_scale(dfeat, mask, B, Ch, per_channel=True, out=dfeat)
         return dfeat

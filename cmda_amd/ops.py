@@ -390,6 +390,28 @@ def permute4(src, dst, dims, perm, flipmask=0, accumulate=False):
     return dst
 
 
+def conv_co1_ok(x, C, K, pad):
+    return x.dtype == torch.bfloat16 and C == 64 and K == 7 and pad == 3
+
+
+def conv_co1(x, w, bias, B, H, W, C, K, pad, reflect, act):
+    """x [B*H*W, C] NHWC, w [K*K*C] khwc (activation dtype) -> fp32 [B,H,W] = act(bias + conv): one output channel"""
+    check_dev(x, w, bias)
+    out = torch.empty(B, H, W, dtype=torch.float32, device=x.device)
+    call('cmda_conv_co1', ptr(x), ptr(w), ptr(bias), ptr(out), c_i32(B), c_i32(H), c_i32(W), c_i32(C), c_i32(K), c_i32(pad),
+         c_i32(int(reflect)), c_i32(ACT[act]), dtype_tag(x), stream_of(x))
+    return out
+
+
+def cast_pad_cols(src32, cp, dtype):
+    """fp32 [rows, c] -> dtype [rows, cp], columns >= c zero"""
+    check_dev(src32)
+    rows, c = src32.shape
+    dst = torch.empty(rows, cp, dtype=dtype, device=src32.device)
+    call('cmda_cast_pad_cols', ptr(src32), ptr(dst), c_i64(rows), c_i32(c), c_i32(cp), dtype_tag(dst), stream_of(src32))
+    return dst
+
+
 def rows_fill(out, bias):
     """out fp32 [rows, C] = bias[C] broadcast (zeros when bias is None)"""
     check_dev(out, bias)

@@ -92,6 +92,13 @@ typedef struct cmda_gemm_params_t {
 
 int cmda_gemm(const cmda_gemm_params_t* p, void* stream);
 
+/* K x K convolution with ONE output channel, stride 1, reflection (or zero) padding `pad`, NHWC x [B,H,W,C] and khwc weights
+ * [K*K*C] in the activation dtype, out fp32 [B,H,W] = act(bias[0] + sum): the last layer of the Motion-Extractor generator
+ * (ReflectionPad2d(3) + Conv2d(64,1,7) + Tanh, cyclegan/cyclegan_model.py:366-369).  Built for bf16, K = 7, C = 64, pad = 3;
+ * CMDA_ERR_UNSUPPORTED otherwise (the caller then uses cmda_gemm). */
+int cmda_conv_co1(const void* x, const void* w, const float* bias, float* out, int B, int H, int W, int C, int K, int pad,
+    int reflect, int act, int dtype, void* stream);
+
 /* GROUPED launch of n GEMMs in list order semantics-wise independent of each other (no problem reads another's output): the
  * DEFERRED weight gradients of a backward pass -- `dW += dY^T X` of every nn.Linear / nn.Conv2d the pass walked
  * (mix_transformer.py:31-44,62-76,169-173; decode_heads/segformer_head.py:25-28 under torch autograd) -- as ONE grid per (tile,
@@ -227,6 +234,9 @@ typedef struct cmda_permute_desc_t {
 /* dst (activation dtype) = src; src (fp32, n % 4 == 0) = 0: drains a persistent accumulation workspace and leaves it zeroed */
 int cmda_cast_clear(float* src, void* dst, int64_t n, int dst_dtype, void* stream);
 int cmda_permute4_batch(const void* desc, const int* blocks, int nblocks, void* stream);
+/* fp32 [rows, c] -> activation dtype [rows, cp >= c], zero-padded columns: the logit gradient of cls_seg's backward
+ * (decode_head.py:563-586 under autograd) padded from 19 to 32 classes */
+int cmda_cast_pad_cols(const float* src, void* dst, int64_t rows, int c, int cp, int dst_dtype, void* stream);
 /* out[r][c] = bias[c] (or 0), fp32 [rows, C]: the accumulator of a split-K convolution -- the spatial-reduction convolution of
  * Attention (mix_transformer.py:73-75: B*256 output rows, K up to 4096) runs as 8 K-slices accumulating with atomics on top of it */
 int cmda_rows_fill(float* out, const float* bias, int64_t rows, int C, void* stream);
