@@ -60,6 +60,12 @@ int launch_dtype(GemmParams& p, void* stream) {
     // 256x256 (8 waves, one block per CU) from ~4 blocks per CU on deep contractions: 8192^3 1302 -> 1060 us, the head's
     // 3x3 bottleneck conv 2134 -> 1570 us; short-K or narrow problems lose to the 128x128 tile
     if (sizeof(T) == 2 && p.N >= 256 && p.K >= 256 && (blocks(256, 256) * sp >= 1024 || (blocks(256, 256) * sp >= 200 && p.K >= 2048))) tile = 3;  // (4096^3: one block per CU, 1113 vs 883 TFLOP/s on 128x128)
+    // output-bound GEMMs with a plain epilogue (MixFFN fc1 of stages 1 / 2: 131072 x 256 x 64, 32768 x 512 x 128; the head's pointwise
+    // convolution over the teacher's 98304 rows): the ping-pong kernel's bf16 row image stores 16-byte pieces of whole rows
+    // (29.6 against 38.4 us, 18.4 against 24.3 us; at 16384 x 512 the 64-wide tiles are still ahead)
+    else if (sizeof(T) == 2 && (p.N & 255) == 0 && p.K <= 1024 && blocks(256, 256) * sp >= 256 && !p.a_kstrided && !p.b_kstrided && p.A.conv != 1 &&
+             p.B.conv != 1 && !p.res && !p.rowscale && p.beta == 0.f && !p.out_f32 && !p.atomic && p.c_patch_ow == 0)
+      tile = 3;
     // N = 320 (64 x odd): the last 128-wide tile column would be half empty -- with enough blocks the 128x64 tile wins
     // (batch 64, M = 65536: q 42.2 -> 38.9 us, dfc1 110.8 -> 99.6 us; at batch 16 the 128x128 tile is still ahead)
     else if (p.N > 64 && (p.N & 127) > 0 && (p.N & 127) <= 64 && blocks(128, 64) * sp >= 2048) tile = 1;

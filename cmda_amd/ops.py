@@ -325,11 +325,15 @@ _CG = {'regions': {}, 'touched': {}, 'plans': {}}
 def conv_grad_shadow(grad, ci_pad=0):
     """grad: fp32 [Co,Ci,KH,KW] parameter gradient -> its [Co, KH*KW*Ci] shadow, or None outside a deferral scope.  ci_pad > Ci:
     the shadow carries the padded channels of the GEMM ([Co, KH*KW*ci_pad]); the drain keeps the real ones."""
+    Co, Ci, KH, KW = grad.shape
+    if ci_pad <= Ci and not grad.is_contiguous() and grad.permute(0, 2, 3, 1).is_contiguous():
+        # channels-last stored gradient (optim.FlatAdamW): its memory is the GEMM's own [Co][KH][KW][Ci] order -- accumulate in place,
+        # nothing to drain
+        return grad.permute(0, 2, 3, 1).reshape(Co, KH * KW * Ci)
     if _LN_DEFER['depth'] == 0:
         return None
     key = grad.data_ptr()
     r = _CG['regions'].get(key)
-    Co, Ci, KH, KW = grad.shape
     cs = max(Ci, ci_pad)
     if r is None or r[0].device != grad.device or r[0].shape[1] != KH * KW * cs:
         r = _CG['regions'][key] = (torch.zeros(Co, KH * KW * cs, dtype=torch.float32, device=grad.device), grad)

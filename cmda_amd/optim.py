@@ -62,9 +62,20 @@ class FlatAdamW:
                 start = off
                 for p in ps:
                     n = p.numel()
-                    self.flat_p[off:off + n].copy_(p.data.reshape(-1))
-                    p.data = self.flat_p[off:off + n].view(p.shape)
-                    p.grad = self.flat_g[off:off + n].view(p.shape)
+                    if _khwc_candidate(p):
+                        # CHANNELS-LAST storage: the slot holds [Co,KH,KW,Ci] -- the implicit GEMM's own weight layout -- and the
+                        # parameter is a permuted view of it with the reference's logical shape [Co,Ci,KH,KW] (state_dict, copy_,
+                        # the oracle comparisons all see that shape).  The bf16 mirror the AdamW kernel maintains IS then the GEMM
+                        # operand, and the weight-gradient GEMM accumulates straight into the gradient's memory: neither the per-step
+                        # re-layout of ~100 M conv weights (0.7 ms) nor the gradient-shadow drain (0.5 ms) exists for these.
+                        Co, Ci, KH, KW = p.shape
+                        self.flat_p[off:off + n].copy_(p.data.permute(0, 2, 3, 1).reshape(-1))
+                        p.data = self.flat_p[off:off + n].view(Co, KH, KW, Ci).permute(0, 3, 1, 2)
+                        p.grad = self.flat_g[off:off + n].view(Co, KH, KW, Ci).permute(0, 3, 1, 2)
+                    else:
+                        self.flat_p[off:off + n].copy_(p.data.reshape(-1))
+                        p.data = self.flat_p[off:off + n].view(p.shape)
+                        p.grad = self.flat_g[off:off + n].view(p.shape)
                     off += (n + 7) // 8 * 8
                 self.segments.append((start, off, lm, dm))
         # bf16 compute copies of every parameter, kept current by the AdamW kernel itself (no per-step cast launches)
@@ -74,7 +85,7 @@ class FlatAdamW:
             base = self.flat_p.data_ptr()
             for _, p in uniq:
                 o = (p.data.data_ptr() - base) // 4
-                p._cmda_bf16 = self.flat_bf16[o:o + p.numel()].view(p.shape)
+                p._cmda_bf16 = _slot_view(self.flat_bf16, o, p)
             self.sync_bf16()
         self.step_count = 0
         rt.invalidate()
@@ -129,8 +140,8 @@ class FlatAdamW:
             lo, hi = self._slot(p)
             lm, dm = seg_of(lo)
             if self.step_count > 0:
-                state[i] = {'step': self.step_count, 'exp_avg': self.flat_m[lo:hi].view(p.shape).detach().cpu().clone(),
-                            'exp_avg_sq': self.flat_v[lo:hi].view(p.shape).detach().cpu().clone()}
+                state[i] = {'step': self.step_count, 'exp_avg': _slot_view(self.flat_m, lo, p).detach().cpu().contiguous().clone(),
+                            'exp_avg_sq': _slot_view(self.flat_v, lo, p).detach().cpu().contiguous().clone()}
             groups.append({'lr': self.lr * lm, 'betas': tuple(self.betas), 'eps': self.eps, 'weight_decay': self.weight_decay * dm,
                            'amsgrad': False, 'params': [i]})
         return {'state': state, 'param_groups': groups}
@@ -144,12 +155,32 @@ class FlatAdamW:
                 if st is None:
                     continue
                 lo, hi = self._slot(p)
-                self.flat_m[lo:hi].copy_(st['exp_avg'].reshape(-1))
-                self.flat_v[lo:hi].copy_(st['exp_avg_sq'].reshape(-1))
+                _slot_view(self.flat_m, lo, p).copy_(st['exp_avg'].view(p.shape))
+                _slot_view(self.flat_v, lo, p).copy_(st['exp_avg_sq'].view(p.shape))
                 steps.add(int(st['step']))
         if len(steps) > 1:
             raise ValueError(f'per-parameter step counts differ ({sorted(steps)}): the fused update keeps one step count')
         self.step_count = steps.pop() if steps else 0
+
+
+def khwc_stored(p):
+    """True when the 4-D parameter p ([Co,Ci,KH,KW] logically) is stored [Co,KH,KW,Ci] in memory (see FlatAdamW)"""
+    return p.dim() == 4 and not p.is_contiguous() and p.permute(0, 2, 3, 1).is_contiguous()
+
+
+def _khwc_candidate(p):
+    """convolution weights whose implicit-GEMM layout is a plain re-ordering of the parameter: [Co,Ci,KH,KW] with Ci % 8 == 0
+    (not depthwise [C,1,3,3], not the 3-channel patch embed, which runs on a padded copy)"""
+    return p.dim() == 4 and p.shape[1] % 8 == 0 and p.shape[2] * p.shape[3] > 1
+
+
+def _slot_view(flat, off, p):
+    """p's slot of a flat buffer with p's logical shape: a permuted view of [Co,KH,KW,Ci] memory for khwc-stored parameters"""
+    n = p.numel()
+    if khwc_stored(p):
+        Co, Ci, KH, KW = p.shape
+        return flat[off:off + n].view(Co, KH, KW, Ci).permute(0, 3, 1, 2)
+    return flat[off:off + n].view(p.shape)
 
 
 def poly_warm_scale(it, max_iters=40000, power=1.0, warmup_iters=1500, warmup_ratio=1e-6):

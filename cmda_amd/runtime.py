@@ -144,6 +144,12 @@ def refresh_frozen(module=None):
 _plans = {}
 
 
+def _mem_view(param):
+    """the parameter's storage as a contiguous tensor (channels-last stored conv weights: [Co,KH,KW,Ci])"""
+    d = param.data
+    return d if d.is_contiguous() else d.permute(0, 2, 3, 1)
+
+
 def _compute_copy(param, kind, dst_shape, dst_dtype, dims, perm, flip=0):
     key = (id(param), kind)
     store = _frozen if getattr(param, '_cmda_frozen', False) else _cache
@@ -170,7 +176,7 @@ def _compute_copy(param, kind, dst_shape, dst_dtype, dims, perm, flip=0):
             e.dst._keep = (dd, bb)   # (the launch reads them asynchronously)
         else:
             dst = torch.empty(dst_shape, dtype=dst_dtype, device=param.device)
-            ops.permute4(param.data, dst, dims, perm, flipmask=flip)
+            ops.permute4(_mem_view(param), dst, dims, perm, flipmask=flip)
             e = store[key] = _Entry(param, dst, dims, perm, flip)
     return e.dst
 
@@ -189,6 +195,18 @@ def wconv(param, kind='khwc', ci_pad=0):
     """Conv weight [Co,Ci,KH,KW] repacked for the implicit GEMM (see module docstring).  ci_pad > Ci: the input channels padded
     with zeros ([Co, KH, KW, ci_pad]; the 3-channel patch embed -> 8, conv_channel_pad)."""
     Co, Ci, KH, KW = param.shape
+    if not param.is_contiguous() and param.permute(0, 2, 3, 1).is_contiguous():
+        # CHANNELS-LAST stored parameter (optim.FlatAdamW): its memory -- in the bf16 mode the mirror the AdamW / EMA kernels keep
+        # current -- already IS the implicit-GEMM layout [Co, KH*KW*Ci]
+        if kind == 'khwc' and ci_pad <= Ci:
+            if _state['dtype'] == torch.float32:
+                return param.data.permute(0, 2, 3, 1).reshape(Co, KH * KW * Ci)
+            live = getattr(param, '_cmda_bf16', None)
+            if live is not None:
+                return live.permute(0, 2, 3, 1).reshape(Co, KH * KW * Ci)
+            return _compute_copy(param, 'khwc_cl', (Co, KH * KW * Ci), _state['dtype'], (Co * KH * KW * Ci, 1, 1, 1), (0, 1, 2, 3))
+        if kind == 'dgrad':   # [Ci,KH,KW,Co] with the taps flipped, from [Co,KH,KW,Ci] memory
+            return _compute_copy(param, 'dgrad_cl', (Ci, KH * KW * Co), _state['dtype'], (Co, KH, KW, Ci), (3, 1, 2, 0), flip=0b0110)
     if kind == 'khwc' and ci_pad > Ci:
         return _compute_copy(param, f'khwc{ci_pad}', (Co, KH * KW * ci_pad), _state['dtype'], (Co, ci_pad, KH, KW), (0, 2, 3, 1),
                              flip=(2 << 8) | (Ci << 16))

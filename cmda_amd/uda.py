@@ -140,11 +140,14 @@ class DACS(nn.Module):
         for n, p in self.model.named_parameters():
             offsets[n] = (p.data_ptr() - base) // 4
         ema_flat = torch.zeros_like(flat_p)
+        from .optim import _slot_view
+        student = dict(self.model.named_parameters())
         with torch.no_grad():
             for n, p in self.ema_model.named_parameters():
                 off = offsets[n]
-                ema_flat[off:off + p.numel()].copy_(p.data.reshape(-1))
-                p.data = ema_flat[off:off + p.numel()].view(p.shape)
+                view = _slot_view(ema_flat, off, student[n])   # same storage order as the student's slot (channels-last conv weights)
+                view.copy_(p.data)
+                p.data = view
         self._flat = (flat_p, ema_flat)
         # bf16 compute copies of the teacher in one flat mirror too, refreshed by ONE cast after each EMA update (without
         # it every teacher Linear weight is cast on its own: ~1100 extra launches per iteration)
@@ -152,8 +155,7 @@ class DACS(nn.Module):
         if rt.compute_dtype() == torch.bfloat16 and ema_flat.is_cuda:
             self._ema_bf16 = torch.empty(ema_flat.numel(), dtype=torch.bfloat16, device=ema_flat.device)
             for n, p in self.ema_model.named_parameters():
-                off = offsets[n]
-                p._cmda_bf16 = self._ema_bf16[off:off + p.numel()].view(p.shape)
+                p._cmda_bf16 = _slot_view(self._ema_bf16, offsets[n], student[n])
             self._sync_ema_bf16()
 
     def _sync_ema_bf16(self):
@@ -161,12 +163,19 @@ class DACS(nn.Module):
             n = self._flat[1].numel()
             ops.permute4(self._flat[1], self._ema_bf16, (n, 1, 1, 1), (0, 1, 2, 3))
 
+    @staticmethod
+    def _ema_one(e, p, alpha):
+        if e.data.is_contiguous() and p.data.is_contiguous():
+            ops.ema_update(e.data.view(-1), p.data.view(-1), alpha)
+        else:   # differently stored tensors (a channels-last student slot against a plain teacher tensor): by logical index
+            e.data.mul_(alpha).add_(p.data, alpha=1.0 - alpha)
+
     def _init_ema_weights(self):
         if self._flat is not None:
             ops.ema_update(self._flat[1], self._flat[0], 0.0, mirror=getattr(self, '_ema_bf16', None))
         else:
             for e, p in zip(self.ema_model.parameters(), self.model.parameters()):
-                ops.ema_update(e.data.view(-1), p.data.view(-1), 0.0)
+                self._ema_one(e, p, 0.0)
         rt.invalidate()
 
     def _update_ema(self, it):
@@ -175,7 +184,7 @@ class DACS(nn.Module):
             ops.ema_update(self._flat[1], self._flat[0], alpha_teacher, mirror=getattr(self, '_ema_bf16', None))
         else:
             for e, p in zip(self.ema_model.parameters(), self.model.parameters()):
-                ops.ema_update(e.data.view(-1), p.data.view(-1), alpha_teacher)
+                self._ema_one(e, p, alpha_teacher)
         rt.invalidate()
 
     # -- one UDA iteration ---------------------------------------------------------------------------------------------------
