@@ -22,7 +22,7 @@ int launch_dtype(GemmParams& p, void* stream) {
       // (the im2col-view weight gradient spills on the 256x256 tile: 11.7 ms against 9.6 ms on 128x128 at batch 64)
       // 256x256: gemm_wg.hip (32x32x16 MFMA; both operands stream from beyond L2, so the tile size is the speed: the head's pointwise
       // weight gradients 256 x 1024 over 262144 pixels are 4 tiles x 64 splits, its 3x3 bottleneck 36 tiles x 7 splits)
-      if (sizeof(T) == 2 && p.M >= 256 && p.N >= 256 && !p.colsum && p.A.conv != 1 && (blocks(256, 256) >= 32 || (blocks(256, 256) >= 4 && nkt >= 1024)))
+      if (sizeof(T) == 2 && p.M >= 256 && p.N >= 256 && p.A.conv != 1 && (blocks(256, 256) >= 32 || (blocks(256, 256) >= 4 && nkt >= 1024)))
         tile = 3;
       else if (blocks(128, 128) >= 64 || (blocks(128, 128) >= 16 && nkt >= 1024)) tile = 0;  // very deep K: split further
       else if (blocks(128, 64) >= 48 && nkt >= 256) tile = 1;  // e.g. the 320x1280 MixFFN weight gradients at K >= 16 k rows (57 vs 72 us on
@@ -111,7 +111,7 @@ int launch_dtype(GemmParams& p, void* stream) {
       if (tile == 3 && pp_shape && !(p.tile_hint > 0 && (p.tile_hint & 512)) && !aks && !bc && !p.atomic && p.splits == 1 && !p.res &&
           !p.rowscale && p.beta == 0.f && !p.out_f32 && p.c_patch_ow == 0 && !p.colsum)
         return cmda_gemm_pp_(p, stream);
-      if (tile == 3 && aks && bks && !ac && p.atomic && p.out_f32 && !p.colsum && !(p.tile_hint > 0 && (p.tile_hint & 512)))
+      if (tile == 3 && aks && bks && !ac && p.atomic && p.out_f32 && !(p.tile_hint > 0 && (p.tile_hint & 512)))
         return cmda_gemm_wg_(p, stream);   // weight-gradient form: gemm_wg.hip
       if (tile == 3) return cmda_gemm_glds_t3_(p, stream);
       if (tile == 0) return cmda_gemm_glds_t0_(p, stream);

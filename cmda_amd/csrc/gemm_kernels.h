@@ -1021,6 +1021,7 @@ int cmda_gemm_grouped_t2_(const cmda_gemm_params_t* tab, const void* blk, int nb
 int cmda_gemm_grouped_t0_(const cmda_gemm_params_t* tab, const void* blk, int nblocks, int bconv, void* stream);  // gemm_g0.hip: 128x128
 int cmda_gemm_grouped_t1_(const cmda_gemm_params_t* tab, const void* blk, int nblocks, int bconv, void* stream);  // gemm_g1.hip: 128x64
 int cmda_gemm_grouped_t3_(const cmda_gemm_params_t* tab, const void* blk, int nblocks, int bconv, void* stream);  // gemm_g3.hip: 64x128
+int cmda_gemm_wg_grouped_(const cmda_gemm_params_t* tab, const void* blk, int nblocks, int bconv, void* stream);  // gemm_wg.hip, grouped
 int cmda_gemm_wg_(const cmda_gemm_params_t& p, void* stream);             // gemm_wg.hip: 256x256 weight-gradient kernel (32x32x16 MFMA, atomics)
 int cmda_gemm_pp_(const cmda_gemm_params_t& p, void* stream);             // gemm_pp.hip: 256x256 ping-pong kernel (32x32x16 MFMA)
 int cmda_gemm_reg_(const cmda_gemm_params_t& p, int tile, void* stream);  // gemm_reg.hip: register-staged kernels, dispatch

@@ -61,19 +61,16 @@ static __device__ __forceinline__ u16x8 wg_frag(const bf16_t* tile, int c0, int 
 // (WG_BK, WG_NS) = (32, 4) for plain operands (three k-tiles of 32 KB in flight: the pointwise gradient 347 -> 296 us) and (64, 2)
 // for the im2col view (its per-piece address arithmetic runs once per k-tile: the bottleneck 1787 us against 2163 at (32, 4))
 template <bool BCONV, int WG_BK, int WG_NS>
-__global__ __launch_bounds__(512, 1) void gemm_wg_kernel(GemmParams p) {
+static __device__ __forceinline__ void wg_body(const GemmParams& p, char* smem, int bt, int z) {
   typedef bf16_t T;
   constexpr int WG_SZ = WG_T * WG_BK;   // elements per operand per stage
   constexpr int PCS = WG_BK / 16;       // DMA pieces per wave per operand per k-tile
-  __shared__ __attribute__((aligned(1024))) char smem[(size_t)2 * WG_NS * WG_SZ * sizeof(T)];
   T* const sAbase = reinterpret_cast<T*>(smem);
   T* const sBbase = sAbase + WG_NS * WG_SZ;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int tiles_n = (p.N + WG_T - 1) / WG_T;
-  const int bt = blockIdx.x;
   const long m0 = (long)(bt / tiles_n) * WG_T, n0 = (long)(bt % tiles_n) * WG_T;
-  const int z = blockIdx.z;
   const int bz = z / p.splits, split = z - bz * p.splits;
   const int batch = bz / p.batch2, batch2 = bz - batch * p.batch2;
   const int nkt = (p.K + WG_BK - 1) / WG_BK;
@@ -104,6 +101,10 @@ __global__ __launch_bounds__(512, 1) void gemm_wg_kernel(GemmParams p) {
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // optional fused bias gradient (nn.Linear under autograd: db = column sums of dY): the workgroups of the first n-tile also add
+  // up their A tile along k
+  const bool do_colsum = p.colsum != nullptr && n0 == 0;
+  float bsum = 0.f;
 
 #pragma unroll
   for (int s = 0; s < WG_NS - 1; ++s)
@@ -121,6 +122,10 @@ __global__ __launch_bounds__(512, 1) void gemm_wg_kernel(GemmParams p) {
     }
     const T* sA = sAbase + st * WG_SZ;
     const T* sB = sBbase + st * WG_SZ;
+    if (do_colsum && tid < WG_T) {
+#pragma unroll 8
+      for (int k = 0; k < WG_BK; ++k) bsum += bf2f(sA[k * WG_T + (((tid >> 3) ^ (k & 7)) << 3) + (tid & 7)]);
+    }
 #pragma unroll
     for (int s = 0; s < WG_BK / 16; ++s) {
       u16x8 fa[2], fb[4];
@@ -136,6 +141,7 @@ __global__ __launch_bounds__(512, 1) void gemm_wg_kernel(GemmParams p) {
     if (++st == WG_NS) st = 0;
   }
 
+  if (do_colsum && tid < WG_T && m0 + tid < p.M) atomicAdd(p.colsum + m0 + tid, bsum);
   // acc[i][j][r]: m = m0 + wm*64 + i*32 + (r & 3) + 8*(r >> 2) + 4*(lane >> 5), n = n0 + wn*128 + j*32 + (lane & 31): one register
   // of one accumulator = two 128-byte runs (rows m and m + 4)
   const long cb = (long)batch * p.c_batch_stride + (long)batch2 * p.c_batch2_stride;
@@ -157,7 +163,39 @@ __global__ __launch_bounds__(512, 1) void gemm_wg_kernel(GemmParams p) {
     }
 }
 
+template <bool BCONV, int WG_BK, int WG_NS>
+__global__ __launch_bounds__(512, 1) void gemm_wg_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(1024))) char smem[(size_t)2 * WG_NS * WG_T * WG_BK * 2];
+  wg_body<BCONV, WG_BK, WG_NS>(p, smem, blockIdx.x, blockIdx.z);
+}
+
+// grouped form (gemm_grouped.hip: the deferred weight gradients of an encoder stage whose outputs are at least 256 x 256 -- MiT
+// stages 3 / 4: 320 ... 2048 channels): `tab` / `blk` as for gemm_glds_grouped_kernel, block index inside a problem = z * tiles + tile
+template <bool BCONV, int WG_BK, int WG_NS>
+__global__ __launch_bounds__(512, 1) void gemm_wg_grouped_kernel(const GemmParams* __restrict__ tab, const int* __restrict__ blk) {
+  __shared__ __attribute__((aligned(1024))) char smem[(size_t)2 * WG_NS * WG_T * WG_BK * 2];
+#ifndef CMDA_EMU
+  const int prob = __builtin_amdgcn_readfirstlane(blk[2 * blockIdx.x]), loc = __builtin_amdgcn_readfirstlane(blk[2 * blockIdx.x + 1]);
+#else
+  const int prob = blk[2 * blockIdx.x], loc = blk[2 * blockIdx.x + 1];
+#endif
+  if (prob < 0) return;
+  const GemmParams& p = tab[prob];
+  const int ntile = (int)((p.M + WG_T - 1) / WG_T) * ((p.N + WG_T - 1) / WG_T);
+  const int z = loc / ntile;
+  wg_body<BCONV, WG_BK, WG_NS>(p, smem, loc - z * ntile, z);
+}
+
 }  // namespace
+
+int cmda_gemm_wg_grouped_(const cmda_gemm_params_t* tab, const void* blk, int nblocks, int bconv, void* stream) {
+  if (nblocks <= 0) return CMDA_OK;
+  const dim3 grid((unsigned)nblocks), b(512);
+  const int* bp = reinterpret_cast<const int*>(blk);
+  if (bconv) CMDA_LAUNCH((gemm_wg_grouped_kernel<true, 64, 2>), grid, b, 0, stream, tab, bp);
+  else CMDA_LAUNCH((gemm_wg_grouped_kernel<false, 32, 4>), grid, b, 0, stream, tab, bp);
+  CMDA_CHECK_LAUNCH();
+}
 
 // cross-unit entry (gemm.hip decides eligibility and the split count)
 int cmda_gemm_wg_(const cmda_gemm_params_t& p, void* stream) {
