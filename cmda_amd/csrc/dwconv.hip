@@ -184,15 +184,16 @@ __global__ __launch_bounds__(256) void dw_stencil_kernel(const T* __restrict__ x
 // could only run alone); every thread walks runs_per_block/4 runs of its quad with the same prefetched sliding window
 // (4.75 loads per pixel).  The 4 run lanes meet in a 4-slot LDS array (no LDS atomics), then ONE fp32 global atomic per
 // (channel, tap) per block -- few, fat blocks keep the same-address atomic traffic low.
-template <typename T>
+template <typename T, int CQ>
 __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const T* __restrict__ dz, const T* __restrict__ x,
                                                             float* __restrict__ dw, float* __restrict__ dbias, RunGeom g,
                                                             int C, int runs_per_block, int gx_groups) {
   constexpr int RUN = RunLen<T>::value;
-  __shared__ float red[4][64][41];
-  const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;  // py = 0..3
+  constexpr int RL = 256 / CQ;   // run lanes (block shape: see dw_gelu_bwd_fused_kernel)
+  __shared__ float red[RL][CQ][41];
+  const int cx = threadIdx.x % CQ, py = threadIdx.x / CQ;
   const BlockXY blk = xcd_block(gx_groups);
-  const int c = (blk.bx * 64 + cx) * 4;
+  const int c = (blk.bx * CQ + cx) * 4;
   const long r0 = blk.by * runs_per_block;
   const long r1 = min(g.nruns, r0 + runs_per_block);
   float acc[9][4], accb[4] = {0.f, 0.f, 0.f, 0.f};
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const T* __restrict_
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[t][j] = 0.f;
   if (c < C) {
-    for (long run = r0 + py; run < r1; run += 4) {
+    for (long run = r0 + py; run < r1; run += RL) {
       RunPos r;
       if (!decode_run(g, run, RUN, r)) continue;
       Raw<T> raw[3][RUN + 2], rdz[RUN];
@@ -245,11 +246,13 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const T* __restrict_
     for (int j = 0; j < 4; ++j) slot[36 + j] = accb[j];
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < 64 * 40; k += blockDim.x) {
+  for (int k = threadIdx.x; k < CQ * 40; k += blockDim.x) {
     const int gx = k / 40, v = k - gx * 40;
-    const int cc = (blk.bx * 64 + gx) * 4;
+    const int cc = (blk.bx * CQ + gx) * 4;
     if (cc >= C) continue;
-    const float s = red[0][gx][v] + red[1][gx][v] + red[2][gx][v] + red[3][gx][v];
+    float s = 0.f;
+#pragma unroll
+    for (int l = 0; l < RL; ++l) s += red[l][gx][v];
     if (v < 36) {
       const int t = v >> 2, j = v & 3;
       atomicAdd(dw + (cc + j) * 9 + t, s);
@@ -263,17 +266,23 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const T* __restrict_
 // ONE pass over x / da (the prep and weight-gradient kernels above each walk the same 3 x (RUN+2) window of x; fused, the
 // window is loaded once, dz never has to be re-read and one launch per MixFFN backward disappears).  Same block shape and
 // reduction as dw_bwd_weight_kernel; the weight gradient sees dz before its rounding to bf16.
-template <typename T>
+// Block shape: CQ channel-quads x (256 / CQ) run lanes.  The cross-block reduction is one fp32 atomic per (channel, tap) per block,
+// and device-scope atomics are served beyond the XCD's L2 (~50 ns apiece on one address, and each one a memory-side transaction):
+// with 64 quads x 4 run lanes the stage-1 shape (C = 256: ONE channel group) needed 1024 blocks x 2560 atomics and spent 60 % of
+// its time in them (tools/dbg/dw_var.py: 84.8 us, 32.0 without the atomics).  16 quads x 16 run lanes keeps the grid (4 x the
+// channel groups) with 1/4 ... 1/8 of the blocks along the pixel axis, i.e. that much fewer atomics per address and in total.
+template <typename T, int CQ>
 __global__ __launch_bounds__(256, 2) void dw_gelu_bwd_fused_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                                 const float* __restrict__ bias, const T* __restrict__ da,
                                                                 T* __restrict__ dz, float* __restrict__ dw,
                                                                 float* __restrict__ dbias, RunGeom g, int C,
                                                                 int runs_per_block, int gx_groups) {
   constexpr int RUN = 4;  // (8 as in the other kernels needs all 256 VGPRs in bf16: one wave per SIMD)
-  __shared__ float red[4][64][41];
-  const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+  constexpr int RL = 256 / CQ;   // run lanes
+  __shared__ float red[RL][CQ][41];
+  const int cx = threadIdx.x % CQ, py = threadIdx.x / CQ;
   const BlockXY blk = xcd_block(gx_groups);
-  const int c = (blk.bx * 64 + cx) * 4;
+  const int c = (blk.bx * CQ + cx) * 4;
   const long r0 = blk.by * runs_per_block;
   const long r1 = min(g.nruns, r0 + runs_per_block);
   float acc[9][4], accb[4] = {0.f, 0.f, 0.f, 0.f};
@@ -286,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void dw_gelu_bwd_fused_kernel(const T* __re
 #pragma unroll
     for (int t = 0; t < 9; ++t) ld4(w + t * C + c, wr[t]);
     if (bias) ld4(bias + c, bs);
-    for (long run = r0 + py; run < r1; run += 4) {
+    for (long run = r0 + py; run < r1; run += RL) {
       RunPos r;
       if (!decode_run(g, run, RUN, r)) continue;
       Raw<T> raw[3][RUN + 2], rda[RUN];
@@ -341,11 +350,13 @@ __global__ __launch_bounds__(256, 2) void dw_gelu_bwd_fused_kernel(const T* __re
     for (int j = 0; j < 4; ++j) slot[36 + j] = accb[j];
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < 64 * 40; k += blockDim.x) {
+  for (int k = threadIdx.x; k < CQ * 40; k += blockDim.x) {
     const int gx = k / 40, v = k - gx * 40;
-    const int cc = (blk.bx * 64 + gx) * 4;
+    const int cc = (blk.bx * CQ + gx) * 4;
     if (cc >= C) continue;
-    const float s = red[0][gx][v] + red[1][gx][v] + red[2][gx][v] + red[3][gx][v];
+    float s = 0.f;
+#pragma unroll
+    for (int l = 0; l < RL; ++l) s += red[l][gx][v];
     if (v < 36) {
       const int t = v >> 2, j = v & 3;
       atomicAdd(dw + (cc + j) * 9 + t, s);
@@ -398,13 +409,15 @@ extern "C" int cmda_dwconv3x3_bwd_weight(const void* dz, const void* x, float* d
   if ((C & 3) || dil < 1) return CMDA_ERR_SHAPE;
   const RunGeom g = run_geom(B, H, W, dil, run_len(dtype));
   if (too_big(npix) || too_big(g.nruns)) return CMDA_ERR_SHAPE;
-  const int gx = (C / 4 + 63) / 64;
-  // runs per block (4 run lanes): at least 4 runs per thread so the LDS fold + 2560 atomics of a block are amortised
-  // (one run per thread made the stage-3 shape 50 % slower), otherwise ~3 blocks per CU
-  int rpb = 128;
-  while (rpb > 16 && (g.nruns + rpb - 1) / rpb * gx < 768) rpb >>= 1;
+  constexpr int cq = 16, rl = 256 / cq;   // block shape: see dw_gelu_bwd_fused_kernel
+  const int gx = (C / 4 + cq - 1) / cq;
+  // runs per run lane: 8 measured best at the decode head's shapes (16 x 128 x 128 x 1024, dilation 6 / 18: 307 us against 331 for
+  // 16 and 362 for the former 64-quad x 4-lane blocks), fewer when the grid would not fill the chip
+  int k = 8;
+  while (k > 2 && (g.nruns + rl * k - 1) / (rl * k) * gx < 768) k >>= 1;
+  const int rpb = rl * k;
   dim3 grid((unsigned)((g.nruns + rpb - 1) / rpb * gx));
-  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((dw_bwd_weight_kernel<T>), grid, dim3(256), 0, stream, (const T*)dz,
+  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((dw_bwd_weight_kernel<T, cq>), grid, dim3(256), 0, stream, (const T*)dz,
                                          (const T*)x, dw, dbias, g, C, rpb, gx));
   CMDA_CHECK_LAUNCH();
 }
@@ -418,11 +431,14 @@ extern "C" int cmda_dwconv3x3_gelu_bwd_fused(const void* x, const float* w, cons
   if ((C & 3) || dil < 1) return CMDA_ERR_SHAPE;
   const RunGeom g = run_geom(B, H, W, dil, 4);
   if (too_big(npix) || too_big(g.nruns)) return CMDA_ERR_SHAPE;
-  const int gx = (C / 4 + 63) / 64;
-  int rpb = 128;   // as cmda_dwconv3x3_bwd_weight: >= 4 runs per thread, otherwise ~3 blocks per CU
-  while (rpb > 16 && (g.nruns + rpb - 1) / rpb * gx < 768) rpb >>= 1;
+  constexpr int cq = 16, rl = 256 / cq;
+  const int gx = (C / 4 + cq - 1) / cq;
+  // runs per run lane: fat blocks (few atomics) as long as the grid still fills the chip about twice (tools/dbg/dw_var.py)
+  int k = 16;
+  while (k > 2 && (g.nruns + rl * k - 1) / (rl * k) * gx < 512) k >>= 1;
+  const int rpb = rl * k;
   dim3 grid((unsigned)((g.nruns + rpb - 1) / rpb * gx));
-  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((dw_gelu_bwd_fused_kernel<T>), grid, dim3(256), 0, stream, (const T*)x, w, bias,
+  CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((dw_gelu_bwd_fused_kernel<T, cq>), grid, dim3(256), 0, stream, (const T*)x, w, bias,
                                          (const T*)da, (T*)dz, dw, dbias, g, C, rpb, gx));
   CMDA_CHECK_LAUNCH();
 }

@@ -172,7 +172,7 @@ def test_gemm_grouped_tile_walk(tgt, hint, M, N):
 @pytest.mark.parametrize('dt,tag', [(torch.bfloat16, 1), (torch.float32, 0)])
 def test_gemm_deferred_grouped_weight_gradients(tgt, dt, tag):
     """ops.gemm(defer=True) inside a deferral scope queues the weight gradients of a backward pass and gemm_flush_deferred()
-    launches them as grouped grids (cmda_gemm_grouped: 64x64 and 128x128 tiles, plain / patch / im2col B views, fused bias
+    launches them as grouped grids (cmda_gemm_grouped: 64x64 ... 128x128 tiles and gemm_wg.hip's 256x256 tile, plain / patch / im2col B views, fused bias
     gradient, accumulation into non-zero gradients, deep contractions split by the planner); the fp32 parity mode and forced
     tiles fall back to single launches inside the same call.  Result == the same GEMMs launched one by one."""
     import torch.nn.functional as Fn
@@ -181,13 +181,14 @@ def test_gemm_deferred_grouped_weight_gradients(tgt, dt, tag):
     torch.manual_seed(5)
     rt.set_compute_dtype(dt)
     try:
-        shapes = [(520, 64, 64), (4200, 320, 128), (3300, 128, 256), (700, 72, 40), (130, 256, 128), (64, 8, 24), (2000, 256, 64), (9000, 128, 320)]   # (rows M, out N, in K)
+        shapes = [(520, 64, 64), (4200, 320, 128), (3300, 128, 256), (700, 72, 40), (130, 256, 128), (64, 8, 24), (2000, 256, 64), (9000, 128, 320),
+                  (3000, 320, 320), (2100, 640, 320), (1500, 1280, 320), (1100, 320, 1280)]   # (rows M, out N, in K); the last four: 256x256 tiles
         lins = []
         for rows, n, k in shapes:
             lins.append((torch.randn(rows, n).to(dt), torch.randn(rows, k).to(dt), torch.nn.Parameter(tgt.to(torch.randn(n, k))),
                          torch.nn.Parameter(tgt.to(torch.randn(n)))))
         # a spatial-reduction conv (patch view) and a 3x3 conv (im2col view)
-        convs = [(2, 16, 16, 32, 24, 2, 2, 0), (1, 12, 20, 16, 16, 3, 1, 1)]
+        convs = [(2, 16, 16, 32, 24, 2, 2, 0), (1, 12, 20, 16, 16, 3, 1, 1), (1, 12, 20, 32, 272, 3, 1, 1), (2, 16, 16, 320, 320, 2, 2, 0)]
         cvs = []
         for Bc, H, W, Ci, Co, k, st, pd in convs:
             OH, OW = K.conv_out_size(H, W, k, st, pd)
