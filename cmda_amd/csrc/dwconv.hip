@@ -179,6 +179,126 @@ __global__ __launch_bounds__(256) void dw_stencil_kernel(const T* __restrict__ x
   }
 }
 
+// Dilated stencils (the sep-ASPP branches: dilation 6 / 12 / 18 on 128 x 128 maps).  With dilation d the three input rows of an
+// output row lie d rows apart -- 1.5 ... 4.7 MB of activations between them at 1024 channels, so in dw_stencil_kernel's row-major
+// order they come from beyond the XCD's 4 MB L2 three times (the 16-image forward moved ~2.1 GB through the fabric for 0.54 GB in
+// + 0.54 GB out and ran at that limit: 330 us).  A dilated 3x3 convolution is d*d independent unit-stride convolutions on the
+// sub-lattices (h mod d, w mod d); a thread here owns 4 channels x a run of DRUN sub-columns of ONE sub-lattice and walks DOWN its
+// sub-rows with a rolling three-row register window, so every input row is requested once per run (the +-1 halo columns are the
+// neighbouring run's, same workgroup or the next one on the same XCD).  Loads run three sub-rows ahead of the arithmetic.
+// MODE 0: y = conv(x) [+ bias]; MODE 2: dx (+)= conv^T(dy) (mirrored taps).
+constexpr int DRUN = 4;
+struct DilGeom {
+  int H, W, dil, rpc;   // rpc: runs per sub-row = ceil(ceil(W / dil) / DRUN)
+  long nthreads;        // B * dil * dil * rpc
+};
+template <typename T, int MODE, int CQ>
+__global__ __launch_bounds__(256) void dw_dilated_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, T* __restrict__ out, DilGeom g, int C,
+                                                         int act, int accumulate, int gx) {
+  const int cx = threadIdx.x % CQ, py = threadIdx.x / CQ;
+  const BlockXY blk = xcd_block(gx);
+  const int c = (blk.bx * CQ + cx) * 4;
+  const long t = blk.by * (256 / CQ) + py;
+  if (c >= C || t >= g.nthreads) return;
+  // t -> (b, rho_h, rho_w, k): k fastest, so the runs of one sub-row sit in the same / the next workgroup
+  const unsigned tu = (unsigned)t;
+  const int k = (int)(tu % (unsigned)g.rpc);
+  const unsigned t1 = tu / (unsigned)g.rpc;
+  const int rho_w = (int)(t1 % (unsigned)g.dil);
+  const unsigned t2 = t1 / (unsigned)g.dil;
+  const int rho_h = (int)(t2 % (unsigned)g.dil), b = (int)(t2 / (unsigned)g.dil);
+  const int nr = (g.H - rho_h + g.dil - 1) / g.dil;      // sub-rows / sub-columns of this sub-lattice
+  const int ncol = (g.W - rho_w + g.dil - 1) / g.dil;
+  const int k0 = k * DRUN;
+  if (nr <= 0 || k0 >= ncol) return;
+  const long img = (long)b * g.H * g.W;
+  // window column ci <-> sub-column k0 - 1 + ci; out-of-image columns read a clamped address and are zeroed by a select
+  long coff[DRUN + 2];
+  bool cok[DRUN + 2];
+#pragma unroll
+  for (int ci = 0; ci < DRUN + 2; ++ci) {
+    const int kc = k0 - 1 + ci;
+    cok[ci] = kc >= 0 && kc < ncol;
+    coff[ci] = (long)(rho_w + (cok[ci] ? kc : k0) * g.dil) * C + c;
+  }
+  float wr[9][4], bs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp) ld4(w + (MODE == 2 ? 8 - tp : tp) * C + c, wr[tp]);
+  if (MODE != 2 && bias) ld4(bias + c, bs);
+
+  Raw<T> raw[3][DRUN + 2];       // sub-row r waits in raw[r % 3]
+  Raw<T> praw[3][DRUN];          // accumulate mode: the previous dx values of sub-row r, requested with it
+  float win[3][DRUN + 2][4];     // ... and is unpacked into win[r % 3]; sub-row -1 / nr = zero padding
+  float pcur[DRUN][4];           // previous values of the sub-row being written
+  const bool acc_mode = MODE == 2 && accumulate;
+  // (no select on the loaded value here: it would pin the wait for the data right behind the request -- the padding columns are
+  // zeroed when the row is unpacked)
+  auto request = [&](int r, Raw<T> (&dst)[DRUN + 2], Raw<T> (&pdst)[DRUN]) {
+    if (r < nr) {
+      const long rb = (img + (long)(rho_h + r * g.dil) * g.W) * C;
+#pragma unroll
+      for (int ci = 0; ci < DRUN + 2; ++ci) dst[ci].load(x + rb + coff[ci], true);
+      if (acc_mode) {
+#pragma unroll
+        for (int i = 0; i < DRUN; ++i) pdst[i].load(out + rb + coff[i + 1], true);
+      }
+    }
+  };
+  auto unpack = [&](int r, const Raw<T> (&src)[DRUN + 2], float (&dst)[DRUN + 2][4]) {
+#pragma unroll
+    for (int ci = 0; ci < DRUN + 2; ++ci) {
+      if (r < nr && cok[ci]) src[ci].unpack(dst[ci]);
+      else dst[ci][0] = dst[ci][1] = dst[ci][2] = dst[ci][3] = 0.f;
+    }
+  };
+  auto unpack_prev = [&](int r, const Raw<T> (&src)[DRUN]) {
+    if (acc_mode && r < nr) {
+#pragma unroll
+      for (int i = 0; i < DRUN; ++i) src[i].unpack(pcur[i]);
+    }
+  };
+  request(0, raw[0], praw[0]);
+  request(1, raw[1], praw[1]);
+  request(2, raw[2], praw[2]);
+#pragma unroll
+  for (int ci = 0; ci < DRUN + 2; ++ci) win[2][ci][0] = win[2][ci][1] = win[2][ci][2] = win[2][ci][3] = 0.f;   // sub-row -1
+#pragma unroll
+  for (int i = 0; i < DRUN; ++i) pcur[i][0] = pcur[i][1] = pcur[i][2] = pcur[i][3] = 0.f;
+  unpack(0, raw[0], win[0]);
+  unpack_prev(0, praw[0]);
+  request(3, raw[0], praw[0]);
+  for (int j0 = 0; j0 < nr; j0 += 3) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {   // sub-row j = j0 + s lives in slot s
+      const int j = j0 + s;
+      if (j < nr) {   // (thread-private trip count: no cross-lane operation inside)
+        unpack(j + 1, raw[(s + 1) % 3], win[(s + 1) % 3]);
+        T* orow = out + (img + (long)(rho_h + j * g.dil) * g.W) * C;
+#pragma unroll
+        for (int i = 0; i < DRUN; ++i) {
+          float acc[4] = {bs[0], bs[1], bs[2], bs[3]};
+          if (acc_mode) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = pcur[i][q];
+          }
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) acc[q] += win[(s + 2 + kh) % 3][i + kw][q] * wr[kh * 3 + kw][q];
+          if (k0 + i < ncol) {
+            st4(orow + coff[i + 1], acc);
+          }
+        }
+        unpack_prev(j + 1, praw[(s + 1) % 3]);
+        request(j + 4, raw[(s + 1) % 3], praw[(s + 1) % 3]);
+      }
+    }
+  }
+}
+
 // dw[c,tap] += sum_pix dz[pix,c] * x[pix+tap,c];  dbias[c] += sum_pix dz[pix,c]
 // block = 64 channel-quads x 4 run lanes (256 threads: at ~166 VGPRs three such blocks share a CU, a 512-thread block
 // could only run alone); every thread walks runs_per_block/4 runs of its quad with the same prefetched sliding window
@@ -375,9 +495,22 @@ static int launch_stencil(const void* x, const float* w, const float* bias, cons
   const long npix = (long)B * H * W;
   if (npix * C <= 0) return CMDA_OK;
   if ((C & 3) || dil < 1) return CMDA_ERR_SHAPE;
-  const RunGeom g = run_geom(B, H, W, dil, run_len(dtype));
-  if (too_big(npix) || too_big(g.nruns)) return CMDA_ERR_SHAPE;
+  if (too_big(npix)) return CMDA_ERR_SHAPE;
   const int gx = (C / 4 + 63) / 64;
+  if (dil >= 2 && MODE != 1 && (MODE == 2 || act == 0)) {   // sub-lattice walk (dw_dilated_kernel; no fused activation there)
+    DilGeom dg;
+    dg.H = H; dg.W = W; dg.dil = dil;
+    dg.rpc = ((W + dil - 1) / dil + DRUN - 1) / DRUN;
+    dg.nthreads = (long)B * dil * dil * dg.rpc;
+    constexpr int cq = 64;   // channel quads per workgroup (128 / 256 measured the same: tools/dbg/dw_var.py)
+    const long nb = (dg.nthreads + 256 / cq - 1) / (256 / cq) * gx;
+    if (too_big(dg.nthreads) || nb > 0x7fffffffL) return CMDA_ERR_SHAPE;
+    CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((dw_dilated_kernel<T, MODE == 1 ? 0 : MODE, cq>), dim3((unsigned)nb), dim3(256), 0, stream,
+                                           (const T*)x, w, bias, (T*)out, dg, C, act, accumulate, gx));
+    CMDA_CHECK_LAUNCH();
+  }
+  const RunGeom g = run_geom(B, H, W, dil, run_len(dtype));
+  if (too_big(g.nruns)) return CMDA_ERR_SHAPE;
   const long nblk = (g.nruns + 3) / 4 * gx;
   if (nblk > 0x7fffffffL) return CMDA_ERR_SHAPE;
   dim3 grid((unsigned)nblk);

@@ -284,19 +284,30 @@ __global__ void copy2d_kernel(const T* __restrict__ src, T* __restrict__ dst, lo
 }
 
 __global__ void ema_kernel(float* __restrict__ ema, const float* __restrict__ p, float alpha, long n, bf16_t* __restrict__ mirror) {
-  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
-    if (i + 4 <= n) {
-      float e[4], v[4];
-      ld4(ema + i, e);
-      ld4(p + i, v);
+  const long stride = (long)gridDim.x * blockDim.x * 4;
+  for (long i0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i0 < n; i0 += 2 * stride) {
+    float e[2][4], v[2][4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) e[j] = alpha * e[j] + (1.f - alpha) * v[j];
-      st4(ema + i, e);
-      if (mirror) st4(mirror + i, e);   // the teacher's bf16 compute copy, written in the same pass (was a separate cast launch)
-    } else {
-      for (long j = i; j < n; ++j) {
-        ema[j] = alpha * ema[j] + (1.f - alpha) * p[j];
-        if (mirror) stf(mirror + j, ema[j]);
+    for (int u = 0; u < 2; ++u) {   // both vectors requested before either is used
+      const long i = i0 + u * stride;
+      if (i + 4 <= n) {
+        ld4(ema + i, e[u]);
+        ld4(p + i, v[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const long i = i0 + u * stride;
+      if (i + 4 <= n) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[u][j] = alpha * e[u][j] + (1.f - alpha) * v[u][j];
+        st4(ema + i, e[u]);
+        if (mirror) st4(mirror + i, e[u]);   // the teacher's bf16 compute copy, written in the same pass (was a separate cast launch)
+      } else if (i < n) {
+        for (long j = i; j < n; ++j) {
+          ema[j] = alpha * ema[j] + (1.f - alpha) * p[j];
+          if (mirror) stf(mirror + j, ema[j]);
+        }
       }
     }
   }
@@ -304,21 +315,57 @@ __global__ void ema_kernel(float* __restrict__ ema, const float* __restrict__ p,
 
 // torch.optim.AdamW (amsgrad=False): p *= 1 - lr*wd; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+static __device__ __forceinline__ float adamw_one(float pv, float gv, float& mv, float& vv, float lr, float b1, float b2, float eps,
+                                                  float wd, float bc1, float bc2_sqrt) {
+  pv *= 1.f - lr * wd;
+  mv = b1 * mv + (1.f - b1) * gv;
+  vv = b2 * vv + (1.f - b2) * gv * gv;
+  const float denom = sqrtf(vv) / bc2_sqrt + eps;
+  return pv - (lr / bc1) * (mv / denom);
+}
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                              float* __restrict__ v, bf16_t* __restrict__ p_bf16, long n, float lr, float b1, float b2,
                              float eps, float wd, float bc1, float bc2_sqrt) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    float pv = p[i];
-    const float gv = g[i];
-    pv *= 1.f - lr * wd;
-    const float mv = b1 * m[i] + (1.f - b1) * gv;
-    const float vv = b2 * v[i] + (1.f - b2) * gv * gv;
+    float mv = m[i], vv = v[i];
+    const float pv = adamw_one(p[i], g[i], mv, vv, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
     m[i] = mv;
     v[i] = vv;
-    const float denom = sqrtf(vv) / bc2_sqrt + eps;
-    pv -= (lr / bc1) * (mv / denom);
     p[i] = pv;
     if (p_bf16) p_bf16[i] = f2bf(pv);
+  }
+}
+// the same update on 16-byte vectors, two per thread and pass (8 independent 16-byte loads in flight per thread: the scalar kernel
+// moved 30 bytes per parameter at ~2 TB/s); element-wise identical arithmetic.  n4 = vectors; the caller runs the scalar kernel
+// over the ragged tail / unaligned groups.
+__global__ void adamw_vec_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                 float* __restrict__ v, bf16_t* __restrict__ p_bf16, long n4, float lr, float b1, float b2,
+                                 float eps, float wd, float bc1, float bc2_sqrt) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += 2 * stride) {
+    float pv[2][4], gv[2][4], mv[2][4], vv[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const long i = i0 + u * stride;
+      if (i < n4) {
+        ld4(p + 4 * i, pv[u]);
+        ld4(g + 4 * i, gv[u]);
+        ld4(m + 4 * i, mv[u]);
+        ld4(v + 4 * i, vv[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const long i = i0 + u * stride;
+      if (i < n4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pv[u][j] = adamw_one(pv[u][j], gv[u][j], mv[u][j], vv[u][j], lr, b1, b2, eps, wd, bc1, bc2_sqrt);
+        st4(m + 4 * i, mv[u]);
+        st4(v + 4 * i, vv[u]);
+        st4(p + 4 * i, pv[u]);
+        if (p_bf16) st4(p_bf16 + 4 * i, pv[u]);
+      }
+    }
   }
 }
 
@@ -505,7 +552,8 @@ extern "C" int cmda_copy2d(const void* src, void* dst, int64_t rows, int cols, i
 
 extern "C" int cmda_ema_update(float* ema, const float* param, float alpha, int64_t n, void* ema_bf16, void* stream) {
   if (n <= 0) return CMDA_OK;
-  CMDA_LAUNCH(ema_kernel, dim3(grid_for(n, 4)), dim3(256), 0, stream, ema, param, alpha, (long)n, (bf16_t*)ema_bf16);
+  CMDA_LAUNCH(ema_kernel, dim3((unsigned)std::max<long>(1, std::min<long>((n + 2047) / 2048, 4096))), dim3(256), 0, stream, ema, param, alpha,
+              (long)n, (bf16_t*)ema_bf16);
   CMDA_CHECK_LAUNCH();
 }
 
@@ -515,8 +563,16 @@ extern "C" int cmda_adamw_step(float* p, const float* g, float* m, float* v, voi
   if (step < 1) return CMDA_ERR_SHAPE;
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2 = 1.f - powf(beta2, (float)step);
-  CMDA_LAUNCH(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p_bf16, (long)n, lr, beta1,
-              beta2, eps, weight_decay, bc1, sqrtf(bc2));
+  const bool aligned = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && ((uintptr_t)p_bf16 & 7) == 0;
+  const long n4 = aligned ? n / 4 : 0;
+  if (n4 > 0)
+    CMDA_LAUNCH(adamw_vec_kernel, dim3((unsigned)std::max<long>(1, std::min<long>((n4 + 511) / 512, 4096))), dim3(256), 0, stream, p, g, m,
+                v, (bf16_t*)p_bf16, n4, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2));
+  if (const long rest = n - 4 * n4) {
+    bf16_t* pb = p_bf16 ? (bf16_t*)p_bf16 + 4 * n4 : nullptr;
+    CMDA_LAUNCH(adamw_kernel, dim3(grid_for(rest)), dim3(256), 0, stream, p + 4 * n4, g + 4 * n4, m + 4 * n4, v + 4 * n4, pb, rest, lr,
+                beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2));
+  }
   CMDA_CHECK_LAUNCH();
 }
 

@@ -94,6 +94,9 @@ def test_dwconv(tgt, dt, tol, dil, act, shape):
     dz = ops.dwconv_gelu_bwd_prep(xd, wd, bd, dyd, B, H, W, C, dil) if act == 'gelu' else dyd
     dx = ops.dwconv_bwd_data(dz, wd, B, H, W, C, dil)
     assert_close(dx, xr.grad.permute(0, 2, 3, 1), tol * 2, name='dw dx')
+    prev = torch.randn(B, H, W, C).to(dt)   # accumulate=True: dx += (the sep-ASPP branches add into one input gradient)
+    acc = ops.dwconv_bwd_data(dz, wd, B, H, W, C, dil, out=tgt.to(prev.clone()), accumulate=True)
+    assert_close(acc, xr.grad.permute(0, 2, 3, 1) + prev.float(), tol * 3, name='dw dx accumulate')
     dw = torch.zeros(C, 9, device=tgt.device)
     db = torch.zeros(C, device=tgt.device) if act else None
     ops.dwconv_bwd_weight(dz, xd, dw, db, B, H, W, C, dil)

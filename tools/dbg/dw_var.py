@@ -1,4 +1,4 @@
-"""tuning experiment: block shape of the depthwise weight-gradient kernel at the decode head's shapes (CMDA_DW_CQ / CMDA_DW_K)"""
+"""tuning experiment: channel quads per block of the dilated depthwise kernel (CMDA_DW_CQ) at the decode head's shape"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cmda_amd import ops
@@ -13,13 +13,18 @@ def timeit(f, iters=20):
     return s.elapsed_time(e) / iters * 1e3
 
 bf = torch.bfloat16
-for (B, H, C, dil) in ((16, 128, 1024, 6), (16, 128, 1024, 18), (4, 128, 256, 1), (4, 32, 1280, 1)):
-    x = torch.randn(B, H, H, C, device='cuda').to(bf); dy = torch.randn_like(x)
-    dw = torch.zeros(C, 9, device='cuda'); db = torch.zeros(C, device='cuda')
+B, H, C = 16, 128, 1024
+x = torch.randn(B, H, H, C, device='cuda').to(bf); dy = torch.randn_like(x); acc = torch.zeros_like(x)
+w = torch.randn(9, C, device='cuda') * 0.3
+y = torch.empty_like(x)
+t0 = timeit(lambda: y.copy_(x))
+print(f'copy_ 537 MB: {t0:.1f} us')
+for dil in (6, 12, 18):
     out = []
-    for cq, k in (("64", None), ("16", None), ("16", "4"), ("16", "8"), ("16", "32"), ("64", "8"), ("64", "32"), ("64", "64")):
-        os.environ["CMDA_DW_CQ"] = cq
-        if k: os.environ['CMDA_DW_K'] = k
-        else: os.environ.pop('CMDA_DW_K', None)
-        out.append(f'cq{cq}/k{k}: {timeit(lambda: ops.dwconv_bwd_weight(dy, x, dw, db, B, H, H, C, dil)):6.1f}')
-    print(f'B{B} H{H} C{C} d{dil}: ' + '  '.join(out))
+    for cq in ('64', '128', '256'):
+        os.environ['CMDA_DW_CQ'] = cq
+        tf = timeit(lambda: ops.dwconv_fwd(x, w, None, B, H, H, C, dil, None))
+        td = timeit(lambda: ops.dwconv_bwd_data(dy, w, B, H, H, C, dil))
+        ta = timeit(lambda: ops.dwconv_bwd_data(dy, w, B, H, H, C, dil, out=acc, accumulate=True))
+        out.append(f'cq{cq}: fwd {tf:6.1f} data {td:6.1f} data+acc {ta:6.1f}')
+    print(f'd{dil}: ' + ' | '.join(out))

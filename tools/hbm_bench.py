@@ -85,6 +85,14 @@ def main():
         dp = torch.randn_like(s)
         rec(f'softmax fwd R{R} L{L}', timeit(lambda: ops.softmax_fwd_(s, R, L, 0.125)), 2 * R * L * 2)
         rec(f'softmax bwd R{R} L{L}', timeit(lambda: ops.softmax_bwd_(s, dp, R, L, 0.125)), 3 * R * L * 2)
+    # optimiser passes over the flat fp32 parameter store (MiT-B5 x 2 + heads = 170 M parameters in two groups of ~85 M)
+    n = 85_000_000
+    pp, gg, mm, vv = (torch.randn(n, device=dev) for _ in range(4))
+    vv.abs_()
+    mirror = torch.empty(n, device=dev, dtype=bf)
+    rec(f'adamw n={n}', timeit(lambda: ops.adamw_step(pp, gg, mm, vv, 6e-5, 0.9, 0.999, 1e-8, 0.01, 3, p_bf16=mirror)), 30 * n)
+    rec(f'ema n={n}', timeit(lambda: ops.ema_update(mm, pp, 0.999, mirror=mirror)), 14 * n)
+    del pp, gg, mm, vv, mirror
     print(f'{"kernel":44s} {"us":>10s} {"GB/s":>9s} {"frac":>6s}')
     for name, us, gbs in rows:
         print(f'{name:44s} {us:10.1f} {gbs:9.0f} {gbs / 8000:6.3f}')
