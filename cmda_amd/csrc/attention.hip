@@ -22,7 +22,8 @@
 namespace {
 
 constexpr int kHD = 64;     // head dim
-constexpr int kMaxK = 256;  // keys kept in LDS
+constexpr int kMaxK = 256;  // keys kept in LDS (forward and backward)
+constexpr int kMaxKFwd = 320;  // ... by the forward-only instance
 constexpr int kNT = kMaxK / 16;
 
 struct AttnParams {
@@ -49,9 +50,10 @@ static __device__ __forceinline__ unsigned xcd_logical_block() {
 extern __device__ __attribute__((aligned(16))) unsigned g_attn_zero16[4];
 __device__ __attribute__((aligned(16))) unsigned g_attn_zero16[4] = {0u, 0u, 0u, 0u};
 
+template <int MAXK = kMaxK>
 static __device__ __forceinline__ void load_kv_tile(const bf16_t* __restrict__ src, int ld, int Nk, bf16_t* lds, int wid,
                                                     int lane, int nwaves) {
-  for (int i = wid; i < kMaxK / 8; i += nwaves) {
+  for (int i = wid; i < MAXK / 8; i += nwaves) {
     const int row = 8 * i + (lane >> 3);
     const int chunk = (lane & 7) ^ (row & 7);
     const void* s = row < Nk ? static_cast<const void*>(src + (long)row * ld + chunk * 8)
@@ -86,10 +88,11 @@ static __device__ __forceinline__ float col_sum(float v) {
 }
 
 // scores^T of 16 queries against all key tiles, then the softmax over keys: p[t][r] = P^T[key 16t + 4g + r][query l15]
+template <int NT = kNT>
 static __device__ __forceinline__ void scores_softmax(const bf16_t* sK, const u16x8 (&qf)[2], int nt, int Nk, float scale,
-                                                      int g, int l15, f32x4 (&p)[kNT], float* lse_out = nullptr) {
+                                                      int g, int l15, f32x4 (&p)[NT], float* lse_out = nullptr) {
 #pragma unroll
-  for (int t = 0; t < kNT; ++t) {
+  for (int t = 0; t < NT; ++t) {
     p[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (t < nt) {
 #pragma unroll
@@ -98,7 +101,7 @@ static __device__ __forceinline__ void scores_softmax(const bf16_t* sK, const u1
   }
   float m = -INFINITY;
 #pragma unroll
-  for (int t = 0; t < kNT; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool live = 16 * t + 4 * g + r < Nk;
@@ -108,7 +111,7 @@ static __device__ __forceinline__ void scores_softmax(const bf16_t* sK, const u1
   m = col_max(m);
   float l = 0.f;
 #pragma unroll
-  for (int t = 0; t < kNT; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       p[t][r] = __expf(p[t][r] - m);  // exp(-inf) = 0 for the masked keys
@@ -118,7 +121,7 @@ static __device__ __forceinline__ void scores_softmax(const bf16_t* sK, const u1
   if (lse_out) *lse_out = m + __logf(l);
   const float inv = 1.f / l;
 #pragma unroll
-  for (int t = 0; t < kNT; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) p[t][r] *= inv;
 }
@@ -142,17 +145,21 @@ static inline int fwd_queries_per_block(int B, int N, int heads) {
   return (long)((N + 127) / 128) * heads * B < 1024 ? 64 : 128;
 }
 
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
-  __shared__ __attribute__((aligned(1024))) bf16_t sK[kMaxK * kHD];
-  __shared__ __attribute__((aligned(1024))) bf16_t sV[kMaxK * kHD];
+// MAXK: keys held in LDS -- 256 (every stage of a 512 x 512 crop; two blocks per CU) or 320 (inference on 440 x 640 frames,
+// encoder_decoder.py:897-936: 260 / 280 keys after the spatial reduction; forward only, one block per CU)
+template <int MAXK>
+__global__ __launch_bounds__(256, MAXK <= 256 ? 2 : 1) void attn_fwd_kernel(AttnParams p) {
+  constexpr int NT = MAXK / 16;
+  __shared__ __attribute__((aligned(1024))) bf16_t sK[MAXK * kHD];
+  __shared__ __attribute__((aligned(1024))) bf16_t sV[MAXK * kHD];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, l15 = lane & 15;
   const unsigned nqb = (unsigned)((p.N + p.q_per_block - 1) / p.q_per_block);
   const unsigned lb = xcd_logical_block(), bh = lb / nqb;
   const long qblk = lb - bh * nqb;
   const int h = (int)(bh % (unsigned)p.heads), b = (int)(bh / (unsigned)p.heads);
   const bf16_t* kbase = p.kv + (long)b * p.Nk * 2 * p.C + h * kHD;
-  load_kv_tile(kbase, 2 * p.C, p.Nk, sK, wid, lane, 4);
-  load_kv_tile(kbase + p.C, 2 * p.C, p.Nk, sV, wid, lane, 4);
+  load_kv_tile<MAXK>(kbase, 2 * p.C, p.Nk, sK, wid, lane, 4);
+  load_kv_tile<MAXK>(kbase + p.C, 2 * p.C, p.Nk, sV, wid, lane, 4);
   __syncthreads();
   const int nt = (p.Nk + 15) >> 4;
   const bf16_t* qb = p.q + (long)b * p.N * p.C + h * kHD;
@@ -162,13 +169,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     if (q0 >= p.N) break;  // wave-uniform
     u16x8 qf[2];
     load_qfrag(qb, q0, p.N, p.C, g, l15, qf);
-    f32x4 pr[kNT];
-    scores_softmax(sK, qf, nt, p.Nk, p.scale, g, l15, pr);
+    f32x4 pr[NT];
+    scores_softmax<NT>(sK, qf, nt, p.Nk, p.scale, g, l15, pr);
     f32x4 oacc[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int u = 0; u < kNT / 2; ++u) {
+    for (int u = 0; u < NT / 2; ++u) {
       if (2 * u < nt) {
         const u16x8 pb = pack_pair(pr[2 * u], pr[2 * u + 1]);
 #pragma unroll
@@ -429,19 +436,20 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_dkv_kernel(
 
 }  // namespace
 
-// q [B*N, C] bf16, kv [B*Nk, 2C] bf16 -> o [B*N, C] bf16; head_dim = C / heads must be 64, Nk <= 256, C % 8 == 0.
+// q [B*N, C] bf16, kv [B*Nk, 2C] bf16 -> o [B*N, C] bf16; head_dim = C / heads must be 64, Nk <= 320 (the backward: 256), C % 8 == 0.
 extern "C" int cmda_attention_fwd(const void* q, const void* kv, void* o, int B, int N, int Nk, int heads, int C,
                                   float scale, int dtype, void* stream) {
   if (B <= 0 || N <= 0) return CMDA_OK;
   if (dtype != CMDA_BF16) return CMDA_ERR_DTYPE;
-  if (heads <= 0 || C != heads * kHD || Nk <= 0 || Nk > kMaxK) return CMDA_ERR_UNSUPPORTED;
+  if (heads <= 0 || C != heads * kHD || Nk <= 0 || Nk > kMaxKFwd) return CMDA_ERR_UNSUPPORTED;
   if (heads > 65535 || B > 65535) return CMDA_ERR_SHAPE;
   const int qpb = fwd_queries_per_block(B, N, heads);
   AttnParams p{(const bf16_t*)q, (const bf16_t*)kv, (bf16_t*)o, B, N, Nk, heads, C, scale, qpb};
   const long nblk = (long)((N + qpb - 1) / qpb) * heads * B;
   if (nblk > 0x7fffffffL) return CMDA_ERR_SHAPE;
   dim3 grid((unsigned)nblk);
-  CMDA_LAUNCH(attn_fwd_kernel, grid, dim3(256), 0, stream, p);
+  if (Nk <= kMaxK) CMDA_LAUNCH(attn_fwd_kernel<kMaxK>, grid, dim3(256), 0, stream, p);
+  else CMDA_LAUNCH(attn_fwd_kernel<kMaxKFwd>, grid, dim3(256), 0, stream, p);
   CMDA_CHECK_LAUNCH();
 }
 

@@ -112,10 +112,10 @@ def _conv_bwd(dy, x, weight, bias, B, H, W, stride, pad, dil=1, *, need_dx=True,
 
 
 # ------------------------------------------------------------------ attention (scores materialised; v0 path)
-def attention_fwd(q, kv, B, N, Nk, heads, C, scale):
+def attention_fwd(q, kv, B, N, Nk, heads, C, scale, need_grad=True):
     """q [B*N,C], kv [B*Nk,2C] -> o [B*N,C]; returns (o, P): P [B,heads,N,Nk] saved for the backward, or None when the fused
     kernel ran (bf16, head_dim 64, Nk <= 256: the backward recomputes the probabilities in LDS)."""
-    if ops.attention_fused_ok(q, Nk, heads, C) and not os.environ.get('CMDA_NO_FUSED_ATTENTION'):
+    if ops.attention_fused_ok(q, Nk, heads, C, need_grad) and not os.environ.get('CMDA_NO_FUSED_ATTENTION'):
         return ops.attention_fused_fwd(q, kv, B, N, Nk, heads, C, scale), None
     hd = C // heads
     dev = q.device
@@ -201,7 +201,7 @@ def block_fwd(x, p, B, H, W, C, heads, sr, *, eps=1e-6, dp1=None, dp2=None, save
         xs_pre, ms, rs, xs, Nk = None, None, None, xn, N
     kv = linear_fwd(xs, a.kv.weight, a.kv.bias, B * Nk, C)
     hd = C // heads
-    o, P = attention_fwd(q, kv, B, N, Nk, heads, C, hd ** -0.5)
+    o, P = attention_fwd(q, kv, B, N, Nk, heads, C, hd ** -0.5, need_grad=save)
     x1 = linear_fwd(o, a.proj.weight, a.proj.bias, M, C, res=x, rowscale=dp1, rows_per_scale=N, out_dtype=sd)
     xn2, m2, r2 = ops.layernorm_fwd(x1, p.norm2.weight, p.norm2.bias, eps, out_dtype=cd)
     hidden = p.mlp.fc1.weight.shape[0]

@@ -531,8 +531,10 @@ def softmax_bwd_(p, dp, rows, L, alpha):
     return dp
 
 
-def attention_fused_ok(q, Nk, heads, C):
-    return q.dtype == torch.bfloat16 and C == heads * 64 and 0 < Nk <= 256
+def attention_fused_ok(q, Nk, heads, C, need_grad=True):
+    """the fused kernels hold every key of a (batch, head) in LDS: up to 256 with a backward pass to follow, up to 320 forward-only
+    (inference on 440 x 640 frames: 260 / 280 keys, encoder_decoder.py:897-936)"""
+    return q.dtype == torch.bfloat16 and C == heads * 64 and 0 < Nk <= (256 if need_grad else 320)
 
 
 def attention_fused_fwd(q, kv, B, N, Nk, heads, C, scale):

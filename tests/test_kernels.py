@@ -326,3 +326,28 @@ def test_fused_attention(tgt, B, N, Nk, heads):
         dq2 = ops.attention_fused_bwd(qd, kvd, dod, None, B, N, Nk, heads, C, scale, dkv16=dkv16)
         assert_close(dq2, qr.grad, 2e-2, name='attention dq (direct)')
         assert_close(dkv16, kvr.grad, 2e-2, name='attention dkv (direct)')
+
+
+@pytest.mark.parametrize('B,N,Nk,heads', [(1, 1120, 280, 2), (2, 280, 260, 5), (1, 70, 320, 8), (1, 300, 257, 1)])
+def test_fused_attention_eval_keys(tgt, B, N, Nk, heads):
+    """inference on 440 x 640 frames leaves 260 / 280 keys after the spatial reduction (encoder_decoder.py:897-936, mix_transformer.py
+    sr_ratios): the forward-only instance of the fused kernel holds up to 320 keys; the training kernels stay at 256"""
+    torch.manual_seed(N + Nk)
+    C, scale = heads * 64, 0.125
+    q, kv = torch.randn(B * N, C).bfloat16(), torch.randn(B * Nk, 2 * C).bfloat16()
+    ref = _attention_ref(q.float(), kv.float(), B, N, Nk, heads, C, scale)
+    qd, kvd = tgt.to(q), tgt.to(kv)
+    assert ops.attention_fused_ok(qd, Nk, heads, C, need_grad=False) and not ops.attention_fused_ok(qd, Nk, heads, C)
+    o = ops.attention_fused_fwd(qd, kvd, B, N, Nk, heads, C, scale)
+    assert_close(o, ref, 1.6e-2, name='attention o (eval keys)')
+    # and through the block: save=False (no backward to follow) takes the fused kernel, save=True the materialised path; same output
+    from cmda_amd import nn as K
+    import cmda_amd.runtime as rt
+    rt.set_compute_dtype(torch.bfloat16)
+    try:
+        o1, P1 = K.attention_fwd(qd, kvd, B, N, Nk, heads, C, scale, need_grad=False)
+        o2, P2 = K.attention_fwd(qd, kvd, B, N, Nk, heads, C, scale, need_grad=True)
+    finally:
+        rt.set_compute_dtype(torch.float32)
+    assert P1 is None and P2 is not None
+    assert_close(o1, o2.float(), 2e-2, name='fused vs materialised')

@@ -17,7 +17,7 @@ dev = 'cuda'
 r = lambda *s: torch.randn(*s, device=dev).to(bf)
 z = torch.zeros(64, 8, device=dev)
 print('floor (rows_fill tiny):', round(timeit(lambda: z.zero_()), 1))
-shapes = [('fc1 fwd', 'nt', 2048, 1280, 320), ('fc2 fwd', 'nt', 2048, 320, 1280), ('q fwd', 'nt', 2048, 320, 320), ('q fwd B4', 'nt', 4096, 320, 320),
+shapes = [('k64', 'nt', 2048, 320, 64), ('k128', 'nt', 2048, 320, 128), ('k256', 'nt', 2048, 320, 256), ('k640', 'nt', 2048, 320, 640), ('k64 small', 'nt', 256, 64, 64), ('fc1 fwd', 'nt', 2048, 1280, 320), ('fc2 fwd', 'nt', 2048, 320, 1280), ('q fwd', 'nt', 2048, 320, 320), ('q fwd B4', 'nt', 4096, 320, 320),
           ('fc1 fwd B4', 'nt', 4096, 1280, 320), ('fc2 fwd B4', 'nt', 4096, 320, 1280),
           ('fc2 dgrad', 'nn', 2048, 1280, 320), ('fc1 dgrad', 'nn', 2048, 320, 1280), ('kv fwd', 'nt', 512, 640, 320),
           ('s2 fc1', 'nt', 8192, 512, 128), ('s2 fc2', 'nt', 8192, 128, 512), ('s1 fc1', 'nt', 32768, 256, 64), ('s1 fc2', 'nt', 32768, 64, 256)]
