@@ -351,3 +351,89 @@ def test_fused_attention_eval_keys(tgt, B, N, Nk, heads):
         rt.set_compute_dtype(torch.float32)
     assert P1 is None and P2 is not None
     assert_close(o1, o2.float(), 2e-2, name='fused vs materialised')
+
+
+# ------------------------------------------------------------------ round-3 entry points, each against torch
+@pytest.mark.parametrize('C,rows', [(64, 300), (320, 130), (512, 33), (128, 1000)])
+def test_layernorm_fp32_stream_bf16_operands(tgt, C, rows):
+    """cmda_layernorm_fwd2 / bwd2: the fp32 residual stream in, the bf16 GEMM operand out; backward: bf16 gradients in and out, the
+    statistics recomputed from the fp32 input (mix_transformer.py:141-146 with x kept in fp32)"""
+    torch.manual_seed(C + rows)
+    x = torch.randn(rows, C) * 3 + 1
+    g, b = torch.randn(C), torch.randn(C)
+    dy, dres = torch.randn(rows, C).bfloat16(), torch.randn(rows, C).bfloat16()
+    xr = x.clone().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (C,), gr, br, 1e-6)
+    ref.backward(dy.float())
+    xd, gd, bd, dyd, dresd = map(tgt.to, (x, g, b, dy, dres))
+    y, mean, rstd = ops.layernorm_fwd(xd, gd, bd, 1e-6, out_dtype=torch.bfloat16)
+    assert y.dtype == torch.bfloat16
+    assert_close(y, ref, 8e-3, name='ln fwd fp32 -> bf16')            # one rounding of the exact fp32 result
+    assert_close(mean, x.mean(1), 1e-5, name='ln mean')
+    dg, db = torch.zeros(C, device=tgt.device), torch.zeros(C, device=tgt.device)
+    sc = torch.rand(4)
+    rps = (rows + 3) // 4
+    dx, dxs = ops.layernorm_bwd(dyd, xd, gd, mean, rstd, dg, db, dres=dresd, out_scale=tgt.to(sc), rows_per_scale=rps)
+    assert dx.dtype == torch.bfloat16
+    want = xr.grad + dres.float()
+    assert_close(dx, want, 1.6e-2, name='ln dx (bf16 out)')
+    assert_close(dxs, want * sc[torch.arange(rows) // rps, None], 1.6e-2, name='ln dx scaled')
+    assert_close(dg, gr.grad, 2e-5, name='ln dgamma')
+    assert_close(db, br.grad, 2e-5, name='ln dbeta')
+
+
+@pytest.mark.parametrize('M,N,K', [(300, 64, 64), (130, 320, 1280), (1000, 128, 512)])
+def test_gemm_fp32_residual_epilogue(tgt, M, N, K):
+    """x1 = x + drop_path(proj(o)) with x and x1 in fp32 and the GEMM operands in bf16 (cmda_gemm_params_t.res_f32): the residual is
+    added in fp32 in the epilogue, per-sample DropPath scale on the GEMM term only"""
+    torch.manual_seed(M)
+    a, w, bias = torch.randn(M, K).bfloat16(), (torch.randn(N, K) * 0.05).bfloat16(), torch.randn(N)
+    res = torch.randn(M, N) * 50          # large against the GEMM term: a bf16 residual add would lose ~0.2 absolute here
+    sc = torch.tensor([0.0, 1.25, 1.25, 0.0])
+    rps = (M + 3) // 4
+    ref = res + (a.float() @ w.float().t() + bias) * sc[torch.arange(M) // rps, None]
+    out = torch.empty(M, N, dtype=torch.float32, device=tgt.device)
+    ad, wd = tgt.to(a), tgt.to(w)
+    ops.gemm(ops.plain_view(ad, M, K), ops.plain_view(wd, N, K), out, M, N, K, dtype=1, bias=tgt.to(bias), res=tgt.to(res),
+             rowscale=tgt.to(sc), rows_per_scale=rps)
+    err = (out.cpu() - ref).abs().max().item()
+    assert err < 2e-3, f'fp32 residual epilogue: max abs err {err:.3e}'
+
+
+def test_conv_co1(tgt):
+    """the generator's last layer, Conv2d(64, 1, 7, padding 3 reflect) + tanh (cyclegan_model.py:372-374), as a dot-product stencil"""
+    torch.manual_seed(3)
+    B, H, W, C, K = 2, 19, 23, 64, 7
+    x = torch.randn(B, C, H, W).bfloat16()
+    w = (torch.randn(1, C, K, K) * 0.05).bfloat16()
+    bias = torch.randn(1)
+    for reflect in (True, False):
+        xp = F.pad(x.float(), (3, 3, 3, 3), mode='reflect') if reflect else F.pad(x.float(), (3, 3, 3, 3))
+        ref = torch.tanh(F.conv2d(xp, w.float(), bias))[:, 0]
+        xd = tgt.to(x.permute(0, 2, 3, 1).reshape(-1, C).contiguous())
+        wd = tgt.to(w.permute(0, 2, 3, 1).reshape(-1).contiguous())
+        assert ops.conv_co1_ok(xd, C, K, 3)
+        out = ops.conv_co1(xd, wd, tgt.to(bias), B, H, W, C, K, 3, reflect, 'tanh')
+        assert_close(out, ref, 2e-3, name=f'conv_co1 reflect={reflect}')
+
+
+def test_rows_fill_cast_pad_nchw_pad(tgt):
+    torch.manual_seed(4)
+    bias = torch.randn(20)
+    out = ops.rows_fill(torch.full((37, 20), float('nan'), device=tgt.device), tgt.to(bias))
+    assert torch.equal(out.cpu(), bias.expand(37, 20))
+    out = ops.rows_fill(torch.full((5, 8), float('nan'), device=tgt.device), None)
+    assert torch.equal(out.cpu(), torch.zeros(5, 8))
+    src = torch.randn(33, 27)
+    for dt in (torch.float32, torch.bfloat16):
+        dst = ops.cast_pad_cols(tgt.to(src), 32, dt)
+        assert dst.shape == (33, 32) and dst.dtype == dt
+        assert torch.equal(dst[:, :27].cpu().float(), src.to(dt).float()) and not dst[:, 27:].cpu().float().abs().any()
+    img = torch.randn(2, 3, 7, 9)
+    for dt in (torch.float32, torch.bfloat16):
+        dst = torch.full((2 * 63, 8), float('nan'), dtype=dt, device=tgt.device)
+        ops.nchw_to_nhwc_pad(tgt.to(img), dst, 2, 3, 63, 8)
+        want = torch.zeros(2, 7, 9, 8)
+        want[..., :3] = img.permute(0, 2, 3, 1)
+        assert torch.equal(dst.cpu().float(), want.view(-1, 8).to(dt).float())
