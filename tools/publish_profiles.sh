@@ -3,8 +3,8 @@
 tag=${1:-r03final}
 src=gpurun_out/$tag
 cp $src/bench.json profiles/r03_dacs_bench.json
-cp $src/stats_graph/*/*kernel_stats.csv profiles/r03_dacs_graph_kernel_stats.csv
-cp $src/stats_eager/*/*kernel_stats.csv profiles/r03_dacs_eager_kernel_stats.csv
+cp "$(ls -t $src/stats_graph/*/*kernel_stats.csv | head -1)" profiles/r03_dacs_graph_kernel_stats.csv   # (newest: a re-run into the same tag leaves the older PID's files)
+cp "$(ls -t $src/stats_eager/*/*kernel_stats.csv | head -1)" profiles/r03_dacs_eager_kernel_stats.csv
 cp $src/bench_prof_graph.json profiles/r03_dacs_graph_profiled.json
 cp $src/bench_prof_eager.json profiles/r03_dacs_eager_profiled.json
 cp $src/pmc_traffic_dacs.json profiles/pmc_traffic_dacs.json
