@@ -192,20 +192,21 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(GemmParams p) {
   // Measured alternative (profiles/r03_pp_phases.txt): the next phase's fragment reads issued right behind the MFMAs and the DMA
   // pieces between the MFMAs -- a piece then costs the issuing wave ~140 cycles of MFMA issue instead of ~60-100 in the LOAD
   // segment (6060 against 4580 cycles per k-tile).
-  u16x8 fa[2][4], fb[4];
+  u16x8 fa[2][4], fb[2][4];   // both N halves of the B fragments stay in registers: phase 3 re-uses phase 0's (no LDS read at all)
   for (int kt = 0; kt < nkt; ++kt) {
     const int st = kt & 1;
     const T* sA = sAbase + st * PP_SZ;
     const T* sB = sBbase + st * PP_SZ;
     const bool more = kt + 1 < nkt;
-    // quadrant order (mh, nh) = (0,0) (0,1) (1,1) (1,0): A fragments are re-read twice, B three times per k-tile
+    // quadrant order (mh, nh) = (0,0) (0,1) (1,1) (1,0): every fragment is read from LDS once per k-tile (A halves in phases 0 / 2,
+    // B halves in phases 0 / 1)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int mh = q >> 1, nh = (q == 1 || q == 2) ? 1 : 0;
       // ---- LOAD segment
       PP_STAMP(0);
       if (q == 0 || q == 2) load_a(sA, mh, fa);
-      if (q != 2) load_b(sB, nh, fb);
+      if (q < 2) load_b(sB, nh, fb[nh]);
       if (more) {   // 2 + 4 + 2 pieces: the read-heavy phase 0 (12 ds_read_b128) carries the fewest
         if (q == 0) { piece(st ^ 1, kt + 1, 0); piece(st ^ 1, kt + 1, 4); }
         if (q == 1) { piece(st ^ 1, kt + 1, 1); piece(st ^ 1, kt + 1, 2); piece(st ^ 1, kt + 1, 5); piece(st ^ 1, kt + 1, 6); }
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(GemmParams p) {
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) acc[mh * 2 + i][nh] = mfma_bf16_32x32x16(fb[s], fa[i][s], acc[mh * 2 + i][nh]);
+        for (int i = 0; i < 2; ++i) acc[mh * 2 + i][nh] = mfma_bf16_32x32x16(fb[nh][s], fa[i][s], acc[mh * 2 + i][nh]);
       prio(0);
       PP_STAMP(2);
       if (q == 3 && grp == 0) wait_dma_lds();
