@@ -166,7 +166,14 @@ static __device__ __forceinline__ void wg_body(const GemmParams& p, char* smem, 
 template <bool BCONV, int WG_BK, int WG_NS>
 __global__ __launch_bounds__(512, 1) void gemm_wg_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(1024))) char smem[(size_t)2 * WG_NS * WG_T * WG_BK * 2];
-  wg_body<BCONV, WG_BK, WG_NS>(p, smem, blockIdx.x, blockIdx.z);
+  // Workgroups are dealt round-robin to the 8 XCDs in launch order (tile fastest, then split).  The tiles of ONE split read the same K
+  // slice of dY (and, for an im2col B, the same pixels under nine taps): dealt out as launched, every XCD streams every split's slice
+  // through its own L2.  Give each XCD a contiguous range of (split, tile) pairs instead -- at most two splits per XCD for the
+  // 36 x 7 grid of the 3x3 bottleneck.
+  const unsigned nb = gridDim.x * gridDim.z, lin = blockIdx.x + gridDim.x * blockIdx.z;
+  const unsigned q = nb / 8, r = nb % 8, xcd = lin % 8, loc = lin / 8;
+  const unsigned logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  wg_body<BCONV, WG_BK, WG_NS>(p, smem, (int)(logical % gridDim.x), (int)(logical / gridDim.x));
 }
 
 // grouped form (gemm_grouped.hip: the deferred weight gradients of an encoder stage whose outputs are at least 256 x 256 -- MiT
