@@ -1,6 +1,7 @@
 """Thin tensor-level wrappers over the C ABI (include/cmda_hip.h).  No autograd here: the
 differentiable building blocks live in cmda_amd/functional.py and call these for both passes."""
 import ctypes
+import os
 
 import torch
 
@@ -46,7 +47,7 @@ ACT = {None: 0, 'none': 0, 'relu': 1, 'gelu': 2, 'tanh': 3}
 # bench.py's roofline leg: when a list is installed here every GEMM launch is bracketed by events on the launch stream
 GEMM_PROFILE = None
 # cmda_gemm_params_t.tile_hint for every GEMM issued from here (0 = the library's heuristics); set by tuning sweeps / tests
-GEMM_TILE_HINT = 0
+GEMM_TILE_HINT = int(os.environ.get('CMDA_GEMM_TILE_HINT', '0'))   # cmda_gemm_params_t.tile_hint of every launch (tuning sweeps, forced-tile tests)
 
 
 def gemm(A, B, out, M, N, K, *, a_kstrided=False, b_kstrided=False, ldc=None, batch=1, c_batch_stride=0,
