@@ -530,12 +530,25 @@ def self_launch(n):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     try:
-        for p in procs:
-            p.wait()
-            rc = rc or p.returncode
+        live = list(procs)
+        while live and rc == 0:      # POLL: a rank that dies (OOM, RCCL init failure) must not leave the launcher blocked on a
+            for p in list(live):     # peer that sits in a collective waiting for it
+                r = p.poll()
+                if r is None:
+                    continue
+                live.remove(p)
+                rc = rc or r
+            if live and rc == 0:
+                time.sleep(0.2)
     finally:
-        for p in procs:          # a rank died: do not leave its peers waiting in a collective
+        for p in procs:          # a rank died (or we were interrupted): end its peers
             if p.poll() is None:
+                p.terminate()
+        deadline = time.time() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
                 p.kill()
     return rc
 

@@ -143,6 +143,54 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict
   }
 }
 
+// Mixed storage types (the Motion-Extractor generator in the bf16 mode): x in TX (the convolution's fp32 output -- its statistics and
+// the normalisation see the unrounded sums), y in TY; optional fp32 residual added AFTER the normalisation (ResnetBlock:
+// x + conv_block(x), cyclegan_model.py:431-434, the stream itself stays fp32) and an optional bf16 copy y2 of the result (pitch C),
+// the operand of the next convolution.
+template <typename TX, typename TY>
+__global__ void bn_apply2_kernel(const TX* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                 const float* __restrict__ gamma, const float* __restrict__ beta, TY* __restrict__ y,
+                                 const float* __restrict__ res, bf16_t* __restrict__ y2, long M, int C, int relu, int ldy,
+                                 int rows_per_block) {
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + cx) * 4;
+  if (c >= C) return;
+  x += (long)blockIdx.z * M * C;
+  y += (long)blockIdx.z * M * ldy;
+  if (res) res += (long)blockIdx.z * M * C;
+  if (y2) y2 += (long)blockIdx.z * M * C;
+  mean += (long)blockIdx.z * C;
+  rstd += (long)blockIdx.z * C;
+  const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float mu[4], rs[4], g[4], b[4];
+  ld4(mean + c, mu);
+  ld4(rstd + c, rs);
+  ld4(gamma + c, g);
+  ld4(beta + c, b);
+  for (long r = r0 + ry; r < r1; r += 4 * kRowUnroll) {
+    float v[kRowUnroll][4], q[kRowUnroll][4];
+#pragma unroll
+    for (int u = 0; u < kRowUnroll; ++u) {
+      const long ru = r + 4 * u < r1 ? r + 4 * u : r;
+      ld4(x + ru * C + c, v[u]);
+      if (res) ld4(res + ru * C + c, q[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < kRowUnroll; ++u) {
+      const long ru = r + 4 * u;
+      if (ru >= r1) break;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[u][j] = (v[u][j] - mu[j]) * rs[j] * g[j] + b[j];
+        if (relu) v[u][j] = fmaxf(v[u][j], 0.f);
+        if (res) v[u][j] += q[u][j];
+      }
+      st4(y + ru * ldy + c, v[u]);
+      if (y2) st4(y2 + ru * C + c, v[u]);
+    }
+  }
+}
+
 // ws[0:C] += sum dyr, ws[C:2C] += sum dyr*xhat, dyr = dy masked by the ReLU of the recomputed output
 template <typename T>
 __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ mean,
@@ -321,6 +369,38 @@ extern "C" int cmda_bn_train_fwd(const void* x, const float* gamma, const float*
     CMDA_LAUNCH((bn_apply_kernel<T>), agrid, dim3(256), 0, stream, (const T*)x, mean, rstd, gamma, beta, (T*)y + coff, (long)M,
                 C, relu, ldy, 0, arpb);
   });
+  CMDA_CHECK_LAUNCH();
+}
+
+// x_dtype / y_dtype independent; res32 (fp32 [groups*M, C]) is added after the normalisation (+ReLU); y2_bf16 (bf16 [groups*M, C])
+// receives a second copy of the result.  Otherwise cmda_bn_train_fwd.
+extern "C" int cmda_bn_train_fwd2(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
+                                  float* mean, float* rstd, float* running_mean, float* running_var, float* ws, int64_t M, int C,
+                                  float eps, float momentum, int relu, int ldy, int coff, int groups, const int* order,
+                                  const float* res32, void* y2_bf16, void* stream) {
+  if (M <= 0 || C <= 0) return CMDA_OK;
+  if ((C & 3) || (ldy & 3) || (coff & 3) || groups < 1 || groups > 8) return CMDA_ERR_SHAPE;
+  if ((x_dtype != CMDA_F32 && x_dtype != CMDA_BF16) || (y_dtype != CMDA_F32 && y_dtype != CMDA_BF16)) return CMDA_ERR_DTYPE;
+  BnOrder ord;
+  for (int i = 0; i < 8; ++i) ord.g[i] = (order && i < groups) ? order[i] : i;
+  for (int i = 0; i < groups; ++i)
+    if (ord.g[i] < 0 || ord.g[i] >= groups) return CMDA_ERR_SHAPE;
+  cmda_zero_async(ws, sizeof(float) * (size_t)groups * (kBnSlots + 1) * 2 * C, stream);
+  const int gx = (C / 4 + 63) / 64;
+  const int rpb = rows_per_block(M * groups, gx);
+  dim3 rgrid(gx, (unsigned)((M + rpb - 1) / rpb), groups);
+  const int arpb = rows_per_block_apply(M * groups, gx);
+  dim3 agrid(gx, (unsigned)((M + arpb - 1) / arpb), groups);
+#define CMDA_BN2_APPLY(TX, TY)                                                                                                    \
+  CMDA_LAUNCH((bn_apply2_kernel<TX, TY>), agrid, dim3(256), 0, stream, (const TX*)x, mean, rstd, gamma, beta, (TY*)y + coff,      \
+              res32, (bf16_t*)y2_bf16, (long)M, C, relu, ldy, arpb)
+  CMDA_DISPATCH_DTYPE(x_dtype, {
+    CMDA_LAUNCH((bn_reduce_kernel<T>), rgrid, dim3(256), 0, stream, (const T*)x, ws, (long)M, C, rpb);
+    CMDA_LAUNCH((bn_finalize_kernel<T>), dim3((C + 255) / 256), dim3(256), 0, stream, (const T*)x, ws, mean, rstd,
+                running_mean, running_var, (long)M, C, eps, momentum, groups, ord);
+    if (y_dtype == CMDA_F32) CMDA_BN2_APPLY(T, float); else CMDA_BN2_APPLY(T, bf16_t);
+  });
+#undef CMDA_BN2_APPLY
   CMDA_CHECK_LAUNCH();
 }
 

@@ -440,6 +440,7 @@ extern "C" int cmda_permute4(const void* src, void* dst, int d0, int d1, int d2,
     seen |= 1 << p[a];
   }
   if (seen != 15) return CMDA_ERR_SHAPE;
+  if (flipmask & ~15) return CMDA_ERR_UNSUPPORTED;   // channel-padding bits (8.., 16..) are cmda_permute4_batch's: not understood here
   if (src_dtype == CMDA_F32 && dst_dtype == CMDA_F32) return launch_permute<float, float>(src, dst, d, p, flipmask, accumulate, stream);
   if (src_dtype == CMDA_F32 && dst_dtype == CMDA_BF16) return launch_permute<float, bf16_t>(src, dst, d, p, flipmask, accumulate, stream);
   if (src_dtype == CMDA_BF16 && dst_dtype == CMDA_F32) return launch_permute<bf16_t, float>(src, dst, d, p, flipmask, accumulate, stream);

@@ -45,31 +45,41 @@ class ResnetGenerator(nn.Module):
         self.n_blocks = n_blocks
         self._ident = {}
 
-    def _inorm(self, x, B, HW, C, relu, res=None):
-        """InstanceNorm2d(affine=False, eps 1e-5) (+ReLU) (+residual) on NHWC-flat x [B*HW, C]: the grouped column-statistics
-        kernels with one group per sample (up to 8 samples per launch)."""
+    def _inorm(self, x, B, HW, C, relu, res=None, out_dtype=None, copy=False):
+        """InstanceNorm2d(affine=False, eps 1e-5) (+ReLU) (+ fp32 residual) on NHWC-flat x [B*HW, C]: the grouped column-statistics
+        kernels with one group per sample (up to 8 samples per launch).  x is the convolution's fp32 output in both modes; the
+        result is stored as `out_dtype` (default: the compute dtype, the next convolution's operand).  copy=True (the residual
+        stream, kept fp32: out_dtype = float32): also returns a compute-dtype copy for the next convolution, written by the same
+        launch in the bf16 mode."""
         key = (C, str(x.device))
         ident = self._ident.get(key)
         if ident is None:
             ident = self._ident[key] = (torch.ones(C, dtype=torch.float32, device=x.device),
                                         torch.zeros(C, dtype=torch.float32, device=x.device))
         one, zero = ident
-        y = torch.empty_like(x)
+        cd = rt.compute_dtype()
+        y = torch.empty(x.shape, dtype=out_dtype or cd, device=x.device)
+        y2 = torch.empty(x.shape, dtype=cd, device=x.device) if (copy and y.dtype != cd) else None
         for b0 in range(0, B, 8):
             g = min(8, B - b0)
-            ops.bn_train_fwd(x[b0 * HW:(b0 + g) * HW], one, zero, y[b0 * HW:(b0 + g) * HW], None, None, HW, C, 1e-5, 0.0, relu,
-                             groups=g)
-        return y if res is None else ops.axpby(y, res, 1.0, 1.0, out=y)
+            sl = slice(b0 * HW, (b0 + g) * HW)
+            ops.bn_train_fwd2(x[sl], one, zero, y[sl], HW, C, 1e-5, relu, groups=g, res32=None if res is None else res[sl],
+                              y2=None if y2 is None else y2[sl])
+        return (y, y if y2 is None else y2) if copy else y
 
     def _conv(self, x, conv, B, H, W, stride, pad, reflect, act=None):
-        y, OH, OW = K.conv_fwd(x, conv.weight, conv.bias, B, H, W, stride, pad, 1, act=act, reflect=reflect)
+        """fp32 output in both modes: the InstanceNorm behind every convolution takes its statistics from the unrounded sums"""
+        Co, _, KH, _ = conv.weight.shape
+        OH, OW = K.conv_out_size(H, W, KH, stride, pad)
+        out = torch.empty(B * OH * OW, Co, dtype=torch.float32, device=x.device)
+        y, OH, OW = K.conv_fwd(x, conv.weight, conv.bias, B, H, W, stride, pad, 1, act=act, reflect=reflect, out=out)
         return y, OH, OW
 
     def _convT(self, x, ct, B, H, W):
         """ConvTranspose2d(k3, s2, p1, output_padding 1) = conv of the zero-inserted input with the flipped kernel."""
         Ci, Co, KH, KW = ct.weight.shape
         OH, OW = 2 * H, 2 * W
-        y = torch.empty(B * OH * OW, Co, dtype=rt.compute_dtype(), device=x.device)
+        y = torch.empty(B * OH * OW, Co, dtype=torch.float32, device=x.device)
         ops.gemm(conv_view(x, B, H, W, Ci, KH, KW, 1, KH - 1 - 1, 1, OH=OH, OW=OW, in_dil=2),
                  plain_view(rt.wconv(ct.weight, 'dgrad'), Co, KH * KW * Ci), y, B * OH * OW, Co, KH * KW * Ci,
                  dtype=rt.tag(), bias=ct.bias)
@@ -89,27 +99,31 @@ class ResnetGenerator(nn.Module):
         x = torch.empty(B * H * W, cp, dtype=rt.compute_dtype(), device=inp.device)
         if cp != Cin:
             ops.nchw_to_nhwc_pad(inp.contiguous(), x, B, Cin, H * W, cp)
-            x, H1, W1 = K.conv_fwd(x, m[1].weight, m[1].bias, B, H, W, 1, 3, 1, reflect=1, ci_pad=cp)
+            H1, W1 = K.conv_out_size(H + 6, W + 6, 7, 1, 0)
+            c = torch.empty(B * H1 * W1, m[1].out_channels, dtype=torch.float32, device=inp.device)
+            K.conv_fwd(x, m[1].weight, m[1].bias, B, H, W, 1, 3, 1, reflect=1, ci_pad=cp, out=c)
         else:
             ops.permute4(inp.contiguous(), x, (B, Cin, H, W), (0, 2, 3, 1))
-            x, H1, W1 = self._conv(x, m[1], B, H, W, 1, 3, 1)
-        x = self._inorm(x, B, H1 * W1, m[1].out_channels, True)
-        x, H2, W2 = self._conv(x, m[4], B, H1, W1, 2, 1, 0)
-        x = self._inorm(x, B, H2 * W2, m[4].out_channels, True)
-        x, H3, W3 = self._conv(x, m[7], B, H2, W2, 2, 1, 0)
+            c, H1, W1 = self._conv(x, m[1], B, H, W, 1, 3, 1)
+        x = self._inorm(c, B, H1 * W1, m[1].out_channels, True)
+        c, H2, W2 = self._conv(x, m[4], B, H1, W1, 2, 1, 0)
+        x = self._inorm(c, B, H2 * W2, m[4].out_channels, True)
+        c, H3, W3 = self._conv(x, m[7], B, H2, W2, 2, 1, 0)
         C = m[7].out_channels
-        x = self._inorm(x, B, H3 * W3, C, True)
+        # the residual stream of the nine ResNet blocks stays fp32 (xs); xb = its compute-dtype copy, the convolutions' operand
+        xs, xb = self._inorm(c, B, H3 * W3, C, True, out_dtype=torch.float32, copy=True)
         for i in range(self.n_blocks):
             cb = m[10 + i].conv_block
-            y, _, _ = self._conv(x, cb[1], B, H3, W3, 1, 1, 1)
-            y = self._inorm(y, B, H3 * W3, C, True)
-            y, _, _ = self._conv(y, cb[5], B, H3, W3, 1, 1, 1)
-            x = self._inorm(y, B, H3 * W3, C, False, res=x)
+            c, _, _ = self._conv(xb, cb[1], B, H3, W3, 1, 1, 1)
+            y = self._inorm(c, B, H3 * W3, C, True)
+            c, _, _ = self._conv(y, cb[5], B, H3, W3, 1, 1, 1)
+            xs, xb = self._inorm(c, B, H3 * W3, C, False, res=xs, out_dtype=torch.float32, copy=True)
+        x = xb
         k = 10 + self.n_blocks
-        x, H4, W4 = self._convT(x, m[k], B, H3, W3)
-        x = self._inorm(x, B, H4 * W4, m[k].out_channels, True)
-        x, H5, W5 = self._convT(x, m[k + 3], B, H4, W4)
-        x = self._inorm(x, B, H5 * W5, m[k + 3].out_channels, True)
+        c, H4, W4 = self._convT(x, m[k], B, H3, W3)
+        x = self._inorm(c, B, H4 * W4, m[k].out_channels, True)
+        c, H5, W5 = self._convT(x, m[k + 3], B, H4, W4)
+        x = self._inorm(c, B, H5 * W5, m[k + 3].out_channels, True)
         last = m[k + 7]
         Co = last.out_channels
         Ci = last.in_channels

@@ -170,6 +170,8 @@ class CityscapesICDataset(_SyntheticBase):
             classes = torch.unique(torch.stack(labs))
             out['label'] = _stack_dev(labs, dev)
             out['label']._cmda_classes = classes
+            # (validated by the consumer: an in-place refill of this buffer bumps _version and the stale set is dropped)
+            out['label']._cmda_classes_key = (out['label'].data_ptr(), out['label']._version)
             if dev.type == 'cuda':
                 out['label']._cmda_ready = torch.cuda.Event()
                 out['label']._cmda_ready.record()

@@ -94,6 +94,10 @@ def gemm(A, B, out, M, N, K, *, a_kstrided=False, b_kstrided=False, ldc=None, ba
         assert res is None and batch == 1 and batch2 == 1 and not atomic
         p.c_patch_ow, p.c_patch_kh, p.c_patch_kwci = c_patch
         p.c_vec_ok = int(p.C % 16 == 0 and c_patch[2] % 4 == 0 and (bias is None or bias.data_ptr() % 16 == 0))
+    if defer:
+        # deferred problems are launched AFTER the grouped ones of their flush whatever their list position (cmda_gemm_grouped): only
+        # commutative accumulation may be deferred
+        assert atomic and beta == 0.0, 'ops.gemm(defer=True) is for atomic accumulation only'
     if defer and _LN_DEFER['depth'] > 0 and GEMM_DEFER:
         es = 4 if dtype == 0 else 2
         nb = batch * batch2
@@ -624,6 +628,21 @@ def bn_train_fwd(x, gamma, beta, y, running_mean, running_var, M, C, eps, moment
     call('cmda_bn_train_fwd', ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), ptr(running_mean),
          ptr(running_var), ptr(ws), c_i64(M), c_i32(C), c_f32(eps), c_f32(momentum), c_i32(int(relu)),
          c_i32(C if ldy is None else ldy), c_i32(coff), c_i32(groups), order_c, dtype_tag(x), stream_of(x))
+    return mean, rstd
+
+
+def bn_train_fwd2(x, gamma, beta, y, M, C, eps, relu, groups=1, res32=None, y2=None, ldy=None, coff=0):
+    """cmda_bn_train_fwd2: x and y of independent storage types, no running statistics; res32 (fp32 [groups*M, C]) is added after
+    the normalisation, y2 (bf16 [groups*M, C]) receives a copy of the result.  Returns mean, rstd [groups, C]."""
+    check_dev(x, gamma, beta, y, res32, y2)
+    assert res32 is None or res32.dtype == torch.float32
+    assert y2 is None or y2.dtype == torch.bfloat16
+    mean = torch.empty(groups, C, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(groups, C, dtype=torch.float32, device=x.device)
+    ws = torch.empty(groups * L.lib().cmda_bn_ws_floats(C), dtype=torch.float32, device=x.device)
+    call('cmda_bn_train_fwd2', ptr(x), dtype_tag(x), ptr(gamma), ptr(beta), ptr(y), dtype_tag(y), ptr(mean), ptr(rstd), None, None,
+         ptr(ws), c_i64(M), c_i32(C), c_f32(eps), c_f32(0.0), c_i32(int(relu)), c_i32(C if ldy is None else ldy), c_i32(coff),
+         c_i32(groups), None, ptr(res32), ptr(y2), stream_of(x))
     return mean, rstd
 
 

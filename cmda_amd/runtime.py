@@ -138,7 +138,10 @@ def refresh_frozen(module=None):
         if e.dst.device != prm.device:
             del _frozen[(pid, _kind)]
             continue
-        ops.permute4(prm.data, e.dst, e.dims, e.perm, flipmask=e.flip)
+        if e.flip >> 8:   # channel-padded copy (the generator's first convolution in the bf16 mode): the batched re-layout only
+            _fill_padded(prm, e.dst, e.dims, e.perm, e.flip)
+        else:
+            ops.permute4(_mem_view(prm), e.dst, e.dims, e.perm, flipmask=e.flip)
 
 
 _plans = {}
@@ -148,6 +151,23 @@ def _mem_view(param):
     """the parameter's storage as a contiguous tensor (channels-last stored conv weights: [Co,KH,KW,Ci])"""
     d = param.data
     return d if d.is_contiguous() else d.permute(0, 2, 3, 1)
+
+
+def _fill_padded(param, dst, dims, perm, flip):
+    """(re)write a channel-padded compute copy through a one-entry cmda_permute4_batch plan -- only the batched re-layout knows the
+    padding bits of `flip` (cmda_permute_desc_t.flipmask)"""
+    import numpy as np
+    d = list(dims) + [1] * (4 - len(dims))
+    total = 1
+    for v in d:
+        total *= v
+    desc = np.zeros(1, dtype=[('src', '<u8'), ('dst', '<u8'), ('d', '<i4', 4), ('p', '<i4', 4), ('flip', '<i4'), ('bf16', '<i4'), ('total', '<i8')])
+    desc[0] = (param.data.data_ptr(), dst.data_ptr(), d, list(perm) + list(range(len(perm), 4)), flip, int(dst.dtype == torch.bfloat16), total)
+    blocks = [(0, c) for c in range((total + 1023) // 1024)]
+    dd = torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()).to(param.device)
+    bb = torch.tensor(blocks, dtype=torch.int32).to(param.device)
+    ops.permute4_batch(dd, bb, len(blocks))
+    dst._keep = (dd, bb)   # (the launch reads them asynchronously)
 
 
 def _compute_copy(param, kind, dst_shape, dst_dtype, dims, perm, flip=0):
@@ -160,20 +180,9 @@ def _compute_copy(param, kind, dst_shape, dst_dtype, dims, perm, flip=0):
         e = None
     if e is None:
         if flip >> 8:   # channel-padded copy: only the batched re-layout knows the padding -- fill it through a one-entry plan
-            import numpy as np
             dst = torch.zeros(dst_shape, dtype=dst_dtype, device=param.device)
             e = store[key] = _Entry(param, dst, dims, perm, flip)
-            d = list(dims) + [1] * (4 - len(dims))
-            total = 1
-            for v in d:
-                total *= v
-            desc = np.zeros(1, dtype=[('src', '<u8'), ('dst', '<u8'), ('d', '<i4', 4), ('p', '<i4', 4), ('flip', '<i4'), ('bf16', '<i4'), ('total', '<i8')])
-            desc[0] = (param.data.data_ptr(), dst.data_ptr(), d, list(perm) + list(range(len(perm), 4)), flip, int(dst_dtype == torch.bfloat16), total)
-            blocks = [(0, c) for c in range((total + 1023) // 1024)]
-            dd = torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()).to(param.device)
-            bb = torch.tensor(blocks, dtype=torch.int32).to(param.device)
-            ops.permute4_batch(dd, bb, len(blocks))
-            e.dst._keep = (dd, bb)   # (the launch reads them asynchronously)
+            _fill_padded(param, dst, dims, perm, flip)
         else:
             dst = torch.empty(dst_shape, dtype=dst_dtype, device=param.device)
             ops.permute4(_mem_view(param), dst, dims, perm, flipmask=flip)

@@ -207,6 +207,8 @@ class DACS(nn.Module):
         sample with np.random.choice.  One small device->host read (<= 20 class ids), as in the reference.  Returns a CPU
         int64 [B, Kmax] tensor padded with -1 (Kmax fixed by num_classes, so the launch shapes never change)."""
         host = getattr(labels, '_cmda_classes', None)
+        if host is not None and getattr(labels, '_cmda_classes_key', None) != (labels.data_ptr(), labels._version):
+            host = None   # the label buffer was refilled in place after the loader attached its class set: recompute (dacs_transforms.py:103)
         if host is not None:
             # the loader took the class set on the host from the cropped labels before the H2D copy (datasets.CityscapesICDataset):
             # no device read, no sync, nothing to order

@@ -99,7 +99,9 @@ int cmda_gemm(const cmda_gemm_params_t* p, void* stream);
 int cmda_conv_co1(const void* x, const void* w, const float* bias, float* out, int B, int H, int W, int C, int K, int pad,
     int reflect, int act, int dtype, void* stream);
 
-/* GROUPED launch of n GEMMs in list order semantics-wise independent of each other (no problem reads another's output): the
+/* GROUPED launch of n GEMMs that are independent of each other (no problem reads another's output, and outputs shared between
+ * problems are ACCUMULATED -- atomic != 0 -- so any order is correct: the grouped buckets are launched first, the problems that
+ * cannot be grouped afterwards, NOT in list order): the
  * DEFERRED weight gradients of a backward pass -- `dW += dY^T X` of every nn.Linear / nn.Conv2d the pass walked
  * (mix_transformer.py:31-44,62-76,169-173; decode_heads/segformer_head.py:25-28 under torch autograd) -- as ONE grid per (tile,
  * operand mode) instead of n latency-bound launches.  Problems in weight-gradient form (bf16, atomic fp32 output, both operands
@@ -190,6 +192,13 @@ int64_t cmda_bn_ws_floats(int C);
 int cmda_bn_train_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, float*
     running_mean, float* running_var, float* ws, int64_t M, int C, float eps, float momentum, int relu, int ldy, int
     coff, int groups, const int* order, int dtype, void* stream);
+/* Mixed storage types: x in x_dtype, y in y_dtype; res32 (optional fp32 [groups*M, C]) is added AFTER the normalisation (+ReLU) and
+ * y2_bf16 (optional bf16 [groups*M, C]) receives a second copy of the result -- ResnetBlock of the Motion-Extractor generator in the
+ * bf16 mode (cyclegan/cyclegan_model.py:377-434: out = x + conv_block(x)): the convolution output and the residual stream stay fp32,
+ * the bf16 copy is the next convolution's operand. */
+int cmda_bn_train_fwd2(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype, float* mean,
+    float* rstd, float* running_mean, float* running_var, float* ws, int64_t M, int C, float eps, float momentum, int relu, int ldy,
+    int coff, int groups, const int* order, const float* res32, void* y2_bf16, void* stream);
 int cmda_bn_apply(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, void* y,
     int64_t M, int C, int relu, int ldy, int coff, int dtype, void* stream);
 int cmda_bn_train_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const

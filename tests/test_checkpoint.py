@@ -111,3 +111,38 @@ def test_flat_adamw_state_dict_roundtrip_and_release_strip(tmp_path):
         ck.save_checkpoint(m, f, optimizer=object())
     full = {'model.backbone.a': 1, 'ema_model.backbone.a': 2, 'cyclegan_itrd2en.model.1.weight': 3, 'model.decode_head.b': 4}
     assert list(ck.strip_for_release(full)) == ['model.backbone.a', 'model.decode_head.b']
+
+
+def test_refresh_frozen_rebuilds_channel_padded_copies(tgt):
+    """the Motion-Extractor generator's first convolution is, in the bf16 mode, a FROZEN compute copy with its one
+    input channel padded to 8 (runtime.wconv(ci_pad=8)).  A checkpoint load after a forward pass goes through
+    runtime.refresh_frozen, which must rebuild that copy with the padding-aware batched re-layout -- the plain permute kernel
+    indexed the [Co,1,7,7] master as [Co,8,7,7] (out-of-bounds read, garbage weights)."""
+    import cmda_amd.runtime as rt
+    from cmda_amd import _lib, ops
+    rt.set_compute_dtype(torch.bfloat16)
+    try:
+        torch.manual_seed(2)
+        p = torch.nn.Parameter(tgt.to(torch.randn(16, 1, 7, 7)))
+        p._cmda_frozen = True
+        q = torch.nn.Parameter(tgt.to(torch.randn(8, 4, 3, 3)))   # an unpadded frozen copy next to it
+        q._cmda_frozen = True
+
+        def want(w, cp):
+            ref = torch.zeros(w.shape[0], w.shape[2], w.shape[3], cp)
+            ref[..., :w.shape[1]] = w.detach().cpu().permute(0, 2, 3, 1)
+            return ref.reshape(w.shape[0], -1).bfloat16().float()
+        c1, c2 = rt.wconv(p, ci_pad=8), rt.wconv(q)
+        assert torch.equal(c1.float().cpu(), want(p, 8)) and torch.equal(c2.float().cpu(), want(q, 4))
+        with torch.no_grad():   # "checkpoint load": the masters change in place
+            p.mul_(-3.0)
+            q.add_(1.0)
+        rt.refresh_frozen()
+        assert rt.wconv(p, ci_pad=8) is c1 and rt.wconv(q) is c2, 'the copies keep their storage'
+        assert torch.equal(c1.float().cpu(), want(p, 8)), 'padded frozen copy after refresh_frozen'
+        assert torch.equal(c2.float().cpu(), want(q, 4))
+        # the plain permute entry point refuses the padding bits instead of reading out of bounds
+        with pytest.raises(_lib.CmdaError):
+            ops.permute4(p.data, torch.empty_like(c1), (16, 8, 7, 7), (0, 2, 3, 1), flipmask=(2 << 8) | (1 << 16))
+    finally:
+        rt.set_compute_dtype(torch.float32)

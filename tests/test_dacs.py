@@ -23,7 +23,7 @@ from weights import seeded_fill, seeded_randn  # noqa: E402
 import cmda_amd  # noqa: E402,F401
 import cmda_amd.runtime as rt  # noqa: E402
 from cmda_amd.registry import build_train_model  # noqa: E402
-from conftest import assert_close  # noqa: E402
+from conftest import assert_close, check_ge, check_le  # noqa: E402
 from oracle import cyclegan as ocg, dacs_iter, fusion as ofu, head as ohd, mit as omit, segmentor as oseg  # noqa: E402
 
 DEPTHS = [1, 1, 1, 1]
@@ -141,11 +141,11 @@ def check_iteration(out, exact, tol_loss, tol_grad, label_agree=0.999):
     if o['day_events'] is not None:
         assert_close(mix['day_events'], o['day_events'], 2e-4 if exact else 6e-2, name='generator output (day events)')
     agree = (mix['pseudo_label'].cpu() == o['pseudo_label']).float().mean().item()
-    assert agree > label_agree, f'pseudo-label agreement {agree}'
+    check_ge('pseudo-label agreement', agree, label_agree, strict=True)
     if exact:
         assert_close(mix['mixed_img'], o['mixed_img'], 1e-4, atol=2e-4, name='mixed image', outlier_frac=1e-3, outlier_rtol=2.0)
         same = (mix['mixed_lbl'].cpu() == o['mixed_lbl']).float().mean().item()
-        assert same > label_agree
+        check_ge('mixed-label agreement', same, label_agree, strict=True)
         # uint8 truncation of the jittered image can move one gray level where the two colour-jitter implementations differ
         # in the last bit: the ISR is compared on the bulk
         assert_close(mix['mixed_isr'], o['mixed_isr'], 1e-5, atol=1e-6, name='mixed ISR', outlier_frac=5e-3, outlier_rtol=2.0)
@@ -156,7 +156,7 @@ def check_iteration(out, exact, tol_loss, tol_grad, label_agree=0.999):
     for n, q in ref_grads.items():
         e = (grads[n] - q).abs().max().item() / (q.abs().max().item() + 1e-12)
         worst = max(worst, e)
-    assert worst < tol_grad, f'worst accumulated-gradient relative error {worst}'
+    check_le('worst accumulated-gradient relative error', worst, tol_grad, strict=True)
 
 
 def test_dacs_iteration_matches_oracle(tgt):
@@ -289,14 +289,18 @@ def test_dacs_iteration_full_depth_512_gpu(mode):
               f'agreement {agree:.6f}; mixed-label agreement {lbl_same:.6f}; source loss {ls:.6f} vs {rs:.6f}; mixed loss {lm:.6f} vs '
               f'{rm:.6f}; gradient rel err median {errs[len(errs) // 2]:.2e}, 90th pct {errs[int(len(errs) * 0.9)]:.2e}, worst {errs[-1]:.2e}')
         if mode == 'f32':
-            assert logit_err < 1e-3
-            assert agree >= 0.9999 and lbl_same >= 0.9999
-            assert abs(ls - rs) < 1e-4 * max(1.0, abs(rs)) and abs(lm - rm) < 2e-3 * max(1.0, abs(rm))
+            check_le('teacher logits rel err', logit_err, 1e-3, strict=True)
+            check_ge('pseudo-label agreement', agree, 0.9999)
+            check_ge('mixed-label agreement', lbl_same, 0.9999)
+            check_le('source loss abs err', abs(ls - rs), 1e-4 * max(1.0, abs(rs)), strict=True)
+            check_le('mixed loss abs err', abs(lm - rm), 2e-3 * max(1.0, abs(rm)), strict=True)
             assert_close(mix['mixed_img'], o['mixed_img'], 1e-4, atol=2e-4, name='mixed image', outlier_frac=1e-3, outlier_rtol=2.0)
-            assert errs[int(len(errs) * 0.9)] < 2e-2, 'bulk of the accumulated parameter gradients'
+            check_le('90th-percentile accumulated-gradient rel err', errs[int(len(errs) * 0.9)], 2e-2, strict=True)
         else:
-            assert logit_err < 6e-2 and agree > float(os.environ.get('CMDA_TEST_BF16_LABEL_AGREE', 0.95))
-            assert abs(ls - rs) < 2e-2 * max(1.0, abs(rs)) and abs(lm - rm) < 0.1 * max(1.0, abs(rm))
+            check_le('bf16 teacher logits rel err', logit_err, 6e-2, strict=True)
+            check_ge('bf16 pseudo-label agreement', agree, float(os.environ.get('CMDA_TEST_BF16_LABEL_AGREE', 0.95)), strict=True)
+            check_le('bf16 source loss abs err', abs(ls - rs), 2e-2 * max(1.0, abs(rs)), strict=True)
+            check_le('bf16 mixed loss abs err', abs(lm - rm), 0.1 * max(1.0, abs(rm)), strict=True)
     finally:
         rt.set_compute_dtype(torch.float32)
 

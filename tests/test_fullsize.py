@@ -24,7 +24,7 @@ import cmda_amd  # noqa: E402,F401
 import cmda_amd.runtime as rt  # noqa: E402
 from cmda_amd import ops  # noqa: E402
 from cmda_amd.registry import build_segmentor  # noqa: E402
-from conftest import Target, assert_close  # noqa: E402
+from conftest import Target, assert_close, check_ge, check_le  # noqa: E402
 from oracle import fusion as ofu, head as ohd, mit as omit, segmentor as oseg, uda as ouda  # noqa: E402
 
 DIMS = [64, 128, 320, 512]
@@ -155,7 +155,7 @@ def test_mit_b5_daformer_512_vs_oracle(mode):
           f'{losses["decode.loss_seg"].item():.6f} vs {rl["decode.loss_seg"].item():.6f}, worst grad rel err {worst:.3e}, '
           f'{within:.1%} of gradient tensors within 2e-2')
     if mode == 'f32':
-        assert e_log < 1e-3, f'fp32 logits rel err {e_log}'
+        check_le('fp32 logits rel err', e_log, 1e-3, strict=True)
         assert_close(losses['decode.loss_seg'], rl['decode.loss_seg'], 1e-4, name='loss')
         # gradients: every tensor within 2e-2 once the channels whose BatchNorm + ReLU pre-activation sits within round-off of zero
         # (a flipped mask bit moves that channel's gradient) are left out of THEIR layer's comparison -- no blanket 0.2 bound
@@ -163,11 +163,11 @@ def test_mit_b5_daformer_512_vs_oracle(mode):
         nsus = sum(len(v) for v in probe.suspect.values())
         print(f'[{mode}] {probe.total} pre-activations within round-off of zero in {nsus} (layer, channel) pairs; worst masked gradient errors: '
               + '; '.join(f'{n} {m:.2e} (raw {r:.2e}, {k} channels out)' for m, r, n, k in me[:6]))
-        assert me[0][0] < 2e-2, me[:6]
+        check_le('worst masked gradient rel err', me[0][0], 2e-2, strict=True)
         assert nsus < 0.25 * sum(m.num_features for m in ref.decode_head.modules() if isinstance(m, nn.BatchNorm2d)), 'probe masks too much'
     else:
-        assert e_log < 6e-2, f'bf16 logits rel err {e_log}'
-        assert agree > 0.97
+        check_le('bf16 logits rel err', e_log, 6e-2, strict=True)
+        check_ge('bf16 argmax agreement', agree, 0.97, strict=True)
         assert_close(losses['decode.loss_seg'], rl['decode.loss_seg'], 2e-2, name='loss')
     rt.set_compute_dtype(torch.float32)
 
@@ -208,11 +208,12 @@ def test_fusion_student_512_vs_oracle(mode):
     print(f'[{mode}] 512x512 fusion student: logits rel err {errs}, loss {losses["decode.loss_seg"].item():.6f} vs '
           f'{rl["decode.loss_seg"].item():.6f}, worst grad rel err {worst:.3e}, {within:.1%} of gradient tensors within 2e-2')
     if mode == 'f32':
-        assert max(errs.values()) < 1e-3, errs
+        check_le('fp32 logits rel err (worst branch)', max(errs.values()), 1e-3, strict=True)
         assert_close(losses['decode.loss_seg'], rl['decode.loss_seg'], 1e-4, name='loss')
-        assert within > 0.97 and worst < 0.2
+        check_ge('fraction of gradient tensors within 2e-2', within, 0.97, strict=True)
+        check_le('worst gradient rel err', worst, 0.2, strict=True)
     else:
-        assert max(errs.values()) < 6e-2, errs
+        check_le('bf16 logits rel err (worst branch)', max(errs.values()), 6e-2, strict=True)
         assert_close(losses['decode.loss_seg'], rl['decode.loss_seg'], 2e-2, name='loss')
     rt.set_compute_dtype(torch.float32)
 
@@ -297,9 +298,11 @@ def test_stochastic_paths_with_injected_masks(tgt, mode):
     med, p90, worst = errs[len(errs) // 2], errs[int(len(errs) * 0.9)], errs[-1]
     print(f'[{mode}] injected masks: gradient rel err median {med:.2e}, 90th percentile {p90:.2e}, worst {worst:.2e}')
     if mode == 'f32':
-        assert p90 < 2e-2 and worst < 0.2, (med, p90, worst)
+        check_le('gradient rel err 90th pct', p90, 2e-2, strict=True)
+        check_le('gradient rel err worst', worst, 0.2, strict=True)
     else:   # bf16 activations: bounded in the bulk (tensors with tiny gradients carry large relative max-norm errors)
-        assert med < 0.1 and p90 < 0.5, (med, p90, worst)
+        check_le('bf16 gradient rel err median', med, 0.1, strict=True)
+        check_le('bf16 gradient rel err 90th pct', p90, 0.5, strict=True)
     rt.set_compute_dtype(torch.float32)
 
 
@@ -362,12 +365,16 @@ def test_fusion_simple_test_440x640_vs_oracle():
         agree = float((pred == want_pred).mean())
         m = metrics.mean_iou([torch.from_numpy(pred)], [torch.from_numpy(gt)], 19, 255)['mIoU'].item()
         print(f'[{dt}] 440x640 fusion simple_test: logits rel err {e:.3e}, label agreement {agree:.5f}, mIoU {m:.5f} vs {m_ref:.5f}')
-        assert pred.shape == (440, 640) and e < tol and agree >= agree_min and abs(m - m_ref) <= miou_tol
+        assert pred.shape == (440, 640)
+        check_le(f'{dt} logits rel err', e, tol, strict=True)
+        check_ge(f'{dt} label agreement', agree, agree_min)
+        check_le(f'{dt} mIoU abs err', abs(m - m_ref), miou_tol)
     # rescale to a different ori_shape (a test pipeline that resized the image): the second bilinear resize of :926-934
     meta2 = dict(ori_shape=(480, 700, 3), flip=True, flip_direction='horizontal')
     pred2 = model.simple_test(True, warp_image=tgt.to(img), events_vg=tgt.to(ev), img_metas=meta2)[0]
     want2 = torch.softmax(ohd.resize(want, (480, 700)), 1).flip(dims=(3,)).argmax(1)[0].numpy()
-    assert pred2.shape == (480, 700) and float((pred2 == want2).mean()) > 0.9995
+    assert pred2.shape == (480, 700)
+    check_ge('rescaled + flipped label agreement', float((pred2 == want2).mean()), 0.9995, strict=True)
 
 
 @pytest.mark.gpu

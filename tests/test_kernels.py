@@ -4,7 +4,7 @@ import torch
 import torch.nn.functional as F
 
 from cmda_amd import ops
-from conftest import assert_close
+from conftest import assert_close, check_le
 
 DT = [(torch.float32, 3e-5), (torch.bfloat16, 1.6e-2)]
 
@@ -398,7 +398,7 @@ def test_gemm_fp32_residual_epilogue(tgt, M, N, K):
     ops.gemm(ops.plain_view(ad, M, K), ops.plain_view(wd, N, K), out, M, N, K, dtype=1, bias=tgt.to(bias), res=tgt.to(res),
              rowscale=tgt.to(sc), rows_per_scale=rps)
     err = (out.cpu() - ref).abs().max().item()
-    assert err < 2e-3, f'fp32 residual epilogue: max abs err {err:.3e}'
+    check_le('fp32 residual epilogue: max abs err', err, 2e-3, strict=True)
 
 
 def test_conv_co1(tgt):

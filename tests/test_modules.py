@@ -14,7 +14,7 @@ from weights import sample_grad, seeded_fill, seeded_randn  # noqa: E402
 
 import cmda_amd.runtime as rt  # noqa: E402
 from cmda_amd import backbones as bb  # noqa: E402
-from conftest import assert_close  # noqa: E402
+from conftest import assert_close, check_ge, check_le  # noqa: E402
 
 
 def gold(name):
@@ -291,9 +291,9 @@ def test_eval_path_440x640_matches_oracle():
             rt.set_compute_dtype(torch.float32)
         assert got.shape == want.shape == (1, 19, 440, 640)
         err = (got - want).abs().max().item() / want.abs().max().item()
-        assert err < tol, f'{dt}: logits relative error {err}'
+        check_le(f'{dt}: logits relative error', err, tol, strict=True)
         agree = float((torch.from_numpy(pred) == want.argmax(1)[0]).float().mean())
-        assert agree >= agree_min, f'{dt}: argmax agreement {agree}'
+        check_ge(f'{dt}: argmax agreement', agree, agree_min)
         r = metrics.mean_iou([torch.from_numpy(pred).to(dev)], [want.argmax(1)[0].to(dev)], 19, 255)
         assert r['aAcc'].item() >= agree_min and r['IoU'].device.type == 'cuda'
 
