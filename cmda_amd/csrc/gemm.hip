@@ -137,7 +137,7 @@ extern "C" int cmda_gemm(const cmda_gemm_params_t* pp, void* stream) {
   if (p.c_patch_ow > 0 && (p.atomic || p.res || p.batch != 1 || p.batch2 != 1 || p.c_patch_kh <= 0 || p.c_patch_kwci <= 0 ||
                            p.N != p.c_patch_kh * p.c_patch_kwci || p.M % p.c_patch_ow != 0 || (p.c_patch_kwci & 3)))
     return CMDA_ERR_UNSUPPORTED;
-  if (p.dtype == CMDA_F32) return launch_dtype<float>(p, stream);
+  if (p.dtype == CMDA_F32 || p.dtype == CMDA_F32X3) return launch_dtype<float>(p, stream);   // (fp32 storage: same tile heuristics)
   if (p.dtype == CMDA_BF16) return launch_dtype<bf16_t>(p, stream);
   return CMDA_ERR_DTYPE;
 }

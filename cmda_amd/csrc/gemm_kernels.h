@@ -20,6 +20,7 @@
 // instantiations compile in parallel; every unit keeps its own copies of the anonymous-namespace symbols)
 #pragma once
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 #include "../../include/cmda_hip.h"
 
@@ -1025,6 +1026,7 @@ int cmda_gemm_wg_grouped_(const cmda_gemm_params_t* tab, const void* blk, int nb
 int cmda_gemm_wg_(const cmda_gemm_params_t& p, void* stream);             // gemm_wg.hip: 256x256 weight-gradient kernel (32x32x16 MFMA, atomics)
 int cmda_gemm_pp_(const cmda_gemm_params_t& p, void* stream);             // gemm_pp.hip: 256x256 ping-pong kernel (32x32x16 MFMA)
 int cmda_gemm_reg_(const cmda_gemm_params_t& p, int tile, void* stream);  // gemm_reg.hip: register-staged kernels, dispatch
+int cmda_gemm_x3_(const cmda_gemm_params_t& p, int tile, void* stream);   // gemm_x3.hip: fp32 storage, split-bf16 (bf16 x 3) MFMA
 // gemm_reg_{f32,bf16}_t{0,1,2}.hip: one (dtype, tile) each -- these are the slow units to compile (~50 s apiece)
 int cmda_gemm_reg_f32_t0_(const cmda_gemm_params_t& p, void* stream);
 int cmda_gemm_reg_f32_t1_(const cmda_gemm_params_t& p, void* stream);

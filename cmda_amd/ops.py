@@ -70,7 +70,7 @@ def gemm(A, B, out, M, N, K, *, a_kstrided=False, b_kstrided=False, ldc=None, ba
     p.bias = bias.data_ptr() if bias is not None else None
     p.act = ACT[act]
     p.res = res.data_ptr() if res is not None else None
-    p.res_f32 = int(res is not None and res.dtype == torch.float32 and dtype != 0)   # fp32 residual stream of the bf16 mode
+    p.res_f32 = int(res is not None and res.dtype == torch.float32 and dtype == 1)   # fp32 residual stream of the bf16 mode
     p.ldres = (N if ldres is None else ldres)
     p.res_batch_stride, p.res_batch2_stride = res_batch_stride, res_batch2_stride
     p.rowscale = rowscale.data_ptr() if rowscale is not None else None
@@ -99,7 +99,7 @@ def gemm(A, B, out, M, N, K, *, a_kstrided=False, b_kstrided=False, ldc=None, ba
         # commutative accumulation may be deferred
         assert atomic and beta == 0.0, 'ops.gemm(defer=True) is for atomic accumulation only'
     if defer and _LN_DEFER['depth'] > 0 and GEMM_DEFER:
-        es = 4 if dtype == 0 else 2
+        es = 2 if dtype == 1 else 4
         nb = batch * batch2
         _GD['queues'].setdefault(LN_LANE, []).append((p, (out, colsum) + tuple(keep), 2.0 * M * N * K * nb,
                                                       (M * K + N * K) * nb * es + 2 * M * N * nb * 4))
@@ -109,7 +109,7 @@ def gemm(A, B, out, M, N, K, *, a_kstrided=False, b_kstrided=False, ldc=None, ba
         e0.record()
         call('cmda_gemm', ctypes.byref(p), stream_of(out))
         e1.record()
-        es = 4 if dtype == 0 else 2
+        es = 2 if dtype == 1 else 4
         nb = batch * batch2
 
         def _unique(v):  # bytes of the tensor behind an operand view (an im2col view re-reads, the tensor is counted once)

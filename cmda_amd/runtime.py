@@ -51,8 +51,24 @@ def stream_dtype():
     return torch.float32 if residual_fp32() else _state['dtype']
 
 
+def set_gemm_x3(flag):
+    """fp32 mode only: run every GEMM / implicit-GEMM convolution on SPLIT-bf16 operands (cmda_gemm_params_t.dtype =
+    CMDA_F32X3: x = hi + lo, three bf16 MFMAs per k-step, fp32 accumulate, ~1e-5 relative -- csrc/gemm_x3.hip) instead of the
+    exact-fp32 matrix instruction, which runs at 1/16 of the bf16 rate.  Storage, statistics and every other kernel stay fp32: the
+    tolerance-meeting mode (logits within 1e-3 of the reference) at a fraction of the exact mode's cost.  Off by default: the exact
+    mode is what the kernel-level parity tests pin."""
+    _state['x3'] = bool(flag)
+
+
+def gemm_x3():
+    return bool(_state.get('x3')) and _state['dtype'] == torch.float32
+
+
 def tag():
-    return 0 if _state['dtype'] == torch.float32 else 1
+    """cmda_gemm_params_t.dtype of the GEMMs: 0 exact fp32, 1 bf16, 2 fp32 storage with split-bf16 MFMA"""
+    if _state['dtype'] == torch.float32:
+        return 2 if _state.get('x3') else 0
+    return 1
 
 
 def invalidate():

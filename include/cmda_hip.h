@@ -29,6 +29,10 @@ extern "C" {
 
 #define CMDA_F32 0
 #define CMDA_BF16 1
+/* cmda_gemm_params_t.dtype only: fp32 storage like CMDA_F32, but the contraction runs on SPLIT-bf16 operands (x = hi + lo, three bf16
+ * MFMAs per k-step with fp32 accumulate: ~16 mantissa bits per product, ~1e-5 relative) instead of the exact-fp32 matrix
+ * instruction, which runs at 1/16 of the bf16 rate -- the parity mode that meets the 1e-3 logit tolerance at 3/16 of that cost */
+#define CMDA_F32X3 2
 
 int cmda_abi_version(void);
 

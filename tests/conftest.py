@@ -108,6 +108,19 @@ def tgt(request):
     _lib._unbind_for_tests()
 
 
+def assert_close_robust(got, ref, p999_rtol, max_rtol, name=''):
+    """for quantities whose MAX depends on a summation order (fp32 atomics in the statistics kernels): gate the 99.9th percentile of
+    |got - ref| (relative to max |ref|) and keep only a loose hard bound on the single worst element"""
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, f'{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}'
+    d = (got - ref).abs().flatten()
+    scale = max(ref.abs().max().item(), 1e-30)
+    k = max(1, int(0.999 * d.numel()))
+    check_le(name + ' [99.9th percentile, rel]', d.kthvalue(k).values.item() / scale, p999_rtol)
+    check_le(name + ' [max, rel]', d.max().item() / scale, max_rtol)
+
+
 def assert_close(got, ref, rtol, atol=0.0, name='', outlier_frac=0.0, outlier_rtol=0.05):
     """max-norm check.  `outlier_frac` > 0 tolerates that fraction of elements up to `outlier_rtol`: a train-mode
     BN+ReLU pre-activation within 1e-7 of zero flips its mask under a different fp32 summation order (atomics), which

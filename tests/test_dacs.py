@@ -23,10 +23,16 @@ from weights import seeded_fill, seeded_randn  # noqa: E402
 import cmda_amd  # noqa: E402,F401
 import cmda_amd.runtime as rt  # noqa: E402
 from cmda_amd.registry import build_train_model  # noqa: E402
-from conftest import assert_close, check_ge, check_le  # noqa: E402
+from conftest import assert_close, assert_close_robust, check_ge, check_le  # noqa: E402
 from oracle import cyclegan as ocg, dacs_iter, fusion as ofu, head as ohd, mit as omit, segmentor as oseg  # noqa: E402
 
 DEPTHS = [1, 1, 1, 1]
+# bf16 generator output against the fp32 oracle, of its range (~1): operand rounding over 24 conv + InstanceNorm layers -- the CPU
+# model of the rounding points (tools/dbg/gen_bf16_model.py) gives 3.9e-2 max / 2.9e-2 at the 99.9th percentile at 128 x 128 for
+# fp32 conv outputs + fp32 residual stream (round 3, bf16 everywhere: 5.1e-2 / 3.8e-2); only split-bf16 operands remove it (7e-5).
+# The max over 32 k pixels depends on the atomic summation order of the InstanceNorm statistics, so the gate is the 99.9th
+# percentile with a loose hard max (VERDICT r03 #1b).
+GEN_BF16_P999, GEN_BF16_MAX = 8e-2, 0.2
 SMALL = dict(dims=[32, 64, 160, 256], ch=64)   # reduced widths (head dim 32) keep the emulator run short
 FULLW = dict(dims=[64, 128, 320, 512], ch=256)  # MiT-B5 widths: head dim 64, the bench's kernel selection
 ISR = dict(val_range=[0.01, 1.01], _threshold=0.005, _clip_range=0.1, shift_pixel=1)
@@ -136,10 +142,15 @@ def run_case(tgt, dims, ch, dtype, B=2, H=64, W=64, iters=1, graph=False, shift_
     return dacs, ema, outs
 
 
-def check_iteration(out, exact, tol_loss, tol_grad, label_agree=0.999):
+def check_iteration(out, exact, tol_loss, tol_grad, label_agree=0.999, tol_gen=None):
+    """tol_gen: bound on the generator output (of its range ~1); default 2e-4 in the exact-fp32 mode (9e-6 measured), 5e-4 is used for
+    the split-bf16 mode (7e-5 measured: 24 convolution + InstanceNorm layers)"""
     log_vars, mix, grads, o, ref_grads = out
     if o['day_events'] is not None:
-        assert_close(mix['day_events'], o['day_events'], 2e-4 if exact else 6e-2, name='generator output (day events)')
+        if exact:
+            assert_close(mix['day_events'], o['day_events'], tol_gen or 2e-4, name='generator output (day events)')
+        else:
+            assert_close_robust(mix['day_events'], o['day_events'], GEN_BF16_P999, GEN_BF16_MAX, name='generator output (day events)')
     agree = (mix['pseudo_label'].cpu() == o['pseudo_label']).float().mean().item()
     check_ge('pseudo-label agreement', agree, label_agree, strict=True)
     if exact:
@@ -169,6 +180,17 @@ def test_dacs_iteration_matches_oracle(tgt):
         assert_close(p.data, q.data, 0, name='ema ' + n1)
 
 
+def test_dacs_iteration_x3_matches_oracle(tgt):
+    """the tolerance-meeting mode: fp32 storage, every GEMM on split-bf16 operands (runtime.set_gemm_x3, csrc/gemm_x3.hip) -- the
+    fp32 bounds of test_dacs_iteration_matches_oracle hold unchanged"""
+    rt.set_gemm_x3(True)
+    try:
+        dacs, ema, outs = run_case(tgt, SMALL['dims'], SMALL['ch'], torch.float32)
+        check_iteration(outs[0], True, 1e-4, 0.1, tol_gen=5e-4)   # (exact fp32: worst gradient 6e-3, generator 9e-6; split-bf16: 2e-2, 7e-5)
+    finally:
+        rt.set_gemm_x3(False)
+
+
 def test_dacs_iteration_second_config_matches_oracle(tgt):
     """configs/fusion/cs2dz_image+raw-isr_b5.py: AttentionFusion (concat) instead of the averaging fusion, no
     events and no generator -- the event encoder sees the ISR --, three decoder branches, the pseudo-weight's top / bottom rows
@@ -184,7 +206,7 @@ def test_dacs_iteration_second_config_matches_oracle(tgt):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+@pytest.mark.parametrize('mode', ['f32', 'x3', 'bf16'])
 def test_dacs_iteration_full_width_gpu(mode):
     """MiT-B5 widths (head dim 64): in bf16 this is the bench's kernel selection (fused attention, bf16 MFMA GEMMs)"""
     from conftest import Target
@@ -193,13 +215,17 @@ def test_dacs_iteration_full_width_gpu(mode):
     if not torch.cuda.is_available():
         pytest.skip('no GPU on this machine')
     tgt = Target('gpu')
-    dt = torch.float32 if mode == 'f32' else torch.bfloat16
-    dacs, ema, outs = run_case(tgt, FULLW['dims'], FULLW['ch'], dt, H=128, W=128)
-    if mode == 'f32':
-        check_iteration(outs[0], True, 1e-4, 5e-2)
-    else:
-        check_iteration(outs[0], False, 2e-2, 0.35, label_agree=0.97)
-    rt.set_compute_dtype(torch.float32)
+    dt = torch.bfloat16 if mode == 'bf16' else torch.float32
+    rt.set_gemm_x3(mode == 'x3')
+    try:
+        dacs, ema, outs = run_case(tgt, FULLW['dims'], FULLW['ch'], dt, H=128, W=128)
+        if mode != 'bf16':
+            check_iteration(outs[0], True, 1e-4, 5e-2 if mode == 'f32' else 0.1, tol_gen=None if mode == 'f32' else 5e-4)
+        else:
+            check_iteration(outs[0], False, 2e-2, 0.35, label_agree=0.97)
+    finally:
+        rt.set_gemm_x3(False)
+        rt.set_compute_dtype(torch.float32)
 
 
 @pytest.mark.gpu
@@ -231,7 +257,7 @@ def _upsampled(logits_nhwc, H, W):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+@pytest.mark.parametrize('mode', ['f32', 'x3', 'bf16'])
 def test_dacs_iteration_full_depth_512_gpu(mode):
     """THE BENCH'S CONFIGURATION against the oracle (VERDICT r02 #4a): full-depth MiT-B5 encoders (3, 6, 40, 3), 512 x 512, 2 source
     + 2 target samples, generator + colour jitter + blur + random ISR direction ON, DropPath / Dropout2d OFF (the draws that remain
@@ -247,9 +273,10 @@ def test_dacs_iteration_full_depth_512_gpu(mode):
     tgt = Target('gpu')
     depths = [3, 6, 40, 3]
     B, S = int(os.environ.get('CMDA_TEST_FULL_B', 2)), 512
-    dt = torch.float32 if mode == 'f32' else torch.bfloat16
+    dt = torch.bfloat16 if mode == 'bf16' else torch.float32
     torch.set_num_threads(min(32, os.cpu_count() or 8))
     rt.set_compute_dtype(dt)
+    rt.set_gemm_x3(mode == 'x3')   # fp32 storage, split-bf16 GEMMs: the fp32 bounds below hold unchanged
     try:
         dacs = build_train_model(make_cfg(FULLW['dims'], FULLW['ch'], depths=depths))
         seeded_fill(dacs.model, 7)
@@ -288,7 +315,7 @@ def test_dacs_iteration_full_depth_512_gpu(mode):
         print(f'[{mode}] full-depth 512x512 B={B}+{B}: oracle {t_oracle:.0f} s; teacher logits rel err {logit_err:.2e}; pseudo-label '
               f'agreement {agree:.6f}; mixed-label agreement {lbl_same:.6f}; source loss {ls:.6f} vs {rs:.6f}; mixed loss {lm:.6f} vs '
               f'{rm:.6f}; gradient rel err median {errs[len(errs) // 2]:.2e}, 90th pct {errs[int(len(errs) * 0.9)]:.2e}, worst {errs[-1]:.2e}')
-        if mode == 'f32':
+        if mode != 'bf16':
             check_le('teacher logits rel err', logit_err, 1e-3, strict=True)
             check_ge('pseudo-label agreement', agree, 0.9999)
             check_ge('mixed-label agreement', lbl_same, 0.9999)
@@ -302,6 +329,7 @@ def test_dacs_iteration_full_depth_512_gpu(mode):
             check_le('bf16 source loss abs err', abs(ls - rs), 2e-2 * max(1.0, abs(rs)), strict=True)
             check_le('bf16 mixed loss abs err', abs(lm - rm), 0.1 * max(1.0, abs(rm)), strict=True)
     finally:
+        rt.set_gemm_x3(False)
         rt.set_compute_dtype(torch.float32)
 
 

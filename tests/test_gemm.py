@@ -6,7 +6,8 @@ import torch.nn.functional as F
 from cmda_amd import ops
 from conftest import assert_close
 
-DT = [(torch.float32, 0, 2e-5), (torch.bfloat16, 1, 1.5e-2)]
+# tag 2 = CMDA_F32X3: fp32 storage, split-bf16 (bf16 x 3) MFMA -- ~16 mantissa bits per product (gemm_x3.hip)
+DT = [(torch.float32, 0, 2e-5), (torch.bfloat16, 1, 1.5e-2), (torch.float32, 2, 1e-4)]
 
 
 @pytest.mark.parametrize('dt,tag,tol', DT)
@@ -35,7 +36,7 @@ def test_gemm_layouts(tgt, dt, tag, tol, M, N, K):
     out = torch.zeros(M, N, dtype=torch.float32, device=tgt.device)
     ops.gemm(ops.plain_view(atd, K, M), ops.plain_view(btd, K, N), out, M, N, K, a_kstrided=True, b_kstrided=True,
              dtype=tag, atomic=True, splits=3)
-    assert_close(out, ref, 1e-5, name='TN split-K atomic')
+    assert_close(out, ref, 1e-5 if tag != 2 else tol, name='TN split-K atomic')
     out = torch.ones(M, N, dtype=dt, device=tgt.device)
     ops.gemm(ops.plain_view(atd, K, M), ops.plain_view(bd, N, K), out, M, N, K, a_kstrided=True, dtype=tag, beta=1.0)
     assert_close(out, ref + 1, tol, name='TT-ish (A k-strided, B k-contig) beta=1')
@@ -91,7 +92,7 @@ def test_conv_implicit_gemm(tgt, dt, tag, tol, Bc, H, W, Ci, Co, KH, st, pd, dl)
     dW = torch.zeros(Co, K, device=tgt.device)
     ops.gemm(ops.plain_view(dyd, Bc * OH * OW, Co), ops.conv_view(xd, Bc, H, W, Ci, KH, KH, st, pd, dl), dW, Co, K,
              Bc * OH * OW, a_kstrided=True, b_kstrided=True, dtype=tag, atomic=True, splits=2)
-    assert_close(dW.view(Co, KH, KH, Ci).permute(0, 3, 1, 2), wr.grad, 1e-5, name='conv wgrad')
+    assert_close(dW.view(Co, KH, KH, Ci).permute(0, 3, 1, 2), wr.grad, 1e-5 if tag != 2 else tol, name='conv wgrad')
     if st == 1:
         wd = tgt.to(w.flip(2, 3).permute(1, 2, 3, 0).contiguous().view(Ci, -1))
         dx = torch.empty(Bc, H, W, Ci, dtype=dt, device=tgt.device)
