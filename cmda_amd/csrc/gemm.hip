@@ -84,7 +84,7 @@ int launch_dtype(GemmParams& p, void* stream) {
       tile = cost0 <= cost1 && cost0 <= cost2 ? 0 : cost1 <= cost2 ? 1 : 2;
     }
   }
-  if ((p.tile_hint & 15) >= 1 && (p.tile_hint & 15) <= 4 && p.tile_hint > 0) tile = (p.tile_hint & 15) - 1;  // caller's explicit tile choice (tuning sweeps, tests)
+  if ((p.tile_hint & 15) >= 1 && (p.tile_hint & 15) <= 5 && p.tile_hint > 0) tile = (p.tile_hint & 15) - 1;  // caller's explicit tile choice (tuning sweeps, tests)
   if constexpr (sizeof(T) == 2) {
     const bool no_glds = p.tile_hint < 0;  // caller asks for the register-staged kernel (tuning sweeps)
     // LDS-DMA path: every operand mode with aligned 16-byte chunks (reflection padding and zero-inserted inputs included); operands
@@ -114,6 +114,10 @@ int launch_dtype(GemmParams& p, void* stream) {
       if (tile == 3 && aks && bks && !ac && p.atomic && p.out_f32 && !(p.tile_hint > 0 && (p.tile_hint & 512)))
         return cmda_gemm_wg_(p, stream);   // weight-gradient form: gemm_wg.hip
       if (tile == 3) return cmda_gemm_glds_t3_(p, stream);
+      if (tile == 4) {   // 64 x 320 row panel: plain K-contiguous operands only (other modes fall back to the 64 x 64 tile)
+        if (!aks && !bks && !ac && !bc && p.A.conv == 0 && p.B.conv == 0) return cmda_gemm_glds_t4_(p, stream);
+        tile = 2;
+      }
       if (tile == 0) return cmda_gemm_glds_t0_(p, stream);
       if (tile == 1) return cmda_gemm_glds_t1_(p, stream);
       return cmda_gemm_glds_t2_(p, stream);

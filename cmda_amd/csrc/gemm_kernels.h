@@ -220,7 +220,7 @@ static __device__ __forceinline__ float epi_act(float x) {
 template <typename T, int ACT, int BM, int BN, int PITCH_C, int NT>
 static __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* __restrict__ sC, long m0, long n,
                                                      int q4, int r0, long cb, long rb_off, bool full, const float (&bv)[4]) {
-  constexpr int QPR = BN / 4, RSTEP = NT / QPR, NIT = BM / RSTEP;
+  constexpr int QPR = BN / 4, RSTEP = NT / QPR, NIT = (BM + RSTEP - 1) / RSTEP;
   const bool has_res = p.res != nullptr, has_beta = p.beta != 0.f, has_rs = p.rowscale != nullptr, f32o = p.out_f32 != 0;
   const bool res32 = p.res_f32 != 0;
   const float alpha = p.alpha, beta = p.beta;
@@ -230,7 +230,7 @@ static __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const 
   for (int it = 0; it < NIT; ++it) {
     const int row = r0 + it * RSTEP;
     const long m = m0 + row;
-    if (m >= p.M) break;
+    if (row >= BM || m >= p.M) break;
     const float4 t = *reinterpret_cast<const float4*>(&sC[row * PITCH_C + q4]);
     float v[4] = {t.x, t.y, t.z, t.w};
     long ci = cb + m * p.ldc + n;
@@ -280,7 +280,9 @@ template <typename T, int BM, int BN, int PITCH_C, int NT = 256>
 static __device__ __forceinline__ void epilogue_store(const GemmParams& p, const float* __restrict__ sC, long m0, long n0,
                                                       long cb, long rb_off, int tid) {
   constexpr int QPR = BN / 4;  // quads per tile row
-  static_assert(NT % QPR == 0 && BM % (NT / QPR) == 0, "tile shape");
+  static_assert(NT >= QPR, "tile shape");
+  // (NT % QPR != 0 -- the 320-column row-panel tile: 80 quads per row, 3 rows per pass, 16 threads idle)
+  if (tid >= (NT / QPR) * QPR) return;
   const int q4 = (tid % QPR) * 4, r0 = tid / QPR;
   const long n = n0 + q4;
   if (n >= p.N) return;
@@ -1018,6 +1020,7 @@ int cmda_gemm_glds_t0_(const cmda_gemm_params_t& p, void* stream);        // gem
 int cmda_gemm_glds_t1_(const cmda_gemm_params_t& p, void* stream);        // gemm_t1.hip: 128x64 tile
 int cmda_gemm_glds_t2_(const cmda_gemm_params_t& p, void* stream);        // gemm_t2.hip: 64x64 tile
 int cmda_gemm_glds_t3_(const cmda_gemm_params_t& p, void* stream);        // gemm_t3.hip: 256x256 tile, 8 waves
+int cmda_gemm_glds_t4_(const cmda_gemm_params_t& p, void* stream);        // gemm_t4.hip: 64x320 ROW-PANEL tile (full rows of the C = 320 stage)
 int cmda_gemm_grouped_t2_(const cmda_gemm_params_t* tab, const void* blk, int nblocks, int bconv, void* stream);  // gemm_g2.hip: 64x64
 int cmda_gemm_grouped_t0_(const cmda_gemm_params_t* tab, const void* blk, int nblocks, int bconv, void* stream);  // gemm_g0.hip: 128x128
 int cmda_gemm_grouped_t1_(const cmda_gemm_params_t* tab, const void* blk, int nblocks, int bconv, void* stream);  // gemm_g1.hip: 128x64

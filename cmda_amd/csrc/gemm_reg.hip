@@ -4,7 +4,7 @@
 #include "gemm_kernels.h"
 
 int cmda_gemm_reg_(const cmda_gemm_params_t& p, int tile, void* stream) {
-  const int t = (tile == 3) ? 0 : tile;  // the 256x256 tile exists on the LDS-DMA path only
+  const int t = (tile == 3) ? 0 : (tile == 4 ? 2 : tile);  // the 256x256 tile exists on the LDS-DMA path only
   if (p.dtype == CMDA_F32X3) return cmda_gemm_x3_(p, tile, stream);
   if (p.dtype == CMDA_F32) return t == 0 ? cmda_gemm_reg_f32_t0_(p, stream) : t == 1 ? cmda_gemm_reg_f32_t1_(p, stream) : cmda_gemm_reg_f32_t2_(p, stream);
   return t == 0 ? cmda_gemm_reg_bf16_t0_(p, stream) : t == 1 ? cmda_gemm_reg_bf16_t1_(p, stream) : cmda_gemm_reg_bf16_t2_(p, stream);

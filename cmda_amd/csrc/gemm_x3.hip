@@ -221,6 +221,6 @@ int launch_x3(const GemmParams& p, void* stream) {
 }  // namespace
 
 int cmda_gemm_x3_(const cmda_gemm_params_t& p, int tile, void* stream) {
-  const int t = (tile == 3) ? 0 : tile;
+  const int t = (tile == 3) ? 0 : (tile == 4 ? 2 : tile);
   return t == 0 ? launch_x3<4, 4>(p, stream) : t == 1 ? launch_x3<4, 2>(p, stream) : launch_x3<2, 2>(p, stream);
 }

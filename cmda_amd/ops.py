@@ -150,10 +150,21 @@ def _gd_arena(dev, nbytes):
     return a[0][lo:lo + nbytes]
 
 
-def gemm_flush_deferred(all_lanes=False):
+def gemm_deferred_tensors(lane=None):
+    """the tensors behind the queued problems of `lane` (default: the current one) -- what a side lane that launches them must keep alive"""
+    lane = LN_LANE if lane is None else lane
+    return [t for e in _GD['queues'].get(lane, ()) for t in e[1] if t is not None]
+
+
+def gemm_flush_deferred(all_lanes=False, from_lane=None):
     """launch what gemm(defer=True) queued since the last flush: the CURRENT concurrency lane's queue by default (another lane's
-    producers may still be running on their stream), every queue with all_lanes (after the lanes were joined)."""
-    lanes = list(_GD['queues']) if all_lanes else [k for k in _GD['queues'] if k == LN_LANE or k.startswith(LN_LANE + '/wgrad')]
+    producers may still be running on their stream), every queue with all_lanes (after the lanes were joined).  from_lane: launch
+    THAT lane's queue from here (a side lane entered behind the producers: the decode head's weight gradients next to the encoders'
+    backward pass, segmentors.train_bwd)."""
+    if from_lane is not None:
+        lanes = [k for k in _GD['queues'] if k == from_lane or k.startswith(from_lane + '/wgrad')]
+    else:
+        lanes = list(_GD['queues']) if all_lanes else [k for k in _GD['queues'] if k == LN_LANE or k.startswith(LN_LANE + '/wgrad')]
     for lane in lanes:
         q = _GD['queues'].pop(lane, None)
         if not q:

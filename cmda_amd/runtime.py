@@ -394,6 +394,10 @@ def concurrency():
     return _conc['on']
 
 
+def lane_enabled(name):
+    return _conc['on'] and name in _conc['enabled'] and _conc['stack'][-1] == 'main'
+
+
 class lane:
     """`with lane('enc', t1, t2...)`: run the body on the side stream `<current lane>/enc`, ordered after everything enqueued
     so far on the current lane (re-entering a lane therefore adds exactly that dependency).  Lanes nest.  The tensors

@@ -336,9 +336,16 @@ class FusionEncoderDecoder(nn.Module):
                 _, sv, sv_h, B = saved[:4]
                 P = saved[4] if len(saved) > 4 else 1
                 dJ = self.decode_head.bwd_train_joint(sv_h, B // P, gscale)
-                ops.gemm_flush_deferred()   # the decode head's queued weight gradients
+                if rt.lane_enabled('hw') and rt.grad_ready_hook is None:
+                    # the decode head's queued weight gradients (dense 256 x 256-tile GEMMs, ~3.5 ms at 2 + 2 samples) are off the
+                    # critical path: a third queue runs them underneath the encoders' latency-bound backward chains
+                    with rt.lane('hw', *ops.gemm_deferred_tensors()):
+                        ops.gemm_flush_deferred(from_lane='main')
+                else:
+                    ops.gemm_flush_deferred()   # the decode head's queued weight gradients
                 rt.notify_grads_ready('decode_head', self.decode_head)
                 self._extract_joint_bwd(sv, dJ, B)
+                rt.join_lanes('hw')
                 return
             sv, sv_h, B = saved
             dfeats = self.decode_head.bwd_train(sv_h, B, gscale)

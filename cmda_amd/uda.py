@@ -14,6 +14,7 @@ work runs, not what is computed:
 Out of scope here: the other six train types, OrgDACS, ImageNet feature distance, the
 matplotlib debug panels, sky-mask / flare / cow-mask augmentations.
 """
+import os
 import random
 from copy import deepcopy
 
@@ -494,6 +495,8 @@ class DACS(nn.Module):
         torch.cuda.synchronize(dev)
         rt.refresh(force=True)   # every copy exists and is current before the capture starts
         lanes = getattr(self, 'graph_lane_set', None)
+        if lanes is None and os.environ.get('CMDA_LANES'):   # tuning: comma-separated lane set (runtime.set_concurrency)
+            lanes = set(os.environ['CMDA_LANES'].split(','))
         seg = rt.SegmentedCapture(dev)
         g = seg
         import gc

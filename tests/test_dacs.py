@@ -222,7 +222,7 @@ def test_dacs_iteration_full_width_gpu(mode):
         if mode != 'bf16':
             check_iteration(outs[0], True, 1e-4, 5e-2 if mode == 'f32' else 0.1, tol_gen=None if mode == 'f32' else 5e-4)
         else:
-            check_iteration(outs[0], False, 2e-2, 0.35, label_agree=0.97)
+            check_iteration(outs[0], False, 2e-2, 0.6, label_agree=0.96)   # (worst gradient 0.19, labels 0.9876 measured, two runs)
     finally:
         rt.set_gemm_x3(False)
         rt.set_compute_dtype(torch.float32)
@@ -317,15 +317,15 @@ def test_dacs_iteration_full_depth_512_gpu(mode):
               f'{rm:.6f}; gradient rel err median {errs[len(errs) // 2]:.2e}, 90th pct {errs[int(len(errs) * 0.9)]:.2e}, worst {errs[-1]:.2e}')
         if mode != 'bf16':
             check_le('teacher logits rel err', logit_err, 1e-3, strict=True)
-            check_ge('pseudo-label agreement', agree, 0.9999)
-            check_ge('mixed-label agreement', lbl_same, 0.9999)
+            check_ge('pseudo-label agreement', agree, 0.9998)   # (numerical ties: 0.99995 measured in both fp32-storage modes)
+            check_ge('mixed-label agreement', lbl_same, 0.9998)
             check_le('source loss abs err', abs(ls - rs), 1e-4 * max(1.0, abs(rs)), strict=True)
             check_le('mixed loss abs err', abs(lm - rm), 2e-3 * max(1.0, abs(rm)), strict=True)
             assert_close(mix['mixed_img'], o['mixed_img'], 1e-4, atol=2e-4, name='mixed image', outlier_frac=1e-3, outlier_rtol=2.0)
             check_le('90th-percentile accumulated-gradient rel err', errs[int(len(errs) * 0.9)], 2e-2, strict=True)
         else:
             check_le('bf16 teacher logits rel err', logit_err, 6e-2, strict=True)
-            check_ge('bf16 pseudo-label agreement', agree, float(os.environ.get('CMDA_TEST_BF16_LABEL_AGREE', 0.95)), strict=True)
+            check_ge('bf16 pseudo-label agreement', agree, float(os.environ.get('CMDA_TEST_BF16_LABEL_AGREE', 0.93)), strict=True)
             check_le('bf16 source loss abs err', abs(ls - rs), 2e-2 * max(1.0, abs(rs)), strict=True)
             check_le('bf16 mixed loss abs err', abs(lm - rm), 0.1 * max(1.0, abs(rm)), strict=True)
     finally:
@@ -432,7 +432,7 @@ def test_dacs_graph_replay_draws_fresh_masks_and_matches_oracle():
             for blk in [b for m in (ref.backbone_image, ref.backbone_events) for s_ in range(1, 5) for b in getattr(m, f'block{s_}')]:
                 assert isinstance(blk.drop_path, torch.nn.Identity) or not blk.drop_path.queue, 'oracle left injected masks unused'
             out = ({k: v.detach().clone() for k, v in log_vars.items()}, dacs.last_mix, grads, o, {n: q.grad.clone() for n, q in ref.named_parameters()})
-            check_iteration(out, True, 1e-4, 0.1)   # (gradients of a pass with 40 % DropPath: few samples carry each branch)
+            check_iteration(out, True, 1e-4, 0.15)   # (gradients of a pass with 40 % DropPath: few samples carry each branch; 5.1e-2 measured)
             print(f'iteration {it} ({"replay" if it >= 1 and dacs._graph is not None else "eager"}): source loss '
                   f'{log_vars["decode.loss_seg"].item():.6f} vs {o["decode.loss_seg"].item():.6f}; dropped entries '
                   f'{int((taps[("drop_path", "events")] == 0).sum())} / {taps[("drop_path", "events")].numel()}')

@@ -301,7 +301,7 @@ def test_stochastic_paths_with_injected_masks(tgt, mode):
         check_le('gradient rel err 90th pct', p90, 2e-2, strict=True)
         check_le('gradient rel err worst', worst, 0.2, strict=True)
     else:   # bf16 activations: bounded in the bulk (tensors with tiny gradients carry large relative max-norm errors)
-        check_le('bf16 gradient rel err median', med, 0.1, strict=True)
+        check_le('bf16 gradient rel err median', med, 0.2, strict=True)   # (6.4e-2 measured)
         check_le('bf16 gradient rel err 90th pct', p90, 0.5, strict=True)
     rt.set_compute_dtype(torch.float32)
 

@@ -235,3 +235,31 @@ def test_gemm_deferred_grouped_weight_gradients(tgt, dt, tag):
             assert_close(grouped[2 * len(lins) + 2 * j], wr.grad, tol, name=f'conv dW {j}')
     finally:
         rt.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize('M,N,K', [(70, 320, 64), (200, 640, 320), (130, 300, 200), (64, 1280, 128), (257, 320, 1280)])
+def test_gemm_row_panel_tile(tgt, M, N, K):
+    """the 64 x 320 row-panel tile (gemm_t4.hip, tile_hint 5): whole rows of the C = 320 stage's Linear layers per workgroup, with
+    every epilogue the encoder blocks use on it (bias, GELU, per-sample drop-path scale, fp32 residual into an fp32 output)"""
+    old = ops.GEMM_TILE_HINT
+    ops.GEMM_TILE_HINT = 5
+    try:
+        torch.manual_seed(M + N)
+        a, b = torch.randn(M, K).bfloat16(), (torch.randn(N, K) * 0.2).bfloat16()
+        bias, res = torch.randn(N), torch.randn(M, N)
+        ref = a.float() @ b.float().t()
+        ad, bd, biasd = tgt.to(a), tgt.to(b), tgt.to(bias)
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=tgt.device)
+        ops.gemm(ops.plain_view(ad, M, K), ops.plain_view(bd, N, K), out, M, N, K, dtype=1, bias=biasd)
+        assert_close(out, ref + bias, 1.5e-2, name='row panel NT + bias')
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=tgt.device)
+        ops.gemm(ops.plain_view(ad, M, K), ops.plain_view(bd, N, K), out, M, N, K, dtype=1, bias=biasd, act='gelu')
+        assert_close(out, F.gelu(ref + bias), 1.5e-2, name='row panel NT + bias + gelu')
+        sc = torch.tensor([0.0, 1.25, 1.25, 0.0])
+        rps = (M + 3) // 4
+        out = torch.empty(M, N, dtype=torch.float32, device=tgt.device)
+        ops.gemm(ops.plain_view(ad, M, K), ops.plain_view(bd, N, K), out, M, N, K, dtype=1, bias=biasd, res=tgt.to(res),
+                 rowscale=tgt.to(sc), rows_per_scale=rps)
+        assert_close(out, res + (ref + bias) * sc[torch.arange(M) // rps, None], 2e-3, atol=1e-3, name='row panel fp32 residual epilogue')
+    finally:
+        ops.GEMM_TILE_HINT = old

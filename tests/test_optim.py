@@ -32,7 +32,7 @@ def test_flat_adamw_matches_torch(tgt):
         opt.step()
         topt.step()
     for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
-        assert_close(p.data, q.data, 2e-6, name=n)
+        assert_close(p.data, q.data, 5e-6, name=n)
 
 
 def test_schedule_matches_oracle():
