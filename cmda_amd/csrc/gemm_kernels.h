@@ -537,8 +537,19 @@ __device__ unsigned long long g_stamps[256 * 8];
 // the 256-byte bank row; with (line & 7) lines r and r + 8 share one)
 // BKT: depth of a k-tile (64; 32 for K-STRIDED tiles only -- gemm_wg.hip's four half-depth stages: a K-strided stage is BKT whole lines,
 // a K-contiguous one would halve its lines to 64 bytes)
-template <bool KS, int TILE, bool CONV, int NW = 4, int SWZ = 0, int BKT = 64>
+// MODE (compile time, chosen by the host launcher from the operand views -- the state of the other modes is dead code and costs no
+// registers: the 8-wave kernels sit at 256 VGPRs per wave):
+//   0  general: src() derives every address with its range tests (ragged K, patch views, K-strided im2col, anything)
+//   1  FAST, plain operands (no im2col / patch view) whose K extent is a multiple of the k-tile: the zero block is never needed past
+//      the first decision -- the source of instruction j is a running pointer plus a constant per k-tile (0 for lanes parked on the
+//      zero block).  src() costs ~25 instructions and two branches per DMA instruction per k-tile.
+//   2  CELL-FAST, K-contiguous im2col operands whose channel count is a multiple of the k-tile (the head's 3 x 3 bottleneck over 1024
+//      channels, the generator's 256-channel convolutions): a k-tile never straddles a (kh, kw) cell, so only the first k-tile of a cell
+//      needs the tap arithmetic and the border test -- the other C / 64 - 1 advance the running pointer by 64 channels.
+template <bool KS, int TILE, bool CONV, int NW = 4, int SWZ = 0, int BKT = 64, int MODE_ = 0>
 struct DmaSrc {
+  static constexpr int MODE = MODE_;
+  static_assert(MODE == 0 || (MODE == 1 && !CONV) || (MODE == 2 && CONV && !KS), "DMA source mode");
   static constexpr int BK = BKT;
   static_assert(BKT == 64 || KS, "half-depth k-tiles: K-strided operands only");
   static constexpr int J = TILE * BKT / (512 * NW);                 // DMA instructions per wave per stage
@@ -554,8 +565,13 @@ struct DmaSrc {
   //   K-contiguous (fwd / dgrad):  (ci, kh, kw) of the chunk's first channel      K-strided (wgrad):  (b, oh, ow) of the row
   int s0[J], s1[J], s2[J];
   static constexpr bool conv = CONV;
+  const char* cur[J];     // modes 1 / 2: running source of instruction j
+  int stepb[J];           // modes 1 / 2: bytes per k-tile (0: parked on the zero block)
+  int cellk, cellpos;     // mode 2: k-tiles per (kh, kw) cell; position of the NEXT k-tile inside its cell (wave-uniform)
 
   __device__ __forceinline__ void init(const GemmView& v, const bf16_t* base, int wid, int lane, long t0, int kt0) {
+    cellk = MODE == 2 ? v.C / BK : 1;
+    cellpos = MODE == 2 ? (int)(((long)kt0 * BK % v.C) / BK) : 0;
 #pragma unroll
     for (int j = 0; j < J; ++j) {
       const int ln = (wid * J + j) * LPI + lane / CPL;              // K-contig: tile row; K-strided: k row
@@ -614,7 +630,83 @@ struct DmaSrc {
           }
         }
       }
+      if (MODE == 1) {   // running source: k-tile kt0 of this lane's (line, chunk), or the zero block (step 0)
+        if (fixed[j] >= 0 && ptr[j] != nullptr) {
+          stepb[j] = (int)((KS ? (long)BK * v.ld : (long)BK) * (long)sizeof(bf16_t));
+          cur[j] = reinterpret_cast<const char*>(ptr[j]) + (long)kt0 * stepb[j];
+        } else {
+          stepb[j] = 0;
+          cur[j] = reinterpret_cast<const char*>(g_zero16);
+        }
+      } else {
+        stepb[j] = 0;
+        cur[j] = nullptr;
+      }
     }
+  }
+
+  // cell-fast path, first k-tile issued by this block or first k-tile of a (kh, kw) cell: full address (channel offset of the
+  // k-tile inside the cell included), later k-tiles of the cell: cell_next
+  __device__ __forceinline__ const void* cell_first(const GemmView& v, const bf16_t* base, int j, int kt) {
+    const char* zero = reinterpret_cast<const char*>(g_zero16);
+    cur[j] = zero;
+    stepb[j] = 0;
+    if (fixed[j] < 0) return zero;
+    const unsigned c0 = (unsigned)(kt * BK), cell = c0 / (unsigned)v.C, ci0 = c0 - cell * (unsigned)v.C;   // wave-uniform
+    const int kh = (int)(cell / (unsigned)v.KW), kw = (int)(cell - (unsigned)kh * (unsigned)v.KW);
+    int ih = (cbc[j] >> 16) + kh * v.dil, iw = (int)(short)(cbc[j] & 0xffff) + kw * v.dil;
+    if (v.in_dil > 1) {
+      if (ih < 0 || iw < 0) return zero;
+      if (v.in_dil == 2) {
+        if ((ih | iw) & 1) return zero;
+        ih >>= 1;
+        iw >>= 1;
+      } else {
+        if ((ih % v.in_dil) || (iw % v.in_dil)) return zero;
+        ih /= v.in_dil;
+        iw /= v.in_dil;
+      }
+    }
+    if (v.reflect) {
+      ih = reflect_idx(ih, v.H);
+      iw = reflect_idx(iw, v.W);
+    } else if (ih < 0 || ih >= v.H || iw < 0 || iw >= v.W) {
+      return zero;
+    }
+    cur[j] = reinterpret_cast<const char*>(base + ((long)(ca[j] + ih) * v.W + iw) * v.C + (int)ci0 + chunk[j] * 8);
+    stepb[j] = BK * (int)sizeof(bf16_t);
+    return cur[j];
+  }
+  __device__ __forceinline__ const void* cell_next(int j) {
+    cur[j] += stepb[j];
+    return cur[j];
+  }
+
+  // mode 1: source of instruction j for the NEXT k-tile in issue order (kt0, kt0 + 1, ...)
+  __device__ __forceinline__ const void* next(int j) {
+    const char* s = cur[j];
+    cur[j] = s + stepb[j];
+    return s;
+  }
+
+  // mode 2: call ONCE per k-tile (before the get() calls of that k-tile): is it the first of its cell / of this block?
+  __device__ __forceinline__ bool cell_begin(int kt, int kt0) {
+    if (MODE != 2) return false;
+    const bool first = cellpos == 0 || kt == kt0;
+    cellpos = cellpos + 1 == cellk ? 0 : cellpos + 1;
+    return first;
+  }
+  // every mode: source of instruction j of k-tile kt; every (j, k-tile) exactly once, k-tiles in order
+  __device__ __forceinline__ const void* get(const GemmView& v, const bf16_t* base, int j, int kt, bool first) {
+    if (MODE == 1) return next(j);
+    if (MODE == 2) return first ? cell_first(v, base, j, kt) : cell_next(j);
+    return src(v, base, j, kt);
+  }
+  // HOST: may this view run in mode 1 (plain) / 2 (K-contiguous im2col)?
+  static bool mode_ok(const GemmView& v, int mode) {
+    if (mode == 1) return v.conv == 0 && ((KS ? v.R : v.Cc) % BKT) == 0 && (KS ? (long)BKT * v.ld * 2 : (long)BKT * 2) < (1L << 31);
+    if (mode == 2) return v.conv == 1 && !KS && v.vec_ok && (v.C % BKT) == 0;
+    return true;
   }
 
   // source address of this lane's 16 bytes for instruction j of k-tile kt.  Conv views: must be called once per (j, kt)
@@ -728,7 +820,10 @@ struct GldsCfg {
 // The kernel body.  (bt_raw, ntile, z) = this workgroup's tile index, the number of tiles of the problem and its (batch, split)
 // index: blockIdx.x / gridDim.x / blockIdx.z of a plain launch, or read from the block map of a GROUPED launch (many problems
 // of the same template instance in one grid -- the deferred weight gradients of a backward pass, gemm_glds_grouped_kernel).
-template <int TM, int TN, bool AKS, bool BKS, bool ACONV, bool BCONV, int NW, int NSV>
+// FAST: every operand in its fast DMA-source mode (plain -> 1, K-contiguous im2col -> 2; a K-strided im2col operand stays general)
+template <bool KS, bool CONV, bool FAST> struct DmaMode { static constexpr int value = !FAST ? 0 : (CONV ? (KS ? 0 : 2) : 1); };
+
+template <int TM, int TN, bool AKS, bool BKS, bool ACONV, bool BCONV, int NW, int NSV, bool FAST = false>
 static __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, char* smem, int bt_raw, int ntile_raw, int z_raw, bool xcd_walk) {
   typedef bf16_t T;
   typedef GldsCfg<TM, TN, NW, NSV> Cfg;
@@ -777,17 +872,18 @@ static __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, char*
   const T* baseB = reinterpret_cast<const T*>(p.B.ptr) + (long)batch * p.B.batch_stride + (long)batch2 * p.B.batch2_stride;
 
   CMDA_STAMP(0);
-  DmaSrc<AKS, BM, ACONV, NW> dA;
-  DmaSrc<BKS, BN, BCONV, NW> dB;
+  DmaSrc<AKS, BM, ACONV, NW, 0, 64, DmaMode<AKS, ACONV, FAST>::value> dA;
+  DmaSrc<BKS, BN, BCONV, NW, 0, 64, DmaMode<BKS, BCONV, FAST>::value> dB;
   dA.init(p.A, baseA, wid, lane, m0, kt0);
   dB.init(p.B, baseB, wid, lane, n0, kt0);
   auto issue = [&](int stage, int kt) {
     char* la = reinterpret_cast<char*>(sAbase + stage * SZ_A) + wid * dA.J * 1024;
     char* lb = reinterpret_cast<char*>(sBbase + stage * SZ_B) + wid * dB.J * 1024;
+    const bool fa = dA.cell_begin(kt, kt0), fb = dB.cell_begin(kt, kt0);
 #pragma unroll
-    for (int j = 0; j < dA.J; ++j) glds16(dA.src(p.A, baseA, j, kt), la + j * 1024);
+    for (int j = 0; j < dA.J; ++j) glds16(dA.get(p.A, baseA, j, kt, fa), la + j * 1024);
 #pragma unroll
-    for (int j = 0; j < dB.J; ++j) glds16(dB.src(p.B, baseB, j, kt), lb + j * 1024);
+    for (int j = 0; j < dB.J; ++j) glds16(dB.get(p.B, baseB, j, kt, fb), lb + j * 1024);
   };
 
   f32x4 acc[TM][TN];
@@ -920,10 +1016,10 @@ static __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, char*
   CMDA_STAMP(5);
 }
 
-template <int TM, int TN, bool AKS, bool BKS, bool ACONV, bool BCONV, int NW = 4, int NSV = 0>
+template <int TM, int TN, bool AKS, bool BKS, bool ACONV, bool BCONV, int NW = 4, int NSV = 0, bool FAST = false>
 __global__ __launch_bounds__(64 * NW, (GldsCfg<TM, TN, NW, NSV>::MIN_WAVES)) void gemm_glds_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(1024))) char smem[GldsCfg<TM, TN, NW, NSV>::LDS_BYTES];
-  gemm_glds_body<TM, TN, AKS, BKS, ACONV, BCONV, NW, NSV>(p, smem, blockIdx.x, gridDim.x, blockIdx.z, true);
+  gemm_glds_body<TM, TN, AKS, BKS, ACONV, BCONV, NW, NSV, FAST>(p, smem, blockIdx.x, gridDim.x, blockIdx.z, true);
 }
 
 // GROUPED launch: one grid over MANY problems of this template instance.  `tab` = DEVICE array of parameter blocks (splits already
@@ -950,18 +1046,29 @@ __global__ __launch_bounds__(64 * NW, (GldsCfg<TM, TN, NW, NSV>::MIN_WAVES)) voi
   gemm_glds_body<TM, TN, AKS, BKS, ACONV, BCONV, NW, NSV>(p, smem, loc - z * ntile, ntile, z, false);
 }
 
+template <int TM, int TN, int NW, int NSV, bool AKS, bool BKS, bool ACONV, bool BCONV>
+int launch_glds_mode(const GemmParams& p, const dim3& grid, void* stream) {
+  constexpr int BM = 16 * TM * (NW / 2), BN = 32 * TN;
+  const dim3 blk(64 * NW);
+  typedef DmaSrc<AKS, BM, ACONV, NW, 0, 64, DmaMode<AKS, ACONV, true>::value> FA;
+  typedef DmaSrc<BKS, BN, BCONV, NW, 0, 64, DmaMode<BKS, BCONV, true>::value> FB;
+  const bool fast = FA::mode_ok(p.A, FA::MODE) && FB::mode_ok(p.B, FB::MODE) && (FA::MODE != 0 || FB::MODE != 0) &&
+                    !(p.tile_hint > 0 && (p.tile_hint & 2048));   // (tile_hint bit 11: force the general address path, tuning A/B)
+  if (fast) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, AKS, BKS, ACONV, BCONV, NW, NSV, true>), grid, blk, 0, stream, p);
+  else CMDA_LAUNCH((gemm_glds_kernel<TM, TN, AKS, BKS, ACONV, BCONV, NW, NSV, false>), grid, blk, 0, stream, p);
+  CMDA_CHECK_LAUNCH();
+}
+
 template <int TM, int TN, int NW, int NSV>
 int launch_glds_ns(const GemmParams& p, const dim3& grid, void* stream) {
-  const dim3 blk(64 * NW);
   const bool aks = p.a_kstrided != 0, bks = p.b_kstrided != 0, ac = p.A.conv == 1, bc = p.B.conv == 1;  // (2 = patch view: plain fills)
-  if (!aks && !bks && !ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, false, false, false, false, NW, NSV>), grid, blk, 0, stream, p);
-  else if (!aks && bks && !ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, false, true, false, false, NW, NSV>), grid, blk, 0, stream, p);
-  else if (aks && bks && !ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, true, true, false, false, NW, NSV>), grid, blk, 0, stream, p);
-  else if (aks && !bks && !ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, true, false, false, false, NW, NSV>), grid, blk, 0, stream, p);
-  else if (!aks && !bks && ac && !bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, false, false, true, false, NW, NSV>), grid, blk, 0, stream, p);
-  else if (aks && bks && !ac && bc) CMDA_LAUNCH((gemm_glds_kernel<TM, TN, true, true, false, true, NW, NSV>), grid, blk, 0, stream, p);
-  else return CMDA_ERR_UNSUPPORTED;
-  CMDA_CHECK_LAUNCH();
+  if (!aks && !bks && !ac && !bc) return launch_glds_mode<TM, TN, NW, NSV, false, false, false, false>(p, grid, stream);
+  if (!aks && bks && !ac && !bc) return launch_glds_mode<TM, TN, NW, NSV, false, true, false, false>(p, grid, stream);
+  if (aks && bks && !ac && !bc) return launch_glds_mode<TM, TN, NW, NSV, true, true, false, false>(p, grid, stream);
+  if (aks && !bks && !ac && !bc) return launch_glds_mode<TM, TN, NW, NSV, true, false, false, false>(p, grid, stream);
+  if (!aks && !bks && ac && !bc) return launch_glds_mode<TM, TN, NW, NSV, false, false, true, false>(p, grid, stream);
+  if (aks && bks && !ac && bc) return launch_glds_mode<TM, TN, NW, NSV, true, true, false, true>(p, grid, stream);
+  return CMDA_ERR_UNSUPPORTED;
 }
 
 template <int TM, int TN, int NW = 4>

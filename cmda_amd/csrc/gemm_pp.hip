@@ -90,7 +90,7 @@ static __device__ __forceinline__ float pp_act(float x) {
   return x;
 }
 
-template <bool BKS, bool ACONV>
+template <bool BKS, bool ACONV, bool FAST = false>
 __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(GemmParams p) {
   typedef bf16_t T;
   __shared__ __attribute__((aligned(1024))) char smem[PP_LDS];
@@ -135,14 +135,18 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(GemmParams p) {
   const T* baseA = reinterpret_cast<const T*>(p.A.ptr) + (long)batch * p.A.batch_stride + (long)batch2 * p.A.batch2_stride;
   const T* baseB = reinterpret_cast<const T*>(p.B.ptr) + (long)batch * p.B.batch_stride + (long)batch2 * p.B.batch2_stride;
 
-  DmaSrc<false, PP_BM, ACONV, PP_NW, 1> dA;
-  DmaSrc<BKS, PP_BN, false, PP_NW, 1> dB;
+  DmaSrc<false, PP_BM, ACONV, PP_NW, 1, 64, DmaMode<false, ACONV, FAST>::value> dA;   // (FAST: gemm_kernels.h DmaSrc modes)
+  DmaSrc<BKS, PP_BN, false, PP_NW, 1, 64, DmaMode<BKS, false, FAST>::value> dB;
   dA.init(p.A, baseA, wid, lane, m0, 0);
   dB.init(p.B, baseB, wid, lane, n0, 0);
   // piece i of k-tile kt into `stage`: pieces 0-3 = A, 4-7 = B (1 KB each, this wave's share of the stage)
+  bool cellA = false;
   auto piece = [&](int stage, int kt, int i) {
-    if (i < 4) glds16(dA.src(p.A, baseA, i, kt), reinterpret_cast<char*>(sAbase + stage * PP_SZ) + (wid * 4 + i) * 1024);
-    else glds16(dB.src(p.B, baseB, i - 4, kt), reinterpret_cast<char*>(sBbase + stage * PP_SZ) + (wid * 4 + (i - 4)) * 1024);
+    // (every (piece, k-tile) is issued exactly once, k-tiles in order: what DmaSrc's running-pointer modes need; piece 0 is the first A
+    // piece of its k-tile: the im2col cell test of mode 2 runs there)
+    if (i == 0) cellA = dA.cell_begin(kt, 0);
+    if (i < 4) glds16(dA.get(p.A, baseA, i, kt, cellA), reinterpret_cast<char*>(sAbase + stage * PP_SZ) + (wid * 4 + i) * 1024);
+    else glds16(dB.get(p.B, baseB, i - 4, kt, false), reinterpret_cast<char*>(sBbase + stage * PP_SZ) + (wid * 4 + (i - 4)) * 1024);
   };
 
   f32x16 acc[4][2];
@@ -311,9 +315,21 @@ int cmda_gemm_pp_(const cmda_gemm_params_t& p, void* stream) {
   const dim3 grid((unsigned)tiles, 1, (unsigned)zz), blk(512);
   const bool bks = p.b_kstrided != 0, ac = p.A.conv == 1;
   if (p.a_kstrided || p.B.conv == 1) return CMDA_ERR_UNSUPPORTED;
-  if (!bks && !ac) CMDA_LAUNCH((gemm_pp_kernel<false, false>), grid, blk, 0, stream, p);
-  else if (!bks && ac) CMDA_LAUNCH((gemm_pp_kernel<false, true>), grid, blk, 0, stream, p);
-  else if (bks && !ac) CMDA_LAUNCH((gemm_pp_kernel<true, false>), grid, blk, 0, stream, p);
+  const bool nofast = p.tile_hint > 0 && (p.tile_hint & 2048);
+  typedef DmaSrc<false, PP_BM, false, PP_NW, 1, 64, 1> FA;
+  typedef DmaSrc<false, PP_BM, true, PP_NW, 1, 64, 2> FAC;
+  typedef DmaSrc<false, PP_BN, false, PP_NW, 1, 64, 1> FB;
+  typedef DmaSrc<true, PP_BN, false, PP_NW, 1, 64, 1> FBK;
+  if (!bks && !ac) {
+    if (!nofast && FA::mode_ok(p.A, 1) && FB::mode_ok(p.B, 1)) CMDA_LAUNCH((gemm_pp_kernel<false, false, true>), grid, blk, 0, stream, p);
+    else CMDA_LAUNCH((gemm_pp_kernel<false, false, false>), grid, blk, 0, stream, p);
+  } else if (!bks && ac) {
+    if (!nofast && FAC::mode_ok(p.A, 2) && FB::mode_ok(p.B, 1)) CMDA_LAUNCH((gemm_pp_kernel<false, true, true>), grid, blk, 0, stream, p);
+    else CMDA_LAUNCH((gemm_pp_kernel<false, true, false>), grid, blk, 0, stream, p);
+  } else if (bks && !ac) {
+    if (!nofast && FA::mode_ok(p.A, 1) && FBK::mode_ok(p.B, 1)) CMDA_LAUNCH((gemm_pp_kernel<true, false, true>), grid, blk, 0, stream, p);
+    else CMDA_LAUNCH((gemm_pp_kernel<true, false, false>), grid, blk, 0, stream, p);
+  }
   else return CMDA_ERR_UNSUPPORTED;
   CMDA_CHECK_LAUNCH();
 }

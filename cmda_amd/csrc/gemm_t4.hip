@@ -14,5 +14,9 @@ int cmda_gemm_glds_t4_(const cmda_gemm_params_t& p, void* stream) {
   const long zz = (long)p.batch * p.batch2 * p.splits;
   if (tiles > 0x7fffffffL || zz > 65535) return CMDA_ERR_SHAPE;
   dim3 grid((unsigned)tiles, 1, (unsigned)zz);
+  const int var = p.tile_hint > 0 ? ((p.tile_hint >> 4) & 15) : 0;   // tuning: wave count / stage variants
+  if (var == 1) return launch_glds_ns<1, 10, 8, 3>(p, grid, stream);   // 8 waves (4 x 2), 16 x 160 per wave
+  if (var == 2) return launch_glds_ns<1, 10, 8, 2>(p, grid, stream);
+  if (var == 3) return launch_glds_ns<2, 10, 4, 2>(p, grid, stream);
   return launch_glds_ns<2, 10, 4, 3>(p, grid, stream);
 }

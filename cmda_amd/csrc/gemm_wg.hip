@@ -60,7 +60,7 @@ static __device__ __forceinline__ u16x8 wg_frag(const bf16_t* tile, int c0, int 
 
 // (WG_BK, WG_NS) = (32, 4) for plain operands (three k-tiles of 32 KB in flight: the pointwise gradient 347 -> 296 us) and (64, 2)
 // for the im2col view (its per-piece address arithmetic runs once per k-tile: the bottleneck 1787 us against 2163 at (32, 4))
-template <bool BCONV, int WG_BK, int WG_NS>
+template <bool BCONV, int WG_BK, int WG_NS, bool FAST = false>
 static __device__ __forceinline__ void wg_body(const GemmParams& p, char* smem, int bt, int z) {
   typedef bf16_t T;
   constexpr int WG_SZ = WG_T * WG_BK;   // elements per operand per stage
@@ -80,17 +80,17 @@ static __device__ __forceinline__ void wg_body(const GemmParams& p, char* smem, 
   const T* baseA = reinterpret_cast<const T*>(p.A.ptr) + (long)batch * p.A.batch_stride + (long)batch2 * p.A.batch2_stride;
   const T* baseB = reinterpret_cast<const T*>(p.B.ptr) + (long)batch * p.B.batch_stride + (long)batch2 * p.B.batch2_stride;
 
-  DmaSrc<true, WG_T, false, WG_NW, 0, WG_BK> dA;
-  DmaSrc<true, WG_T, BCONV, WG_NW, 0, WG_BK> dB;
+  DmaSrc<true, WG_T, false, WG_NW, 0, WG_BK, DmaMode<true, false, FAST>::value> dA;   // (FAST: gemm_kernels.h DmaSrc modes; a K-strided
+  DmaSrc<true, WG_T, BCONV, WG_NW, 0, WG_BK, DmaMode<true, BCONV, FAST>::value> dB;   //  im2col B stays general)
   dA.init(p.A, baseA, wid, lane, m0, kt0);
   dB.init(p.B, baseB, wid, lane, n0, kt0);
   auto issue = [&](int stage, int kt) {
     char* la = reinterpret_cast<char*>(sAbase + stage * WG_SZ) + wid * PCS * 1024;
     char* lb = reinterpret_cast<char*>(sBbase + stage * WG_SZ) + wid * PCS * 1024;
 #pragma unroll
-    for (int j = 0; j < PCS; ++j) glds16(dA.src(p.A, baseA, j, kt), la + j * 1024);
+    for (int j = 0; j < PCS; ++j) glds16(dA.get(p.A, baseA, j, kt, false), la + j * 1024);
 #pragma unroll
-    for (int j = 0; j < PCS; ++j) glds16(dB.src(p.B, baseB, j, kt), lb + j * 1024);
+    for (int j = 0; j < PCS; ++j) glds16(dB.get(p.B, baseB, j, kt, false), lb + j * 1024);
   };
   static_assert(decltype(dA)::J == PCS && decltype(dB)::J == PCS, "pieces per wave per k-tile");
 
@@ -163,7 +163,7 @@ static __device__ __forceinline__ void wg_body(const GemmParams& p, char* smem, 
     }
 }
 
-template <bool BCONV, int WG_BK, int WG_NS>
+template <bool BCONV, int WG_BK, int WG_NS, bool FAST = false>
 __global__ __launch_bounds__(512, 1) void gemm_wg_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(1024))) char smem[(size_t)2 * WG_NS * WG_T * WG_BK * 2];
   // Workgroups are dealt round-robin to the 8 XCDs in launch order (tile fastest, then split).  The tiles of ONE split read the same K
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(512, 1) void gemm_wg_kernel(GemmParams p) {
   const unsigned nb = gridDim.x * gridDim.z, lin = blockIdx.x + gridDim.x * blockIdx.z;
   const unsigned q = nb / 8, r = nb % 8, xcd = lin % 8, loc = lin / 8;
   const unsigned logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  wg_body<BCONV, WG_BK, WG_NS>(p, smem, (int)(logical % gridDim.x), (int)(logical / gridDim.x));
+  wg_body<BCONV, WG_BK, WG_NS, FAST>(p, smem, (int)(logical % gridDim.x), (int)(logical / gridDim.x));
 }
 
 // grouped form (gemm_grouped.hip: the deferred weight gradients of an encoder stage whose outputs are at least 256 x 256 -- MiT
@@ -210,7 +210,15 @@ int cmda_gemm_wg_(const cmda_gemm_params_t& p, void* stream) {
   const long zz = (long)p.batch * p.batch2 * p.splits;
   if (tiles > 0x7fffffffL || zz > 65535) return CMDA_ERR_SHAPE;
   const dim3 grid((unsigned)tiles, 1, (unsigned)zz), blk(512);
-  if (p.B.conv == 1) CMDA_LAUNCH((gemm_wg_kernel<true, 64, 2>), grid, blk, 0, stream, p);
-  else CMDA_LAUNCH((gemm_wg_kernel<false, 32, 4>), grid, blk, 0, stream, p);
+  const bool nofast = p.tile_hint > 0 && (p.tile_hint & 2048);
+  if (p.B.conv == 1) {
+    typedef DmaSrc<true, WG_T, false, WG_NW, 0, 64, 1> FA;
+    if (!nofast && FA::mode_ok(p.A, 1)) CMDA_LAUNCH((gemm_wg_kernel<true, 64, 2, true>), grid, blk, 0, stream, p);
+    else CMDA_LAUNCH((gemm_wg_kernel<true, 64, 2, false>), grid, blk, 0, stream, p);
+  } else {
+    typedef DmaSrc<true, WG_T, false, WG_NW, 0, 32, 1> FA;
+    if (!nofast && FA::mode_ok(p.A, 1) && FA::mode_ok(p.B, 1)) CMDA_LAUNCH((gemm_wg_kernel<false, 32, 4, true>), grid, blk, 0, stream, p);
+    else CMDA_LAUNCH((gemm_wg_kernel<false, 32, 4, false>), grid, blk, 0, stream, p);
+  }
   CMDA_CHECK_LAUNCH();
 }
