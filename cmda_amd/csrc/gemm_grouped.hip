@@ -19,7 +19,9 @@ namespace {
 // kind 4 = gemm_wg.hip's 256x256 tile (8 waves, 32x32x16 MFMA): outputs of at least 256 x 256 -- both operands of these contractions
 // stream from beyond L2, so operand bytes per FLOP decide
 constexpr int kTileBM[5] = {64, 128, 64, 128, 256}, kTileBN[5] = {64, 64, 128, 128, 256}, kTileRes[5] = {4, 3, 3, 2, 1};
-constexpr int kBuckets = 10;   // bucket = tile kind * 2 + (B is an im2col view)
+// bucket = tile kind * 3 + operand class: 0 = both operands plain with K a multiple of 64 (the kernels' running-pointer DMA sources,
+// gemm_kernels.h DmaSrc mode 1), 1 = plain / patch views in general, 2 = B is an im2col view
+constexpr int kBuckets = 15;
 
 struct Plan {
   int bucket;       // -1 = single launch through cmda_gemm
@@ -54,7 +56,9 @@ static Plan classify(const GemmParams& p) {
   const long pm = (p.M + 255) / 256 * 256, pn = (p.N + 255) / 256 * 256;
   const bool big = p.M >= 256 && p.N >= 256 && (double)pm * pn <= 1.1 * (double)p.M * p.N;
   const int kind = big ? 4 : (p.M % 128 == 0 ? 1 : 0) + (p.N % 128 == 0 ? 2 : 0);
-  pl.bucket = kind * 2 + (p.B.conv == 1 ? 1 : 0);
+  typedef DmaSrc<true, 64, false, 4, 0, 64, 1> FK;   // (tile size irrelevant for the eligibility test)
+  const bool fast = FK::mode_ok(p.A, 1) && FK::mode_ok(p.B, 1);
+  pl.bucket = kind * 3 + (p.B.conv == 1 ? 2 : fast ? 0 : 1);
   pl.tiles = ((p.M + kTileBM[kind] - 1) / kTileBM[kind]) * ((p.N + kTileBN[kind] - 1) / kTileBN[kind]);
   pl.nkt = (p.K + 63) / 64;
   return pl;
@@ -134,7 +138,7 @@ static void plan_all(const GemmParams* params, int n, GroupPlan& g) {
   for (int b = 0; b < kBuckets; ++b) {
     g.start[b] = g.total;
     if (members[b].empty()) continue;
-    plan_bucket(params, g.plans, members[b], b >> 1, g.buckets[b]);
+    plan_bucket(params, g.plans, members[b], b / 3, g.buckets[b]);
     g.total += g.buckets[b].rows * 8;
   }
 }
@@ -195,7 +199,7 @@ extern "C" int cmda_gemm_grouped(const cmda_gemm_params_t* params, int n, void* 
       const long cnt = g.buckets[b].rows * 8;
       if (!cnt) continue;
       const void* bptr = dblk + g.start[b] * 8;
-      const int kind = b >> 1, bc = b & 1;
+      const int kind = b / 3, bc = b % 3;   // bc: operand class (0 fast plain, 1 general, 2 im2col B)
       const int rc = kind == 0 ? cmda_gemm_grouped_t2_(dtab, bptr, (int)cnt, bc, stream)
                    : kind == 1 ? cmda_gemm_grouped_t1_(dtab, bptr, (int)cnt, bc, stream)
                    : kind == 2 ? cmda_gemm_grouped_t3_(dtab, bptr, (int)cnt, bc, stream)

@@ -568,10 +568,21 @@ struct DmaSrc {
   const char* cur[J];     // modes 1 / 2: running source of instruction j
   int stepb[J];           // modes 1 / 2: bytes per k-tile (0: parked on the zero block)
   int cellk, cellpos;     // mode 2: k-tiles per (kh, kw) cell; position of the NEXT k-tile inside its cell (wave-uniform)
+                          // mode 1, K-contiguous PATCH view: k-tiles per kh segment of KW*C contiguous elements, position inside it
+  int jumpb;              // mode 1, K-contiguous patch view: extra bytes when the k-tiles cross into the next kh segment (next input row)
 
   __device__ __forceinline__ void init(const GemmView& v, const bf16_t* base, int wid, int lane, long t0, int kt0) {
     cellk = MODE == 2 ? v.C / BK : 1;
     cellpos = MODE == 2 ? (int)(((long)kt0 * BK % v.C) / BK) : 0;
+    jumpb = 0;
+    if (MODE == 1 && !KS && v.conv == 2) {   // patch view, K-contiguous: kh segments of KW*C elements, one input row apart
+      const int seg = v.KW * v.C;
+      cellk = seg / BK;
+      cellpos = (int)(((long)kt0 * BK % seg) / BK);
+      jumpb = (int)(((long)v.W * v.C - seg) * (long)sizeof(bf16_t));
+    } else if (MODE == 1) {
+      cellk = 0x7fffffff;   // plain operand: never crosses a segment
+    }
 #pragma unroll
     for (int j = 0; j < J; ++j) {
       const int ln = (wid * J + j) * LPI + lane / CPL;              // K-contig: tile row; K-strided: k row
@@ -632,8 +643,18 @@ struct DmaSrc {
       }
       if (MODE == 1) {   // running source: k-tile kt0 of this lane's (line, chunk), or the zero block (step 0)
         if (fixed[j] >= 0 && ptr[j] != nullptr) {
-          stepb[j] = (int)((KS ? (long)BK * v.ld : (long)BK) * (long)sizeof(bf16_t));
-          cur[j] = reinterpret_cast<const char*>(ptr[j]) + (long)kt0 * stepb[j];
+          if (v.conv == 2 && !KS) {          // patch view, K-contiguous: segment kh0 of k-tile kt0, offset inside it
+            const long c0 = (long)kt0 * BK, seg = (long)v.KW * v.C, kh0 = c0 / seg;
+            stepb[j] = BK * (int)sizeof(bf16_t);
+            cur[j] = reinterpret_cast<const char*>(ptr[j] + kh0 * v.W * v.C + (c0 - kh0 * seg));
+          } else if (v.conv == 2) {          // patch view, K-strided, OW divides the k-tile: this lane's ow never changes and its
+                                             // pixel row q advances BK / OW rows per k-tile -- a constant step
+            stepb[j] = (int)((long)(BK / v.OW) * v.stride * v.W * v.C * (long)sizeof(bf16_t));
+            cur[j] = reinterpret_cast<const char*>(ptr[j] + (long)s1[j] * v.stride * v.W * v.C + (long)s2[j] * v.stride * v.C);
+          } else {
+            stepb[j] = (int)((KS ? (long)BK * v.ld : (long)BK) * (long)sizeof(bf16_t));
+            cur[j] = reinterpret_cast<const char*>(ptr[j]) + (long)kt0 * stepb[j];
+          }
         } else {
           stepb[j] = 0;
           cur[j] = reinterpret_cast<const char*>(g_zero16);
@@ -689,8 +710,15 @@ struct DmaSrc {
     return s;
   }
 
-  // mode 2: call ONCE per k-tile (before the get() calls of that k-tile): is it the first of its cell / of this block?
+  // call ONCE per k-tile (before the get() calls of that k-tile).  Mode 2: is it the first k-tile of its cell / of this block?
+  // Mode 1 on a K-contiguous patch view: did the PREVIOUS k-tile end a kh segment (the running pointers then jump to the next row)?
   __device__ __forceinline__ bool cell_begin(int kt, int kt0) {
+    if (MODE == 1) {
+      if (KS) return false;
+      const bool cross = cellpos == cellk;   // (plain operands: cellk = INT_MAX, never)
+      cellpos = cross ? 1 : cellpos + 1;
+      return cross;
+    }
     if (MODE != 2) return false;
     const bool first = cellpos == 0 || kt == kt0;
     cellpos = cellpos + 1 == cellk ? 0 : cellpos + 1;
@@ -698,13 +726,23 @@ struct DmaSrc {
   }
   // every mode: source of instruction j of k-tile kt; every (j, k-tile) exactly once, k-tiles in order
   __device__ __forceinline__ const void* get(const GemmView& v, const bf16_t* base, int j, int kt, bool first) {
-    if (MODE == 1) return next(j);
+    if (MODE == 1) {
+      if (!KS && first) cur[j] += stepb[j] ? jumpb : 0;
+      return next(j);
+    }
     if (MODE == 2) return first ? cell_first(v, base, j, kt) : cell_next(j);
     return src(v, base, j, kt);
   }
   // HOST: may this view run in mode 1 (plain) / 2 (K-contiguous im2col)?
   static bool mode_ok(const GemmView& v, int mode) {
-    if (mode == 1) return v.conv == 0 && ((KS ? v.R : v.Cc) % BKT) == 0 && (KS ? (long)BKT * v.ld * 2 : (long)BKT * 2) < (1L << 31);
+    if (mode == 1) {
+      if (((KS ? v.R : v.Cc) % BKT) != 0 || v.conv == 1) return false;
+      if (v.conv == 0) return (KS ? (long)BKT * v.ld * 2 : (long)BKT * 2) < (1L << 31);
+      // patch views (kernel == stride convolutions: the spatial-reduction convs): K-contiguous always (KW*C % 64 == 0 is a condition of
+      // the LDS-DMA path), K-strided when the output row length divides the k-tile
+      if (!KS) return ((long)v.KW * v.C) % BKT == 0 && (long)v.W * v.C * 2 < (1L << 31);
+      return v.OW > 0 && (BKT % v.OW) == 0 && (long)(BKT / v.OW) * v.stride * v.W * v.C * 2 < (1L << 31);
+    }
     if (mode == 2) return v.conv == 1 && !KS && v.vec_ok && (v.C % BKT) == 0;
     return true;
   }
@@ -1029,7 +1067,7 @@ __global__ __launch_bounds__(64 * NW, (GldsCfg<TM, TN, NW, NSV>::MIN_WAVES)) voi
 // tiles read the same K slice of both operands through that XCD's L2.  Used for the DEFERRED weight gradients of a backward pass (ops.gemm_deferral):
 // ~300 latency-bound launches of 100-200 blocks each per encoder stage become one launch of ~50 k blocks that runs at the
 // MFMA / atomic rate.  The XCD-aware tile walk is off (weight-gradient outputs are a few tiles; nothing to share through L2).
-template <int TM, int TN, bool AKS, bool BKS, bool ACONV, bool BCONV, int NW = 4, int NSV = 0>
+template <int TM, int TN, bool AKS, bool BKS, bool ACONV, bool BCONV, int NW = 4, int NSV = 0, bool FAST = false>
 __global__ __launch_bounds__(64 * NW, (GldsCfg<TM, TN, NW, NSV>::MIN_WAVES)) void gemm_glds_grouped_kernel(const GemmParams* __restrict__ tab,
                                                                                                             const int* __restrict__ blk) {
   __shared__ __attribute__((aligned(1024))) char smem[GldsCfg<TM, TN, NW, NSV>::LDS_BYTES];
@@ -1043,7 +1081,7 @@ __global__ __launch_bounds__(64 * NW, (GldsCfg<TM, TN, NW, NSV>::MIN_WAVES)) voi
   constexpr int BM = GldsCfg<TM, TN, NW, NSV>::BM, BN = GldsCfg<TM, TN, NW, NSV>::BN;
   const int ntile = (int)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   const int z = loc / ntile;
-  gemm_glds_body<TM, TN, AKS, BKS, ACONV, BCONV, NW, NSV>(p, smem, loc - z * ntile, ntile, z, false);
+  gemm_glds_body<TM, TN, AKS, BKS, ACONV, BCONV, NW, NSV, FAST>(p, smem, loc - z * ntile, ntile, z, false);
 }
 
 template <int TM, int TN, int NW, int NSV, bool AKS, bool BKS, bool ACONV, bool BCONV>
@@ -1101,8 +1139,10 @@ int launch_glds_grouped(const GemmParams* tab, const void* blk, int nblocks, int
   if (nblocks <= 0) return CMDA_OK;
   const dim3 grid((unsigned)nblocks), blkdim(256);
   const int* b = reinterpret_cast<const int*>(blk);
-  if (bconv) CMDA_LAUNCH((gemm_glds_grouped_kernel<TM, TN, true, true, false, true, 4, 0>), grid, blkdim, 0, stream, tab, b);
-  else CMDA_LAUNCH((gemm_glds_grouped_kernel<TM, TN, true, true, false, false, 4, 0>), grid, blkdim, 0, stream, tab, b);
+  // bconv = operand class of the bucket (gemm_grouped.hip): 0 every problem plain with K % 64 == 0, 1 plain / patch views, 2 im2col B
+  if (bconv == 2) CMDA_LAUNCH((gemm_glds_grouped_kernel<TM, TN, true, true, false, true, 4, 0, false>), grid, blkdim, 0, stream, tab, b);
+  else if (bconv == 1) CMDA_LAUNCH((gemm_glds_grouped_kernel<TM, TN, true, true, false, false, 4, 0, false>), grid, blkdim, 0, stream, tab, b);
+  else CMDA_LAUNCH((gemm_glds_grouped_kernel<TM, TN, true, true, false, false, 4, 0, true>), grid, blkdim, 0, stream, tab, b);
   CMDA_CHECK_LAUNCH();
 }
 

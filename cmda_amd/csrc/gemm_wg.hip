@@ -178,7 +178,7 @@ __global__ __launch_bounds__(512, 1) void gemm_wg_kernel(GemmParams p) {
 
 // grouped form (gemm_grouped.hip: the deferred weight gradients of an encoder stage whose outputs are at least 256 x 256 -- MiT
 // stages 3 / 4: 320 ... 2048 channels): `tab` / `blk` as for gemm_glds_grouped_kernel, block index inside a problem = z * tiles + tile
-template <bool BCONV, int WG_BK, int WG_NS>
+template <bool BCONV, int WG_BK, int WG_NS, bool FAST = false>
 __global__ __launch_bounds__(512, 1) void gemm_wg_grouped_kernel(const GemmParams* __restrict__ tab, const int* __restrict__ blk) {
   __shared__ __attribute__((aligned(1024))) char smem[(size_t)2 * WG_NS * WG_T * WG_BK * 2];
 #ifndef CMDA_EMU
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(512, 1) void gemm_wg_grouped_kernel(const GemmParam
   const GemmParams& p = tab[prob];
   const int ntile = (int)((p.M + WG_T - 1) / WG_T) * ((p.N + WG_T - 1) / WG_T);
   const int z = loc / ntile;
-  wg_body<BCONV, WG_BK, WG_NS>(p, smem, loc - z * ntile, z);
+  wg_body<BCONV, WG_BK, WG_NS, FAST>(p, smem, loc - z * ntile, z);
 }
 
 }  // namespace
@@ -199,8 +199,10 @@ int cmda_gemm_wg_grouped_(const cmda_gemm_params_t* tab, const void* blk, int nb
   if (nblocks <= 0) return CMDA_OK;
   const dim3 grid((unsigned)nblocks), b(512);
   const int* bp = reinterpret_cast<const int*>(blk);
-  if (bconv) CMDA_LAUNCH((gemm_wg_grouped_kernel<true, 64, 2>), grid, b, 0, stream, tab, bp);
-  else CMDA_LAUNCH((gemm_wg_grouped_kernel<false, 32, 4>), grid, b, 0, stream, tab, bp);
+  // bconv = operand class of the bucket (gemm_grouped.hip): 0 plain with K % 64 == 0 (running-pointer DMA sources), 1 general, 2 im2col B
+  if (bconv == 2) CMDA_LAUNCH((gemm_wg_grouped_kernel<true, 64, 2, false>), grid, b, 0, stream, tab, bp);
+  else if (bconv == 1) CMDA_LAUNCH((gemm_wg_grouped_kernel<false, 32, 4, false>), grid, b, 0, stream, tab, bp);
+  else CMDA_LAUNCH((gemm_wg_grouped_kernel<false, 32, 4, true>), grid, b, 0, stream, tab, bp);
   CMDA_CHECK_LAUNCH();
 }
 

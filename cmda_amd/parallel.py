@@ -63,6 +63,27 @@ def reduce_log_vars(log_vars, group=None):
     return out
 
 
+def broadcast_bn_buffers(model, src=0, group=None):
+    """DistEvalHook._do_evaluate's first step (mmseg/core/evaluation/eval_hooks.py:92-100): DDP does not synchronise BatchNorm's
+    running statistics, and in this recipe they really differ between ranks (every rank's decoder sees its own samples), so before
+    a distributed evaluation rank `src`'s running_mean / running_var are broadcast to every rank -- all ranks then score the SAME
+    model.  The reference issues two broadcasts per BatchNorm layer; here all statistics of the model travel as ONE flat fp32
+    vector.  Returns the number of BatchNorm layers synchronised (0 without an initialised group / at world size 1)."""
+    bns = [m for m in model.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.track_running_stats
+           and m.running_mean is not None]
+    if not bns or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) <= 1:
+        return 0
+    bufs = [b for m in bns for b in (m.running_var, m.running_mean)]
+    flat = torch.cat([b.detach().reshape(-1).float() for b in bufs])
+    dist.broadcast(flat, src, group=group)
+    off = 0
+    for b in bufs:
+        n = b.numel()
+        b.copy_(flat[off:off + n].view_as(b))
+        off += n
+    return len(bns)
+
+
 class GradAllReducer:
     """Mean all-reduce of a flat gradient buffer in large buckets.
 

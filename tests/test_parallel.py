@@ -409,3 +409,41 @@ def test_bench_gpus_2_launches_itself():
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--dry-run'], env=dict(env, WORLD_SIZE='1', RANK='0'),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
+
+
+def _bn_worker(rank, world, port, out):
+    from cmda_amd.parallel import broadcast_bn_buffers
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(7)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 1), torch.nn.BatchNorm2d(8), torch.nn.ReLU(), torch.nn.Conv2d(8, 4, 1),
+                              torch.nn.BatchNorm2d(4), torch.nn.LayerNorm([4, 5, 5])).train()
+    torch.manual_seed(100 + rank)                      # rank-local batches: the running statistics drift apart, as in training
+    for _ in range(3):
+        net(torch.randn(2, 3, 5, 5) * (1 + rank))
+    before = [b.clone() for n, b in net.named_buffers() if 'running' in n]
+    params = [p.detach().clone() for p in net.parameters()]
+    n = broadcast_bn_buffers(net)
+    after = torch.cat([b.reshape(-1) for nme, b in net.named_buffers() if 'running' in nme])
+    gathered = [torch.empty_like(after) for _ in range(world)]
+    dist.all_gather(gathered, after)
+    b0 = torch.cat([b.reshape(-1) for b in before])
+    g0 = [torch.empty_like(b0) for _ in range(world)]
+    dist.all_gather(g0, b0)
+    out[rank] = dict(n=n, same=all(torch.equal(gathered[0], g) for g in gathered), src=torch.equal(gathered[0], g0[0]),
+                     differed=not torch.equal(g0[0], g0[1]),
+                     params=all(torch.equal(p, q) for p, q in zip(params, net.parameters())),
+                     nbt=[int(b) for nme, b in net.named_buffers() if 'num_batches' in nme])
+    dist.destroy_process_group()
+
+
+def test_bn_buffers_broadcast_before_distributed_eval_world2():
+    """eval_hooks.py:92-100: rank 0's BatchNorm running statistics reach every rank before a distributed evaluation; parameters
+    and the batch counters are untouched"""
+    world = 2
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_bn_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        for r in range(world):
+            assert out[r]['n'] == 2 and out[r]['differed'] and out[r]['same'] and out[r]['src'] and out[r]['params'], out[r]
+            assert out[r]['nbt'] == [3, 3]
