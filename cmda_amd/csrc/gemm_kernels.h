@@ -546,10 +546,14 @@ __device__ unsigned long long g_stamps[256 * 8];
 //   2  CELL-FAST, K-contiguous im2col operands whose channel count is a multiple of the k-tile (the head's 3 x 3 bottleneck over 1024
 //      channels, the generator's 256-channel convolutions): a k-tile never straddles a (kh, kw) cell, so only the first k-tile of a cell
 //      needs the tap arithmetic and the border test -- the other C / 64 - 1 advance the running pointer by 64 channels.
+//   3  ROW-FAST, K-strided im2col operands of a stride-1 "same" convolution whose output rows are whole k-tiles (the weight gradient
+//      of the head's 3 x 3 bottleneck: 128-pixel rows, 64- or 32-pixel k-tiles): a k-tile is BK consecutive pixels of ONE output row,
+//      so (row, segment) are wave-uniform scalars, the pixel index -- and with H == OH, W == OW the source address -- advances by a
+//      constant, and the border test is two compares of uniform coordinates against per-lane tap offsets.
 template <bool KS, int TILE, bool CONV, int NW = 4, int SWZ = 0, int BKT = 64, int MODE_ = 0>
 struct DmaSrc {
   static constexpr int MODE = MODE_;
-  static_assert(MODE == 0 || (MODE == 1 && !CONV) || (MODE == 2 && CONV && !KS), "DMA source mode");
+  static_assert(MODE == 0 || (MODE == 1 && !CONV) || (MODE == 2 && CONV && !KS) || (MODE == 3 && CONV && KS), "DMA source mode");
   static constexpr int BK = BKT;
   static_assert(BKT == 64 || KS, "half-depth k-tiles: K-strided operands only");
   static constexpr int J = TILE * BKT / (512 * NW);                 // DMA instructions per wave per stage
@@ -570,11 +574,22 @@ struct DmaSrc {
   int cellk, cellpos;     // mode 2: k-tiles per (kh, kw) cell; position of the NEXT k-tile inside its cell (wave-uniform)
                           // mode 1, K-contiguous PATCH view: k-tiles per kh segment of KW*C contiguous elements, position inside it
   int jumpb;              // mode 1, K-contiguous patch view: extra bytes when the k-tiles cross into the next kh segment (next input row)
+  int dh[J], iw0[J];      // mode 3: tap row offset (kh*dil - pad; out-of-range columns: a value no row can satisfy) and ln + (kw*dil - pad)
+  int u_oh, u_seg;        // mode 3: output row / BK-pixel segment of the NEXT k-tile (wave-uniform); c_oh / c_ow0: of the current one
+  int c_oh, c_ow0, nseg;
 
   __device__ __forceinline__ void init(const GemmView& v, const bf16_t* base, int wid, int lane, long t0, int kt0) {
     cellk = MODE == 2 ? v.C / BK : 1;
     cellpos = MODE == 2 ? (int)(((long)kt0 * BK % v.C) / BK) : 0;
     jumpb = 0;
+    u_oh = u_seg = c_oh = c_ow0 = 0;
+    nseg = 1;
+    if (MODE == 3) {
+      nseg = v.OW / BK;
+      const long row = (long)kt0 / nseg;          // (b*OH + oh) of k-tile kt0
+      u_seg = (int)((long)kt0 - row * nseg);
+      u_oh = (int)(row % v.OH);
+    }
     if (MODE == 1 && !KS && v.conv == 2) {   // patch view, K-contiguous: kh segments of KW*C elements, one input row apart
       const int seg = v.KW * v.C;
       cellk = seg / BK;
@@ -641,7 +656,19 @@ struct DmaSrc {
           }
         }
       }
-      if (MODE == 1) {   // running source: k-tile kt0 of this lane's (line, chunk), or the zero block (step 0)
+      if (MODE == 3) {   // pixel r0 = kt0*BK + ln under tap (dh, dw): element (r0 + dh*W + dw)*C + ci -- linear in r0 (H == OH, W == OW)
+        if (fixed[j] >= 0) {
+          dh[j] = cbc[j] >> 16;
+          const int dw = (int)(short)(cbc[j] & 0xffff);
+          iw0[j] = ln + dw;
+          cur[j] = reinterpret_cast<const char*>(base + ((long)kt0 * BK + ln + (long)dh[j] * v.W + dw) * v.C + ca[j]);
+        } else {
+          dh[j] = 1 << 24;
+          iw0[j] = 0;
+          cur[j] = reinterpret_cast<const char*>(g_zero16);
+        }
+        stepb[j] = (int)((long)BK * v.C * (long)sizeof(bf16_t));
+      } else if (MODE == 1) {   // running source: k-tile kt0 of this lane's (line, chunk), or the zero block (step 0)
         if (fixed[j] >= 0 && ptr[j] != nullptr) {
           if (v.conv == 2 && !KS) {          // patch view, K-contiguous: segment kh0 of k-tile kt0, offset inside it
             const long c0 = (long)kt0 * BK, seg = (long)v.KW * v.C, kh0 = c0 / seg;
@@ -712,7 +739,16 @@ struct DmaSrc {
 
   // call ONCE per k-tile (before the get() calls of that k-tile).  Mode 2: is it the first k-tile of its cell / of this block?
   // Mode 1 on a K-contiguous patch view: did the PREVIOUS k-tile end a kh segment (the running pointers then jump to the next row)?
-  __device__ __forceinline__ bool cell_begin(int kt, int kt0) {
+  __device__ __forceinline__ bool cell_begin(int kt, int kt0, const GemmView* v = nullptr) {
+    if (MODE == 3) {   // uniform coordinates of this k-tile; advance to the next
+      c_oh = u_oh;
+      c_ow0 = u_seg * BK;
+      if (++u_seg == nseg) {
+        u_seg = 0;
+        if (++u_oh == v->OH) u_oh = 0;
+      }
+      return false;
+    }
     if (MODE == 1) {
       if (KS) return false;
       const bool cross = cellpos == cellk;   // (plain operands: cellk = INT_MAX, never)
@@ -731,6 +767,12 @@ struct DmaSrc {
       return next(j);
     }
     if (MODE == 2) return first ? cell_first(v, base, j, kt) : cell_next(j);
+    if (MODE == 3) {
+      const char* s = cur[j];
+      cur[j] = s + stepb[j];
+      const bool ok = (unsigned)(c_oh + dh[j]) < (unsigned)v.H && (unsigned)(c_ow0 + iw0[j]) < (unsigned)v.W;
+      return ok ? s : reinterpret_cast<const char*>(g_zero16);
+    }
     return src(v, base, j, kt);
   }
   // HOST: may this view run in mode 1 (plain) / 2 (K-contiguous im2col)?
@@ -744,6 +786,8 @@ struct DmaSrc {
       return v.OW > 0 && (BKT % v.OW) == 0 && (long)(BKT / v.OW) * v.stride * v.W * v.C * 2 < (1L << 31);
     }
     if (mode == 2) return v.conv == 1 && !KS && v.vec_ok && (v.C % BKT) == 0;
+    if (mode == 3) return v.conv == 1 && KS && v.vec_ok && v.stride == 1 && v.in_dil <= 1 && !v.reflect && v.H == v.OH && v.W == v.OW &&
+                          (v.OW % BKT) == 0 && (v.R % BKT) == 0 && (long)BKT * v.C * 2 < (1L << 31);
     return true;
   }
 
@@ -859,7 +903,7 @@ struct GldsCfg {
 // index: blockIdx.x / gridDim.x / blockIdx.z of a plain launch, or read from the block map of a GROUPED launch (many problems
 // of the same template instance in one grid -- the deferred weight gradients of a backward pass, gemm_glds_grouped_kernel).
 // FAST: every operand in its fast DMA-source mode (plain -> 1, K-contiguous im2col -> 2; a K-strided im2col operand stays general)
-template <bool KS, bool CONV, bool FAST> struct DmaMode { static constexpr int value = !FAST ? 0 : (CONV ? (KS ? 0 : 2) : 1); };
+template <bool KS, bool CONV, bool FAST> struct DmaMode { static constexpr int value = !FAST ? 0 : (CONV ? (KS ? 3 : 2) : 1); };
 
 template <int TM, int TN, bool AKS, bool BKS, bool ACONV, bool BCONV, int NW, int NSV, bool FAST = false>
 static __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, char* smem, int bt_raw, int ntile_raw, int z_raw, bool xcd_walk) {
@@ -917,7 +961,7 @@ static __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, char*
   auto issue = [&](int stage, int kt) {
     char* la = reinterpret_cast<char*>(sAbase + stage * SZ_A) + wid * dA.J * 1024;
     char* lb = reinterpret_cast<char*>(sBbase + stage * SZ_B) + wid * dB.J * 1024;
-    const bool fa = dA.cell_begin(kt, kt0), fb = dB.cell_begin(kt, kt0);
+    const bool fa = dA.cell_begin(kt, kt0, &p.A), fb = dB.cell_begin(kt, kt0, &p.B);
 #pragma unroll
     for (int j = 0; j < dA.J; ++j) glds16(dA.get(p.A, baseA, j, kt, fa), la + j * 1024);
 #pragma unroll

@@ -87,6 +87,8 @@ static __device__ __forceinline__ void wg_body(const GemmParams& p, char* smem, 
   auto issue = [&](int stage, int kt) {
     char* la = reinterpret_cast<char*>(sAbase + stage * WG_SZ) + wid * PCS * 1024;
     char* lb = reinterpret_cast<char*>(sBbase + stage * WG_SZ) + wid * PCS * 1024;
+    dA.cell_begin(kt, kt0, &p.A);
+    dB.cell_begin(kt, kt0, &p.B);
 #pragma unroll
     for (int j = 0; j < PCS; ++j) glds16(dA.get(p.A, baseA, j, kt, false), la + j * 1024);
 #pragma unroll
@@ -214,8 +216,16 @@ int cmda_gemm_wg_(const cmda_gemm_params_t& p, void* stream) {
   const dim3 grid((unsigned)tiles, 1, (unsigned)zz), blk(512);
   const bool nofast = p.tile_hint > 0 && (p.tile_hint & 2048);
   if (p.B.conv == 1) {
+    // FAST: dY in the running-pointer mode, the im2col operand in the row-fast mode (stride-1 "same" convolution, output rows of
+    // whole k-tiles: the head's 3 x 3 bottleneck); with the address arithmetic gone from the LOAD segments the plain operands' four
+    // half-depth stages serve the im2col view too (tile_hint bit 12: keep the two full-depth stages, tuning A/B)
     typedef DmaSrc<true, WG_T, false, WG_NW, 0, 64, 1> FA;
-    if (!nofast && FA::mode_ok(p.A, 1)) CMDA_LAUNCH((gemm_wg_kernel<true, 64, 2, true>), grid, blk, 0, stream, p);
+    typedef DmaSrc<true, WG_T, true, WG_NW, 0, 64, 3> FB;
+    typedef DmaSrc<true, WG_T, false, WG_NW, 0, 32, 1> FA32;
+    typedef DmaSrc<true, WG_T, true, WG_NW, 0, 32, 3> FB32;
+    if (!nofast && FA32::mode_ok(p.A, 1) && FB32::mode_ok(p.B, 3) && !(p.tile_hint > 0 && (p.tile_hint & 4096)))
+      CMDA_LAUNCH((gemm_wg_kernel<true, 32, 4, true>), grid, blk, 0, stream, p);
+    else if (!nofast && FA::mode_ok(p.A, 1) && FB::mode_ok(p.B, 3)) CMDA_LAUNCH((gemm_wg_kernel<true, 64, 2, true>), grid, blk, 0, stream, p);
     else CMDA_LAUNCH((gemm_wg_kernel<true, 64, 2, false>), grid, blk, 0, stream, p);
   } else {
     typedef DmaSrc<true, WG_T, false, WG_NW, 0, 32, 1> FA;

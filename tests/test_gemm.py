@@ -71,7 +71,10 @@ CONVS = [(2, 9, 11, 8, 24, 3, 1, 1, 1), (1, 16, 16, 3, 16, 7, 4, 3, 1), (1, 12, 
          # kernel == stride (spatial-reduction convs): patch views, filled like plain operands when KW*Ci % 64 == 0
          (2, 8, 12, 32, 24, 2, 2, 0, 1), (1, 16, 8, 64, 16, 4, 4, 0, 1), (3, 8, 8, 96, 40, 2, 2, 0, 1), (2, 32, 16, 8, 16, 8, 8, 0, 1),
          # OW = 16 divides the 64-pixel k-tile and the pixel count is a multiple of it: the K-strided patch view's constant-step DMA source
-         (1, 32, 32, 32, 8, 2, 2, 0, 1), (2, 32, 64, 16, 24, 4, 4, 0, 1)]
+         (1, 32, 32, 32, 8, 2, 2, 0, 1), (2, 32, 64, 16, 24, 4, 4, 0, 1),
+         # stride-1 'same' convolutions whose output rows are whole k-tiles: the row-fast DMA source of the K-strided im2col operand
+         # (weight gradient; DmaSrc mode 3), plain and dilated, two images (the pixel index runs across image boundaries)
+         (2, 4, 64, 8, 16, 3, 1, 1, 1), (1, 8, 64, 8, 8, 3, 1, 2, 2), (2, 3, 128, 16, 8, 3, 1, 1, 1)]
 
 
 @pytest.mark.parametrize('dt,tag,tol', DT)
