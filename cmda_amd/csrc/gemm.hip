@@ -152,6 +152,7 @@ extern "C" int cmda_gemm(const cmda_gemm_params_t* pp, void* stream) {
 #include "gemm_t1.hip"
 #include "gemm_t2.hip"
 #include "gemm_t3.hip"
+#include "gemm_t4.hip"
 #include "gemm_reg.hip"
 #include "gemm_reg_f32_t0.hip"
 #include "gemm_reg_f32_t1.hip"

@@ -217,13 +217,13 @@ int cmda_gemm_wg_(const cmda_gemm_params_t& p, void* stream) {
   const bool nofast = p.tile_hint > 0 && (p.tile_hint & 2048);
   if (p.B.conv == 1) {
     // FAST: dY in the running-pointer mode, the im2col operand in the row-fast mode (stride-1 "same" convolution, output rows of
-    // whole k-tiles: the head's 3 x 3 bottleneck); with the address arithmetic gone from the LOAD segments the plain operands' four
-    // half-depth stages serve the im2col view too (tile_hint bit 12: keep the two full-depth stages, tuning A/B)
+    // whole k-tiles: the head's 3 x 3 bottleneck).  tile_hint bit 12 (tuning A/B): the plain operands' four half-depth stages for the
+    // im2col view too -- measured SLOWER (1907 against 1690 us on the general path's two full-depth stages, gpurun r04f)
     typedef DmaSrc<true, WG_T, false, WG_NW, 0, 64, 1> FA;
     typedef DmaSrc<true, WG_T, true, WG_NW, 0, 64, 3> FB;
     typedef DmaSrc<true, WG_T, false, WG_NW, 0, 32, 1> FA32;
     typedef DmaSrc<true, WG_T, true, WG_NW, 0, 32, 3> FB32;
-    if (!nofast && FA32::mode_ok(p.A, 1) && FB32::mode_ok(p.B, 3) && !(p.tile_hint > 0 && (p.tile_hint & 4096)))
+    if (!nofast && FA32::mode_ok(p.A, 1) && FB32::mode_ok(p.B, 3) && (p.tile_hint > 0 && (p.tile_hint & 4096)))
       CMDA_LAUNCH((gemm_wg_kernel<true, 32, 4, true>), grid, blk, 0, stream, p);
     else if (!nofast && FA::mode_ok(p.A, 1) && FB::mode_ok(p.B, 3)) CMDA_LAUNCH((gemm_wg_kernel<true, 64, 2, true>), grid, blk, 0, stream, p);
     else CMDA_LAUNCH((gemm_wg_kernel<true, 64, 2, false>), grid, blk, 0, stream, p);

@@ -45,6 +45,15 @@ def nt(M, N, K, hint, dt=torch.bfloat16, tag=1, res=False):
     return t
 
 
+_t = torch.zeros(256, device=dev)
+print(f'dependent-launch floor (graph replay, trivial kernel): {timeit(lambda: ops.axpby(_t, _t, 1.0, 0.0, out=_t)):.2f} us per launch')
+_x = torch.randn(8192, 320, device=dev)
+_g, _b = torch.ones(320, device=dev), torch.zeros(320, device=dev)
+print(f'LayerNorm fwd fp32 -> bf16, 8192 x 320: {timeit(lambda: ops.layernorm_fwd(_x, _g, _b, 1e-6, out_dtype=torch.bfloat16)):.2f} us per launch')
+if os.environ.get('RP_SHORT'):
+    for M, N, K in ((2048, 320, 320), (8192, 320, 320), (8192, 1280, 320), (8192, 320, 1280)):
+        print(f'  {M} x {N} x {K}: {nt(M, N, K, 0):.2f} us')
+    sys.exit(0)
 print('row panel (hint 5) vs heuristics, bf16, us per launch (back-to-back launches)')
 for M in (2048, 4096, 8192, 16384):
     for N, K, res in ((320, 320, False), (320, 320, True), (640, 320, False), (1280, 320, False), (320, 1280, True)):
