@@ -1128,6 +1128,30 @@ __global__ __launch_bounds__(64 * NW, (GldsCfg<TM, TN, NW, NSV>::MIN_WAVES)) voi
   gemm_glds_body<TM, TN, AKS, BKS, ACONV, BCONV, NW, NSV, FAST>(p, smem, loc - z * ntile, ntile, z, false);
 }
 
+// PAIR launch: two independent problems of the SAME template instance in one grid (blocks [0, nt0) run p0, the rest p1) -- the
+// q projection and the spatial-reduction convolution of a MiT block read the same LayerNorm output (mix_transformer.py:86-92), the
+// data gradients of q and kv are independent too: one dependent launch instead of two in chains that are bound by their launch count.
+template <int TM, int TN, bool AKS, bool BKS, int NW = 4, bool FAST = false>
+__global__ __launch_bounds__(64 * NW, (GldsCfg<TM, TN, NW, 0>::MIN_WAVES)) void gemm_glds_pair_kernel(GemmParams p0, GemmParams p1, int nt0, int nt1) {
+  __shared__ __attribute__((aligned(1024))) char smem[GldsCfg<TM, TN, NW, 0>::LDS_BYTES];
+  if ((int)blockIdx.x < nt0) gemm_glds_body<TM, TN, AKS, BKS, false, false, NW, 0, FAST>(p0, smem, blockIdx.x, nt0, 0, true);
+  else gemm_glds_body<TM, TN, AKS, BKS, false, false, NW, 0, FAST>(p1, smem, blockIdx.x - nt0, nt1, 0, true);
+}
+
+template <int TM, int TN, bool AKS, bool BKS>
+int launch_glds_pair(const GemmParams& p0, const GemmParams& p1, void* stream) {
+  constexpr int BM = 16 * TM * 2, BN = 32 * TN;
+  const long t0 = (long)((p0.M + BM - 1) / BM) * ((p0.N + BN - 1) / BN), t1 = (long)((p1.M + BM - 1) / BM) * ((p1.N + BN - 1) / BN);
+  if (t0 + t1 > 0x7fffffffL) return CMDA_ERR_SHAPE;
+  typedef DmaSrc<AKS, BM, false, 4, 0, 64, 1> FA;
+  typedef DmaSrc<BKS, BN, false, 4, 0, 64, 1> FB;
+  const bool fast = FA::mode_ok(p0.A, 1) && FB::mode_ok(p0.B, 1) && FA::mode_ok(p1.A, 1) && FB::mode_ok(p1.B, 1);
+  const dim3 grid((unsigned)(t0 + t1)), blk(256);
+  if (fast) CMDA_LAUNCH((gemm_glds_pair_kernel<TM, TN, AKS, BKS, 4, true>), grid, blk, 0, stream, p0, p1, (int)t0, (int)t1);
+  else CMDA_LAUNCH((gemm_glds_pair_kernel<TM, TN, AKS, BKS, 4, false>), grid, blk, 0, stream, p0, p1, (int)t0, (int)t1);
+  CMDA_CHECK_LAUNCH();
+}
+
 template <int TM, int TN, int NW, int NSV, bool AKS, bool BKS, bool ACONV, bool BCONV>
 int launch_glds_mode(const GemmParams& p, const dim3& grid, void* stream) {
   constexpr int BM = 16 * TM * (NW / 2), BN = 32 * TN;
@@ -1211,6 +1235,7 @@ int cmda_gemm_glds_t0_(const cmda_gemm_params_t& p, void* stream);        // gem
 int cmda_gemm_glds_t1_(const cmda_gemm_params_t& p, void* stream);        // gemm_t1.hip: 128x64 tile
 int cmda_gemm_glds_t2_(const cmda_gemm_params_t& p, void* stream);        // gemm_t2.hip: 64x64 tile
 int cmda_gemm_glds_t3_(const cmda_gemm_params_t& p, void* stream);        // gemm_t3.hip: 256x256 tile, 8 waves
+int cmda_gemm_glds_pair_t2_(const cmda_gemm_params_t& p0, const cmda_gemm_params_t& p1, void* stream);  // gemm_t2.hip: 64x64 pair launch
 int cmda_gemm_glds_t4_(const cmda_gemm_params_t& p, void* stream);        // gemm_t4.hip: 64x320 ROW-PANEL tile (full rows of the C = 320 stage)
 int cmda_gemm_grouped_t2_(const cmda_gemm_params_t* tab, const void* blk, int nblocks, int bconv, void* stream);  // gemm_g2.hip: 64x64
 int cmda_gemm_grouped_t0_(const cmda_gemm_params_t* tab, const void* blk, int nblocks, int bconv, void* stream);  // gemm_g0.hip: 128x128

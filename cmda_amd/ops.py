@@ -52,11 +52,13 @@ GEMM_TILE_HINT = int(os.environ.get('CMDA_GEMM_TILE_HINT', '0'))   # cmda_gemm_p
 
 def gemm(A, B, out, M, N, K, *, a_kstrided=False, b_kstrided=False, ldc=None, batch=1, c_batch_stride=0,
          batch2=1, c_batch2_stride=0, res_batch2_stride=0, splits=1, alpha=1.0, beta=0.0, bias=None, act=None, res=None, ldres=None, res_batch_stride=0,
-         rowscale=None, rows_per_scale=1, atomic=False, dtype=None, c_offset=0, colsum=None, c_patch=None, c_perm=None, defer=False, keep=()):
+         rowscale=None, rows_per_scale=1, atomic=False, dtype=None, c_offset=0, colsum=None, c_patch=None, c_perm=None, defer=False, keep=(),
+         hold=False):
     """out[m,n] = epi(alpha * sum_k A(m,k) B(n,k)); A/B are `View`s built by plain_view / conv_view.
     defer=True (weight gradients: nothing reads `out` before the pass ends): inside a deferral scope (`ln_deferral`) the launch is
     only QUEUED and goes out with the next `gemm_flush_deferred()` as part of a grouped launch; `keep` = the tensors behind the
-    operand views (kept alive until then)."""
+    operand views (kept alive until then).
+    hold=True: build the problem but do NOT launch it -- returns a handle for `gemm_pair` (two independent problems, one launch)."""
     check_dev(out, bias, res, rowscale)
     out_f32 = out.dtype == torch.float32
     p = GemmParams()
@@ -104,22 +106,47 @@ def gemm(A, B, out, M, N, K, *, a_kstrided=False, b_kstrided=False, ldc=None, ba
         _GD['queues'].setdefault(LN_LANE, []).append((p, (out, colsum) + tuple(keep), 2.0 * M * N * K * nb,
                                                       (M * K + N * K) * nb * es + 2 * M * N * nb * 4))
         return out
-    if GEMM_PROFILE is not None and out.is_cuda:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        call('cmda_gemm', ctypes.byref(p), stream_of(out))
-        e1.record()
+    if hold or (GEMM_PROFILE is not None and out.is_cuda):
         es = 2 if dtype == 1 else 4
         nb = batch * batch2
 
         def _unique(v):  # bytes of the tensor behind an operand view (an im2col view re-reads, the tensor is counted once)
             return (v.R // max(1, v.OH * v.OW) * v.H * v.W * v.C if v.conv else v.R * v.Cc * nb) * es
         cbytes = M * N * nb * (4 if out_f32 else es) * (2 if (atomic or beta != 0.0) else 1)
-        GEMM_PROFILE.append((2.0 * M * N * K * nb, e0, e1, _unique(A) + _unique(B) + cbytes + (M * N * nb * es if res is not None else 0),
-                             (M, N, K, nb, splits, bool(A.conv or B.conv), bool(a_kstrided), bool(b_kstrided), bool(atomic), out_f32)))
+        meta = (2.0 * M * N * K * nb, _unique(A) + _unique(B) + cbytes + (M * N * nb * es if res is not None else 0),
+                (M, N, K, nb, splits, bool(A.conv or B.conv), bool(a_kstrided), bool(b_kstrided), bool(atomic), out_f32))
+        if hold:
+            return (p, meta, out, (bias, res, rowscale, colsum) + tuple(keep))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        call('cmda_gemm', ctypes.byref(p), stream_of(out))
+        e1.record()
+        GEMM_PROFILE.append((meta[0], e0, e1, meta[1], meta[2]))
         return out
     call('cmda_gemm', ctypes.byref(p), stream_of(out))
     return out
+
+
+GEMM_PAIR = os.environ.get('CMDA_GEMM_PAIR', '1') != '0'   # False: gemm_pair launches its two problems one after the other (tuning A/B)
+
+
+def gemm_pair(h0, h1):
+    """launch two held problems (gemm(..., hold=True)) that are INDEPENDENT of each other as one grid (cmda_gemm_pair); the library
+    falls back to two launches for problems its pair kernel does not take"""
+    (p0, m0, out0, _k0), (p1, m1, out1, _k1) = h0, h1
+    prof = GEMM_PROFILE is not None and out0.is_cuda
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    if GEMM_PAIR:
+        call('cmda_gemm_pair', ctypes.byref(p0), ctypes.byref(p1), stream_of(out0))
+    else:
+        call('cmda_gemm', ctypes.byref(p0), stream_of(out0))
+        call('cmda_gemm', ctypes.byref(p1), stream_of(out1))
+    if prof:
+        e1.record()
+        GEMM_PROFILE.append((m0[0] + m1[0], e0, e1, m0[1] + m1[1], ('pair',) + m0[2][1:]))
+    return out0, out1
 
 
 # ---- deferred weight gradients: queued by gemm(defer=True) inside a deferral scope, launched in groups (cmda_gemm_grouped) ----------

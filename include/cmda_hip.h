@@ -96,6 +96,12 @@ typedef struct cmda_gemm_params_t {
 
 int cmda_gemm(const cmda_gemm_params_t* p, void* stream);
 
+/* Two INDEPENDENT GEMMs in one launch (neither reads the other's output): Attention's q projection and its spatial-reduction
+ * convolution consume the same LayerNorm output (mix_transformer.py:86-92), and under autograd the data gradients of q and kv are
+ * independent as well -- in chains bound by their launch count a pair costs one dependent launch.  Problems the pair kernel does not
+ * take (fp32, split-K, batched, im2col views, different operand orientations) are launched one after the other through cmda_gemm. */
+int cmda_gemm_pair(const cmda_gemm_params_t* a, const cmda_gemm_params_t* b, void* stream);
+
 /* K x K convolution with ONE output channel, stride 1, reflection (or zero) padding `pad`, NHWC x [B,H,W,C] and khwc weights
  * [K*K*C] in the activation dtype, out fp32 [B,H,W] = act(bias[0] + sum): the last layer of the Motion-Extractor generator
  * (ReflectionPad2d(3) + Conv2d(64,1,7) + Tanh, cyclegan/cyclegan_model.py:366-369).  Built for bf16, K = 7, C = 64, pad = 3;

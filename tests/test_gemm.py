@@ -268,3 +268,44 @@ def test_gemm_row_panel_tile(tgt, M, N, K):
         assert_close(out, res + (ref + bias) * sc[torch.arange(M) // rps, None], 2e-3, atol=1e-3, name='row panel fp32 residual epilogue')
     finally:
         ops.GEMM_TILE_HINT = old
+
+
+@pytest.mark.parametrize('nn', [False, True], ids=['NT', 'NN'])
+def test_gemm_pair_launch(tgt, nn):
+    """cmda_gemm_pair: two independent problems in one grid -- a plain Linear next to a patch-view convolution (q and the
+    spatial-reduction conv of a MiT block: same input, different shapes and epilogues), and two data gradients (K-strided weights,
+    one accumulating into its output).  Must equal the two single launches bit for bit."""
+    torch.manual_seed(17)
+    Bc, H, W, C, s = 1, 8, 16, 32, 2          # tokens 128, channels 32; sr conv: kernel = stride = 2 -> 32 rows x K = 128
+    M = Bc * H * W
+    x = tgt.to(torch.randn(M, C).bfloat16())
+    if not nn:
+        wq, bq = tgt.to((torch.randn(96, C) * 0.2).bfloat16()), tgt.to(torch.randn(96))
+        ws, bs = tgt.to((torch.randn(C, s * s * C) * 0.1).bfloat16()), tgt.to(torch.randn(C))
+        OH, OW = H // s, W // s
+
+        def build(hold):
+            q = torch.empty(M, 96, dtype=torch.bfloat16, device=tgt.device)
+            xs = torch.empty(Bc * OH * OW, C, dtype=torch.bfloat16, device=tgt.device)
+            h0 = ops.gemm(ops.plain_view(x, M, C), ops.plain_view(wq, 96, C), q, M, 96, C, dtype=1, bias=bq, act='gelu', hold=hold)
+            h1 = ops.gemm(ops.conv_view(x, Bc, H, W, C, s, s, s, 0), ops.plain_view(ws, C, s * s * C), xs, Bc * OH * OW, C, s * s * C,
+                          dtype=1, bias=bs, hold=hold)
+            return q, xs, h0, h1
+    else:
+        dy0, dy1 = tgt.to(torch.randn(M, 64).bfloat16()), tgt.to(torch.randn(40, 128).bfloat16())
+        w0, w1 = tgt.to((torch.randn(64, C) * 0.2).bfloat16()), tgt.to((torch.randn(128, C) * 0.2).bfloat16())   # [N_out, K_in]
+        prev = tgt.to(torch.randn(40, C).bfloat16())
+
+        def build(hold):
+            d0 = torch.empty(M, C, dtype=torch.bfloat16, device=tgt.device)
+            d1 = prev.clone()
+            h0 = ops.gemm(ops.plain_view(dy0, M, 64), ops.plain_view(w0, 64, C), d0, M, C, 64, b_kstrided=True, dtype=1, hold=hold)
+            h1 = ops.gemm(ops.plain_view(dy1, 40, 128), ops.plain_view(w1, 128, C), d1, 40, C, 128, b_kstrided=True, dtype=1, beta=1.0, hold=hold)
+            return d0, d1, h0, h1
+    a0, a1, _, _ = build(False)
+    b0, b1, h0, h1 = build(True)
+    ops.gemm_pair(h0, h1)
+    assert torch.equal(a0.float().cpu(), b0.float().cpu()) and torch.equal(a1.float().cpu(), b1.float().cpu())
+    if not nn:
+        ref = torch.nn.functional.gelu(x.float().cpu() @ wq.float().cpu().t() + bq.cpu())
+        assert_close(b0, ref, 1.5e-2, name='pair: q')
