@@ -1,0 +1,269 @@
+// gemm_lean.hip -- the LEAN instance of the LDS-DMA GEMM for the launches that dominate the UDA step's count: the encoders' Linear
+// layers and their data gradients at 2 + 2 samples per GPU (q / kv / proj / fc1 / fc2 of mix_transformer.py:31-44,62-66,80-102, ~1.8 k
+// launches per step of 0.2 - 7 GFLOP each).  Same tiles, same LDS image, same k-loop and the same fused epilogue as
+// gemm_glds_kernel (gemm_kernels.h) -- what differs is everything AROUND the k-loop, which at these sizes is most of the kernel:
+// the phase stamps of the general kernel on 4096 x 320 x 320 (tools/gemm_phase.py, gpurun r04h) read
+//     setup 1.28 us | first stage 0.16 | k-loop 1.60 | stage-C 0.36 | store 1.48      (block total 4.9 us)
+// -- the 300-byte parameter block arrives in six dependent scalar-load round trips spread over the branches of the general prologue
+// (operand-view modes, batch / split-K / patch / im2col arithmetic, the tile-group walk: ~1900 instructions ahead of the first DMA),
+// and the epilogue starts its bias / residual loads only when the accumulators are final.  Here the host digests the problem into a
+// 128-byte block that is read in ONE round trip, the prologue is straight-line pointer arithmetic, and the epilogue's bias and
+// residual loads are issued before the k-loop's last barrier.
+// Eligibility (host, cmda_gemm -> launch_dtype): bf16, plain operands (no im2col / patch view), A K-contiguous, B K-contiguous or
+// K-strided, K % 64 == 0, no batch, no split-K, no atomic / patch-store / column-sum output; tiles 64 x 64 and 128 x 64.
+#include "gemm_kernels.h"
+
+namespace {
+
+struct LeanParams {
+  const bf16_t* A;
+  const bf16_t* B;
+  void* C;
+  const float* bias;
+  const void* res;
+  const float* rowscale;
+  long lda, ldb, ldc, ldres;
+  int M, N, nkt, tiles_n;
+  int ntile, rows_per_scale, act, flags;   // flags: 1 out_f32, 2 res_f32, 4 c_vec_ok
+  float alpha, beta;
+};
+
+template <int TM, int TN, bool BKS>
+__global__ __launch_bounds__(256, (GldsCfg<TM, TN, 4, 0>::MIN_WAVES)) void gemm_lean_kernel(LeanParams q) {
+  typedef bf16_t T;
+  typedef GldsCfg<TM, TN, 4, 0> Cfg;
+  constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = 64, NS = 2;
+  constexpr int SZ_A = Cfg::SZ_A, SZ_B = Cfg::SZ_B, PITCH_C = Cfg::PITCH_C;
+  __shared__ __attribute__((aligned(1024))) char smem[Cfg::LDS_BYTES];
+  T* const sAbase = reinterpret_cast<T*>(smem);
+  T* const sBbase = sAbase + NS * SZ_A;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1, g = lane >> 4, l15 = lane & 15;
+  // every field of the parameter block is consumed in this straight-line prologue (one scalar-load round trip)
+  const int M = q.M, N = q.N, nkt = q.nkt, tiles_n = q.tiles_n, ntile = q.ntile;
+  const long lda = q.lda, ldb = q.ldb;
+  int bt = blockIdx.x;
+  {   // XCD-contiguous tile ranges (blocks b and b + 8 share an L2): n-tiles of one m-panel first
+    const int qq = ntile >> 3, rr = ntile & 7, xcd = bt & 7, loc = bt >> 3;
+    bt = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + loc;
+  }
+  const int mt = (int)((unsigned)bt / (unsigned)tiles_n), nt = bt - mt * tiles_n;
+  const long m0 = (long)mt * BM, n0 = (long)nt * BN;
+
+  // DMA sources: running pointers (gemm_kernels.h DmaSrc mode 1), the LDS image of gemm_glds_body: line r, slot = chunk ^ (r & 7)
+  constexpr int JA = BM * BK / 2048, JB = BN * BK / 2048;
+  constexpr int CPL_B = BKS ? BN / 8 : 8, LPI_B = 64 / CPL_B;
+  const char* curA[JA];
+  const char* curB[JB];
+  int stepA[JA], stepB[JB];
+  const char* zero = reinterpret_cast<const char*>(g_zero16);
+#pragma unroll
+  for (int j = 0; j < JA; ++j) {
+    const int ln = (wid * JA + j) * 8 + (lane >> 3), chunk = (lane & 7) ^ (ln & 7);
+    const long r = m0 + ln;
+    const bool ok = r < M;
+    curA[j] = ok ? reinterpret_cast<const char*>(q.A + r * lda + chunk * 8) : zero;
+    stepA[j] = ok ? BK * 2 : 0;
+  }
+#pragma unroll
+  for (int j = 0; j < JB; ++j) {
+    const int ln = (wid * JB + j) * LPI_B + lane / CPL_B, chunk = (lane % CPL_B) ^ (ln & 7);
+    if constexpr (!BKS) {
+      const long r = n0 + ln;
+      const bool ok = r < N;
+      curB[j] = ok ? reinterpret_cast<const char*>(q.B + r * ldb + chunk * 8) : zero;
+      stepB[j] = ok ? BK * 2 : 0;
+    } else {
+      const long c = n0 + chunk * 8;
+      const bool ok = c + 8 <= N;
+      curB[j] = ok ? reinterpret_cast<const char*>(q.B + (long)ln * ldb + c) : zero;
+      stepB[j] = ok ? (int)((long)BK * ldb * 2) : 0;
+    }
+  }
+  auto issue = [&](int stage) {
+    char* la = reinterpret_cast<char*>(sAbase + stage * SZ_A) + wid * JA * 1024;
+    char* lb = reinterpret_cast<char*>(sBbase + stage * SZ_B) + wid * JB * 1024;
+#pragma unroll
+    for (int j = 0; j < JA; ++j) {
+      glds16(curA[j], la + j * 1024);
+      curA[j] += stepA[j];
+    }
+#pragma unroll
+    for (int j = 0; j < JB; ++j) {
+      glds16(curB[j], lb + j * 1024);
+      curB[j] += stepB[j];
+    }
+  };
+  issue(0);
+
+  // epilogue operands requested NOW: the thread's bias quad (and, below, its residual rows before the last barrier)
+  constexpr int QPR = BN / 4, RSTEP = 256 / QPR, NIT = BM / RSTEP;
+  const int q4 = (tid % QPR) * 4, er0 = tid / QPR;
+  const long en = n0 + q4;
+  const bool ecol = en < N;
+  const bool full = (q.flags & 4) != 0 && en + 4 <= N;
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (q.bias && ecol) {
+    if (full) ld4(q.bias + en, bv);
+    else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (en + e < N) bv[e] = q.bias[en + e];
+    }
+  }
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int st = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    pipe_barrier<0>();                 // tile kt has landed; every wave is done reading the other stage
+    if (kt + 1 < nkt) issue(st ^ 1);
+    const T* sA = sAbase + st * SZ_A;
+    const T* sB = sBbase + st * SZ_B;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      u16x8 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * 16 * TM + i * 16 + l15;
+        fa[i] = *reinterpret_cast<const u16x8*>(&sA[row * BK + (((kk * 4 + g) ^ (row & 7)) << 3)]);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int nr = wn * 16 * TN + j * 16;
+        if constexpr (!BKS) {
+          const int row = nr + l15;
+          fb[j] = *reinterpret_cast<const u16x8*>(&sB[row * BK + (((kk * 4 + g) ^ (row & 7)) << 3)]);
+        } else {
+          const int qd = l15 >> 2, pp = l15 & 3;
+          const int k0 = kk * 32 + 8 * g + qd, k1 = k0 + 4;
+          const int cidx = (nr >> 3) + (pp >> 1), half = (pp & 1) << 2;
+          const u16x4 lo = lds_read_tr16(&sB[k0 * BN + ((cidx ^ (k0 & 7)) << 3) + half]);
+          const u16x4 hi = lds_read_tr16(&sB[k1 * BN + ((cidx ^ (k1 & 7)) << 3) + half]);
+          fb[j] = u16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16_16x16x32(fa[i], fb[j], acc[i][j]);
+    }
+    st ^= 1;
+  }
+  // residual rows of this thread: requested before the accumulators go through LDS (their latency hides behind the staging)
+  const bool has_res = q.res != nullptr, res32 = (q.flags & 2) != 0, f32o = (q.flags & 1) != 0;
+  float rv[NIT][4];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    rv[it][0] = rv[it][1] = rv[it][2] = rv[it][3] = 0.f;
+    const long m = m0 + er0 + it * RSTEP;
+    if (has_res && ecol && m < M) {
+      const long ri = m * q.ldres + en;
+      if (full) {
+        if (res32) ld4(reinterpret_cast<const float*>(q.res) + ri, rv[it]);
+        else ld4(reinterpret_cast<const T*>(q.res) + ri, rv[it]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (en + e < N) rv[it][e] = res32 ? reinterpret_cast<const float*>(q.res)[ri + e] : ldf(reinterpret_cast<const T*>(q.res) + ri + e);
+      }
+    }
+  }
+  __syncthreads();
+  float* sC = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        sC[(wm * 16 * TM + i * 16 + 4 * g + r) * PITCH_C + wn * 16 * TN + j * 16 + l15] = acc[i][j][r];
+  __syncthreads();
+  if (!ecol) return;
+  const float alpha = q.alpha, beta = q.beta;
+  const bool has_beta = beta != 0.f, has_rs = q.rowscale != nullptr;
+  const int act = q.act;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int row = er0 + it * RSTEP;
+    const long m = m0 + row;
+    if (m >= M) break;
+    const float4 t = *reinterpret_cast<const float4*>(&sC[row * PITCH_C + q4]);
+    float v[4] = {t.x, t.y, t.z, t.w};
+    const long ci = m * q.ldc + en;
+    float ov[4] = {0.f, 0.f, 0.f, 0.f};
+    float rs = 1.f;
+    if (has_rs) rs = q.rowscale[m / q.rows_per_scale];
+    if (has_beta) {
+      if (full) {
+        if (f32o) ld4(reinterpret_cast<const float*>(q.C) + ci, ov);
+        else ld4(reinterpret_cast<const T*>(q.C) + ci, ov);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (en + e < N) ov[e] = f32o ? reinterpret_cast<const float*>(q.C)[ci + e] : ldf(reinterpret_cast<const T*>(q.C) + ci + e);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float x = alpha * v[e] + bv[e];
+      const float a = act == 0 ? x : act == 1 ? epi_act<1>(x) : act == 2 ? epi_act<2>(x) : epi_act<3>(x);
+      v[e] = a * rs + rv[it][e] + beta * ov[e];
+    }
+    if (full) {
+      if (f32o) st4(reinterpret_cast<float*>(q.C) + ci, v);
+      else st4(reinterpret_cast<T*>(q.C) + ci, v);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (en + e >= N) continue;
+        if (f32o) reinterpret_cast<float*>(q.C)[ci + e] = v[e];
+        else stf(reinterpret_cast<T*>(q.C) + ci + e, v[e]);
+      }
+    }
+  }
+}
+
+template <int TM, int TN>
+int launch_lean(const GemmParams& p, void* stream) {
+  constexpr int BM = 16 * TM * 2, BN = 32 * TN;
+  LeanParams q;
+  q.A = reinterpret_cast<const bf16_t*>(p.A.ptr);
+  q.B = reinterpret_cast<const bf16_t*>(p.B.ptr);
+  q.C = p.C;
+  q.bias = p.bias;
+  q.res = p.res;
+  q.rowscale = p.rowscale;
+  q.lda = p.A.ld; q.ldb = p.B.ld; q.ldc = p.ldc; q.ldres = p.ldres;
+  q.M = p.M; q.N = p.N; q.nkt = p.K / 64;
+  q.tiles_n = (p.N + BN - 1) / BN;
+  const long tiles = (long)((p.M + BM - 1) / BM) * q.tiles_n;
+  if (tiles > 0x7fffffffL) return CMDA_ERR_SHAPE;
+  q.ntile = (int)tiles;
+  q.rows_per_scale = p.rows_per_scale > 0 ? p.rows_per_scale : 1;
+  q.act = p.act;
+  q.flags = (p.out_f32 ? 1 : 0) | (p.res_f32 ? 2 : 0) | (p.c_vec_ok ? 4 : 0);
+  q.alpha = p.alpha; q.beta = p.beta;
+  const dim3 grid((unsigned)tiles), blk(256);
+  if (p.b_kstrided) CMDA_LAUNCH((gemm_lean_kernel<TM, TN, true>), grid, blk, 0, stream, q);
+  else CMDA_LAUNCH((gemm_lean_kernel<TM, TN, false>), grid, blk, 0, stream, q);
+  CMDA_CHECK_LAUNCH();
+}
+
+}  // namespace
+
+// HOST: does the lean kernel take this problem?  (tile: launch_dtype's choice, 1 = 128 x 64, 2 = 64 x 64)
+bool cmda_gemm_lean_ok_(const cmda_gemm_params_t& p, int tile) {
+  auto plain = [](const GemmView& v) { return v.conv == 0 && v.vec_ok && (v.ld % 8) == 0 && v.R < (1L << 31) && v.Cc < (1L << 31); };
+  return (tile == 1 || tile == 2) && p.dtype == CMDA_BF16 && !p.a_kstrided && plain(p.A) && plain(p.B) && (p.K % 64) == 0 && p.K >= 64 &&
+         p.batch == 1 && p.batch2 <= 1 && p.splits <= 1 && !p.atomic && !p.colsum && p.c_patch_ow == 0 && p.c_perm_ci == 0 &&
+         (!p.b_kstrided || 64L * p.B.ld * 2 < (1L << 31)) && !(p.tile_hint > 0 && (p.tile_hint & 8192));   // (tile_hint bit 13: general kernel, tuning A/B)
+}
+
+int cmda_gemm_lean_(const cmda_gemm_params_t& p, int tile, void* stream) {
+  return tile == 1 ? launch_lean<4, 2>(p, stream) : launch_lean<2, 2>(p, stream);
+}
