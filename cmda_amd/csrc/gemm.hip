@@ -119,12 +119,13 @@ int launch_dtype(GemmParams& p, void* stream) {
         tile = 2;
       }
       if (tile == 0) return cmda_gemm_glds_t0_(p, stream);
-      // the encoders' Linear layers / data gradients on the two small tiles: the lean instance (gemm_lean.hip) unless the 4-stage
-      // latency configuration applies (>= 12 k-tiles on a grid that is resident at once: launch_glds)
+      // the encoders' Linear layers / data gradients on the two small tiles: the lean instance (gemm_lean.hip), in the 4-stage latency
+      // configuration where launch_glds would choose it (>= 12 k-tiles on a grid that is resident at once)
       if (cmda_gemm_lean_ok_(p, tile)) {
         const long tl = tile == 1 ? blocks(128, 64) : blocks(64, 64);
-        const bool four_stage = tl <= 256L * (tile == 1 ? 1 : 2) && nkt >= 12;
-        if (!four_stage) return cmda_gemm_lean_(p, tile, stream);
+        const int force = p.tile_hint > 0 ? ((p.tile_hint >> 4) & 15) : 0;
+        const bool four_stage = force ? force == 4 : (tl <= 256L * (tile == 1 ? 1 : 2) && nkt >= 12);
+        return cmda_gemm_lean_(p, tile, four_stage ? 1 : 0, stream);
       }
       if (tile == 1) return cmda_gemm_glds_t1_(p, stream);
       return cmda_gemm_glds_t2_(p, stream);

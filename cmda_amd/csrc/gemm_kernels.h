@@ -1236,7 +1236,7 @@ int cmda_gemm_glds_t1_(const cmda_gemm_params_t& p, void* stream);        // gem
 int cmda_gemm_glds_t2_(const cmda_gemm_params_t& p, void* stream);        // gemm_t2.hip: 64x64 tile
 int cmda_gemm_glds_t3_(const cmda_gemm_params_t& p, void* stream);        // gemm_t3.hip: 256x256 tile, 8 waves
 bool cmda_gemm_lean_ok_(const cmda_gemm_params_t& p, int tile);           // gemm_lean.hip: lean plain-operand instance (64x64 / 128x64)
-int cmda_gemm_lean_(const cmda_gemm_params_t& p, int tile, void* stream);
+int cmda_gemm_lean_(const cmda_gemm_params_t& p, int tile, int four_stage, void* stream);
 int cmda_gemm_glds_pair_t2_(const cmda_gemm_params_t& p0, const cmda_gemm_params_t& p1, void* stream);  // gemm_t2.hip: 64x64 pair launch
 int cmda_gemm_glds_t4_(const cmda_gemm_params_t& p, void* stream);        // gemm_t4.hip: 64x320 ROW-PANEL tile (full rows of the C = 320 stage)
 int cmda_gemm_grouped_t2_(const cmda_gemm_params_t* tab, const void* blk, int nblocks, int bconv, void* stream);  // gemm_g2.hip: 64x64

@@ -28,11 +28,13 @@ struct LeanParams {
   float alpha, beta;
 };
 
-template <int TM, int TN, bool BKS>
-__global__ __launch_bounds__(256, (GldsCfg<TM, TN, 4, 0>::MIN_WAVES)) void gemm_lean_kernel(LeanParams q) {
+// NSV = 0: two LDS stages (most resident blocks); NSV = 4: the latency configuration for grids that are resident at once and run
+// >= 12 k-tiles per block (fc2 / its data gradient at K = 1280 ... 2048: three k-tiles in flight) -- launch_glds's rule
+template <int TM, int TN, bool BKS, int NSV = 0>
+__global__ __launch_bounds__(256, (GldsCfg<TM, TN, 4, NSV>::MIN_WAVES)) void gemm_lean_kernel(LeanParams q) {
   typedef bf16_t T;
-  typedef GldsCfg<TM, TN, 4, 0> Cfg;
-  constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = 64, NS = 2;
+  typedef GldsCfg<TM, TN, 4, NSV> Cfg;
+  constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = 64, NS = Cfg::NS;
   constexpr int SZ_A = Cfg::SZ_A, SZ_B = Cfg::SZ_B, PITCH_C = Cfg::PITCH_C;
   __shared__ __attribute__((aligned(1024))) char smem[Cfg::LDS_BYTES];
   T* const sAbase = reinterpret_cast<T*>(smem);
@@ -94,7 +96,9 @@ __global__ __launch_bounds__(256, (GldsCfg<TM, TN, 4, 0>::MIN_WAVES)) void gemm_
       curB[j] += stepB[j];
     }
   };
-  issue(0);
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nkt) issue(s);
 
   // epilogue operands requested NOW: the thread's bias quad (and, below, its residual rows before the last barrier)
   constexpr int QPR = BN / 4, RSTEP = 256 / QPR, NIT = BM / RSTEP;
@@ -118,10 +122,17 @@ __global__ __launch_bounds__(256, (GldsCfg<TM, TN, 4, 0>::MIN_WAVES)) void gemm_
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  constexpr int LPT = JA + JB;           // DMA instructions per wave per k-tile
   int st = 0;
   for (int kt = 0; kt < nkt; ++kt) {
-    pipe_barrier<0>();                 // tile kt has landed; every wave is done reading the other stage
-    if (kt + 1 < nkt) issue(st ^ 1);
+    // tile kt has landed (NS - 2 younger tiles may stay in flight; the tail drains); every wave is done reading stage st - 1
+    if (kt + NS - 2 < nkt) pipe_barrier<(NS - 2) * LPT>();
+    else pipe_barrier<0>();
+    {
+      int sn = st + NS - 1;
+      if (sn >= NS) sn -= NS;
+      if (kt + NS - 1 < nkt) issue(sn);
+    }
     const T* sA = sAbase + st * SZ_A;
     const T* sB = sBbase + st * SZ_B;
 #pragma unroll
@@ -152,7 +163,7 @@ __global__ __launch_bounds__(256, (GldsCfg<TM, TN, 4, 0>::MIN_WAVES)) void gemm_
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16_16x16x32(fa[i], fb[j], acc[i][j]);
     }
-    st ^= 1;
+    if (++st == NS) st = 0;
   }
   // residual rows of this thread: requested before the accumulators go through LDS (their latency hides behind the staging)
   const bool has_res = q.res != nullptr, res32 = (q.flags & 2) != 0, f32o = (q.flags & 1) != 0;
@@ -228,7 +239,7 @@ __global__ __launch_bounds__(256, (GldsCfg<TM, TN, 4, 0>::MIN_WAVES)) void gemm_
   }
 }
 
-template <int TM, int TN>
+template <int TM, int TN, int NSV = 0>
 int launch_lean(const GemmParams& p, void* stream) {
   constexpr int BM = 16 * TM * 2, BN = 32 * TN;
   LeanParams q;
@@ -249,8 +260,8 @@ int launch_lean(const GemmParams& p, void* stream) {
   q.flags = (p.out_f32 ? 1 : 0) | (p.res_f32 ? 2 : 0) | (p.c_vec_ok ? 4 : 0);
   q.alpha = p.alpha; q.beta = p.beta;
   const dim3 grid((unsigned)tiles), blk(256);
-  if (p.b_kstrided) CMDA_LAUNCH((gemm_lean_kernel<TM, TN, true>), grid, blk, 0, stream, q);
-  else CMDA_LAUNCH((gemm_lean_kernel<TM, TN, false>), grid, blk, 0, stream, q);
+  if (p.b_kstrided) CMDA_LAUNCH((gemm_lean_kernel<TM, TN, true, NSV>), grid, blk, 0, stream, q);
+  else CMDA_LAUNCH((gemm_lean_kernel<TM, TN, false, NSV>), grid, blk, 0, stream, q);
   CMDA_CHECK_LAUNCH();
 }
 
@@ -264,6 +275,7 @@ bool cmda_gemm_lean_ok_(const cmda_gemm_params_t& p, int tile) {
          (!p.b_kstrided || 64L * p.B.ld * 2 < (1L << 31)) && !(p.tile_hint > 0 && (p.tile_hint & 8192));   // (tile_hint bit 13: general kernel, tuning A/B)
 }
 
-int cmda_gemm_lean_(const cmda_gemm_params_t& p, int tile, void* stream) {
+int cmda_gemm_lean_(const cmda_gemm_params_t& p, int tile, int four_stage, void* stream) {
+  if (four_stage) return tile == 1 ? launch_lean<4, 2, 4>(p, stream) : launch_lean<2, 2, 4>(p, stream);
   return tile == 1 ? launch_lean<4, 2>(p, stream) : launch_lean<2, 2>(p, stream);
 }

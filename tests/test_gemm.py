@@ -12,7 +12,8 @@ DT = [(torch.float32, 0, 2e-5), (torch.bfloat16, 1, 1.5e-2), (torch.float32, 2, 
 
 @pytest.mark.parametrize('dt,tag,tol', DT)
 @pytest.mark.parametrize('M,N,K', [(70, 50, 40), (130, 19, 147), (256, 128, 64), (33, 200, 8), (300, 260, 96),
-                                   (300, 260, 128), (130, 19, 192), (700, 64, 320)])
+                                   (300, 260, 128), (130, 19, 192), (700, 64, 320),
+                                   (130, 64, 1024), (257, 96, 768)])   # >= 12 k-tiles on a resident grid: the 4-stage configurations
 def test_gemm_layouts(tgt, dt, tag, tol, M, N, K):
     torch.manual_seed(M * 7 + N)
     a, b = torch.randn(M, K).to(dt), torch.randn(N, K).to(dt)
