@@ -126,8 +126,9 @@ class ASPPWrapper(nn.Module):
                 dz = _bn_bwd(pwm.bn, dcat, z, st_z, M, Ch, True, nb * Ch, j * Ch, groups=groups)
                 dub = K.linear_bwd(dz, ub, pwm.conv.weight, None, M, Cin)
                 du = _bn_bwd(dwm.bn, dub, u, st_u, M, Cin, True, groups=groups)
-                with rt.lane('wgrad', du, x):
-                    ops.dwconv_bwd_weight(du, x, rt.grad(dwm.conv.weight).view(Cin, 9), None, B, H, W, Cin, d)
+                # (off the critical path: with a tail queue open -- segmentors.train_bwd -- it runs in the tail of the backward pass)
+                ops.tail_defer(lambda du=du, gw=rt.grad(dwm.conv.weight).view(Cin, 9), d=d:
+                               ops.dwconv_bwd_weight(du, x, gw, None, B, H, W, Cin, d))
                 ops.dwconv_bwd_data(du, rt.wdw(dwm.conv.weight), B, H, W, Cin, d, out=dx, accumulate=not first)
             first = False
         return dx

@@ -103,7 +103,7 @@ def gemm(A, B, out, M, N, K, *, a_kstrided=False, b_kstrided=False, ldc=None, ba
     if defer and _LN_DEFER['depth'] > 0 and GEMM_DEFER:
         es = 2 if dtype == 1 else 4
         nb = batch * batch2
-        _GD['queues'].setdefault(LN_LANE, []).append((p, (out, colsum) + tuple(keep), 2.0 * M * N * K * nb,
+        _GD['queues'].setdefault(GD_QUEUE_KEY or LN_LANE, []).append((p, (out, colsum) + tuple(keep), 2.0 * M * N * K * nb,
                                                       (M * K + N * K) * nb * es + 2 * M * N * nb * 4))
         return out
     if hold or (GEMM_PROFILE is not None and out.is_cuda):
@@ -151,6 +151,12 @@ def gemm_pair(h0, h1):
 
 # ---- deferred weight gradients: queued by gemm(defer=True) inside a deferral scope, launched in groups (cmda_gemm_grouped) ----------
 import os as _os
+# queue key override for gemm(defer=True) (None: the current lane).  The decode head's weight gradients are queued under their own
+# key when they are to run in the TAIL of the backward pass (segmentors.train_bwd): the per-stage flushes of the encoders' backward
+# passes, which run on the same lane in between, must not launch them.
+GD_QUEUE_KEY = None
+# work postponed to the same tail (closures: the head's depthwise weight-gradient kernels), run by `run_tail()`
+_TAIL_FNS = []
 GEMM_DEFER = _os.environ.get('CMDA_GEMM_DEFER', '1') != '0'    # False: defer=True launches in place (A/B switch for tuning, tests of the single-launch path)
 _GD = {'queues': {}, 'plans': {}, 'arena': None, 'pinned_plans': False}
 _GD_ARENA_BYTES = 192 << 20
@@ -175,6 +181,23 @@ def _gd_arena(dev, nbytes):
     lo = a[1]
     a[1] = lo + nbytes
     return a[0][lo:lo + nbytes]
+
+
+def tail_defer(fn):
+    """run fn() now -- or, while a tail queue is open (GD_QUEUE_KEY set inside a deferral scope), together with that queue"""
+    if GD_QUEUE_KEY is not None and _LN_DEFER['depth'] > 0:
+        _TAIL_FNS.append(fn)
+    else:
+        fn()
+
+
+def run_tail(key):
+    """launch everything postponed under `key`: the queued weight gradients (grouped launch) and the postponed closures"""
+    fns = list(_TAIL_FNS)
+    del _TAIL_FNS[:]
+    for fn in fns:
+        fn()
+    gemm_flush_deferred(from_lane=key)
 
 
 def gemm_deferred_tensors(lane=None):
@@ -301,8 +324,13 @@ class ln_deferral:
         _LN_DEFER['depth'] -= 1
         if _LN_DEFER['depth'] == 0:
             if exc[0] is None:
+                fns = list(_TAIL_FNS)   # (a tail nobody ran: run it here)
+                del _TAIL_FNS[:]
+                for fn in fns:
+                    fn()
                 ln_fold_deferred(all_lanes=True)
             else:   # the pass died half way: drop what it queued / touched instead of folding it into the next pass
+                del _TAIL_FNS[:]
                 _LN_DEFER['touched'] = {}
                 _CG['touched'] = {}
                 _GD['queues'].clear()

@@ -8,6 +8,8 @@ backward pass and accumulates parameter gradients in place.
 """
 from collections import OrderedDict
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -279,7 +281,7 @@ class FusionEncoderDecoder(nn.Module):
         feats = [(J, h, w) for J, (h, w) in zip(joint, shapes)]
         return feats, names, (sv_i, sv_e, sv_f, n, G), B
 
-    def _extract_joint_bwd(self, sv, dJ, B):
+    def _extract_joint_bwd(self, sv, dJ, B, tail_key=None):
         """dJ: {level: d J_l}; the gradient blocks are consumed in place (fusion contributions are added into blocks 0 and 2)"""
         sv_i, sv_e, sv_f, n, G = sv
         d = [dJ.get(i) for i in range(4)]
@@ -302,6 +304,8 @@ class FusionEncoderDecoder(nn.Module):
         with rt.lane('enc', *[t for t in d if t is not None]):
             self.backbone_events.bwd(sv_e, d_ev)
         self.backbone_image.bwd(sv_i, d_img)
+        if tail_key is not None:   # the decode head's postponed weight gradients: behind the (shorter) image-encoder chain
+            ops.run_tail(tail_key)
         rt.join_lanes('enc')
         rt.join_lanes('wgrad')
 
@@ -335,7 +339,22 @@ class FusionEncoderDecoder(nn.Module):
             if saved[0] == 'joint':
                 _, sv, sv_h, B = saved[:4]
                 P = saved[4] if len(saved) > 4 else 1
-                dJ = self.decode_head.bwd_train_joint(sv_h, B // P, gscale)
+                # TAIL mode (single GPU, lanes on): the decode head's weight gradients (dense GEMMs + the depthwise weight-gradient
+                # stencils, ~4 ms at 2 + 2 samples) are off the critical path.  The image encoder's backward chain ends ~2 ms before
+                # the event encoder's (half the samples), so they are queued under their own key and launched on the main lane
+                # BEHIND the image encoder's backward pass, in the gap before the join.  (With a gradient exchange armed the head's
+                # gradients must be final before the encoders start: flushed in place, as before.)
+                tail = (rt.concurrency() and rt.grad_ready_hook is None and not rt.lane_enabled('hw') and
+                        os.environ.get('CMDA_HEAD_TAIL', '1') != '0')
+                if tail:
+                    ops.GD_QUEUE_KEY = 'main/headtail'
+                try:
+                    dJ = self.decode_head.bwd_train_joint(sv_h, B // P, gscale)
+                finally:
+                    ops.GD_QUEUE_KEY = None
+                if tail:
+                    self._extract_joint_bwd(sv, dJ, B, tail_key='main/headtail')
+                    return
                 if rt.lane_enabled('hw') and rt.grad_ready_hook is None:
                     # the decode head's queued weight gradients (dense 256 x 256-tile GEMMs, ~3.5 ms at 2 + 2 samples) are off the
                     # critical path: a third queue runs them underneath the encoders' latency-bound backward chains
