@@ -1,9 +1,11 @@
-// gemm_t4.hip -- the 64 x 320 ROW-PANEL instantiation of the LDS-DMA GEMM kernel: one workgroup owns 64 full rows of a 320-column
-// output (or one 320-column slice of a wider one), three 48-KiB LDS stages.  For the Linear layers of the MiT stage with C = 320 (40
-// of MiT-B5's 52 blocks: q / proj 320 x 320, kv 640 x 320, fc1 1280 x 320, fc2 320 x 1280 -- mix_transformer.py:31-44,62-66,80-102)
-// at the UDA step's 2 + 2 samples (M = 2048 ... 8192 rows): a lone 64 x 64 block keeps one 16-KiB k-tile in flight against ~1 us of
-// load latency (~15 B/clk per CU), the row panel keeps 96 KiB in flight, reads the weights ONCE per 64 rows instead of once per tile
-// row, and its workgroups hold whole rows -- what a LayerNorm epilogue needs.  Templates: gemm_kernels.h; chosen by launch_dtype.
+// gemm_t4.hip -- the 64 x 320 ROW-PANEL instantiation of the LDS-DMA GEMM kernel: one workgroup (8 waves, 16 x 160 each) owns 64 full
+// rows of a 320-column output (or one 320-column slice of a wider one), two 48-KiB LDS stages.  Built for the Linear layers of the MiT
+// stage with C = 320 (q / proj 320 x 320, kv 640 x 320, fc1 1280 x 320, fc2 320 x 1280 -- mix_transformer.py:31-44,62-66,80-102) as
+// the carrier of a LayerNorm epilogue (whole rows per workgroup: VERDICT r03 item 2 ii).  MEASURED AND NOT SELECTED by the heuristics
+// (tile_hint 5 only: tuning sweeps and tests): graph-timed on MI355X (tools/dbg/rp_bench.py, gpurun r04d) 8192 x 320 x 320 takes 12.1 us
+// against 7.9 on the 64 x 64 tile, 8192 x 320 x 1280 29.4 against 17.7 -- per k-tile every wave re-reads 22 KiB of B fragments from LDS
+// for 20 MFMAs, and the 4-wave form (32 x 160 per wave) serialises its fragment reads behind its MFMAs (15.0 / 35.8 us); the 4-12 us
+// lost exceed the ~7.8 us LayerNorm launch the epilogue would remove.  Templates: gemm_kernels.h.
 #include "gemm_kernels.h"
 
 int cmda_gemm_glds_t4_(const cmda_gemm_params_t& p, void* stream) {
@@ -14,9 +16,5 @@ int cmda_gemm_glds_t4_(const cmda_gemm_params_t& p, void* stream) {
   const long zz = (long)p.batch * p.batch2 * p.splits;
   if (tiles > 0x7fffffffL || zz > 65535) return CMDA_ERR_SHAPE;
   dim3 grid((unsigned)tiles, 1, (unsigned)zz);
-  const int var = p.tile_hint > 0 ? ((p.tile_hint >> 4) & 15) : 0;   // tuning: wave count / stage variants
-  if (var == 1) return launch_glds_ns<1, 10, 8, 3>(p, grid, stream);   // 8 waves (4 x 2), 16 x 160 per wave
-  if (var == 2) return launch_glds_ns<1, 10, 8, 2>(p, grid, stream);
-  if (var == 3) return launch_glds_ns<2, 10, 4, 2>(p, grid, stream);
-  return launch_glds_ns<2, 10, 4, 3>(p, grid, stream);
+  return launch_glds_mode<1, 10, 8, 2, false, false, false, false>(p, grid, stream);   // 8 waves (4 x 2), 16 x 160 per wave
 }

@@ -58,12 +58,12 @@ print('row panel (hint 5) vs heuristics, bf16, us per launch (back-to-back launc
 for M in (2048, 4096, 8192, 16384):
     for N, K, res in ((320, 320, False), (320, 320, True), (640, 320, False), (1280, 320, False), (320, 1280, True)):
         t0 = nt(M, N, K, 0, res=res)
-        ts = [nt(M, N, K, 5 | (v << 4), res=res) for v in range(4)]
+        ts = [nt(M, N, K, 5, res=res)]
         tt = [nt(M, N, K, h, res=res) for h in (3, 3 | (4 << 4), 2, 2 | (4 << 4), 1, 1 | (4 << 4))]
         tg = [nt(M, N, K, h | 2048, res=res) for h in (3, 2, 1)]   # general address path
         fl = 2.0 * M * N * K
         print(f'  {M:6d} x {N:5d} x {K:5d} {"+res32" if res else "      "}: heuristics {t0:6.1f} us ({fl / t0 / 1e6:5.0f} TF) | 64x64 {tt[0]:5.1f} 4st {tt[1]:5.1f} | 128x64 {tt[2]:5.1f} 4st {tt[3]:5.1f} | '
-              f'128x128 {tt[4]:5.1f} 4st {tt[5]:5.1f} | general path 64x64 {tg[0]:5.1f} 128x64 {tg[1]:5.1f} 128x128 {tg[2]:5.1f} | row panel 4w3s {ts[0]:5.1f} 8w3s {ts[1]:5.1f} 8w2s {ts[2]:5.1f} 4w2s {ts[3]:5.1f}')
+              f'128x128 {tt[4]:5.1f} 4st {tt[5]:5.1f} | general path 64x64 {tg[0]:5.1f} 128x64 {tg[1]:5.1f} 128x128 {tg[2]:5.1f} | row panel (8 waves, 2 stages) {ts[0]:5.1f}')
 print('split-bf16 (dtype 2) vs exact fp32 (dtype 0), fp32 storage')
 for M, N, K in ((8192, 1280, 320), (8192, 320, 1280), (65536, 256, 1024), (16384, 1024, 1024), (4096, 4096, 4096)):
     t0 = nt(M, N, K, 0, torch.float32, 0)
