@@ -52,7 +52,7 @@ _g, _b = torch.ones(320, device=dev), torch.zeros(320, device=dev)
 print(f'LayerNorm fwd fp32 -> bf16, 8192 x 320: {timeit(lambda: ops.layernorm_fwd(_x, _g, _b, 1e-6, out_dtype=torch.bfloat16)):.2f} us per launch')
 if os.environ.get('RP_SHORT'):
     for M, N, K in ((2048, 320, 320), (8192, 320, 320), (8192, 1280, 320), (8192, 320, 1280)):
-        print(f'  {M} x {N} x {K}: {nt(M, N, K, 0):.2f} us')
+        print(f'  {M} x {N} x {K}: lean {nt(M, N, K, 0):.2f} us   general kernel {nt(M, N, K, 8192):.2f} us   general + general address path {nt(M, N, K, 8192 | 2048):.2f} us')
     sys.exit(0)
 print('row panel (hint 5) vs heuristics, bf16, us per launch (back-to-back launches)')
 for M in (2048, 4096, 8192, 16384):
