@@ -148,10 +148,8 @@ __global__ void ce_bwd_kernel(const float* __restrict__ logits, const long long*
   const float gscale = (gscale_ptr ? *gscale_ptr : 1.f) * gscale_mul;
   const long total = (long)B * h * w;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int x = (int)(i % w);
-    const long t = i / w;
-    const int y = (int)(t % h);
-    const int b = (int)(t / h);
+    const unsigned iu = (unsigned)i, tu = iu / (unsigned)w, bu = tu / (unsigned)h;   // (32-bit: B*h*w < 2^32, checked by the launcher)
+    const int x = (int)(iu - tu * (unsigned)w), y = (int)(tu - bu * (unsigned)h), b = (int)bu;
     int Y0 = (int)floorf(((float)y - 0.5f) * ish - 0.5f) - 1, Y1 = (int)ceilf(((float)y + 1.5f) * ish - 0.5f) + 1;
     int X0 = (int)floorf(((float)x - 0.5f) * isw - 0.5f) - 1, X1 = (int)ceilf(((float)x + 1.5f) * isw - 0.5f) + 1;
     if (y == 0) Y0 = 0;
@@ -218,12 +216,8 @@ __global__ __launch_bounds__(256) void ce_bwd_gather_kernel(const float* __restr
   if (i >= total) return;
   const float sh = (float)h / (float)H, sw = (float)w / (float)W;
   const float ish = (float)H / (float)h, isw = (float)W / (float)w;
-  const int c = (int)(i % nc);
-  const long p = i / nc;
-  const int x = (int)(p % w);
-  const long t = p / w;
-  const int y = (int)(t % h);
-  const int b = (int)(t / h);
+  const unsigned iu = (unsigned)i, pu = iu / (unsigned)nc, tu = pu / (unsigned)w, bu = tu / (unsigned)h;   // (32-bit: checked by the launcher)
+  const int c = (int)(iu - pu * (unsigned)nc), x = (int)(pu - tu * (unsigned)w), y = (int)(tu - bu * (unsigned)h), b = (int)bu;
   int Y0, Y1, X0, X1;
   lo_hi_range(y, h, H, ish, Y0, Y1);
   lo_hi_range(x, w, W, isw, X0, X1);
@@ -313,10 +307,8 @@ __global__ void upsample_logits_nchw_kernel(const float* __restrict__ logits, fl
   const float sh = (float)h / (float)H, sw = (float)w / (float)W;
   const long total = (long)B * H * W;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int X = (int)(i % W);
-    const long t = i / W;
-    const int Y = (int)(t % H);
-    const int b = (int)(t / H);
+    const unsigned iu = (unsigned)i, tu = iu / (unsigned)W, bu = tu / (unsigned)H;   // (32-bit: B*H*W < 2^32, checked by the launcher)
+    const int X = (int)(iu - tu * (unsigned)W), Y = (int)(tu - bu * (unsigned)H), b = (int)bu;
     const BilinTap ty = bilin_tap(Y, h, H, sh), tx = bilin_tap(X, w, W, sw);
     float s[kMaxClasses];
     upsample_scores<kMaxClasses>(logits, b, h, w, nc, ty, tx, s);
@@ -360,6 +352,7 @@ extern "C" int cmda_ce_upsample_bwd(const float* logits, const int64_t* label, c
                                     int H, int W, int nc, int ignore_index, void* stream) {
   if ((long)B * h * w <= 0) return CMDA_OK;
   if (nc <= 0 || nc > kMaxClasses) return CMDA_ERR_SHAPE;
+  if ((long)B * h * w * nc >= (1L << 32)) return CMDA_ERR_SHAPE;   // (32-bit index arithmetic in the kernels)
   // column taps one low-resolution pixel can receive (lo_hi_range's window): the register-resident form holds up to 16
   const long taps = (long)ceil(2.0 * W / w) + 4;
   if (taps <= kMaxTapsX && h <= H && w <= W) {
@@ -398,6 +391,7 @@ extern "C" int cmda_upsample_logits_nchw(const float* logits, float* out, int B,
                                          void* stream) {
   if ((long)B * H * W <= 0) return CMDA_OK;
   if (nc <= 0 || nc > kMaxClasses) return CMDA_ERR_SHAPE;
+  if ((long)B * H * W >= (1L << 32)) return CMDA_ERR_SHAPE;   // (32-bit index arithmetic in the kernel)
   CMDA_LAUNCH(upsample_logits_nchw_kernel, dim3(grid_for((long)B * H * W)), dim3(256), 0, stream, logits, out, B, h, w,
               H, W, nc);
   CMDA_CHECK_LAUNCH();

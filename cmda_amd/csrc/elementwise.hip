@@ -258,8 +258,17 @@ template <typename T>
 __global__ void sample_scale_kernel(const T* __restrict__ x, const float* __restrict__ scale, T* __restrict__ out,
                                     long per_sample, int C, int per_channel, long n) {
   for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
-    const long b = i / per_sample;
-    const int c = (int)(i % C);
+    // (32-bit index arithmetic when the tensor allows it: 64-bit integer division is emulated, ~70 instructions)
+    long b;
+    int c;
+    if (n < (1L << 32)) {
+      const unsigned iu = (unsigned)i, bu = iu / (unsigned)per_sample;
+      b = bu;
+      c = (int)(iu % (unsigned)C);
+    } else {
+      b = i / per_sample;
+      c = (int)(i % C);
+    }
     float v[4];
     ld4(x + i, v);
 #pragma unroll
@@ -275,7 +284,9 @@ __global__ void copy2d_kernel(const T* __restrict__ src, T* __restrict__ dst, lo
   const int cg = cols >> 2;
   const long total = rows * cg;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long r = i / cg;
+    long r;
+    if (total < (1L << 32)) r = (unsigned)i / (unsigned)cg;   // (32-bit division: see sample_scale_kernel)
+    else r = i / cg;
     const int c = (int)(i - r * cg) * 4;
     float v[4];
     ld4(src + r * src_ld + c, v);
@@ -378,7 +389,17 @@ __global__ void class_mix_kernel(const T* __restrict__ src, const T* __restrict_
   const long total = (long)B * HW * Cch;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     long b, pix;
-    if (channels_last) {
+    if (total < (1L << 32)) {   // (32-bit division: see sample_scale_kernel)
+      const unsigned iu = (unsigned)i;
+      if (channels_last) {
+        const unsigned bp = iu / (unsigned)Cch, bu = bp / (unsigned)HW;
+        b = bu;
+        pix = bp - bu * (unsigned)HW;
+      } else {
+        b = iu / ((unsigned)Cch * (unsigned)HW);
+        pix = iu % (unsigned)HW;
+      }
+    } else if (channels_last) {
       const long bp = i / Cch;
       b = bp / HW;
       pix = bp - b * HW;
@@ -399,7 +420,7 @@ __global__ void class_mix_label_kernel(const long long* __restrict__ src, const 
                                        const long long* __restrict__ classes, int max_classes, int B, int HW) {
   const long total = (long)B * HW;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long b = i / HW;
+    const long b = total < (1L << 32) ? (long)((unsigned)i / (unsigned)HW) : i / HW;
     const long long lab = src_label[i];
     long long msk = 0;
     for (int k = 0; k < max_classes; ++k) msk += (classes[b * max_classes + k] == lab) ? 1 : 0;
@@ -463,7 +484,7 @@ template <typename TD>
 __global__ void cast_pad_cols_kernel(const float* __restrict__ src, TD* __restrict__ dst, long rows, int c, int cp) {
   const long total = rows * cp;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long r = i / cp;
+    const long r = total < (1L << 32) ? (long)((unsigned)i / (unsigned)cp) : i / cp;   // (32-bit division: see sample_scale_kernel)
     const int k = (int)(i - r * cp);
     stf(dst + i, k < c ? src[r * c + k] : 0.f);
   }

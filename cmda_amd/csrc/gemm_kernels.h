@@ -242,7 +242,7 @@ static __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const 
     const long ri = rb_off + m * p.ldres + n;
     float rv[4] = {0.f, 0.f, 0.f, 0.f}, ov[4] = {0.f, 0.f, 0.f, 0.f};
     float rs = 1.f;
-    if (has_rs) rs = p.rowscale[m / p.rows_per_scale];
+    if (has_rs) rs = p.rowscale[(unsigned)m / (unsigned)p.rows_per_scale];   // (32-bit: row indices are < 2^31 on every GEMM path)
     if (full) {
       if (has_res) {
         if (res32) ld4(reinterpret_cast<const float*>(p.res) + ri, rv);

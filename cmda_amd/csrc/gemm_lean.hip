@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256, (GldsCfg<TM, TN, 4, NSV>::MIN_WAVES)) void gem
     const long ci = m * q.ldc + en;
     float ov[4] = {0.f, 0.f, 0.f, 0.f};
     float rs = 1.f;
-    if (has_rs) rs = q.rowscale[m / q.rows_per_scale];
+    if (has_rs) rs = q.rowscale[(unsigned)m / (unsigned)q.rows_per_scale];   // (32-bit: M < 2^31)
     if (has_beta) {
       if (full) {
         if (f32o) ld4(reinterpret_cast<const float*>(q.C) + ci, ov);

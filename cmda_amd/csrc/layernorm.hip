@@ -130,8 +130,18 @@ __global__ void ln_bwd_kernel(const T* __restrict__ dy, const TX* __restrict__ x
       mean = mean_in[row];
       rstd = rstd_in[row];
     }
-    float xh[NV][4], g[NV][4];
+    float xh[NV][4], g[NV][4], rr[NV][4];
     float s1 = 0.f, s2 = 0.f;
+    // every load of the row is issued before the first use (the residual gradient and the DropPath factor used to be requested
+    // behind the row reduction: a second exposed load latency per row in a kernel that holds one row per wave)
+    float sc = 1.f;
+    if (dx_scaled && live) sc = out_scale[(unsigned)row / (unsigned)rows_per_scale];   // (rows < 2^31: checked by the launcher)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int vi = i * lpr + li;
+      rr[i][0] = rr[i][1] = rr[i][2] = rr[i][3] = 0.f;
+      if (live && vi < nvec && dres) ld4(dres + row * C + vi * 4, rr[i]);
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int vi = i * lpr + li;
@@ -161,14 +171,11 @@ __global__ void ln_bwd_kernel(const T* __restrict__ dy, const TX* __restrict__ x
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = rstd * (g[i][j] - s1 - xh[i][j] * s2);
         if (dres) {
-          float r[4];
-          ld4(dres + row * C + vi * 4, r);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] += r[j];
+          for (int j = 0; j < 4; ++j) o[j] += rr[i][j];
         }
         st4(dx + row * C + vi * 4, o);
         if (dx_scaled) {
-          const float sc = out_scale[row / rows_per_scale];
 #pragma unroll
           for (int j = 0; j < 4; ++j) o[j] *= sc;
           st4(dx_scaled + row * C + vi * 4, o);
@@ -301,6 +308,7 @@ extern "C" int cmda_layernorm_bwd2(const void* dy, const void* x, int x_dtype, c
                                    int dtype, void* stream) {
   if (rows <= 0) return CMDA_OK;
   if (C <= 0 || (C & 3) || C > kMaxVec * 256 || (dx_scaled && (!out_scale || rows_per_scale <= 0))) return CMDA_ERR_SHAPE;
+  if (dx_scaled && (rows >= (1L << 31) || rows_per_scale >= (1L << 31))) return CMDA_ERR_SHAPE;   // (32-bit row / rows_per_scale in the kernel)
   const int wpb = 4, lpr = lanes_per_row(C);
   int grid = (int)ln_bwd_grid(rows, C);
   const int nv = ((C >> 2) + lpr - 1) / lpr;

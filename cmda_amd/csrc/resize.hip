@@ -16,12 +16,10 @@ __global__ void resize_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, in
   const float sh = (float)IH / (float)OH, sw = (float)IW / (float)OW;
   const long total = (long)B * OH * OW * cg;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % cg) * 4;
-    long pix = i / cg;
-    const int ox = (int)(pix % OW);
-    pix /= OW;
-    const int oy = (int)(pix % OH);
-    const int b = (int)(pix / OH);
+    // (32-bit index arithmetic: 64-bit integer division is a ~70-instruction emulation on gfx950 and six of them per output
+    // made this HBM-bound kernel VALU-bound; the launcher rejects tensors of 2^32 or more 4-channel groups)
+    const unsigned iu = (unsigned)i, pu = iu / (unsigned)cg, ru = pu / (unsigned)OW, bu = ru / (unsigned)OH;
+    const int c = (int)(iu - pu * (unsigned)cg) * 4, ox = (int)(pu - ru * (unsigned)OW), oy = (int)(ru - bu * (unsigned)OH), b = (int)bu;
     const BilinTap ty = bilin_tap(oy, IH, OH, sh), tx = bilin_tap(ox, IW, OW, sw);
     float v00[4], v01[4], v10[4], v11[4], o[4];
     const T* xb = x + (long)b * IH * IW * C + c;
@@ -48,12 +46,8 @@ __global__ void resize_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, 
   const float ish = (float)OH / (float)IH, isw = (float)OW / (float)IW;
   const long total = (long)B * IH * IW * cg;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % cg) * 4;
-    long pix = i / cg;
-    const int ix = (int)(pix % IW);
-    pix /= IW;
-    const int iy = (int)(pix % IH);
-    const int b = (int)(pix / IH);
+    const unsigned iu = (unsigned)i, pu = iu / (unsigned)cg, ru = pu / (unsigned)IW, bu = ru / (unsigned)IH;   // (32-bit: see resize_fwd_kernel)
+    const int c = (int)(iu - pu * (unsigned)cg) * 4, ix = (int)(pu - ru * (unsigned)IW), iy = (int)(ru - bu * (unsigned)IH), b = (int)bu;
     // conservative candidate window: src in [iy-1, iy+1)  <=>  oy in [(iy-0.5)*ish-0.5, (iy+1.5)*ish-0.5)
     int oy0 = (int)floorf(((float)iy - 0.5f) * ish - 0.5f) - 1, oy1 = (int)ceilf(((float)iy + 1.5f) * ish - 0.5f) + 1;
     int ox0 = (int)floorf(((float)ix - 0.5f) * isw - 0.5f) - 1, ox1 = (int)ceilf(((float)ix + 1.5f) * isw - 0.5f) + 1;
@@ -117,6 +111,7 @@ extern "C" int cmda_bilinear_fwd(const void* x, void* y, int B, int IH, int IW, 
                                  int coff, int dtype, void* stream) {
   if ((long)B * OH * OW * C <= 0) return CMDA_OK;
   if ((C & 3) || (ldy & 3) || (coff & 3) || coff + C > ldy) return CMDA_ERR_SHAPE;
+  if ((long)B * OH * OW * (C / 4) >= (1L << 32)) return CMDA_ERR_SHAPE;   // (32-bit index arithmetic in the kernel)
   CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((resize_fwd_kernel<T>), dim3(grid_for((long)B * OH * OW * (C / 4))), dim3(256),
                                          0, stream, (const T*)x, (T*)y, B, IH, IW, OH, OW, C, ldy, coff));
   CMDA_CHECK_LAUNCH();
@@ -128,6 +123,7 @@ extern "C" int cmda_bilinear_bwd(const void* dy, void* dx, int B, int IH, int IW
   if ((C & 3) || (ldy & 3) || (coff & 3) || coff + C > ldy) return CMDA_ERR_SHAPE;
   // columns of the candidate window: ceil(2 * OW / IW) + 4 at most (see the kernel)
   const long nx = (long)ceil(2.0 * OW / IW) + 4;
+  if ((long)B * IH * IW * (C / 4) >= (1L << 32)) return CMDA_ERR_SHAPE;   // (32-bit index arithmetic in the kernel)
   const dim3 grid(grid_for((long)B * IH * IW * (C / 4)));
 #define CMDA_RESIZE_BWD(NXV) \
   CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((resize_bwd_kernel<T, NXV>), grid, dim3(256), 0, stream, (const T*)dy, (T*)dx, B, IH, IW, OH, OW, C, ldy, coff))
