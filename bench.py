@@ -263,11 +263,10 @@ def profile_json(name):
 
 def rocprof_gemm_stats(workload):
     """GEMM-family launches / average duration in the committed rocprofv3 --kernel-trace --stats summary of this command's eager
-    launch sequence (profiles/r03_<workload>_eager_kernel_stats.csv), for the cross-check against the live HIP-event figure"""
+    launch sequence (profiles/r04_<workload>_eager_kernel_stats.csv, else the latest earlier round's), for the cross-check against the live HIP-event figure"""
     import csv
-    path = os.path.join(ROOT, 'profiles', f'r03_{workload}_eager_kernel_stats.csv')
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, 'profiles', f'r02_{workload}_eager_kernel_stats.csv')
+    path = next((p for p in (os.path.join(ROOT, 'profiles', f'{r}_{workload}_eager_kernel_stats.csv') for r in ('r04', 'r03', 'r02'))
+                 if os.path.exists(p)), os.path.join(ROOT, 'profiles', f'r02_{workload}_eager_kernel_stats.csv'))
     try:
         calls = ns = 0
         with open(path) as f:

@@ -1,0 +1,28 @@
+#!/bin/bash
+# The round's judged artefacts for the default bench line (configs[3], 2+2 samples): the bench line itself (with the two fp32-storage
+# child runs and the cpu baseline), rocprofv3 kernel statistics of the same command (graph replay and eager launches), the two PMC
+# passes (FETCH_SIZE / WRITE_SIZE, eager), lanes timeline, large-GEMM and HBM-kernel micro-benchmarks, the single-rank reducer line.
+# usage: gpurun -- 'bash tools/gpu/collect_r04.sh <tag>'; then tools/publish_profiles.sh <tag> copies the summaries to profiles/
+tag=${1:-r04final}
+out=gpurun_out/$tag
+mkdir -p $out
+python bench.py > $out/bench.json 2> $out/err_bench
+cut -c1-200 $out/bench.json
+alg=$(python -c "import json;print(json.loads(open('$out/bench.json').read().strip().splitlines()[-1])['roofline']['algorithmic_mb_per_launch'])")
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_graph -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity-mode > $out/bench_prof_graph.json 2> $out/err1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_eager -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity-mode --no-graph > $out/bench_prof_eager.json 2> $out/err2
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-parity-mode --no-graph > $out/pmc_fetch.json 2> $out/err3
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-parity-mode --no-graph > $out/pmc_write.json 2> $out/err4
+python tools/pmc_traffic.py $out/pmc_fetch $out/pmc_write dacs $out/pmc_traffic_dacs $alg
+t=$(find $out/stats_eager -name '*kernel_trace.csv' | head -1); gzip -c $t > $out/trace_eager.csv.gz
+rm -rf $out/pmc_fetch $out/pmc_write $out/stats_*/*/*kernel_trace.csv
+timeout 600 python tools/lanes_timeline.py > $out/lanes_timeline.txt 2> $out/err5
+python tools/gemm_bench.py --big > $out/gemm_big.txt 2>&1
+python tools/hbm_bench.py --batch 8 > $out/hbm_bench.txt 2>&1
+python tools/dbg/rp_bench.py > $out/small_gemm.txt 2>&1
+# the RCCL path with ONE rank (gradient exchange armed, reduce-scatter + all-gather of every bucket on the side stream)
+timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --force-reducer --no-cpu-baseline --no-parity-mode > $out/bench_force_reducer.json 2> $out/err6
+cut -c1-200 $out/bench_force_reducer.json
+timeout 600 python bench.py --workload supervised --no-cpu-baseline > $out/supervised.json 2> $out/err_sup; cut -c1-200 $out/supervised.json
+ls $out
