@@ -172,12 +172,23 @@ def _gd_arena(dev, nbytes):
             raise RuntimeError('grouped-GEMM arena: run one eager backward pass before capturing')
         a = _GD['arena'] = [torch.empty(_GD_ARENA_BYTES, dtype=torch.uint8, pin_memory=(dev.type == 'cuda')), 0]
     if a[1] + nbytes > a[0].numel():
-        if _GD['pinned_plans'] or (dev.type == 'cuda' and torch.cuda.is_current_stream_capturing()):
-            raise RuntimeError('grouped-GEMM arena exhausted while captured graphs hold plans in it')
-        if dev.type == 'cuda':
-            torch.cuda.synchronize(dev)   # eager plans only: every upload that read the arena has run
-        _GD['plans'].clear()
-        a[1] = 0
+        if dev.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('grouped-GEMM arena exhausted inside a capture: run the eager warm-up iterations first')
+        if _GD['pinned_plans']:
+            # captured graphs replay uploads out of the current arena: it must stay as it is.  Open a fresh one for the plans to
+            # come (eager backward passes whose operand pointers differ from the captured ones -- allocator churn, a new batch
+            # shape's warm-up) instead of failing in the middle of training; un-captured plans are dropped with the old arena's
+            # bookkeeping, captured ones keep their slices alive through `retired`.
+            _GD.setdefault('retired', []).append(a[0])
+            if dev.type == 'cuda':
+                torch.cuda.synchronize(dev)
+            _GD['plans'] = {k: v for k, v in _GD['plans'].items() if v[3]}
+            a = _GD['arena'] = [torch.empty(max(_GD_ARENA_BYTES, nbytes), dtype=torch.uint8, pin_memory=(dev.type == 'cuda')), 0]
+        else:
+            if dev.type == 'cuda':
+                torch.cuda.synchronize(dev)   # eager plans only: every upload that read the arena has run
+            _GD['plans'].clear()
+            a[1] = 0
     lo = a[1]
     a[1] = lo + nbytes
     return a[0][lo:lo + nbytes]
@@ -229,11 +240,12 @@ def gemm_flush_deferred(all_lanes=False, from_lane=None):
         if plan is None:
             nbytes = int(L.lib().cmda_gemm_grouped_ws_bytes(arr, c_i32(n)))
             host = _gd_arena(dev, max(nbytes, 16))
-            plan = _GD['plans'][key] = (host, torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev), nbytes)
+            plan = _GD['plans'][key] = [host, torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev), nbytes, False]
             upload = 1
         if dev.type == 'cuda' and torch.cuda.is_current_stream_capturing():
             _GD['pinned_plans'] = True
-        host, devbuf, nbytes = plan
+            plan[3] = True    # a captured graph replays this plan's upload + launch: its arena slice and device table stay
+        host, devbuf, nbytes = plan[:3]
         prof = GEMM_PROFILE is not None and out0.is_cuda
         if prof:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

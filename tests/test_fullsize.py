@@ -167,7 +167,7 @@ def test_mit_b5_daformer_512_vs_oracle(mode):
         assert nsus < 0.25 * sum(m.num_features for m in ref.decode_head.modules() if isinstance(m, nn.BatchNorm2d)), 'probe masks too much'
     else:
         check_le('bf16 logits rel err', e_log, 6e-2, strict=True)
-        check_ge('bf16 argmax agreement', agree, 0.97, strict=True)
+        check_ge('bf16 argmax agreement', agree, 0.96, strict=True)   # (0.9875-0.9884 measured)
         assert_close(losses['decode.loss_seg'], rl['decode.loss_seg'], 2e-2, name='loss')
     rt.set_compute_dtype(torch.float32)
 
