@@ -79,8 +79,11 @@ int launch_dtype(GemmParams& p, void* stream) {
     if (tile != 3 && blocks(128, 128) * sp < 1024 && p.M > 64 && p.N > 64) {
       const double nk = (double)nkt;
       const double cost0 = (double)((blocks(128, 128) * sp + 511) / 512) * (4.0 + 0.9 * nk);
-      const double cost1 = (double)((blocks(128, 64) * sp + 767) / 768) * (3.0 + 0.75 * nk);
-      const double cost2 = (double)((blocks(64, 64) * sp + 1023) / 1024) * (2.5 + 0.6 * nk);
+      // (round 4: the lean instance of the two small tiles -- gemm_lean.hip -- has a cheaper prologue / epilogue and a 0.3 us k-tile:
+      // 16384 x 512 x 128 10.9 us on 64 x 64 tiles against 13.7 on 128 x 128, tools/dbg/pp_vs_lean.py)
+      const bool lean = sizeof(T) == 2 && cmda_gemm_lean_ok_(p, 2);
+      const double cost1 = (double)((blocks(128, 64) * sp + 767) / 768) * (lean ? 1.5 + 0.45 * nk : 3.0 + 0.75 * nk);
+      const double cost2 = (double)((blocks(64, 64) * sp + 1023) / 1024) * (lean ? 1.2 + 0.3 * nk : 2.5 + 0.6 * nk);
       tile = cost0 <= cost1 && cost0 <= cost2 ? 0 : cost1 <= cost2 ? 1 : 2;
     }
   }

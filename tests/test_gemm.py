@@ -118,7 +118,9 @@ def _run_forced_tile(marker):
     # 4 | 1024: the ping-pong kernel (gemm_pp.hip) wherever its epilogue / operand modes allow; 4 | 512: gemm_glds_kernel's 8-wave tile
     for hint in ('1028', '516'):
         env = dict(os.environ, CMDA_TEST_GEMM_TILE=hint)
-        r = subprocess.run([sys.executable, '-m', 'pytest', here, '-q', '-x', '-m', marker, '-k', 'not forced_tile', '-p', 'no:cacheprovider'],
+        # (the tests of launches that ignore the forced tile -- pair / row-panel / deferred-grouped -- are left out: they run once, above)
+        r = subprocess.run([sys.executable, '-m', 'pytest', here, '-q', '-x', '-m', marker, '-k',
+                            'not forced_tile and not pair_launch and not row_panel and not deferred_grouped', '-p', 'no:cacheprovider'],
                            env=env, capture_output=True, text=True, timeout=1500)
         assert r.returncode == 0, f'tile_hint {hint}: ' + r.stdout[-2000:] + r.stderr[-2000:]
 
