@@ -30,10 +30,11 @@ struct LeanParams {
 
 // NSV = 0: two LDS stages (most resident blocks); NSV = 4: the latency configuration for grids that are resident at once and run
 // >= 12 k-tiles per block (fc2 / its data gradient at K = 1280 ... 2048: three k-tiles in flight) -- launch_glds's rule
-template <int TM, int TN, bool BKS, int NSV = 0>
-__global__ __launch_bounds__(256, (GldsCfg<TM, TN, 4, NSV>::MIN_WAVES)) void gemm_lean_kernel(LeanParams q) {
+template <int TM, int TN, bool BKS, int NSV = 0, int NW = 4>
+__global__ __launch_bounds__(64 * NW, (GldsCfg<TM, TN, NW, NSV>::MIN_WAVES)) void gemm_lean_kernel(LeanParams q) {
   typedef bf16_t T;
-  typedef GldsCfg<TM, TN, 4, NSV> Cfg;
+  typedef GldsCfg<TM, TN, NW, NSV> Cfg;
+  constexpr int NT = 64 * NW;
   constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = 64, NS = Cfg::NS;
   constexpr int SZ_A = Cfg::SZ_A, SZ_B = Cfg::SZ_B, PITCH_C = Cfg::PITCH_C;
   __shared__ __attribute__((aligned(1024))) char smem[Cfg::LDS_BYTES];
@@ -53,7 +54,8 @@ __global__ __launch_bounds__(256, (GldsCfg<TM, TN, 4, NSV>::MIN_WAVES)) void gem
   const long m0 = (long)mt * BM, n0 = (long)nt * BN;
 
   // DMA sources: running pointers (gemm_kernels.h DmaSrc mode 1), the LDS image of gemm_glds_body: line r, slot = chunk ^ (r & 7)
-  constexpr int JA = BM * BK / 2048, JB = BN * BK / 2048;
+  constexpr int JA = BM * BK / (512 * NW), JB = BN * BK / (512 * NW);
+  static_assert(JA >= 1 && JB >= 1, "tile too small for the wave count");
   constexpr int CPL_B = BKS ? BN / 8 : 8, LPI_B = 64 / CPL_B;
   const char* curA[JA];
   const char* curB[JB];
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(256, (GldsCfg<TM, TN, 4, NSV>::MIN_WAVES)) void gem
     if (s < nkt) issue(s);
 
   // epilogue operands requested NOW: the thread's bias quad (and, below, its residual rows before the last barrier)
-  constexpr int QPR = BN / 4, RSTEP = 256 / QPR, NIT = BM / RSTEP;
+  constexpr int QPR = BN / 4, RSTEP = NT / QPR, NIT = BM / RSTEP;
   const int q4 = (tid % QPR) * 4, er0 = tid / QPR;
   const long en = n0 + q4;
   const bool ecol = en < N;
@@ -239,9 +241,9 @@ __global__ __launch_bounds__(256, (GldsCfg<TM, TN, 4, NSV>::MIN_WAVES)) void gem
   }
 }
 
-template <int TM, int TN, int NSV = 0>
+template <int TM, int TN, int NSV = 0, int NW = 4>
 int launch_lean(const GemmParams& p, void* stream) {
-  constexpr int BM = 16 * TM * 2, BN = 32 * TN;
+  constexpr int BM = 16 * TM * (NW / 2), BN = 32 * TN;
   LeanParams q;
   q.A = reinterpret_cast<const bf16_t*>(p.A.ptr);
   q.B = reinterpret_cast<const bf16_t*>(p.B.ptr);
@@ -259,9 +261,9 @@ int launch_lean(const GemmParams& p, void* stream) {
   q.act = p.act;
   q.flags = (p.out_f32 ? 1 : 0) | (p.res_f32 ? 2 : 0) | (p.c_vec_ok ? 4 : 0);
   q.alpha = p.alpha; q.beta = p.beta;
-  const dim3 grid((unsigned)tiles), blk(256);
-  if (p.b_kstrided) CMDA_LAUNCH((gemm_lean_kernel<TM, TN, true, NSV>), grid, blk, 0, stream, q);
-  else CMDA_LAUNCH((gemm_lean_kernel<TM, TN, false, NSV>), grid, blk, 0, stream, q);
+  const dim3 grid((unsigned)tiles), blk(64 * NW);
+  if (p.b_kstrided) CMDA_LAUNCH((gemm_lean_kernel<TM, TN, true, NSV, NW>), grid, blk, 0, stream, q);
+  else CMDA_LAUNCH((gemm_lean_kernel<TM, TN, false, NSV, NW>), grid, blk, 0, stream, q);
   CMDA_CHECK_LAUNCH();
 }
 
@@ -276,6 +278,12 @@ bool cmda_gemm_lean_ok_(const cmda_gemm_params_t& p, int tile) {
 }
 
 int cmda_gemm_lean_(const cmda_gemm_params_t& p, int tile, int four_stage, void* stream) {
+  // The 2-stage configurations run on EIGHT waves (16 x 32 / 32 x 32 of the tile per wave): a lone workgroup's k-tile is bound by how
+  // fast its waves can issue LDS-DMA pieces (0.3 us per 16 KiB with four waves), and twice the waves issue half the pieces each --
+  // 2048 x 320 x 320 5.05 -> 4.31 us, 8192 x 1280 x 320 18.6 -> 16.6, the step 60.2 -> 59.0 ms (gpurun r04u; the 4-stage
+  // configurations measured the same on 4 and 8 waves and stay on 4).  tile_hint bit 14: four waves (tuning A/B).
+  const bool w4 = p.tile_hint > 0 && (p.tile_hint & 16384);
+  if (!four_stage && !w4) return tile == 1 ? launch_lean<2, 2, 0, 8>(p, stream) : launch_lean<1, 2, 0, 8>(p, stream);
   if (four_stage) return tile == 1 ? launch_lean<4, 2, 4>(p, stream) : launch_lean<2, 2, 4>(p, stream);
   return tile == 1 ? launch_lean<4, 2>(p, stream) : launch_lean<2, 2>(p, stream);
 }
