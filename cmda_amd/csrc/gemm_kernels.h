@@ -1202,15 +1202,17 @@ int launch_glds(const GemmParams& p, void* stream) {
 }
 
 // grouped launch of the weight-gradient operand modes (A and B K-strided; B plain / patch view, or an im2col view)
-template <int TM, int TN>
+// (NW = 8 on the same tiles measured SLOWER on the UDA step, 58.9 -> 59.2 ms, gpurun r04v: these grids are many waves of blocks deep,
+// the four-wave blocks' co-residency hides the DMA issue rate that binds a lone block)
+template <int TM, int TN, int NW = 4>
 int launch_glds_grouped(const GemmParams* tab, const void* blk, int nblocks, int bconv, void* stream) {
   if (nblocks <= 0) return CMDA_OK;
-  const dim3 grid((unsigned)nblocks), blkdim(256);
+  const dim3 grid((unsigned)nblocks), blkdim(64 * NW);
   const int* b = reinterpret_cast<const int*>(blk);
   // bconv = operand class of the bucket (gemm_grouped.hip): 0 every problem plain with K % 64 == 0, 1 plain / patch views, 2 im2col B
-  if (bconv == 2) CMDA_LAUNCH((gemm_glds_grouped_kernel<TM, TN, true, true, false, true, 4, 0, false>), grid, blkdim, 0, stream, tab, b);
-  else if (bconv == 1) CMDA_LAUNCH((gemm_glds_grouped_kernel<TM, TN, true, true, false, false, 4, 0, false>), grid, blkdim, 0, stream, tab, b);
-  else CMDA_LAUNCH((gemm_glds_grouped_kernel<TM, TN, true, true, false, false, 4, 0, true>), grid, blkdim, 0, stream, tab, b);
+  if (bconv == 2) CMDA_LAUNCH((gemm_glds_grouped_kernel<TM, TN, true, true, false, true, NW, 0, false>), grid, blkdim, 0, stream, tab, b);
+  else if (bconv == 1) CMDA_LAUNCH((gemm_glds_grouped_kernel<TM, TN, true, true, false, false, NW, 0, false>), grid, blkdim, 0, stream, tab, b);
+  else CMDA_LAUNCH((gemm_glds_grouped_kernel<TM, TN, true, true, false, false, NW, 0, true>), grid, blkdim, 0, stream, tab, b);
   CMDA_CHECK_LAUNCH();
 }
 

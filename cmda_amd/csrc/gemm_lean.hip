@@ -26,11 +26,17 @@ struct LeanParams {
   int M, N, nkt, tiles_n;
   int ntile, rows_per_scale, act, flags;   // flags: 1 out_f32, 2 res_f32, 4 c_vec_ok
   float alpha, beta;
+  // patch view of A (kernel == stride convolution, cmda_view_t.conv == 2): row m = (b, oh, ow) starts at b * p_img + oh * p_row + ow * p_col
+  // elements; its K = KH * KW * C elements are KH segments of p_seg k-tiles (KW * C contiguous elements) p_jump bytes apart
+  long p_img;
+  int p_ohw, p_ow, p_row, p_col, p_seg, p_jump;
 };
 
 // NSV = 0: two LDS stages (most resident blocks); NSV = 4: the latency configuration for grids that are resident at once and run
 // >= 12 k-tiles per block (fc2 / its data gradient at K = 1280 ... 2048: three k-tiles in flight) -- launch_glds's rule
-template <int TM, int TN, bool BKS, int NSV = 0, int NW = 4>
+// PATCH: A is the patch view of a kernel == stride convolution (the spatial-reduction convolutions of the MiT attention,
+// mix_transformer.py:73-75,86-90): the running pointer jumps to the next input row at the end of every KW * C segment
+template <int TM, int TN, bool BKS, int NSV = 0, int NW = 4, bool PATCH = false>
 __global__ __launch_bounds__(64 * NW, (GldsCfg<TM, TN, NW, NSV>::MIN_WAVES)) void gemm_lean_kernel(LeanParams q) {
   typedef bf16_t T;
   typedef GldsCfg<TM, TN, NW, NSV> Cfg;
@@ -64,11 +70,19 @@ __global__ __launch_bounds__(64 * NW, (GldsCfg<TM, TN, NW, NSV>::MIN_WAVES)) voi
 #pragma unroll
   for (int j = 0; j < JA; ++j) {
     const int ln = (wid * JA + j) * 8 + (lane >> 3), chunk = (lane & 7) ^ (ln & 7);
-    const long r = m0 + ln;
-    const bool ok = r < M;
-    curA[j] = ok ? reinterpret_cast<const char*>(q.A + r * lda + chunk * 8) : zero;
-    stepA[j] = ok ? BK * 2 : 0;
+    if constexpr (!PATCH) {
+      const long r = m0 + ln;
+      const bool ok = r < M;
+      curA[j] = ok ? reinterpret_cast<const char*>(q.A + r * lda + chunk * 8) : zero;
+      stepA[j] = ok ? BK * 2 : 0;
+    } else {   // rows past M read row M - 1 (the segment jump is uniform; the epilogue never stores them)
+      const unsigned r = (unsigned)min(m0 + ln, (long)M - 1);
+      const unsigned b = r / (unsigned)q.p_ohw, rem = r - b * (unsigned)q.p_ohw, oh = rem / (unsigned)q.p_ow, ow = rem - oh * (unsigned)q.p_ow;
+      curA[j] = reinterpret_cast<const char*>(q.A + (long)b * q.p_img + (long)oh * q.p_row + (long)ow * q.p_col + chunk * 8);
+      stepA[j] = BK * 2;
+    }
   }
+  int seg_left = PATCH ? q.p_seg : 0;
 #pragma unroll
   for (int j = 0; j < JB; ++j) {
     const int ln = (wid * JB + j) * LPI_B + lane / CPL_B, chunk = (lane % CPL_B) ^ (ln & 7);
@@ -91,6 +105,13 @@ __global__ __launch_bounds__(64 * NW, (GldsCfg<TM, TN, NW, NSV>::MIN_WAVES)) voi
     for (int j = 0; j < JA; ++j) {
       glds16(curA[j], la + j * 1024);
       curA[j] += stepA[j];
+    }
+    if constexpr (PATCH) {
+      if (--seg_left == 0) {
+        seg_left = q.p_seg;
+#pragma unroll
+        for (int j = 0; j < JA; ++j) curA[j] += q.p_jump;
+      }
     }
 #pragma unroll
     for (int j = 0; j < JB; ++j) {
@@ -262,6 +283,19 @@ int launch_lean(const GemmParams& p, void* stream) {
   q.flags = (p.out_f32 ? 1 : 0) | (p.res_f32 ? 2 : 0) | (p.c_vec_ok ? 4 : 0);
   q.alpha = p.alpha; q.beta = p.beta;
   const dim3 grid((unsigned)tiles), blk(64 * NW);
+  if (p.A.conv == 2) {
+    if constexpr (NSV == 0 && NW == 4) return CMDA_ERR_UNSUPPORTED;   // (the four-wave 2-stage tuning variants: plain operands only)
+    else {
+      const GemmView& v = p.A;
+      q.p_img = (long)v.H * v.W * v.C;
+      q.p_ohw = v.OH * v.OW; q.p_ow = v.OW;
+      q.p_row = v.stride * v.W * v.C; q.p_col = v.stride * v.C;
+      q.p_seg = v.KW * v.C / 64;
+      q.p_jump = (v.W - v.KW) * v.C * 2;
+      CMDA_LAUNCH((gemm_lean_kernel<TM, TN, false, NSV, NW, true>), grid, blk, 0, stream, q);
+      CMDA_CHECK_LAUNCH();
+    }
+  }
   if (p.b_kstrided) CMDA_LAUNCH((gemm_lean_kernel<TM, TN, true, NSV, NW>), grid, blk, 0, stream, q);
   else CMDA_LAUNCH((gemm_lean_kernel<TM, TN, false, NSV, NW>), grid, blk, 0, stream, q);
   CMDA_CHECK_LAUNCH();
@@ -272,7 +306,14 @@ int launch_lean(const GemmParams& p, void* stream) {
 // HOST: does the lean kernel take this problem?  (tile: launch_dtype's choice, 1 = 128 x 64, 2 = 64 x 64)
 bool cmda_gemm_lean_ok_(const cmda_gemm_params_t& p, int tile) {
   auto plain = [](const GemmView& v) { return v.conv == 0 && v.vec_ok && (v.ld % 8) == 0 && v.R < (1L << 31) && v.Cc < (1L << 31); };
-  return (tile == 1 || tile == 2) && p.dtype == CMDA_BF16 && !p.a_kstrided && plain(p.A) && plain(p.B) && (p.K % 64) == 0 && p.K >= 64 &&
+  // patch view of a kernel == stride convolution as A (K-contiguous B): KW * C a multiple of the k-tile, 32-bit row arithmetic
+  auto patch = [&](const GemmView& v) {
+    return v.conv == 2 && v.vec_ok && !p.b_kstrided && v.KH == v.stride && v.KW == v.stride && v.pad == 0 && v.dil == 1 && v.in_dil <= 1 &&
+           v.H == v.OH * v.stride && v.W == v.OW * v.stride && ((long)v.KW * v.C) % 64 == 0 && v.R < (1L << 31) &&
+           (long)v.stride * v.W * v.C * 2 < (1L << 31) && (long)v.OH * v.OW < (1L << 31) && p.K == (long)v.KH * v.KW * v.C &&
+           !(p.tile_hint > 0 && (p.tile_hint & 16384));
+  };
+  return (tile == 1 || tile == 2) && p.dtype == CMDA_BF16 && !p.a_kstrided && (plain(p.A) || patch(p.A)) && plain(p.B) && (p.K % 64) == 0 && p.K >= 64 &&
          p.batch == 1 && p.batch2 <= 1 && p.splits <= 1 && !p.atomic && !p.colsum && p.c_patch_ow == 0 && p.c_perm_ci == 0 &&
          (!p.b_kstrided || 64L * p.B.ld * 2 < (1L << 31)) && !(p.tile_hint > 0 && (p.tile_hint & 8192));   // (tile_hint bit 13: general kernel, tuning A/B)
 }

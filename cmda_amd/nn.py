@@ -177,6 +177,12 @@ def attention_bwd(do, q, kv, P, B, N, Nk, heads, C, scale):
     return dq, dkv
 
 
+# split K of a spatial-reduction convolution when its output has at most this many 64 x 64 tiles (block_fwd).  32: the teacher's
+# stage-3 convolution (512 rows x 320 channels, K = 1280: 40 tiles) stays one launch of the lean kernel instead of rows_fill + a
+# split-K grid (59.0 -> 58.5 ms, gpurun r04y; 16 / 0 measured the same as 32)
+SR_SPLITK_TILES = int(os.environ.get('CMDA_SR_SPLITK_TILES', '32'))
+
+
 # ------------------------------------------------------------------ MiT Block (mix_transformer.py:108-148)
 def block_fwd(x, p, B, H, W, C, heads, sr, *, eps=1e-6, dp1=None, dp2=None, save=True):
     """x [B*H*W, C].  p: the Block module (norm1, attn.{q,kv,proj,sr,norm}, norm2, mlp.{fc1,dwconv.dwconv,fc2}).
@@ -191,7 +197,7 @@ def block_fwd(x, p, B, H, W, C, heads, sr, *, eps=1e-6, dp1=None, dp2=None, save
     if sr > 1:
         OH, OW = conv_out_size(H, W, sr, sr, 0)
         Ksr = sr * sr * C
-        splitk = rt.tag() == 1 and Ksr >= 1024 and ((B * OH * OW + 63) // 64) * ((C + 63) // 64) <= 64 and C % 4 == 0
+        splitk = rt.tag() == 1 and Ksr >= 1024 and ((B * OH * OW + 63) // 64) * ((C + 63) // 64) <= SR_SPLITK_TILES and C % 4 == 0
         pair = pair and not splitk
     if pair:   # q and the spatial-reduction convolution read the same xn and are independent: ONE launch (cmda_gemm_pair)
         q, hq = linear_fwd(xn, a.q.weight, a.q.bias, M, C, hold=True)

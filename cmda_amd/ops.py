@@ -127,7 +127,10 @@ def gemm(A, B, out, M, N, K, *, a_kstrided=False, b_kstrided=False, ldc=None, ba
     return out
 
 
-GEMM_PAIR = os.environ.get('CMDA_GEMM_PAIR', '1') != '0'   # False: gemm_pair launches its two problems one after the other (tuning A/B)
+# Pair launches (cmda_gemm_pair) are OFF by default since the lean kernel runs on eight waves and takes the patch view of the
+# spatial-reduction convolutions: two lean launches beat one four-wave pair grid (58.56 -> 58.37 ms, gpurun r04y; with the four-wave
+# lean kernel the pair had been worth 0.5 ms).  CMDA_GEMM_PAIR=1 turns them back on (tuning A/B; tests/test_gemm.py covers the kernel).
+GEMM_PAIR = os.environ.get('CMDA_GEMM_PAIR', '0') != '0'
 
 
 def gemm_pair(h0, h1):

@@ -307,7 +307,12 @@ def test_gemm_pair_launch(tgt, nn):
             return d0, d1, h0, h1
     a0, a1, _, _ = build(False)
     b0, b1, h0, h1 = build(True)
-    ops.gemm_pair(h0, h1)
+    old = ops.GEMM_PAIR
+    ops.GEMM_PAIR = True   # (off by default in the step since round 4's eight-wave lean kernel: ops.GEMM_PAIR)
+    try:
+        ops.gemm_pair(h0, h1)
+    finally:
+        ops.GEMM_PAIR = old
     assert torch.equal(a0.float().cpu(), b0.float().cpu()) and torch.equal(a1.float().cpu(), b1.float().cpu())
     if not nn:
         ref = torch.nn.functional.gelu(x.float().cpu() @ wq.float().cpu().t() + bq.cpu())

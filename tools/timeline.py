@@ -58,3 +58,33 @@ for s, e, n, q in it:
 print('idle time before kernel (ms):')
 for k, v in gap_after.most_common(12):
     print(f'  {v / 1e6:7.2f}  {k}')
+# stretches where ONE queue was busy (the other lane idle) for > 1 ms: kernel families inside, their time and the idle gaps
+by_q = collections.defaultdict(list)
+for s, e, n, q in it:
+    by_q[q].append((s, e, n))
+if len(by_q) >= 2:
+    qs = sorted(by_q, key=lambda k: -len(by_q[k]))[:2]
+    other = {qs[0]: qs[1], qs[1]: qs[0]}
+    for q in qs:
+        oth = sorted(by_q[other[q]])
+        # idle windows of the other queue
+        wins, end = [], t0
+        for s, e, n in oth:
+            if s - end > 1e6:
+                wins.append((end, s))
+            end = max(end, e)
+        if t1 - end > 1e6:
+            wins.append((end, t1))
+        for a, b in wins:
+            ks = [(s, e, n) for s, e, n in by_q[q] if s >= a and e <= b]
+            if not ks:
+                continue
+            fam = collections.Counter()
+            cnt = collections.Counter()
+            for s, e, n in ks:
+                fam[n] += e - s
+                cnt[n] += 1
+            busy = sum(fam.values())
+            print(f'queue {q} alone {(a - t0) / 1e6:.2f} -> {(b - t0) / 1e6:.2f} ms: {len(ks)} kernels, busy {busy / 1e6:.2f} ms of {(b - a) / 1e6:.2f}')
+            for k, v in fam.most_common(30):
+                print(f'    {v / 1e6:7.3f} ms  {cnt[k]:4d} x {v / cnt[k] / 1e3:8.1f} us  {k}')
