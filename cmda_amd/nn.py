@@ -192,8 +192,16 @@ def block_fwd(x, p, B, H, W, C, heads, sr, *, eps=1e-6, dp1=None, dp2=None, save
     a = p.attn
     cd = rt.compute_dtype()
     sd = x.dtype    # residual-stream storage: fp32 in the bf16 mode's fp32-stream option (runtime.residual_fp32), else the compute dtype
-    xn, m1, r1 = ops.layernorm_fwd(x, p.norm1.weight, p.norm1.bias, eps, out_dtype=cd)
     pair = rt.tag() == 1 and sr > 1 and ops.GEMM_PAIR
+    # norm1 -> q and attn.norm -> kv as ONE launch each (cmda_ln_gemm: the Linear's workgroups normalise their own rows) -- OFF by default
+    # (ops.LN_GEMM): measured no faster than the two launches on the step (58.0 - 58.6 against 58.1 - 58.4 ms, gpurun r04ln4)
+    lnq = rt.tag() == 1 and not pair and ops.LN_GEMM
+    if lnq:
+        xn = torch.empty(M, C, dtype=cd, device=x.device)
+        q, hq = linear_fwd(xn, a.q.weight, a.q.bias, M, C, hold=True)
+        m1, r1 = ops.ln_gemm(x, p.norm1.weight, p.norm1.bias, eps, hq)
+    else:
+        xn, m1, r1 = ops.layernorm_fwd(x, p.norm1.weight, p.norm1.bias, eps, out_dtype=cd)
     if sr > 1:
         OH, OW = conv_out_size(H, W, sr, sr, 0)
         Ksr = sr * sr * C
@@ -203,7 +211,7 @@ def block_fwd(x, p, B, H, W, C, heads, sr, *, eps=1e-6, dp1=None, dp2=None, save
         q, hq = linear_fwd(xn, a.q.weight, a.q.bias, M, C, hold=True)
         (xs_pre, OH, OW), hs = conv_fwd(xn, a.sr.weight, a.sr.bias, B, H, W, sr, 0, hold=True)
         ops.gemm_pair(hq, hs)
-    else:
+    elif not lnq:
         q = linear_fwd(xn, a.q.weight, a.q.bias, M, C)
     if sr > 1:
         if pair:
@@ -218,10 +226,16 @@ def block_fwd(x, p, B, H, W, C, heads, sr, *, eps=1e-6, dp1=None, dp2=None, save
         else:
             xs_pre, OH, OW = conv_fwd(xn, a.sr.weight, a.sr.bias, B, H, W, sr, 0)
         Nk = OH * OW
-        xs, ms, rs = ops.layernorm_fwd(xs_pre, a.norm.weight, a.norm.bias, 1e-5, out_dtype=cd)
+        if rt.tag() == 1 and ops.LN_GEMM:
+            xs = torch.empty(B * Nk, C, dtype=cd, device=x.device)
+            kv, hkv = linear_fwd(xs, a.kv.weight, a.kv.bias, B * Nk, C, hold=True)
+            ms, rs = ops.ln_gemm(xs_pre, a.norm.weight, a.norm.bias, 1e-5, hkv, store_xn=save)
+        else:
+            xs, ms, rs = ops.layernorm_fwd(xs_pre, a.norm.weight, a.norm.bias, 1e-5, out_dtype=cd)
+            kv = linear_fwd(xs, a.kv.weight, a.kv.bias, B * Nk, C)
     else:
         xs_pre, ms, rs, xs, Nk = None, None, None, xn, N
-    kv = linear_fwd(xs, a.kv.weight, a.kv.bias, B * Nk, C)
+        kv = linear_fwd(xs, a.kv.weight, a.kv.bias, B * Nk, C)
     hd = C // heads
     o, P = attention_fwd(q, kv, B, N, Nk, heads, C, hd ** -0.5, need_grad=save)
     x1 = linear_fwd(o, a.proj.weight, a.proj.bias, M, C, res=x, rowscale=dp1, rows_per_scale=N, out_dtype=sd)

@@ -131,6 +131,39 @@ def gemm(A, B, out, M, N, K, *, a_kstrided=False, b_kstrided=False, ldc=None, ba
 # spatial-reduction convolutions: two lean launches beat one four-wave pair grid (58.56 -> 58.37 ms, gpurun r04y; with the four-wave
 # lean kernel the pair had been worth 0.5 ms).  CMDA_GEMM_PAIR=1 turns them back on (tuning A/B; tests/test_gemm.py covers the kernel).
 GEMM_PAIR = os.environ.get('CMDA_GEMM_PAIR', '0') != '0'
+# LayerNorm-prologue Linear (cmda_ln_gemm, gemm_ln.hip) for norm1 -> q and attn.norm -> kv of the MiT blocks: OFF by default.  Measured
+# (tools/dbg/ln_gemm_bench.py, gpurun r04ln3/4): a fused launch beats LayerNorm + Linear where rows are short or the grid is at most one
+# workgroup per CU (65536 x 64 x 64: 9.9 against 16.6 us; 2048 x 320 x 320: 7.8 against 8.7) and loses at the student's stage-3 shape
+# (4096 x 320 x 320: 11.8 against 10.4); restricted to the winning shapes, the encoder's forward and the whole step did not move
+# (5.32 / 5.32 ms, 58.0 - 58.6 against 58.1 - 58.4 ms).  CMDA_LN_GEMM=1 turns it on (tests/test_gemm.py covers the kernel either way).
+LN_GEMM = os.environ.get('CMDA_LN_GEMM', '0') != '0'
+
+
+def ln_gemm(x, gamma, beta, eps, h, save_stats=True, store_xn=True):
+    """LayerNorm(x) followed by the held Linear `h` (gemm(..., hold=True) whose A view is the buffer xn the normalised rows go to) in ONE
+    launch (cmda_ln_gemm; the library runs the two kernels one after the other for problems its fused kernel does not take).
+    Returns (mean, rstd) -- fp32 [rows] or (None, None)."""
+    p, meta, out, keep = h
+    xn = keep[4]   # (bias, res, rowscale, colsum) + the caller's keep: the A operand's tensor first
+    check_dev(x, gamma, beta, xn)
+    rows = x.numel() // x.shape[-1]
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    prof = GEMM_PROFILE is not None and out.is_cuda
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    if LN_GEMM:
+        call('cmda_ln_gemm', ctypes.byref(p), ptr(x), dtype_tag(x), ptr(gamma), ptr(beta), c_f32(eps), ptr(mean), ptr(rstd),
+             c_i32(1 if store_xn else 0), stream_of(out))
+    else:
+        call('cmda_layernorm_fwd2', ptr(x), dtype_tag(x), ptr(gamma), ptr(beta), ptr(xn), dtype_tag(xn), ptr(mean), ptr(rstd), c_i64(rows),
+             c_i32(x.shape[-1]), c_f32(eps), stream_of(x))
+        call('cmda_gemm', ctypes.byref(p), stream_of(out))
+    if prof:
+        e1.record()
+        GEMM_PROFILE.append((meta[0], e0, e1, meta[1], meta[2]))
+    return mean, rstd
 
 
 def gemm_pair(h0, h1):

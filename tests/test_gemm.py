@@ -120,7 +120,7 @@ def _run_forced_tile(marker):
         env = dict(os.environ, CMDA_TEST_GEMM_TILE=hint)
         # (the tests of launches that ignore the forced tile -- pair / row-panel / deferred-grouped -- are left out: they run once, above)
         r = subprocess.run([sys.executable, '-m', 'pytest', here, '-q', '-x', '-m', marker, '-k',
-                            'not forced_tile and not pair_launch and not row_panel and not deferred_grouped', '-p', 'no:cacheprovider'],
+                            'not forced_tile and not pair_launch and not row_panel and not deferred_grouped and not ln_gemm', '-p', 'no:cacheprovider'],
                            env=env, capture_output=True, text=True, timeout=1500)
         assert r.returncode == 0, f'tile_hint {hint}: ' + r.stdout[-2000:] + r.stderr[-2000:]
 
@@ -317,3 +317,46 @@ def test_gemm_pair_launch(tgt, nn):
     if not nn:
         ref = torch.nn.functional.gelu(x.float().cpu() @ wq.float().cpu().t() + bq.cpu())
         assert_close(b0, ref, 1.5e-2, name='pair: q')
+
+
+@pytest.mark.parametrize('M,N,K,xdt', [(130, 320, 320, torch.float32), (64, 64, 64, torch.float32), (200, 96, 128, torch.float32),
+                                       (257, 640, 320, torch.bfloat16), (70, 200, 256, torch.float32), (100, 64, 384, torch.float32),
+                                       (90, 128, 512, torch.float32)])
+def test_ln_gemm_matches_two_launches(tgt, M, N, K, xdt):
+    """cmda_ln_gemm (LayerNorm in the prologue of the Linear behind it: norm1 -> q, attn.norm -> kv) against the two separate launches:
+    statistics to fp32 round-off, normalised rows within one bf16 rounding step, the output within the bf16 GEMM tolerance; ragged
+    M / N included; K = 512 exceeds the resident panel and takes the library's two-launch path (bit-identical then)."""
+    torch.manual_seed(M + K)
+    x = tgt.to((torch.randn(M, K) * 2 + 0.5).to(xdt))
+    gamma, beta = tgt.to(torch.randn(K) * 0.5 + 1), tgt.to(torch.randn(K) * 0.1)
+    w, b = tgt.to((torch.randn(N, K) * 0.1).bfloat16()), tgt.to(torch.randn(N))
+    xn_ref, m_ref, r_ref = ops.layernorm_fwd(x, gamma, beta, 1e-6, out_dtype=torch.bfloat16)
+    y_ref = torch.empty(M, N, dtype=torch.bfloat16, device=tgt.device)
+    ops.gemm(ops.plain_view(xn_ref, M, K), ops.plain_view(w, N, K), y_ref, M, N, K, dtype=1, bias=b)
+    exact = K > 384
+    old = ops.LN_GEMM, ops.GEMM_TILE_HINT
+    # (off by default in the step: ops.LN_GEMM; tile_hint bit 15: the fused kernel whatever the grid size -- its shape rule, gemm_ln.hip)
+    ops.LN_GEMM, ops.GEMM_TILE_HINT = True, 32768
+    try:
+        for store in (True, False):
+            xn = torch.zeros(M, K, dtype=torch.bfloat16, device=tgt.device)
+            y = torch.empty(M, N, dtype=torch.bfloat16, device=tgt.device)
+            h = ops.gemm(ops.plain_view(xn, M, K), ops.plain_view(w, N, K), y, M, N, K, dtype=1, bias=b, hold=True, keep=(xn,))
+            m, r = ops.ln_gemm(x, gamma, beta, 1e-6, h, store_xn=store)
+            if exact:
+                assert torch.equal(y.float().cpu(), y_ref.float().cpu()) and torch.equal(xn.float().cpu(), xn_ref.float().cpu())
+                assert torch.equal(m.cpu(), m_ref.cpu()) and torch.equal(r.cpu(), r_ref.cpu())
+                continue
+            assert_close(m, m_ref, 1e-5, name='ln_gemm mean')
+            assert_close(r, r_ref, 1e-5, name='ln_gemm rstd')
+            assert_close(y, y_ref, 4e-3, name='ln_gemm output vs two launches')
+            if store:
+                assert_close(xn, xn_ref, 8e-3, name='ln_gemm normalised rows')   # one bf16 step (2^-8) of the largest entry at most
+                assert float((xn.float() != xn_ref.float()).float().mean()) < 0.01
+            else:
+                assert float(xn.float().abs().max()) == 0.0
+    finally:
+        ops.LN_GEMM, ops.GEMM_TILE_HINT = old
+    # against torch (fp32 LayerNorm, bf16-rounded operands)
+    ref = torch.nn.functional.layer_norm(x.float().cpu(), (K,), gamma.cpu(), beta.cpu(), 1e-6).bfloat16().float() @ w.float().cpu().t() + b.cpu()
+    assert_close(y, ref, 1.5e-2, name='ln_gemm vs torch')
