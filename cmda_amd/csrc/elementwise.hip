@@ -9,6 +9,7 @@
 //  cmda_adamw_step   : fused AdamW over a flat parameter segment (torch.optim.AdamW semantics,
 //                      configs/_base_/schedules/adamw.py), optionally emitting the bf16 compute copy.
 //  cmda_class_mix    : ClassMix of image / events / label / weight, dacs_transforms.py:101-131, dacs.py:716-771.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -294,6 +295,36 @@ __global__ void copy2d_kernel(const T* __restrict__ src, T* __restrict__ dst, lo
   }
 }
 
+// Non-temporal 16-byte accesses for the once-per-step streams over the parameter state (AdamW: 30 bytes per parameter, EMA: 14).
+#ifndef CMDA_EMU
+typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x4_nt __attribute__((ext_vector_type(4)));
+template <bool NT> static __device__ __forceinline__ void ld4s(const float* p, float (&v)[4]) {
+  if constexpr (NT) {
+    const f32x4_nt t = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(p));
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+  } else ld4(p, v);
+}
+template <bool NT> static __device__ __forceinline__ void st4s(float* p, const float (&v)[4]) {
+  if constexpr (NT) {
+    const f32x4_nt t = {v[0], v[1], v[2], v[3]};
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4_nt*>(p));
+  } else st4(p, v);
+}
+template <bool NT> static __device__ __forceinline__ void st4s(bf16_t* p, const float (&v)[4]) {
+  if constexpr (NT) {
+    const u16x4_nt t = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+    __builtin_nontemporal_store(t, reinterpret_cast<u16x4_nt*>(p));
+  } else st4(p, v);
+}
+#else
+template <bool NT> static inline void ld4s(const float* p, float (&v)[4]) { ld4(p, v); }
+template <bool NT> static inline void st4s(float* p, const float (&v)[4]) { st4(p, v); }
+template <bool NT> static inline void st4s(bf16_t* p, const float (&v)[4]) { st4(p, v); }
+#endif
+
+
+template <bool NT>
 __global__ void ema_kernel(float* __restrict__ ema, const float* __restrict__ p, float alpha, long n, bf16_t* __restrict__ mirror) {
   const long stride = (long)gridDim.x * blockDim.x * 4;
   for (long i0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i0 < n; i0 += 2 * stride) {
@@ -302,8 +333,8 @@ __global__ void ema_kernel(float* __restrict__ ema, const float* __restrict__ p,
     for (int u = 0; u < 2; ++u) {   // both vectors requested before either is used
       const long i = i0 + u * stride;
       if (i + 4 <= n) {
-        ld4(ema + i, e[u]);
-        ld4(p + i, v[u]);
+        ld4s<NT>(ema + i, e[u]);
+        ld4s<NT>(p + i, v[u]);
       }
     }
 #pragma unroll
@@ -312,8 +343,8 @@ __global__ void ema_kernel(float* __restrict__ ema, const float* __restrict__ p,
       if (i + 4 <= n) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) e[u][j] = alpha * e[u][j] + (1.f - alpha) * v[u][j];
-        st4(ema + i, e[u]);
-        if (mirror) st4(mirror + i, e[u]);   // the teacher's bf16 compute copy, written in the same pass (was a separate cast launch)
+        st4s<NT>(ema + i, e[u]);
+        if (mirror) st4s<NT>(mirror + i, e[u]);   // the teacher's bf16 compute copy, written in the same pass (was a separate cast launch)
       } else if (i < n) {
         for (long j = i; j < n; ++j) {
           ema[j] = alpha * ema[j] + (1.f - alpha) * p[j];
@@ -349,6 +380,7 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 // the same update on 16-byte vectors, two per thread and pass (8 independent 16-byte loads in flight per thread: the scalar kernel
 // moved 30 bytes per parameter at ~2 TB/s); element-wise identical arithmetic.  n4 = vectors; the caller runs the scalar kernel
 // over the ragged tail / unaligned groups.
+template <bool NT>
 __global__ void adamw_vec_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                  float* __restrict__ v, bf16_t* __restrict__ p_bf16, long n4, float lr, float b1, float b2,
                                  float eps, float wd, float bc1, float bc2_sqrt) {
@@ -359,10 +391,10 @@ __global__ void adamw_vec_kernel(float* __restrict__ p, const float* __restrict_
     for (int u = 0; u < 2; ++u) {
       const long i = i0 + u * stride;
       if (i < n4) {
-        ld4(p + 4 * i, pv[u]);
-        ld4(g + 4 * i, gv[u]);
-        ld4(m + 4 * i, mv[u]);
-        ld4(v + 4 * i, vv[u]);
+        ld4s<NT>(p + 4 * i, pv[u]);
+        ld4s<NT>(g + 4 * i, gv[u]);
+        ld4s<NT>(m + 4 * i, mv[u]);
+        ld4s<NT>(v + 4 * i, vv[u]);
       }
     }
 #pragma unroll
@@ -371,10 +403,10 @@ __global__ void adamw_vec_kernel(float* __restrict__ p, const float* __restrict_
       if (i < n4) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) pv[u][j] = adamw_one(pv[u][j], gv[u][j], mv[u][j], vv[u][j], lr, b1, b2, eps, wd, bc1, bc2_sqrt);
-        st4(m + 4 * i, mv[u]);
-        st4(v + 4 * i, vv[u]);
-        st4(p + 4 * i, pv[u]);
-        if (p_bf16) st4(p_bf16 + 4 * i, pv[u]);
+        st4s<NT>(m + 4 * i, mv[u]);
+        st4s<NT>(v + 4 * i, vv[u]);
+        st4s<NT>(p + 4 * i, pv[u]);
+        if (p_bf16) st4s<NT>(p_bf16 + 4 * i, pv[u]);
       }
     }
   }
@@ -574,7 +606,11 @@ extern "C" int cmda_copy2d(const void* src, void* dst, int64_t rows, int cols, i
 
 extern "C" int cmda_ema_update(float* ema, const float* param, float alpha, int64_t n, void* ema_bf16, void* stream) {
   if (n <= 0) return CMDA_OK;
-  CMDA_LAUNCH(ema_kernel, dim3((unsigned)std::max<long>(1, std::min<long>((n + 2047) / 2048, 4096))), dim3(256), 0, stream, ema, param, alpha,
+  // (non-temporal accesses: 243 -> 195 us over 85 M parameters, AdamW 472 -> 454; tools/hbm_bench.py, gpurun r04 A/B)
+  static const bool nt = getenv("CMDA_STREAM_TEMPORAL") == nullptr;
+  if (nt) CMDA_LAUNCH(ema_kernel<true>, dim3((unsigned)std::max<long>(1, std::min<long>((n + 2047) / 2048, 4096))), dim3(256), 0, stream, ema, param, alpha,
+              (long)n, (bf16_t*)ema_bf16);
+  else CMDA_LAUNCH(ema_kernel<false>, dim3((unsigned)std::max<long>(1, std::min<long>((n + 2047) / 2048, 4096))), dim3(256), 0, stream, ema, param, alpha,
               (long)n, (bf16_t*)ema_bf16);
   CMDA_CHECK_LAUNCH();
 }
@@ -587,8 +623,12 @@ extern "C" int cmda_adamw_step(float* p, const float* g, float* m, float* v, voi
   const float bc2 = 1.f - powf(beta2, (float)step);
   const bool aligned = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && ((uintptr_t)p_bf16 & 7) == 0;
   const long n4 = aligned ? n / 4 : 0;
-  if (n4 > 0)
-    CMDA_LAUNCH(adamw_vec_kernel, dim3((unsigned)std::max<long>(1, std::min<long>((n4 + 511) / 512, 4096))), dim3(256), 0, stream, p, g, m,
+  static const bool nt = getenv("CMDA_STREAM_TEMPORAL") == nullptr;   // (A/B switch: plain loads / stores)
+  if (n4 > 0 && nt)
+    CMDA_LAUNCH(adamw_vec_kernel<true>, dim3((unsigned)std::max<long>(1, std::min<long>((n4 + 511) / 512, 4096))), dim3(256), 0, stream, p, g, m,
+                v, (bf16_t*)p_bf16, n4, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2));
+  else if (n4 > 0)
+    CMDA_LAUNCH(adamw_vec_kernel<false>, dim3((unsigned)std::max<long>(1, std::min<long>((n4 + 511) / 512, 4096))), dim3(256), 0, stream, p, g, m,
                 v, (bf16_t*)p_bf16, n4, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2));
   if (const long rest = n - 4 * n4) {
     bf16_t* pb = p_bf16 ? (bf16_t*)p_bf16 + 4 * n4 : nullptr;

@@ -30,12 +30,27 @@ def main():
     tl = []
     orig = seg.replay
     seg.replay = lambda: orig(timeline=tl)
-    opt.zero_grad()
-    dacs(**batch)
-    opt.step(1.0)
+    marks = []
+    for _ in range(3):                      # three timed iterations: the first one's segments are printed, the gaps between them too
+        e = torch.cuda.Event(enable_timing=True); e.record(); marks.append(('iteration start (host reaches zero_grad)', e))
+        opt.zero_grad()
+        e = torch.cuda.Event(enable_timing=True); e.record(); marks.append(('zero_grad queued', e))
+        dacs(**batch)
+        e = torch.cuda.Event(enable_timing=True); e.record(); marks.append(('graph replay queued', e))
+        opt.step(1.0)
+        e = torch.cuda.Event(enable_timing=True); e.record(); marks.append(('AdamW queued', e))
     torch.cuda.synchronize()
     seg.replay = orig
+    nseg = len(tl) // 3
     t0 = tl[0][2]
+    print('events on the main stream and segment boundaries of three consecutive iterations (ms from the first segment):')
+    for name, e in marks:
+        print(f'  {t0.elapsed_time(e):9.3f}  {name}')
+    for k in range(3):
+        a = min(t0.elapsed_time(r[2]) for r in tl[k * nseg:(k + 1) * nseg])
+        b = max(t0.elapsed_time(r[3]) for r in tl[k * nseg:(k + 1) * nseg])
+        print(f'  iteration {k}: first segment starts {a:9.3f}, last segment ends {b:9.3f}  (span {b - a:.3f})')
+    tl = tl[:nseg]
     streams = {}
     rows = []
     for i, sid, e0, e1 in tl:
