@@ -15,6 +15,7 @@
 // class scores of one full-resolution pixel on the fly.  HBM-bound; algorithmic bytes per sample:
 // fwd  19*h*w*4 + H*W*(8 label + 4 weight + 4 lse out); bwd the same + 19*h*w*4 written.
 // Backward is a deterministic gather over the 1/4-resolution grid (no atomics), one thread per (pixel, class).
+#include <cstdlib>
 #include "bilinear.h"
 
 namespace {
@@ -264,6 +265,149 @@ __global__ __launch_bounds__(256) void ce_bwd_gather_kernel(const float* __restr
   dlogits[i] = (gscale_ptr ? *gscale_ptr : 1.f) * gscale_mul * g;
 }
 
+// TILED gather (the form that runs at the path's sizes).  The thread-per-(pixel, class) kernel above rebuilds exp(s_c - lse) of every
+// full-resolution pixel in EVERY low-resolution pixel's window: ~100 exponentials, label / weight / lse loads and bilinear mixes per
+// output where each full-resolution pixel feeds only the 2 x 2 low-resolution pixels of its taps (94 us per call at 4 x 128 x 128
+// x 19 up-sampled x 4, eight calls per UDA step on the decode head's single lane).  Here a block owns kTLW x kTLH low-resolution
+// pixels of one image; the per-pixel gradient coef * (softmax_c - onehot_c) of the full-resolution rows the tile can receive from is
+// built ONCE into LDS, eight rows at a time, by one thread per full-resolution pixel (forward's tile_scores: same scores, same
+// rounding), and thread (row group, x, c) of the tile then sums its column window of each row from LDS and weights the sum onto the
+// kTLH rows it owns (320 threads = two row groups of 8 x 19).  Deterministic; sums associate per row, then per row group.
+constexpr int kTLW = 8, kTLH = 4, kStripRows = 8, kStripCols = 48, kStripFloats = kStripRows * kStripCols * 20;
+constexpr int kLowPatchFloats = (kTLW + 6) * (kTLH + 6) * 20;   // up-sampling factors >= 2: the region's taps span at most tile + 6 low-resolution rows / columns
+
+// NCT: the class count at compile time (19: the path's; every per-class loop unrolls, the LDS reads of a pixel are in flight
+// together) or 0 = run-time nc
+template <int NCT>
+__global__ __launch_bounds__(320) void ce_bwd_tile_kernel(const float* __restrict__ logits, const long long* __restrict__ label,
+                                                          const float* __restrict__ weight, const float* __restrict__ lse,
+                                                          const float* __restrict__ gscale_ptr, float gscale_mul,
+                                                          float* __restrict__ dlogits, int B, int h, int w, int H, int W,
+                                                          int nc_rt, int ignore_index) {
+  const int nc = NCT ? NCT : nc_rt;
+  __shared__ float G[kStripFloats];          // [strip row][region column][class]
+  __shared__ float patch[kLowPatchFloats];   // low-resolution logits the region's taps read
+  const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+  const float ish = (float)H / (float)h, isw = (float)W / (float)w;
+  const int tiles_x = (w + kTLW - 1) / kTLW, tiles_y = (h + kTLH - 1) / kTLH;
+  const int bt = blockIdx.x;
+  const int b = bt / (tiles_x * tiles_y);
+  const int r = bt - b * tiles_x * tiles_y;
+  const int y0 = (r / tiles_x) * kTLH, x0 = (r % tiles_x) * kTLW;
+  const int y1 = min(y0 + kTLH, h) - 1, x1 = min(x0 + kTLW, w) - 1;
+  // full-resolution region the tile receives from (lo_hi_range of its first and last pixel: conservative by a pixel or two)
+  int YR0, YR1, XR0, XR1, tmp;
+  lo_hi_range(y0, h, H, ish, YR0, tmp);
+  lo_hi_range(y1, h, H, ish, tmp, YR1);
+  lo_hi_range(x0, w, W, isw, XR0, tmp);
+  lo_hi_range(x1, w, W, isw, tmp, XR1);
+  const int ncols = XR1 - XR0 + 1;           // <= kStripCols (launcher)
+  // low-resolution patch: the taps of the region's corners
+  const int py0 = bilin_tap(YR0, h, H, sh).i0, py1 = bilin_tap(YR1, h, H, sh).i1;
+  const int px0 = bilin_tap(XR0, w, W, sw).i0, px1 = bilin_tap(XR1, w, W, sw).i1;
+  const int pcols = px1 - px0 + 1, prows = py1 - py0 + 1, prowf = pcols * nc;   // (prows * prowf <= kLowPatchFloats: launcher)
+  for (int rr = 0; rr < prows; ++rr) {
+    const float* src = logits + ((long)(b * h + py0 + rr) * w + px0) * nc;
+    for (int k = threadIdx.x; k < prowf; k += blockDim.x) patch[rr * prowf + k] = src[k];
+  }
+  // gather role: thread = (row group, x, c) of the tile: blockDim / (kTLW * nc) groups share the strip's rows, kTLH outputs each
+  const int per = kTLW * nc, ngrp = max(1, (int)blockDim.x / per), grp = threadIdx.x / per, tig = threadIdx.x - grp * per;
+  const int gx = tig / nc, gc = tig - gx * nc;
+  const bool gather = grp < ngrp && x0 + gx <= x1;
+  const int x = x0 + gx;
+  float wxs[kMaxTapsX];
+  int X0 = 0, nX = 0;
+  if (gather) {
+    int X1;
+    lo_hi_range(x, w, W, isw, X0, X1);
+    nX = X1 - X0 + 1;
+  }
+#pragma unroll
+  for (int k = 0; k < kMaxTapsX; ++k) {
+    wxs[k] = 0.f;
+    if (k < nX) {
+      const BilinTap tx = bilin_tap(X0 + k, w, W, sw);
+      wxs[k] = (tx.i0 == x ? tx.l0 : 0.f) + (tx.i1 == x ? tx.l1 : 0.f);
+    }
+  }
+  float acc[kTLH];
+#pragma unroll
+  for (int j = 0; j < kTLH; ++j) acc[j] = 0.f;
+  __syncthreads();
+
+  for (int YS = YR0; YS <= YR1; YS += kStripRows) {
+    const int nrows = min(kStripRows, YR1 - YS + 1);
+    // ---- per-pixel gradients of the strip: one thread per full-resolution pixel, all classes
+    for (int pi = threadIdx.x; pi < nrows * ncols; pi += blockDim.x) {
+      const int ry = pi / ncols, rx = pi - ry * ncols;
+      const int Y = YS + ry, X = XR0 + rx;
+      float* gp = G + (ry * kStripCols + rx) * nc;
+      const long gi = ((long)b * H + Y) * W + X;
+      const long long lab = label[gi];
+      const bool live = lab != ignore_index && lab >= 0 && lab < nc;
+      const float coef = live ? (weight ? weight[gi] : 1.f) : 0.f;
+      if (coef == 0.f) {
+#pragma unroll
+        for (int c = 0; c < (NCT ? NCT : kMaxClasses); ++c)
+          if (c < nc) gp[c] = 0.f;
+        continue;
+      }
+      const BilinTap ty = bilin_tap(Y, h, H, sh), tx = bilin_tap(X, w, W, sw);
+      const float* p00 = patch + ((ty.i0 - py0) * pcols + (tx.i0 - px0)) * nc;
+      const float* p01 = patch + ((ty.i0 - py0) * pcols + (tx.i1 - px0)) * nc;
+      const float* p10 = patch + ((ty.i1 - py0) * pcols + (tx.i0 - px0)) * nc;
+      const float* p11 = patch + ((ty.i1 - py0) * pcols + (tx.i1 - px0)) * nc;
+      const float l = lse[gi];
+#pragma unroll
+      for (int c = 0; c < (NCT ? NCT : kMaxClasses); ++c) {
+        if (c < nc) {
+          const float sc = bilin_mix(p00[c], p01[c], p10[c], p11[c], tx.l0, tx.l1, ty.l0, ty.l1);
+          gp[c] = coef * (__expf(sc - l) - (c == (int)lab ? 1.f : 0.f));
+        }
+      }
+    }
+    __syncthreads();
+    // ---- gather: the group's rows of the strip; per row the thread's column window is summed once, then weighted onto its rows
+    if (gather) {
+      for (int ry = grp; ry < nrows; ry += ngrp) {
+        const BilinTap ty = bilin_tap(YS + ry, h, H, sh);
+        const float* gr = G + (ry * kStripCols + (X0 - XR0)) * nc + gc;
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < kMaxTapsX; ++k)
+          if (k < nX) t += wxs[k] * gr[k * nc];
+#pragma unroll
+        for (int j = 0; j < kTLH; ++j) {
+          const int y = y0 + j;
+          const float wy = (ty.i0 == y ? ty.l0 : 0.f) + (ty.i1 == y ? ty.l1 : 0.f);
+          acc[j] += wy * t;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // fold the row groups (group 0 writes): partial sums through the strip buffer
+  if (ngrp > 1) {
+    if (gather && grp > 0) {
+#pragma unroll
+      for (int j = 0; j < kTLH; ++j) G[((grp - 1) * per + tig) * kTLH + j] = acc[j];
+    }
+    __syncthreads();
+    if (gather && grp == 0) {
+      for (int o = 1; o < ngrp; ++o)
+#pragma unroll
+        for (int j = 0; j < kTLH; ++j) acc[j] += G[((o - 1) * per + tig) * kTLH + j];
+    }
+  }
+  if (!gather || grp != 0) return;
+  const float gs = (gscale_ptr ? *gscale_ptr : 1.f) * gscale_mul;
+#pragma unroll
+  for (int j = 0; j < kTLH; ++j) {
+    const int y = y0 + j;
+    if (y <= y1) dlogits[(((long)b * h + y) * w + x) * nc + gc] = gs * acc[j];
+  }
+}
+
 // label = first arg-max of the up-sampled scores; prob = 1 / sum exp(s - max); count += (prob >= thr)
 __global__ __launch_bounds__(256) void pseudo_label_kernel(const float* __restrict__ logits, long long* __restrict__ label_out,
                                                             float* __restrict__ prob_out, int* __restrict__ count, int B, int h, int w,
@@ -355,6 +499,21 @@ extern "C" int cmda_ce_upsample_bwd(const float* logits, const int64_t* label, c
   if ((long)B * h * w * nc >= (1L << 32)) return CMDA_ERR_SHAPE;   // (32-bit index arithmetic in the kernels)
   // column taps one low-resolution pixel can receive (lo_hi_range's window): the register-resident form holds up to 16
   const long taps = (long)ceil(2.0 * W / w) + 4;
+  // tiled form (90 -> 57 us at 2 x 128 x 128 x 19 -> 512 x 512, the step 58.4 -> 58.05 ms; CMDA_CE_GATHER=1: the kernel above, tuning A/B):
+  // up-sampling factors >= 2 (low-resolution patch <= tile + 6 per axis), the tile's full-resolution region
+  // ((kTLW + 1) * factor + 5 columns at most) inside the LDS strip, at most 20 classes
+  {
+    const long rcols = (long)ceil((kTLW + 1.0) * W / w) + 6;
+    if (taps <= kMaxTapsX && 2L * h <= H && 2L * w <= W && rcols <= kStripCols && nc <= 20 && getenv("CMDA_CE_GATHER") == nullptr) {
+      const long tiles = (long)B * ((w + kTLW - 1) / kTLW) * ((h + kTLH - 1) / kTLH);
+      if (tiles > 0x7fffffffL) return CMDA_ERR_SHAPE;
+      if (nc == 19) CMDA_LAUNCH(ce_bwd_tile_kernel<19>, dim3((unsigned)tiles), dim3(320), 0, stream, logits, (const long long*)label, weight, lse, gscale_ptr,
+                                gscale_mul, dlogits, B, h, w, H, W, nc, ignore_index);
+      else CMDA_LAUNCH(ce_bwd_tile_kernel<0>, dim3((unsigned)tiles), dim3(320), 0, stream, logits, (const long long*)label, weight, lse, gscale_ptr,
+                       gscale_mul, dlogits, B, h, w, H, W, nc, ignore_index);
+      CMDA_CHECK_LAUNCH();
+    }
+  }
   if (taps <= kMaxTapsX && h <= H && w <= W) {
     const long blocks = ((long)B * h * w * nc + 255) / 256;
     if (blocks > 0x7fffffffL) return CMDA_ERR_SHAPE;

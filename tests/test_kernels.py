@@ -158,11 +158,12 @@ def test_batchnorm(tgt, dt, tol, relu):
     assert_close(db, bn.bias.grad, 1e-4, name='bn dbeta')
 
 
-@pytest.mark.parametrize('h,w,H,W', [(8, 8, 32, 32), (6, 10, 24, 40), (7, 5, 28, 20), (8, 8, 8, 8), (5, 7, 13, 18), (2, 3, 32, 48), (9, 17, 36, 68)])
+@pytest.mark.parametrize('h,w,H,W', [(8, 8, 32, 32), (6, 10, 24, 40), (7, 5, 28, 20), (8, 8, 8, 8), (5, 7, 13, 18), (2, 3, 32, 48), (9, 17, 36, 68),
+                                     (12, 20, 24, 40), (10, 9, 30, 27), (32, 40, 128, 160), (11, 13, 66, 65)])   # (tiled backward: factors 2 / 3 / 4 / 5-6, several tiles)
 @pytest.mark.parametrize('use_weight', [True, False])
 def test_ce_upsample(tgt, h, w, H, W, use_weight):
     torch.manual_seed(h * 3 + w)
-    B, nc = 2, 19
+    B, nc = 2, (19 if (h + w) % 3 else 7)   # (19: the unrolled instance of the tiled backward; 7: its run-time class count)
     logits = torch.randn(B, h, w, nc) * 2
     label = torch.randint(0, nc, (B, H, W))
     label[torch.rand(B, H, W) < 0.1] = 255
