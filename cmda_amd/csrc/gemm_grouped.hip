@@ -55,6 +55,8 @@ static Plan classify(const GemmParams& p) {
   // this kernel than the operand traffic it saved -- 6.2 ms per step against 5.1 on the small tiles)
   const long pm = (p.M + 255) / 256 * 256, pn = (p.N + 255) / 256 * 256;
   const bool big = p.M >= 256 && p.N >= 256 && (double)pm * pn <= 1.1 * (double)p.M * p.N;
+  // (128-wide tiles over the 320-channel dimensions with a half-empty last tile -- 20 % padding for 20 - 28 % fewer operand bytes --
+  // measured slower as well: the step 58.0 - 58.1 -> 58.2 - 58.4 ms, gpurun r04pad)
   const int kind = big ? 4 : (p.M % 128 == 0 ? 1 : 0) + (p.N % 128 == 0 ? 2 : 0);
   typedef DmaSrc<true, 64, false, 4, 0, 64, 1> FK;   // (tile size irrelevant for the eligibility test)
   const bool fast = FK::mode_ok(p.A, 1) && FK::mode_ok(p.B, 1);
