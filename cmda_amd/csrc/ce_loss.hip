@@ -207,6 +207,20 @@ static __device__ __forceinline__ void lo_hi_range(int y, int h, int H, float is
   Y1 = min(Y1, H - 1);
 }
 
+// The same window for an up-sampling factor f that is a power of two (H = f h; f = 0: lo_hi_range): every product of the source-index
+// arithmetic is exact then, full-resolution row Y has taps {floor((Y + 0.5) / f - 0.5), +1} and low-resolution row y receives from
+// exactly Y in [f y - f/2, f y + f + f/2 - 1] (the border rows from everything beyond them): no margin rows to build and skip.
+static __device__ __forceinline__ void lo_hi_window(int y, int h, int H, float ish, int f, int& Y0, int& Y1) {
+  if (f == 0) {
+    lo_hi_range(y, h, H, ish, Y0, Y1);
+    return;
+  }
+  Y0 = y == 0 ? 0 : f * y - (f >> 1);
+  Y1 = y == h - 1 ? H - 1 : f * y + f + (f >> 1) - 1;
+  Y0 = max(Y0, 0);
+  Y1 = min(Y1, H - 1);
+}
+
 __global__ __launch_bounds__(256) void ce_bwd_gather_kernel(const float* __restrict__ logits, const long long* __restrict__ label,
                                                             const float* __restrict__ weight, const float* __restrict__ lse,
                                                             const float* __restrict__ gscale_ptr, float gscale_mul,
@@ -283,7 +297,7 @@ __global__ __launch_bounds__(320) void ce_bwd_tile_kernel(const float* __restric
                                                           const float* __restrict__ weight, const float* __restrict__ lse,
                                                           const float* __restrict__ gscale_ptr, float gscale_mul,
                                                           float* __restrict__ dlogits, int B, int h, int w, int H, int W,
-                                                          int nc_rt, int ignore_index) {
+                                                          int nc_rt, int ignore_index, int fy, int fx) {
   const int nc = NCT ? NCT : nc_rt;
   __shared__ float G[kStripFloats];          // [strip row][region column][class]
   __shared__ float patch[kLowPatchFloats];   // low-resolution logits the region's taps read
@@ -295,12 +309,13 @@ __global__ __launch_bounds__(320) void ce_bwd_tile_kernel(const float* __restric
   const int r = bt - b * tiles_x * tiles_y;
   const int y0 = (r / tiles_x) * kTLH, x0 = (r % tiles_x) * kTLW;
   const int y1 = min(y0 + kTLH, h) - 1, x1 = min(x0 + kTLW, w) - 1;
-  // full-resolution region the tile receives from (lo_hi_range of its first and last pixel: conservative by a pixel or two)
+  // full-resolution region the tile receives from (lo_hi_range of its first and last pixel: conservative by a pixel or two; exact for
+  // power-of-two factors fy / fx)
   int YR0, YR1, XR0, XR1, tmp;
-  lo_hi_range(y0, h, H, ish, YR0, tmp);
-  lo_hi_range(y1, h, H, ish, tmp, YR1);
-  lo_hi_range(x0, w, W, isw, XR0, tmp);
-  lo_hi_range(x1, w, W, isw, tmp, XR1);
+  lo_hi_window(y0, h, H, ish, fy, YR0, tmp);
+  lo_hi_window(y1, h, H, ish, fy, tmp, YR1);
+  lo_hi_window(x0, w, W, isw, fx, XR0, tmp);
+  lo_hi_window(x1, w, W, isw, fx, tmp, XR1);
   const int ncols = XR1 - XR0 + 1;           // <= kStripCols (launcher)
   // low-resolution patch: the taps of the region's corners
   const int py0 = bilin_tap(YR0, h, H, sh).i0, py1 = bilin_tap(YR1, h, H, sh).i1;
@@ -319,7 +334,7 @@ __global__ __launch_bounds__(320) void ce_bwd_tile_kernel(const float* __restric
   int X0 = 0, nX = 0;
   if (gather) {
     int X1;
-    lo_hi_range(x, w, W, isw, X0, X1);
+    lo_hi_window(x, w, W, isw, fx, X0, X1);
     nX = X1 - X0 + 1;
   }
 #pragma unroll
@@ -507,10 +522,12 @@ extern "C" int cmda_ce_upsample_bwd(const float* logits, const int64_t* label, c
     if (taps <= kMaxTapsX && 2L * h <= H && 2L * w <= W && rcols <= kStripCols && nc <= 20 && getenv("CMDA_CE_GATHER") == nullptr) {
       const long tiles = (long)B * ((w + kTLW - 1) / kTLW) * ((h + kTLH - 1) / kTLH);
       if (tiles > 0x7fffffffL) return CMDA_ERR_SHAPE;
+      auto pow2_factor = [](int out, int in) { const int f = out / in; return (out % in) == 0 && f >= 2 && f <= 16 && (f & (f - 1)) == 0 ? f : 0; };
+      const int fy = pow2_factor(H, h), fx = pow2_factor(W, w);
       if (nc == 19) CMDA_LAUNCH(ce_bwd_tile_kernel<19>, dim3((unsigned)tiles), dim3(320), 0, stream, logits, (const long long*)label, weight, lse, gscale_ptr,
-                                gscale_mul, dlogits, B, h, w, H, W, nc, ignore_index);
+                                gscale_mul, dlogits, B, h, w, H, W, nc, ignore_index, fy, fx);
       else CMDA_LAUNCH(ce_bwd_tile_kernel<0>, dim3((unsigned)tiles), dim3(320), 0, stream, logits, (const long long*)label, weight, lse, gscale_ptr,
-                       gscale_mul, dlogits, B, h, w, H, W, nc, ignore_index);
+                       gscale_mul, dlogits, B, h, w, H, W, nc, ignore_index, fy, fx);
       CMDA_CHECK_LAUNCH();
     }
   }

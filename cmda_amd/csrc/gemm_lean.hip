@@ -24,7 +24,7 @@ struct LeanParams {
   const float* rowscale;
   long lda, ldb, ldc, ldres;
   int M, N, nkt, tiles_n;
-  int ntile, rows_per_scale, act, flags;   // flags: 1 out_f32, 2 res_f32, 4 c_vec_ok
+  int ntile, rows_per_scale, act, flags;   // flags: 1 out_f32, 2 res_f32, 4 c_vec_ok, 8 patch store (p_ow / p_row / p_col = OW / KH / KW*Ci)
   float alpha, beta;
   // patch view of A (kernel == stride convolution, cmda_view_t.conv == 2): row m = (b, oh, ow) starts at b * p_img + oh * p_row + ow * p_col
   // elements; its K = KH * KW * C elements are KH segments of p_seg k-tiles (KW * C contiguous elements) p_jump bytes apart
@@ -221,6 +221,14 @@ __global__ __launch_bounds__(64 * NW, (GldsCfg<TM, TN, NW, NSV>::MIN_WAVES)) voi
   const float alpha = q.alpha, beta = q.beta;
   const bool has_beta = beta != 0.f, has_rs = q.rowscale != nullptr;
   const int act = q.act;
+  // patch store (flags bit 3; plain A only, so the patch-view fields are free: p_ow = OW, p_row = KH, p_col = KW * Ci): the data
+  // gradient of a kernel == stride convolution goes straight into the NHWC input gradient (mix_transformer.py:70-75 under autograd)
+  const bool cpatch = !PATCH && (q.flags & 8) != 0;
+  unsigned pkh = 0, prest = 0;
+  if (cpatch) {
+    pkh = (unsigned)en / (unsigned)q.p_col;
+    prest = (unsigned)en - pkh * (unsigned)q.p_col;
+  }
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int row = er0 + it * RSTEP;
@@ -228,7 +236,11 @@ __global__ __launch_bounds__(64 * NW, (GldsCfg<TM, TN, NW, NSV>::MIN_WAVES)) voi
     if (m >= M) break;
     const float4 t = *reinterpret_cast<const float4*>(&sC[row * PITCH_C + q4]);
     float v[4] = {t.x, t.y, t.z, t.w};
-    const long ci = m * q.ldc + en;
+    long ci = m * q.ldc + en;
+    if (cpatch) {   // un-patchify (cmda_gemm_params_t.c_patch_*): row (b*OH + oh, ow), column (kh, kw*Ci + ci) -> NHWC
+      const unsigned boh = (unsigned)m / (unsigned)q.p_ow, ow = (unsigned)m - boh * (unsigned)q.p_ow;
+      ci = ((long)(boh * (unsigned)q.p_row + pkh) * q.p_ow + ow) * q.p_col + prest;
+    }
     float ov[4] = {0.f, 0.f, 0.f, 0.f};
     float rs = 1.f;
     if (has_rs) rs = q.rowscale[(unsigned)m / (unsigned)q.rows_per_scale];   // (32-bit: M < 2^31)
@@ -296,6 +308,10 @@ int launch_lean(const GemmParams& p, void* stream) {
       CMDA_CHECK_LAUNCH();
     }
   }
+  if (p.c_patch_ow > 0) {
+    q.flags |= 8;
+    q.p_ow = p.c_patch_ow; q.p_row = p.c_patch_kh; q.p_col = p.c_patch_kwci;
+  }
   if (p.b_kstrided) CMDA_LAUNCH((gemm_lean_kernel<TM, TN, true, NSV, NW>), grid, blk, 0, stream, q);
   else CMDA_LAUNCH((gemm_lean_kernel<TM, TN, false, NSV, NW>), grid, blk, 0, stream, q);
   CMDA_CHECK_LAUNCH();
@@ -314,7 +330,8 @@ bool cmda_gemm_lean_ok_(const cmda_gemm_params_t& p, int tile) {
            !(p.tile_hint > 0 && (p.tile_hint & 16384));
   };
   return (tile == 1 || tile == 2) && p.dtype == CMDA_BF16 && !p.a_kstrided && (plain(p.A) || patch(p.A)) && plain(p.B) && (p.K % 64) == 0 && p.K >= 64 &&
-         p.batch == 1 && p.batch2 <= 1 && p.splits <= 1 && !p.atomic && !p.colsum && p.c_patch_ow == 0 && p.c_perm_ci == 0 &&
+         p.batch == 1 && p.batch2 <= 1 && p.splits <= 1 && !p.atomic && !p.colsum && p.c_perm_ci == 0 &&
+         (p.c_patch_ow == 0 || (plain(p.A) && !p.res && (long)p.M * p.N < (1L << 31) && p.c_patch_kwci > 0)) &&
          (!p.b_kstrided || 64L * p.B.ld * 2 < (1L << 31)) && !(p.tile_hint > 0 && (p.tile_hint & 8192));   // (tile_hint bit 13: general kernel, tuning A/B)
 }
 

@@ -134,26 +134,29 @@ def test_forced_tile_256_gpu():
     _run_forced_tile('gpu')
 
 
-def test_gemm_unpatchify_store(tgt):
+@pytest.mark.parametrize('dt,tag,tol,B,OH,OW,Co,Ci,k', [(torch.float32, 0, 2e-5, 2, 3, 5, 24, 8, 2),
+                                                        # bf16 with Co % 64 == 0: the lean kernel's patch-store epilogue (K-strided weights)
+                                                        (torch.bfloat16, 1, 2e-2, 2, 3, 5, 64, 32, 2), (torch.bfloat16, 1, 2e-2, 3, 4, 8, 128, 64, 4),
+                                                        (torch.bfloat16, 1, 2e-2, 1, 9, 7, 192, 8, 2)])
+def test_gemm_unpatchify_store(tgt, dt, tag, tol, B, OH, OW, Co, Ci, k):
     """c_patch: the data gradient of a kernel == stride convolution is stored straight in NHWC (mix_transformer.py:70-75's sr
     conv backward), compared with conv_transpose2d; also with beta accumulation."""
     import torch.nn.functional as F
     from cmda_amd import ops
     torch.manual_seed(5)
-    B, OH, OW, Co, Ci, k = 2, 3, 5, 24, 8, 2
-    dy = torch.randn(B, Co, OH, OW)
-    w = torch.randn(Co, Ci, k, k)
-    want = F.conv_transpose2d(dy, w, stride=k)                       # [B, Ci, OH*k, OW*k]
-    prev = torch.randn(B * OH * k * OW * k, Ci)
+    dy = torch.randn(B, Co, OH, OW).to(dt)
+    w = (torch.randn(Co, Ci, k, k) * (1.0 if tag == 0 else 0.2)).to(dt)
+    want = F.conv_transpose2d(dy.float(), w.float(), stride=k)       # [B, Ci, OH*k, OW*k]
+    prev = torch.randn(B * OH * k * OW * k, Ci).to(dt)
     dy_rows = tgt.to(dy.permute(0, 2, 3, 1).reshape(-1, Co).contiguous())
     w_khwc = tgt.to(w.permute(0, 2, 3, 1).reshape(Co, k * k * Ci).contiguous())
     for beta in (0.0, 1.0):
         dx = tgt.to(prev.clone())
         M, K = B * OH * OW, k * k * Ci
-        ops.gemm(ops.plain_view(dy_rows, M, Co), ops.plain_view(w_khwc, Co, K), dx, M, K, Co, b_kstrided=True, dtype=0,
+        ops.gemm(ops.plain_view(dy_rows, M, Co), ops.plain_view(w_khwc, Co, K), dx, M, K, Co, b_kstrided=True, dtype=tag,
                  beta=beta, c_patch=(OW, k, k * Ci))
-        ref = want.permute(0, 2, 3, 1).reshape(-1, Ci) + beta * prev
-        assert_close(dx, ref, 2e-5, name=f'unpatchify beta={beta}')
+        ref = want.permute(0, 2, 3, 1).reshape(-1, Ci) + beta * prev.float()
+        assert_close(dx, ref, tol, name=f'unpatchify beta={beta}')
 
 
 @pytest.mark.parametrize('hint,M,N', [(3, 600, 1100), (3, 520, 1024), (2, 1100, 1060), (4, 1030, 2100)])
