@@ -82,7 +82,7 @@ typedef struct cmda_gemm_params_t {
    * column buffer.  Off when c_patch_ow == 0; ldc / batch strides / residual are ignored in this mode. */
   int32_t c_patch_ow, c_patch_kh, c_patch_kwci;
   /* 0: the library's tile heuristics; -1: register-staged kernel instead of the LDS-DMA one.  > 0 (tuning sweeps, tests of the rarely
-   * chosen kernels): low 4 bits 1..5 force tile 64x64 / 128x64 / 128x128 / 256x256 / 64x320 row panel; bits 4-7 LDS stages (4 = four);
+   * chosen kernels): low 4 bits 1..5 force tile 128x128 / 128x64 / 64x64 / 256x256 / 64x320 row panel; bits 4-7 LDS stages (4 = four);
    * bit 8 no tile-group walk; bit 9 gemm_glds_kernel instead of the ping-pong / weight-gradient 256x256 kernels; bit 10 ping-pong
    * kernel; bit 11 general DMA address path; bit 12 (32, 4) weight-gradient configuration; bit 13 general kernel instead of the lean
    * one; bit 14 lean kernel on four waves; bit 15 cmda_ln_gemm: fused kernel whatever the grid size. */

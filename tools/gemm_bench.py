@@ -61,7 +61,7 @@ def main():
         rows.append((name + ' wgrad', 2.0 * M * Co * K, timeit(lambda: ops.gemm(ops.plain_view(dy, M, Co), ops.conv_view(x, B, H, W, Ci, k, k, 1, k // 2), dw, Co, K, M, a_kstrided=True, b_kstrided=True, dtype=tag, atomic=True, splits=0), 10)))
 
     if args.big:
-        for hint, tag_ in ((0, 'library heuristics'), (1024 | 4, 'ping-pong 256^2 (gemm_pp.hip) forced'), (512 | 4, 'gemm_glds_kernel 256^2 forced'), (3, '128^2')):
+        for hint, tag_ in ((0, 'library heuristics'), (1024 | 4, 'ping-pong 256^2 (gemm_pp.hip) forced'), (512 | 4, 'gemm_glds_kernel 256^2 forced'), (1, '128^2'), (3, '64^2')):
             ops.GEMM_TILE_HINT = hint
             rows.append((f'--- {tag_} (tile_hint {hint})', 0.0, 1.0))
             nt('NT 8192x8192x8192', 8192, 8192, 8192)
