@@ -170,6 +170,26 @@ static inline void glds16(const void* gsrc, void* lds_wave_base) {
 }
 #endif
 
+// The same copy issued through inline asm, i.e. INVISIBLE to the compiler's wait-count bookkeeping.  With the builtin, hipcc puts
+// `s_waitcnt vmcnt(0)` in front of every LDS read it cannot prove disjoint from a pending DMA destination -- and it treats the
+// destination as "this address and everything above it", so a kernel that reads one LDS buffer while the DMA fills another one
+// BELOW it drains its whole vector-memory queue at every such read (csrc/mixffn.hip: each weight group's latency was exposed).
+// The caller owns the completion: a counted vmcnt wait (pipe_barrier / dma_wait) and a barrier before the data is read.
+// M0 (the wave-uniform LDS destination) is compiler-reserved: saved and restored inside the statement.
+#ifndef CMDA_EMU
+static __device__ __forceinline__ void glds16_asm(const void* gsrc, void* lds_wave_base) {
+  const unsigned dst = __builtin_amdgcn_readfirstlane(
+      (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)lds_wave_base));
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(dst)
+               : "memory");
+}
+#else
+static inline void glds16_asm(const void* gsrc, void* lds_wave_base) { glds16(gsrc, lds_wave_base); }
+#endif
+
 // Barrier of a multi-stage LDS-DMA pipeline: wait until at most N of this wave's DMA loads are still in flight (the older
 // ones -- the stage about to be read -- have landed), then s_barrier WITHOUT the vmcnt(0) drain __syncthreads() implies,
 // so the younger stages stay in flight across the barrier.
@@ -181,6 +201,14 @@ static __device__ __forceinline__ void pipe_barrier() {
 #else
 template <int N>
 static inline void pipe_barrier() { __syncthreads(); }
+#endif
+
+// Workgroup barrier for LDS hand-offs INSIDE an LDS-DMA pipeline: waits for this wave's LDS traffic only (lgkmcnt), not for the
+// vector-memory queue -- __syncthreads() would drain every DMA piece and global store in flight (vmcnt(0)).
+#ifndef CMDA_EMU
+static __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#else
+static inline void lds_barrier() { __syncthreads(); }
 #endif
 
 // Wave-local wait for this wave's own LDS-DMA loads (no barrier): at most N still in flight.
