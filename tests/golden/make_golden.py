@@ -14,7 +14,8 @@ import torch.nn as nn
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import ref_shim  # noqa: E402
-from weights import sample_grad, seeded_fill, seeded_randn  # noqa: E402
+from weights import (DACS_CH, DACS_DIMS, DACS_SEG_SCALE, dacs_batch, sample_grad, seeded_fill,  # noqa: E402
+                     seeded_randn)
 
 torch.set_num_threads(8)
 ns = ref_shim.load_hotpath()
@@ -388,6 +389,148 @@ def segmentor_train():
     save('segmentor_teacher', **{k: v for k, v in out.items() if v is not None})
     with open(os.path.join(HERE, 'segmentor_keys.json'), 'w') as f:
         json.dump(sorted(model.state_dict().keys()), f, indent=0)
+
+
+def dacs_cfg(G_path):
+    """reduced-width FusionEncoderDecoder under the reference's DACS (launcher defaults of SURVEY.md appendix A; DropPath / Dropout
+    rates 0 so that the only draws are the ones recorded below)"""
+    bb = dict(type='MixVisionTransformer', patch_size=4, embed_dims=DACS_DIMS, num_heads=[1, 2, 5, 8], mlp_ratios=[4, 4, 4, 4],
+              qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), depths=[1, 1, 1, 1], sr_ratios=[8, 4, 2, 1],
+              drop_path_rate=0.0)
+    head = dict(type='DAFormerHeadFusion', in_channels=DACS_DIMS, in_index=[0, 1, 2, 3], channels=DACS_CH, dropout_ratio=0.0,
+                num_classes=19, norm_cfg=dict(type='BN', requires_grad=True), align_corners=False,
+                decoder_params=dict(embed_dims=DACS_CH, embed_cfg=dict(type='mlp', act_cfg=None, norm_cfg=None),
+                                    embed_neck_cfg=dict(type='mlp', act_cfg=None, norm_cfg=None),
+                                    fusion_cfg=dict(type='aspp', sep=True, dilations=(1, 6, 12, 18), pool=False,
+                                                    act_cfg=dict(type='ReLU'), norm_cfg=dict(type='BN', requires_grad=True)),
+                                    train_type='cs2dsec_image+events_together', share_decoder=True),
+                loss_decode=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0))
+    model = dict(type='FusionEncoderDecoder', pretrained=None, backbone_image=dict(bb), backbone_events=dict(bb),
+                 fusion_module=dict(type='AttentionAvgFusion', in_channels=DACS_DIMS, drop_path_rate=0.0), decode_head=head,
+                 train_type='cs2dsec_image+events_together', train_cfg=dict(work_dir='/tmp/cmda_golden_dacs'), test_cfg=dict(mode='whole'))
+    return dict(model=model, max_iters=40000, alpha=0.999, pseudo_threshold=0.968, pseudo_weight_ignore_top=0,
+                pseudo_weight_ignore_bottom=0, imnet_feature_dist_lambda=0, imnet_feature_dist_classes=None,
+                imnet_feature_dist_scale_min_ratio=None, mix='class', blur=True, color_jitter_strength=0.2,
+                color_jitter_probability=0.2, debug_img_interval=10 ** 9, print_grad_magnitude=False,
+                train_type='cs2dsec_image+events_together',
+                forward_cfg=dict(loss_weight={'image': 0.5, 'events': 0.5, 'fusion': 0.5, 'img_self_res': 0.25}, gradual_rate=0.0),
+                cyclegan_itrd2en_path=G_path, img_self_res_reg='no', mixed_image_to_mixed_isr=True, random_choice_thres='0.5',
+                shift_type='random', isr_parms=dict(val_range=[0.01, 1.01], _threshold=0.005, _clip_range=0.1, shift_pixel=1),
+                sky_mask=None)
+
+
+def fingerprint(t, n=24):
+    return sample_grad(t, n)
+
+
+@case
+def dacs_step():
+    """the reference's OWN DACS.train_step (mmseg/models/uda/dacs.py:274-315, forward_train :357-860,
+    _init_ema_weights / _update_ema :250-272) for local_iter 0, 1, 2 on one 512 x 512 pair (the mixing code hard-codes width = height
+    = 512, :735), reduced-width model on the CPU, torch AdamW between the iterations; plus _update_ema at it = 1500.
+    kornia is absent: `random.uniform` is patched so that the colour-jitter and blur gates stay closed (values recorded); the class
+    draw (np.random.choice), the events / ISR choice (torch.rand) are seeded and recorded.  Debug plotting (local_iter % interval == 0
+    at iteration 0) is stubbed in the module's namespace."""
+    import random
+    import tempfile
+    nn.Module.cuda = lambda self, *a, **k: self
+    mm = sys.modules['mmseg.models']
+    for k in ('BaseSegmentor', 'BaseSegmentorEvents', 'BaseSegmentorFusion'):
+        setattr(mm, k, getattr(ns.seg_base, k))
+    cg = sys.modules['mmseg.models.cyclegan']
+    cg.define_G, cg.LightNet = ns.cyclegan.define_G, getattr(ns.cyclegan, 'LightNet', None)
+    D = ref_shim.load('mmseg.models.uda.dacs')
+    # the generator checkpoint DACS.__init__ loads (:96-103)
+    G = ns.cyclegan.define_G()
+    seeded_fill(G, 113)
+    gpath = os.path.join(tempfile.mkdtemp(), 'G.pth')
+    torch.save(G.state_dict(), gpath)
+    dacs = D.DACS(**dacs_cfg(gpath))
+    seeded_fill(dacs.model, 111)
+    seeded_fill(dacs.ema_model, 112)      # iteration 0 must overwrite it
+    with torch.no_grad():                 # a peaky classifier: some pixels must clear the 0.968 confidence threshold (:701-705)
+        dacs.model.decode_head.conv_seg.weight.mul_(DACS_SEG_SCALE)
+    dacs.train()
+    # debug plotting off (module namespace, not the source)
+    class _NoPlot:
+        def __getattr__(self, n):
+            if n.startswith('__'):
+                raise AttributeError(n)
+            if n == 'subplots':
+                axs = np.empty((8, 8), dtype=object)
+                for i in range(8):
+                    for j in range(8):
+                        axs[i, j] = _NoPlot()
+                return lambda *a, **k: (_NoPlot(), axs)
+            return _NoPlot()
+
+        def __call__(self, *a, **k):
+            return _NoPlot()
+    D.plt, D.subplotimg = _NoPlot(), (lambda *a, **k: None)
+    opt = torch.optim.AdamW(dacs.model.parameters(), lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01)
+    src, tg = dacs_batch()
+    out = {}
+    captured = {}
+    model = dacs.get_model()
+    orig_ft, orig_ed = model.forward_train, dacs.get_ema_model().encode_decode
+
+    def ft(inputs, gt, seg_weight=None, return_feat=False, cfg=None):
+        if seg_weight is not None:      # the mixed step (:820-860)
+            captured.update(mixed_img=inputs['image'].detach().clone(), mixed_events=inputs['events'].detach().clone(),
+                            mixed_isr=inputs['img_self_res'].detach().clone(), mixed_lbl=gt.detach().clone(),
+                            mixed_weight=seg_weight.detach().clone())
+        return orig_ft(inputs, gt, seg_weight=seg_weight, return_feat=return_feat, cfg=cfg)
+
+    def ed(*a, **k):
+        o = orig_ed(*a, **k)
+        captured['teacher_fusion'] = o['fusion_output'].detach().clone()
+        return o
+    model.forward_train, dacs.get_ema_model().encode_decode = ft, ed
+    uniform = random.uniform
+    gates = [(0.13, 0.31, 0.5), (0.07, 0.44, 0.9), (0.18, 0.12, 0.3)]   # (colour-jitter u <= p = 0.2, blur u <= 0.5, sigma)
+    for it in range(3):
+        seq = iter(gates[it])
+        random.uniform = lambda a, b: next(seq)
+        torch.manual_seed(500 + it)
+        np.random.seed(500 + it)
+        # replay of the class draw get_class_masks will make (dacs_transforms.py:101-112)
+        classes = torch.unique(src['label'])
+        n = classes.shape[0]
+        st = np.random.get_state()
+        chosen = [classes[torch.Tensor(np.random.choice(n, int((n + n % 2) / 2), replace=False)).long()] for _ in range(1)]
+        np.random.set_state(st)
+        batch = dict(source={k: v.clone() for k, v in src.items()}, target={k: v.clone() for k, v in tg.items()})
+        res = dacs.train_step(batch, opt)
+        random.uniform = uniform
+        lv = res['log_vars']
+        prob, plabel = torch.max(torch.softmax(captured['teacher_fusion'], dim=1), dim=1)
+        out[f'it{it}.losses'] = np.array([lv['decode.loss_seg'], lv['decode.acc_seg'], lv['mix.decode.loss_seg'], lv['mix.decode.acc_seg']])
+        out[f'it{it}.choice'] = float(dacs.forward_cfg['isr_events_fusion_choice'])
+        out[f'it{it}.gates'] = np.array(gates[it])
+        out[f'it{it}.classes'] = chosen[0]
+        out[f'it{it}.pseudo_label'] = plabel.to(torch.uint8)
+        out[f'it{it}.pseudo_conf'] = (prob >= 0.968).sum()
+        out[f'it{it}.teacher_fusion_s'] = captured['teacher_fusion'][..., ::16, ::16]
+        out[f'it{it}.mixed_img_s'] = captured['mixed_img'][..., ::4, ::4]
+        out[f'it{it}.mixed_events_s'] = captured['mixed_events'][:, :1, ::4, ::4]
+        out[f'it{it}.mixed_isr_s'] = captured['mixed_isr'][:, :1, ::2, ::2].half()
+        out[f'it{it}.mixed_lbl'] = captured['mixed_lbl'].to(torch.uint8)
+        out[f'it{it}.mixed_weight_s'] = captured['mixed_weight'][..., ::8, ::8]
+        out[f'it{it}.num_samples'] = res['num_samples']
+        for k, p in dacs.model.named_parameters():
+            out[f'it{it}.grad.{k}'] = fingerprint(p.grad)
+            out[f'it{it}.param.{k}'] = fingerprint(p.data)
+        for k, p in dacs.ema_model.named_parameters():
+            out[f'it{it}.ema.{k}'] = fingerprint(p.data)
+        for k, b_ in dacs.model.named_buffers():
+            if 'running' in k and k.startswith('decode_head.fuse_layer_image'):
+                out[f'it{it}.bn.{k}'] = b_.clone()
+        print('iteration', it, lv, 'choice', out[f'it{it}.choice'], 'classes', chosen[0].tolist(), 'conf', int(out[f'it{it}.pseudo_conf']))
+    assert dacs.local_iter == 3
+    dacs._update_ema(1500)
+    for k, p in dacs.ema_model.named_parameters():
+        out[f'ema1500.{k}'] = fingerprint(p.data)
+    save('dacs_step', **out)
 
 
 if __name__ == '__main__':

@@ -454,3 +454,92 @@ def test_dacs_graph_replay_draws_fresh_masks_and_matches_oracle():
             assert (seen[2][k] == 0).any() and (seen[2][k] > 0).any()
     finally:
         rt.taps = None
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The HIP step against the reference's OWN DACS.train_step (tests/golden/dacs_step.npz, written by make_golden.py::dacs_step from
+# mmseg/models/uda/dacs.py:274-315,357-860 run on the CPU for local_iter 0, 1, 2 -- SURVEY 8c items 7 and 11).  The oracle is not
+# involved: the fixture holds what the reference produced.
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['f32', 'x3'])
+def test_dacs_train_step_against_reference_fixture_gpu(mode):
+    """three train_step calls (EMA init / update, source step, teacher + pseudo-labels, ClassMix + ISR of the mixed image, mixed
+    step, FlatAdamW) on one 512 x 512 pair with the reference's recorded draws injected; compared per iteration: losses, pseudo-labels,
+    confident-pixel count, mixed image / events / ISR / label / pseudo-weight, accumulated gradients, EMA teacher, student after the
+    optimizer step, BatchNorm running statistics; then _update_ema(1500)."""
+    from conftest import Target
+    from cmda_amd import _lib
+    from cmda_amd.optim import FlatAdamW
+    from weights import DACS_CH, DACS_DIMS, DACS_SEEDS, DACS_SEG_SCALE, dacs_batch, sample_grad
+    _lib._unbind_for_tests()
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU on this machine')
+    tgt = Target('gpu')
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(HERE, 'golden', 'dacs_step.npz')).items()}
+    rt.set_compute_dtype(torch.float32)
+    rt.set_gemm_x3(mode == 'x3')
+    try:
+        dacs = build_train_model(make_cfg(DACS_DIMS, DACS_CH))
+        seeded_fill(dacs.model, DACS_SEEDS['student'])
+        seeded_fill(dacs.ema_model, DACS_SEEDS['teacher'])
+        seeded_fill(dacs.cyclegan_itrd2en, DACS_SEEDS['generator'])
+        with torch.no_grad():
+            dacs.model.decode_head.conv_seg.weight.mul_(DACS_SEG_SCALE)
+        dacs.to(tgt.device).train()
+        opt = FlatAdamW(dacs.model, lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01)
+        src, tg = dacs_batch()
+        kmax = dacs._kmax()
+        exact = mode == 'f32'
+        for it in range(3):
+            cj, bl, sigma = [float(v) for v in g[f'it{it}.gates']]
+            cls = torch.full((1, kmax), -1, dtype=torch.int64)
+            cls[0, :g[f'it{it}.classes'].numel()] = g[f'it{it}.classes']
+            dacs.inject_draws = dict(choice=float(g[f'it{it}.choice']), color_jitter=cj, blur=bl, sigma=sigma, classes=cls, jitter=None,
+                                     direction=[['leftdown', 'leftup'], ['rightdown', 'rightup']][int(cj * 10) % 2][int(cj * 100) % 2])
+            batch = dict(source={k: tgt.to(v.clone()) for k, v in src.items()}, target={k: tgt.to(v.clone()) for k, v in tg.items()})
+            res = dacs.train_step(batch, opt)
+            torch.cuda.synchronize()
+            lv, mix = res['log_vars'], dacs.last_mix
+            ref_l = g[f'it{it}.losses'].float()
+            got = torch.tensor([float(lv['decode.loss_seg']), float(lv['mix.decode.loss_seg'])])
+            tol_l = (1e-4 if exact else 3e-4) * (1 if it == 0 else 10)
+            assert_close(got, ref_l[[0, 2]], tol_l, name=f'it{it} losses vs reference')
+            accs = torch.tensor([float(lv['decode.acc_seg']), float(lv['mix.decode.acc_seg'])])
+            assert_close(accs, ref_l[[1, 3]], 2e-3, name=f'it{it} accuracies vs reference')
+            agree = (mix['pseudo_label'].cpu().to(torch.uint8) == g[f'it{it}.pseudo_label']).float().mean().item()
+            check_ge(f'it{it} pseudo-label agreement with the reference', agree, 0.999)
+            check_le(f'it{it} confident-pixel count difference', abs(int(mix['pseudo_count']) - int(g[f'it{it}.pseudo_conf'])), 150)
+            assert_close(mix['mixed_img'].cpu()[..., ::4, ::4], g[f'it{it}.mixed_img_s'], 1e-6, name=f'it{it} mixed image')
+            assert_close(mix['mixed_events'].cpu()[:, :1, ::4, ::4], g[f'it{it}.mixed_events_s'], 5e-4, atol=1e-4, name=f'it{it} mixed events')
+            assert_close(mix['mixed_isr'].cpu()[:, :1, ::2, ::2], g[f'it{it}.mixed_isr_s'].float(), 1e-3, name=f'it{it} mixed ISR')
+            same = (mix['mixed_lbl'].cpu().to(torch.uint8) == g[f'it{it}.mixed_lbl']).float().mean().item()
+            check_ge(f'it{it} mixed-label agreement with the reference', same, 0.999)
+            assert_close(mix['pseudo_weight'].cpu()[..., ::8, ::8], g[f'it{it}.mixed_weight_s'], 2e-3, name=f'it{it} mixed pseudo-weight')
+            # gradients (the fixture's fingerprints: strided sample + sum + abs-sum per tensor); AdamW has already consumed them but
+            # leaves them in place.  Bound on the worst tensor, relative to the tensor's own scale.
+            worst, seen = 0.0, 0
+            for k, p in dacs.model.named_parameters():
+                ref_f = g[f'it{it}.grad.{k}']
+                d = (sample_grad(p.grad.cpu(), 24) - ref_f).abs().max().item() / (ref_f.abs().max().item() + 1e-12)
+                worst, seen = max(worst, d), seen + 1
+            assert seen == sum(k.startswith(f'it{it}.grad.') for k in g)
+            check_le(f'it{it} worst gradient fingerprint error vs reference', worst, (2e-2 if exact else 5e-2) * (1 if it == 0 else 2))
+            for k, p in dacs.model.named_parameters():
+                # (AdamW turns the round-off-level gradients of the key half of every kv.bias into +-lr steps of arbitrary sign: up to
+                # 32 elements x 6e-5 per iteration on the fingerprint's sums)
+                assert_close(sample_grad(p.data.cpu(), 24), g[f'it{it}.param.{k}'], 2e-5, atol=8e-4 * (it + 1), name=f'it{it} param {k}')
+            for k, p in dacs.ema_model.named_parameters():
+                assert_close(sample_grad(p.data.cpu(), 24), g[f'it{it}.ema.{k}'], 2e-5, atol=8e-4 * it if it else 1e-6, name=f'it{it} ema {k}')
+            for k, b in dacs.model.named_buffers():
+                if f'it{it}.bn.{k}' in g:
+                    assert_close(b.cpu(), g[f'it{it}.bn.{k}'], 5e-4 if it == 0 else 3e-3, atol=1e-5, name=f'it{it} {k}')
+            print(f'iteration {it}: losses {got.tolist()} vs reference {ref_l[[0, 2]].tolist()}, pseudo-labels {agree:.5f}, worst gradient {worst:.2e}')
+        assert dacs.local_iter == 3
+        dacs._update_ema(1500)
+        torch.cuda.synchronize()
+        for k, p in dacs.ema_model.named_parameters():
+            assert_close(sample_grad(p.data.cpu(), 24), g[f'ema1500.{k}'], 2e-5, atol=2.4e-3, name=f'ema1500 {k}')
+    finally:
+        dacs.inject_draws = None
+        rt.set_gemm_x3(False)
+        rt.set_compute_dtype(torch.float32)

@@ -217,3 +217,93 @@ def test_schedule_and_param_groups():
     assert ouda.param_group_options('model.decode_head.conv_seg.weight', 6e-5, 0.01, keys) == pytest.approx((6e-4, 0.01))
     assert ouda.param_group_options('model.backbone_image.block1.0.norm1.weight', 6e-5, 0.01, keys) == (6e-5, 0.0)
     assert ouda.param_group_options('model.backbone_image.block1.0.attn.q.weight', 6e-5, 0.01, keys) == (6e-5, 0.01)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The step COMPOSITION against the reference's own DACS.train_step (tests/golden/dacs_step.npz written by
+# make_golden.py::dacs_step from mmseg/models/uda/dacs.py:274-315,357-860 and _init_ema_weights / _update_ema :250-272)
+from weights import DACS_CH, DACS_DIMS, DACS_SEEDS, DACS_SEG_SCALE, dacs_batch  # noqa: E402
+
+DACS_FCFG = dict(loss_weight={'image': 0.5, 'events': 0.5, 'fusion': 0.5, 'img_self_res': 0.25}, gradual_rate=0.0)
+DACS_ISR = dict(val_range=[0.01, 1.01], _threshold=0.005, _clip_range=0.1, shift_pixel=1)
+
+
+def dacs_fixture_draws(g, it):
+    """the host decisions the reference made in iteration `it` (recorded in the fixture) as oracle.dacs_iter `draws`"""
+    cj, bl, sigma = [float(v) for v in g[f'it{it}.gates']]
+    return dict(choice=float(g[f'it{it}.choice']), color_jitter=cj, blur=bl, sigma=sigma, classes=[g[f'it{it}.classes']], jitter=None)
+
+
+def dacs_fixture_models():
+    from oracle import dacs_iter  # noqa: F401
+    def net():
+        return oseg.FusionEncoderDecoder(backbone_image=omit.MixVisionTransformer(embed_dims=DACS_DIMS, depths=[1, 1, 1, 1], drop_path_rate=0.0),
+                                         backbone_events=omit.MixVisionTransformer(embed_dims=DACS_DIMS, depths=[1, 1, 1, 1], drop_path_rate=0.0),
+                                         fusion_module=ofu.AttentionAvgFusion(in_channels=DACS_DIMS, drop_path_rate=0.0),
+                                         decode_head=ohd.DAFormerHeadFusion(in_channels=DACS_DIMS, channels=DACS_CH, embed_dims=DACS_CH,
+                                                                            dropout_ratio=0.0, share_decoder=True))
+    student, teacher, G = net(), net(), ocg.ResnetGenerator().eval()
+    seeded_fill(student, DACS_SEEDS['student']).train()
+    seeded_fill(teacher, DACS_SEEDS['teacher']).train()
+    seeded_fill(G, DACS_SEEDS['generator'])
+    with torch.no_grad():
+        student.decode_head.conv_seg.weight.mul_(DACS_SEG_SCALE)
+    return student, teacher, G
+
+
+def check_dacs_fixture_iteration(g, it, o, named_params, named_ema, named_buffers, tol=2e-4, grad_tol=2e-3, n=24):
+    """one iteration's observables against the fixture: o = dict with the oracle.dacs_iter keys"""
+    ref_l = g[f'it{it}.losses']
+    got_l = torch.tensor([float(o['decode.loss_seg']), float(o['decode.acc_seg']), float(o['mix.decode.loss_seg']), float(o['mix.decode.acc_seg'])])
+    assert_close(got_l[[0, 2]], ref_l[[0, 2]].float(), tol, name=f'it{it} losses')
+    assert_close(got_l[[1, 3]], ref_l[[1, 3]].float(), 1e-3, name=f'it{it} accuracies')
+    agree = (o['pseudo_label'].cpu().to(torch.uint8) == g[f'it{it}.pseudo_label']).float().mean().item()
+    assert agree >= 0.9995, f'it{it} pseudo-label agreement {agree}'
+    assert abs(int(o['pseudo_count']) - int(g[f'it{it}.pseudo_conf'])) <= 40, (int(o['pseudo_count']), int(g[f'it{it}.pseudo_conf']))
+    assert_close(o['mixed_img'].cpu()[..., ::4, ::4], g[f'it{it}.mixed_img_s'], 1e-6, name=f'it{it} mixed image')
+    assert_close(o['mixed_events'].cpu()[:, :1, ::4, ::4], g[f'it{it}.mixed_events_s'], tol, atol=1e-5, name=f'it{it} mixed events')
+    assert_close(o['mixed_isr'].cpu()[:, :1, ::2, ::2], g[f'it{it}.mixed_isr_s'].float(), 1e-3, name=f'it{it} mixed ISR')
+    same = (o['mixed_lbl'].cpu().to(torch.uint8) == g[f'it{it}.mixed_lbl']).float().mean().item()
+    assert same >= 0.9995, f'it{it} mixed-label agreement {same}'
+    assert_close(o['mixed_weight'].cpu()[..., ::8, ::8], g[f'it{it}.mixed_weight_s'], 1e-3, name=f'it{it} mixed pseudo-weight')
+    seen = 0
+    for k, p in named_params:
+        assert_close(sample_grad(p.grad, n), g[f'it{it}.grad.{k}'], grad_tol, atol=1e-6, name=f'it{it} grad {k}')
+        seen += 1
+    assert seen == sum(k.startswith(f'it{it}.grad.') for k in g)
+    for k, p in named_ema:
+        assert_close(sample_grad(p.data, n), g[f'it{it}.ema.{k}'], 1e-5, atol=3e-4 if it else 1e-7, name=f'it{it} ema {k}')
+    for k, b in named_buffers:
+        if f'it{it}.bn.{k}' in g:
+            assert_close(b, g[f'it{it}.bn.{k}'], 2e-4 if it == 0 else 2e-3, atol=1e-5, name=f'it{it} {k}')
+
+
+@pytest.mark.slow
+def test_dacs_step_against_reference_train_step():
+    """oracle/dacs_iter.py + torch AdamW, three iterations (local_iter 0, 1, 2) with the reference's recorded draws, against what the
+    reference's own DACS.train_step produced: losses, pseudo-labels, confident-pixel count, mixed image / events / ISR / label /
+    pseudo-weight, accumulated gradients, EMA teacher, student after the optimizer step, BatchNorm running statistics; then
+    _update_ema(1500)"""
+    from oracle import dacs_iter
+    g = gold('dacs_step')
+    student, teacher, G = dacs_fixture_models()
+    opt = torch.optim.AdamW(student.parameters(), lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01)
+    src, tg = dacs_batch()
+    for it in range(3):
+        opt.zero_grad()
+        o = dacs_iter.dacs_iteration(student, teacher, G, {k: v.clone() for k, v in src.items()}, {k: v.clone() for k, v in tg.items()},
+                                     local_iter=it, forward_cfg=DACS_FCFG, isr_parms=DACS_ISR, shift_type='random',
+                                     draws=dacs_fixture_draws(g, it))
+        assert o['use_events'] == (float(g[f'it{it}.choice']) > 0.5)
+        # iteration 0 is compared at fp32 round-off; behind the first optimizer step the two runs differ by AdamW's +-lr noise on the
+        # zero-gradient parameters, which moves a handful of pseudo-labels and with them the pixel-summed gradients
+        check_dacs_fixture_iteration(g, it, o, list(student.named_parameters()), list(teacher.named_parameters()),
+                                     list(student.named_buffers()), grad_tol=2e-3 if it == 0 else 1.5e-2)
+        opt.step()
+        for k, p in student.named_parameters():
+            # (AdamW turns a gradient that is zero up to round-off -- the key half of kv.bias cannot move the softmax -- into +-lr steps of
+            # arbitrary sign: the absolute term is a few lr = 6e-5 on the fingerprint's sums)
+            assert_close(sample_grad(p.data, 24), g[f'it{it}.param.{k}'], 1e-5, atol=3e-4, name=f'it{it} param {k}')
+    ouda.update_ema(list(teacher.parameters()), list(student.parameters()), 1500, 0.999)
+    for k, p in teacher.named_parameters():
+        assert_close(sample_grad(p.data, 24), g[f'ema1500.{k}'], 1e-5, atol=3e-4, name=f'ema1500 {k}')
