@@ -94,7 +94,12 @@ class GradAllReducer:
         stream underneath the rest of the backward pass; `finish()` reduces whatever was not started and joins.
     Every rank must issue the same ranges in the same order (it does: the schedule is a function of the model only)."""
 
-    def __init__(self, flat_grad, bucket_elems=32 * 1024 * 1024, wire_dtype=torch.float32, group=None, force=False):
+    def __init__(self, flat_grad, bucket_elems=32 * 1024 * 1024, wire_dtype=torch.float32, group=None, force=False, exchange='auto'):
+        """exchange: 'auto' = reduce-scatter + all-gather on RCCL, all-reduce elsewhere; 'rs_ag' = the reduce-scatter + all-gather
+        arithmetic on ANY backend (padding to per * world, mean on the owned shard, wire format, gather, copy-back): where the
+        backend has no reduce_scatter_tensor (gloo: the CPU tests run this path at world 2 and 4) the collective itself is an
+        all-reduce of the padded bucket of which the rank keeps its own shard; 'all_reduce' = never split."""
+        assert exchange in ('auto', 'rs_ag', 'all_reduce')
         self.flat = flat_grad
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -108,7 +113,9 @@ class GradAllReducer:
         if wire_dtype != flat_grad.dtype:
             self._wire = torch.empty(min(n, bucket_elems), dtype=wire_dtype, device=flat_grad.device)
         # reduce-scatter + all-gather where the backend has them (RCCL); gloo (the CPU tests) keeps all_reduce
-        self._rs_ag = bool(self.active and flat_grad.is_cuda and dist.get_backend(group) == 'nccl')
+        native = bool(self.active and flat_grad.is_cuda and dist.get_backend(group) == 'nccl')
+        self._rs_ag = bool(self.active and exchange != 'all_reduce' and (native or exchange == 'rs_ag'))
+        self._native_rs = native
         if self._rs_ag:
             cap = min(n, bucket_elems) + self.world
             self._wire_rs = torch.empty(cap, dtype=wire_dtype, device=flat_grad.device)
@@ -131,9 +138,9 @@ class GradAllReducer:
                 if per * self.world > n:
                     w[n:].zero_()
                 shard = self._shard[:per]
-                dist.reduce_scatter_tensor(shard, w, group=self.group)
+                self._reduce_scatter(shard, w, per)
                 shard.mul_(inv)
-                dist.all_gather_into_tensor(w, shard, group=self.group)
+                self._all_gather(w, shard, per)
                 seg.copy_(w[:n])
             elif self._wire is not None:
                 w = self._wire[:e - s]
@@ -144,6 +151,29 @@ class GradAllReducer:
             else:
                 dist.all_reduce(seg, group=self.group)
                 seg.mul_(inv)
+
+    def _reduce_scatter(self, shard, w, per):
+        """shard <- sum over ranks of w[rank * per : (rank + 1) * per]"""
+        if self._native_rs:
+            dist.reduce_scatter_tensor(shard, w, group=self.group)
+            return
+        # stand-in for backends without the collective: all-reduce the padded bucket, keep the owned shard.  gloo has no bf16 sum:
+        # a narrower wire format is summed in fp32 and rounded once, like RCCL's fp32-accumulating reduction.
+        r = dist.get_rank(self.group)
+        t = w.float() if w.dtype != torch.float32 else w.clone()
+        dist.all_reduce(t, group=self.group)
+        shard.copy_(t[r * per:(r + 1) * per])
+
+    def _all_gather(self, w, shard, per):
+        """w[r * per : (r + 1) * per] <- rank r's shard, for every r"""
+        if self._native_rs:
+            dist.all_gather_into_tensor(w, shard, group=self.group)
+            return
+        parts = [torch.empty(per, dtype=torch.float32 if shard.dtype != torch.float32 else shard.dtype, device=shard.device)
+                 for _ in range(self.world)]
+        dist.all_gather(parts, shard.float() if shard.dtype != torch.float32 else shard, group=self.group)
+        for i, t in enumerate(parts):
+            w[i * per:(i + 1) * per].copy_(t)
 
     def start_range(self, lo, hi):
         """Issue the mean all-reduce of flat[lo:hi] now (its gradients are final); returns immediately."""

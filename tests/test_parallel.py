@@ -66,6 +66,45 @@ def test_grad_allreduce_world2(wire):
         assert all(out[r] for r in range(world))
 
 
+def _rs_ag_worker(rank, world, port, wire, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    tol = 1e-6 if wire == torch.float32 else 2e-2
+    ok = True
+    # bucket sizes that do not divide the buffer, buckets that do not divide by the world size (padding to per * world), a last
+    # bucket shorter than the world size
+    for n, bucket in ((100003, 30001), (4099, 1025), (10, 7), (world * 512 + 1, world * 256)):
+        torch.manual_seed(1000 * n + rank)
+        flat = torch.randn(n)
+        mine = flat.clone()
+        red = GradAllReducer(flat, bucket_elems=bucket, wire_dtype=wire, exchange='rs_ag')
+        assert red._rs_ag and not red._native_rs
+        red.start_range(n // 3, n // 2 + 1)     # staged: a slice issued early, the rest in finish()
+        red.finish()
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        ref = sum(gathered) / world
+        ok = ok and torch.allclose(flat, ref, rtol=tol, atol=tol)
+        if wire == torch.float32:   # the same numbers as the all-reduce path, up to the order of the two-term sums
+            flat_b = mine.clone()
+            GradAllReducer(flat_b, bucket_elems=bucket, wire_dtype=wire, exchange='all_reduce').all_reduce_mean()
+            ok = ok and torch.allclose(flat, flat_b, rtol=1e-6, atol=1e-7)
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 4])
+@pytest.mark.parametrize('wire', [torch.float32, torch.bfloat16])
+def test_grad_exchange_reduce_scatter_all_gather_path(world, wire):
+    """GradAllReducer's reduce-scatter + all-gather arithmetic (the branch RCCL takes: padding of a bucket to per * world, mean on the
+    owned shard, bf16 wire, all-gather, copy-back) with world > 1 on the CPU -- gloo has no reduce_scatter_tensor, so the collective
+    is the stand-in of `_reduce_scatter`; everything around it is the production code (mmseg/core/ddp_wrapper.py:70-89's role)"""
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_rs_ag_worker, args=(world, _free_port(), wire, out), nprocs=world, join=True)
+        assert all(out[r] for r in range(world))
+
+
 def test_shard_range():
     assert [shard_range(16, r, 8) for r in range(8)] == [(2 * r, 2 * r + 2) for r in range(8)]
 
@@ -261,7 +300,7 @@ def test_dacs_final_pass_hook_inside_segmented_graph():
                 assert torch.equal(snap, opt.flat_g[lo:hi]), f'iteration {it}, {key[0]}: changed after being reported'
 
 
-def _dacs_worker(rank, world, port, out):
+def _dacs_worker(rank, world, port, out, exchange='auto'):
     """one data-parallel rank of the DACS step on the CPU emulator: own batch, rank-local BatchNorm / ClassMix / pseudo-weight,
     gradients exchanged through GradAllReducer with the final-pass staging (decode head + both encoders start their slices from
     DACS.final_pass_grad_hook inside the LAST backward pass, the rest in finish())"""
@@ -302,7 +341,9 @@ def _dacs_worker(rank, world, port, out):
     seeded_fill(ref, 7).train()
     seeded_fill(ema, 8).train()
     # --- the data-parallel step
-    reducer = GradAllReducer(opt.flat_g, bucket_elems=1 << 20)
+    # exchange='rs_ag': the reduce-scatter + all-gather branch RCCL takes; a bucket size that does not divide the slices (padding)
+    reducer = GradAllReducer(opt.flat_g, bucket_elems=(1 << 20) if exchange == 'auto' else 300007, exchange=exchange)
+    assert reducer._rs_ag == (exchange == 'rs_ag')
     student = dacs.model
     ranges = {('decode_head', id(student.decode_head)): opt.ranges_of(student, ['decode_head.'], min_elems=0)}
     for name in ('backbone_image', 'backbone_events'):
@@ -344,13 +385,15 @@ def _dacs_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_dacs_data_parallel_world2_matches_mean_of_oracle_steps():
+@pytest.mark.parametrize('exchange', ['auto', 'rs_ag'])
+def test_dacs_data_parallel_world2_matches_mean_of_oracle_steps(exchange):
     """global batch 2 over 2 ranks == 2 independent reference-style steps whose gradients are averaged (BatchNorm
-    statistics, ClassMix class draws and the pseudo-weight stay rank-local)."""
+    statistics, ClassMix class draws and the pseudo-weight stay rank-local).  'rs_ag': the same step with the gradients exchanged
+    through the reduce-scatter + all-gather branch (parallel.py `_reduce`), the one the RCCL backend takes."""
     world = 2
     with mp.Manager() as mgr:
         out = mgr.dict()
-        mp.spawn(_dacs_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        mp.spawn(_dacs_worker, args=(world, _free_port(), out, exchange), nprocs=world, join=True)
         for r in range(world):
             assert out[r]['worst'] < 5e-2, out[r]
             assert out[r]['staged'] >= 9 and out[r]['staged_elems'] > 0.5 * out[r]['total'], out[r]   # most bytes start inside the last pass
