@@ -141,3 +141,18 @@ def assert_close(got, ref, rtol, atol=0.0, name='', outlier_frac=0.0, outlier_rt
     scale = ref.abs().max().item() if ref.numel() else 0.0
     _record(name, err, atol + rtol * max(scale, 1e-30), 'le')
     assert err <= atol + rtol * max(scale, 1e-30), f'{name}: max err {err:.3e} vs scale {scale:.3e} (rtol {rtol}, atol {atol})'
+
+
+def assert_close_fingerprint(got, ref, rtol, atol=0.0, name='', outlier_frac=0.0, outlier_rtol=0.05):
+    """weights.sample_grad fingerprints (strided sample of a tensor + its sum + its abs-sum): the SAMPLE is compared relative to the
+    largest sampled element, the two sums relative to the abs-sum (the scale of a sum's rounding error).  Comparing the whole vector
+    in one max-norm, as rounds 1-4 did, let the abs-sum -- orders of magnitude above any element -- set the tolerance of the
+    elements (headrooms of 500-2000x in profiles/r04_test_margins)."""
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape and got.numel() >= 3, f'{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}'
+    assert_close(got[:-2], ref[:-2], rtol, atol=atol, name=name + ' [sample]', outlier_frac=outlier_frac, outlier_rtol=outlier_rtol)
+    scale = max(ref[-1].abs().item(), 1e-30)
+    err = (got[-2:] - ref[-2:]).abs().max().item()
+    _record(name + ' [sums]', err, atol * got.numel() + rtol * scale, 'le')
+    assert err <= atol * got.numel() + rtol * scale, f'{name} [sums]: err {err:.3e} vs abs-sum {scale:.3e} (rtol {rtol})'

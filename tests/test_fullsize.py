@@ -155,7 +155,8 @@ def test_mit_b5_daformer_512_vs_oracle(mode):
           f'{losses["decode.loss_seg"].item():.6f} vs {rl["decode.loss_seg"].item():.6f}, worst grad rel err {worst:.3e}, '
           f'{within:.1%} of gradient tensors within 2e-2')
     if mode == 'f32':
-        check_le('fp32 logits rel err', e_log, 1e-3, strict=True)
+        check_le('fp32 logits rel err', e_log, 1e-3, strict=True)          # the north star's tolerance
+        check_le('fp32 logits rel err [regression gate]', e_log, 1e-5)   # 2.6e-6 measured (profiles/r04_test_margins.txt)
         assert_close(losses['decode.loss_seg'], rl['decode.loss_seg'], 1e-4, name='loss')
         # gradients: every tensor within 2e-2 once the channels whose BatchNorm + ReLU pre-activation sits within round-off of zero
         # (a flipped mask bit moves that channel's gradient) are left out of THEIR layer's comparison -- no blanket 0.2 bound
@@ -166,9 +167,9 @@ def test_mit_b5_daformer_512_vs_oracle(mode):
         check_le('worst masked gradient rel err', me[0][0], 2e-2, strict=True)
         assert nsus < 0.25 * sum(m.num_features for m in ref.decode_head.modules() if isinstance(m, nn.BatchNorm2d)), 'probe masks too much'
     else:
-        check_le('bf16 logits rel err', e_log, 6e-2, strict=True)
+        check_le('bf16 logits rel err', e_log, 3e-2, strict=True)          # (1.0e-2 measured, three boxes)
         check_ge('bf16 argmax agreement', agree, 0.96, strict=True)   # (0.9875-0.9884 measured)
-        assert_close(losses['decode.loss_seg'], rl['decode.loss_seg'], 2e-2, name='loss')
+        assert_close(losses['decode.loss_seg'], rl['decode.loss_seg'], 2e-3, name='loss')   # (1e-5 measured)
     rt.set_compute_dtype(torch.float32)
 
 
@@ -208,13 +209,14 @@ def test_fusion_student_512_vs_oracle(mode):
     print(f'[{mode}] 512x512 fusion student: logits rel err {errs}, loss {losses["decode.loss_seg"].item():.6f} vs '
           f'{rl["decode.loss_seg"].item():.6f}, worst grad rel err {worst:.3e}, {within:.1%} of gradient tensors within 2e-2')
     if mode == 'f32':
-        check_le('fp32 logits rel err (worst branch)', max(errs.values()), 1e-3, strict=True)
+        check_le('fp32 logits rel err (worst branch)', max(errs.values()), 1e-3, strict=True)   # the north star's tolerance
+        check_le('fp32 logits rel err (worst branch) [regression gate]', max(errs.values()), 1e-5)   # 2.9e-6 measured
         assert_close(losses['decode.loss_seg'], rl['decode.loss_seg'], 1e-4, name='loss')
         check_ge('fraction of gradient tensors within 2e-2', within, 0.97, strict=True)
-        check_le('worst gradient rel err', worst, 0.2, strict=True)
+        check_le('worst gradient rel err', worst, 1e-2, strict=True)    # (3.2e-3 measured, three boxes)
     else:
-        check_le('bf16 logits rel err (worst branch)', max(errs.values()), 6e-2, strict=True)
-        assert_close(losses['decode.loss_seg'], rl['decode.loss_seg'], 2e-2, name='loss')
+        check_le('bf16 logits rel err (worst branch)', max(errs.values()), 3.5e-2, strict=True)   # (1.4e-2 measured)
+        assert_close(losses['decode.loss_seg'], rl['decode.loss_seg'], 2e-3, name='loss')
     rt.set_compute_dtype(torch.float32)
 
 
@@ -291,18 +293,18 @@ def test_stochastic_paths_with_injected_masks(tgt, mode):
     rl, rlog = ref.forward_train(img, gt)
     rl['decode.loss_seg'].backward()
     assert not pool, 'the oracle did not consume every injected mask'
-    tol = 1e-3 if mode == 'f32' else 6e-2
+    tol = 1e-5 if mode == 'f32' else 5e-2   # (fp32 2.8e-6, bf16 1.9e-2 of the logit range measured)
     assert_close(logits, rlog, tol, name='logits with injected DropPath / Dropout2d masks')
-    assert_close(losses['decode.loss_seg'], rl['decode.loss_seg'], 1e-4 if mode == 'f32' else 2e-2, name='loss')
+    assert_close(losses['decode.loss_seg'], rl['decode.loss_seg'], 1e-4 if mode == 'f32' else 2e-3, name='loss')
     errs = grad_errors(model, ref)
     med, p90, worst = errs[len(errs) // 2], errs[int(len(errs) * 0.9)], errs[-1]
     print(f'[{mode}] injected masks: gradient rel err median {med:.2e}, 90th percentile {p90:.2e}, worst {worst:.2e}')
     if mode == 'f32':
-        check_le('gradient rel err 90th pct', p90, 2e-2, strict=True)
-        check_le('gradient rel err worst', worst, 0.2, strict=True)
+        check_le('gradient rel err 90th pct', p90, 1e-3, strict=True)    # (3.0e-4 measured)
+        check_le('gradient rel err worst', worst, 1.5e-2, strict=True)    # (4.4e-3 measured)
     else:   # bf16 activations: bounded in the bulk (tensors with tiny gradients carry large relative max-norm errors)
-        check_le('bf16 gradient rel err median', med, 0.2, strict=True)   # (6.4e-2 measured)
-        check_le('bf16 gradient rel err 90th pct', p90, 0.5, strict=True)
+        check_le('bf16 gradient rel err median', med, 0.165, strict=True)   # (6.6e-2 worst of three boxes: 2.5x)
+        check_le('bf16 gradient rel err 90th pct', p90, 0.26, strict=True)   # (0.101)
     rt.set_compute_dtype(torch.float32)
 
 
@@ -354,7 +356,7 @@ def test_fusion_simple_test_440x640_vs_oracle():
     want_pred = torch.softmax(want, 1).argmax(1)[0].numpy()
     gt = labels(1, 640, 7)[0, 0, :440].numpy()
     m_ref = metrics.mean_iou([torch.from_numpy(want_pred)], [torch.from_numpy(gt)], 19, 255)['mIoU'].item()
-    for dt, tol, agree_min, miou_tol in ((torch.float32, 1e-3, 0.9995, 1e-3), (torch.bfloat16, 6e-2, 0.97, 2e-2)):
+    for dt, tol, agree_min, miou_tol in ((torch.float32, 1e-3, 0.9995, 1e-3), (torch.bfloat16, 2e-2, 0.985, 1e-3)):   # bf16: 6.7e-3 / 0.9942 / 4.7e-5 measured (three boxes) -- mIoU inside the north star's 1e-3
         rt.set_compute_dtype(dt)
         try:
             got = model.encode_decode(tgt.to(img), tgt.to(ev), test_cfg={'output_type': 'fusion'}).float().cpu()

@@ -40,10 +40,11 @@ def test_permute_cast_colsum_axpby(tgt, dt, tol):
     wd = tgt.to(w)
     out = torch.empty(6, 3, 3, 5, dtype=dt, device=tgt.device)
     ops.permute4(wd, out, (6, 5, 3, 3), (0, 2, 3, 1))
-    assert_close(out, w.permute(0, 2, 3, 1), 8e-3 if dt == torch.bfloat16 else 0, name='permute')
+    # (bf16: ONE round-to-nearest-even of the fp32 value, i.e. at most 2^-8 of the largest element -- a bound, not a margin)
+    assert_close(out, w.permute(0, 2, 3, 1), 4e-3 if dt == torch.bfloat16 else 0, name='permute')
     out = torch.empty(5, 3, 3, 6, dtype=dt, device=tgt.device)
     ops.permute4(wd, out, (6, 5, 3, 3), (1, 2, 3, 0), flipmask=0b1100)
-    assert_close(out, w.flip(2, 3).permute(1, 2, 3, 0), 8e-3 if dt == torch.bfloat16 else 0, name='permute+flip')
+    assert_close(out, w.flip(2, 3).permute(1, 2, 3, 0), 4e-3 if dt == torch.bfloat16 else 0, name='permute+flip')
     g = torch.randn(6, 3, 3, 5)
     acc = tgt.to(w.clone())
     ops.permute4(tgt.to(g), acc, (6, 3, 3, 5), (0, 3, 1, 2), accumulate=True)
@@ -231,7 +232,7 @@ def test_classmix_ema_adamw(tgt):
         opt.step()
         ops.adamw_step(pd, tgt.to(gr), m, v, 1e-2, 0.9, 0.999, 1e-8, 0.01, step, p_bf16=pb)
     assert_close(pd, prm.data, 2e-6, name='adamw')
-    assert_close(pb, prm.data, 8e-3, name='adamw bf16 copy')
+    assert_close(pb, prm.data, 4e-3, name='adamw bf16 copy')   # one rounding of the updated fp32 master: <= 2^-8 of the largest element
 
 
 def _gold(name):

@@ -14,7 +14,7 @@ from weights import sample_grad, seeded_fill, seeded_randn  # noqa: E402
 
 import cmda_amd.runtime as rt  # noqa: E402
 from cmda_amd import backbones as bb  # noqa: E402
-from conftest import assert_close, assert_close_robust, check_ge, check_le  # noqa: E402
+from conftest import assert_close, assert_close_fingerprint, assert_close_robust, check_ge, check_le  # noqa: E402
 
 
 def gold(name):
@@ -27,7 +27,7 @@ def check_grads(module, g, rtol, n=2048, atol=1e-6, outlier_frac=0.0):
         key = 'grad.' + name
         if key in g:
             assert p.grad is not None, name
-            assert_close(sample_grad(p.grad, n), g[key], rtol, atol=atol, name=key, outlier_frac=outlier_frac)
+            assert_close_fingerprint(sample_grad(p.grad, n), g[key], rtol, atol=atol, name=key, outlier_frac=outlier_frac)
             seen += 1
     assert seen == sum(k.startswith('grad.') for k in g)
 
@@ -56,9 +56,11 @@ def test_block_golden(tgt, mode, tag):
     y = m(x, H, W)
     y.backward(tgt.to(seeded_randn(y.shape, 11, 'dy')))
     f32 = mode == torch.float32
-    assert_close(y, g['y'], 1e-4 if f32 else 3e-2, name='y')
-    assert_close(x.grad, g['dx'], 1e-4 if f32 else 4e-2, name='dx')
-    check_grads(m, g, 2e-4 if f32 else 6e-2, atol=1e-6 if f32 else 1e-3)
+    # bf16 bounds = 2.5x the worst value of the audited GPU runs (gpurun r05modules: y 4.0e-2 of 0.17 -> 7.5e-3 relative, dx 5.7e-2
+    # of 0.31, gradient samples within 1.2e-2 of their largest element)
+    assert_close(y, g['y'], 1e-4 if f32 else 2e-2, name='y')
+    assert_close(x.grad, g['dx'], 1e-4 if f32 else 2.5e-2, name='dx')
+    check_grads(m, g, 2e-4 if f32 else 3e-2, atol=1e-6 if f32 else 1e-3)
 
 
 @pytest.mark.parametrize('mode', [torch.float32], indirect=True)
@@ -115,7 +117,7 @@ def test_head_train_golden(tgt, mode):
         c = dfs[i].shape[1]
         ref = g[f'dfeat{i}'].permute(0, 2, 3, 1).reshape(-1, c)
         assert_close(dfs[i], ref, 3e-4 if f32 else 0.4, atol=1e-8 if f32 else 2e-6, name=f'dfeat{i}', outlier_frac=1e-2 if f32 else 0.0)  # bf16: 3 train-mode BNs amplify rounding (12.7 % of range measured)
-    check_grads(head, g, 5e-4 if f32 else 0.25, atol=1e-6 if f32 else 2e-3, outlier_frac=1e-2 if f32 else 0.0)
+    check_grads(head, g, 5e-4 if f32 else 0.1, atol=1e-6 if f32 else 2e-3, outlier_frac=1e-2 if f32 else 0.0)   # (bf16: worst sample 3.5e-2 of its tensor's largest element, gpurun r05modules)
     if f32:
         for k, v in head.state_dict().items():
             if 'running' in k:

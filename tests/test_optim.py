@@ -32,7 +32,9 @@ def test_flat_adamw_matches_torch(tgt):
         opt.step()
         topt.step()
     for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
-        assert_close(p.data, q.data, 5e-6, name=n)
+        # three fused steps against torch.optim.AdamW: fp32 round-off of a handful of operations per element (1e-6 of the tensor's
+        # largest element measured on the MI355X; the absolute term covers a near-zero bias whose whole range is 3e-3)
+        assert_close(p.data, q.data, 2e-6, atol=5e-9, name=n)
 
 
 def test_schedule_matches_oracle():
