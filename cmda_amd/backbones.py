@@ -233,6 +233,7 @@ class MixVisionTransformer(nn.Module):
             out.append((H, W))
         return out
 
+    @ops.sited('mit')
     def fwd(self, img, save=True, out_feats=None):
         """img: NCHW fp32 [B,3,H,W] (the reference's input layout), or a LIST of such tensors run as ONE batch (the event
         encoder sees the events and the ISR of a sample with the same weights, encoder_decoder.py:703-712: one pass over 2B
@@ -270,6 +271,7 @@ class MixVisionTransformer(nn.Module):
             saved.append((sv_pe, sv_blocks, (xin, m, r), H, W))
         return feats, (saved, B) if save else None
 
+    @ops.sited('mit')
     def bwd(self, saved_all, dfeats):
         """dfeats: list of 4 gradients [B*N_s, C_s] (compute dtype; None = zero).  Accumulates parameter gradients."""
         saved, B = saved_all

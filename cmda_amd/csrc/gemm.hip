@@ -87,7 +87,7 @@ int launch_dtype(GemmParams& p, void* stream) {
       tile = cost0 <= cost1 && cost0 <= cost2 ? 0 : cost1 <= cost2 ? 1 : 2;
     }
   }
-  if ((p.tile_hint & 15) >= 1 && (p.tile_hint & 15) <= 5 && p.tile_hint > 0) tile = (p.tile_hint & 15) - 1;  // caller's explicit tile choice (tuning sweeps, tests)
+  if ((p.tile_hint & 15) >= 1 && (p.tile_hint & 15) <= 4 && p.tile_hint > 0) tile = (p.tile_hint & 15) - 1;  // caller's explicit tile choice (tuning sweeps, tests)
   if constexpr (sizeof(T) == 2) {
     const bool no_glds = p.tile_hint < 0;  // caller asks for the register-staged kernel (tuning sweeps)
     // LDS-DMA path: every operand mode with aligned 16-byte chunks (reflection padding and zero-inserted inputs included); operands
@@ -117,10 +117,6 @@ int launch_dtype(GemmParams& p, void* stream) {
       if (tile == 3 && aks && bks && !ac && p.atomic && p.out_f32 && !(p.tile_hint > 0 && (p.tile_hint & 512)))
         return cmda_gemm_wg_(p, stream);   // weight-gradient form: gemm_wg.hip
       if (tile == 3) return cmda_gemm_glds_t3_(p, stream);
-      if (tile == 4) {   // 64 x 320 row panel: plain K-contiguous operands only (other modes fall back to the 64 x 64 tile)
-        if (!aks && !bks && !ac && !bc && p.A.conv == 0 && p.B.conv == 0) return cmda_gemm_glds_t4_(p, stream);
-        tile = 2;
-      }
       if (tile == 0) return cmda_gemm_glds_t0_(p, stream);
       // the encoders' Linear layers / data gradients on the two small tiles: the lean instance (gemm_lean.hip), in the 4-stage latency
       // configuration where launch_glds would choose it (>= 12 k-tiles on a grid that is resident at once)
@@ -157,38 +153,12 @@ extern "C" int cmda_gemm(const cmda_gemm_params_t* pp, void* stream) {
   return CMDA_ERR_DTYPE;
 }
 
-// Two independent GEMMs in ONE launch (64 x 64 tiles): both must be bf16 LDS-DMA problems of the same operand orientation with plain /
-// patch-view operands, no split-K, no batch; every epilogue of cmda_gemm is available per problem.  Anything else: two cmda_gemm calls.
-extern "C" int cmda_gemm_pair(const cmda_gemm_params_t* a, const cmda_gemm_params_t* b, void* stream) {
-  if (!a || !b) return CMDA_ERR_SHAPE;
-  auto ok = [](const GemmParams& p) {
-    auto vok = [&](const GemmView& v) {
-      return v.vec_ok && v.conv != 1 && v.R < (1L << 31) && v.Cc < (1L << 31) && (v.conv || (v.ld % 8) == 0) && (v.Cc % 8) == 0 &&
-             (v.conv != 2 || ((v.KW * v.C) % 64 == 0 && v.KH == v.stride && v.KW == v.stride && v.pad == 0 && v.dil == 1 &&
-                              v.H == v.OH * v.stride && v.W == v.OW * v.stride && v.H < 32768 && v.W < 32768));
-    };
-    return p.dtype == CMDA_BF16 && !p.a_kstrided && p.batch == 1 && p.batch2 <= 1 && p.splits <= 1 && !p.atomic && !p.colsum &&
-           p.M > 0 && p.N > 0 && p.K > 0 && vok(p.A) && vok(p.B) &&
-           (p.c_patch_ow == 0 || (!p.res && p.c_patch_kh > 0 && p.c_patch_kwci > 0 && p.N == p.c_patch_kh * p.c_patch_kwci &&
-                                  p.M % p.c_patch_ow == 0 && (p.c_patch_kwci & 3) == 0));
-  };
-  GemmParams p0 = *a, p1 = *b;
-  p0.batch2 = p1.batch2 = 1;
-  p0.splits = p1.splits = 1;
-  if (!ok(p0) || !ok(p1) || (p0.b_kstrided != 0) != (p1.b_kstrided != 0)) {
-    const int rc = cmda_gemm(a, stream);
-    return rc != CMDA_OK ? rc : cmda_gemm(b, stream);
-  }
-  return cmda_gemm_glds_pair_t2_(p0, p1, stream);
-}
-
 #ifdef CMDA_GEMM_TIMING
 // the tuning build is ONE translation unit, so that every kernel stamps the same g_stamps array
 #include "gemm_t0.hip"
 #include "gemm_t1.hip"
 #include "gemm_t2.hip"
 #include "gemm_t3.hip"
-#include "gemm_t4.hip"
 #include "gemm_reg.hip"
 #include "gemm_reg_f32_t0.hip"
 #include "gemm_reg_f32_t1.hip"

@@ -58,8 +58,12 @@ static Plan classify(const GemmParams& p) {
   // (128-wide tiles over the 320-channel dimensions with a half-empty last tile -- 20 % padding for 20 - 28 % fewer operand bytes --
   // measured slower as well: the step 58.0 - 58.1 -> 58.2 - 58.4 ms, gpurun r04pad)
   const int kind = big ? 4 : (p.M % 128 == 0 ? 1 : 0) + (p.N % 128 == 0 ? 2 : 0);
-  typedef DmaSrc<true, 64, false, 4, 0, 64, 1> FK;   // (tile size irrelevant for the eligibility test)
-  const bool fast = FK::mode_ok(p.A, 1) && FK::mode_ok(p.B, 1);
+  // the running-pointer ("fast") bucket: eligibility with the k-tile depth of the kernel that will run it -- kind 4 is
+  // gemm_wg_grouped_kernel's 32-deep k-tile, and a K-strided PATCH view whose rows are exactly one 64-deep k-tile (OW == 64) passes
+  // the 64-deep test while its per-lane `ow` does change between 32-deep tiles (wrong weight gradients, latent)
+  typedef DmaSrc<true, 64, false, 4, 0, 64, 1> FK64;   // (tile size irrelevant for the eligibility test)
+  typedef DmaSrc<true, 64, false, 4, 0, 32, 1> FK32;
+  const bool fast = kind == 4 ? (FK32::mode_ok(p.A, 1) && FK32::mode_ok(p.B, 1)) : (FK64::mode_ok(p.A, 1) && FK64::mode_ok(p.B, 1));
   pl.bucket = kind * 3 + (p.B.conv == 1 ? 2 : fast ? 0 : 1);
   pl.tiles = ((p.M + kTileBM[kind] - 1) / kTileBM[kind]) * ((p.N + kTileBN[kind] - 1) / kTileBN[kind]);
   pl.nkt = (p.K + 63) / 64;

@@ -1128,30 +1128,6 @@ __global__ __launch_bounds__(64 * NW, (GldsCfg<TM, TN, NW, NSV>::MIN_WAVES)) voi
   gemm_glds_body<TM, TN, AKS, BKS, ACONV, BCONV, NW, NSV, FAST>(p, smem, loc - z * ntile, ntile, z, false);
 }
 
-// PAIR launch: two independent problems of the SAME template instance in one grid (blocks [0, nt0) run p0, the rest p1) -- the
-// q projection and the spatial-reduction convolution of a MiT block read the same LayerNorm output (mix_transformer.py:86-92), the
-// data gradients of q and kv are independent too: one dependent launch instead of two in chains that are bound by their launch count.
-template <int TM, int TN, bool AKS, bool BKS, int NW = 4, bool FAST = false>
-__global__ __launch_bounds__(64 * NW, (GldsCfg<TM, TN, NW, 0>::MIN_WAVES)) void gemm_glds_pair_kernel(GemmParams p0, GemmParams p1, int nt0, int nt1) {
-  __shared__ __attribute__((aligned(1024))) char smem[GldsCfg<TM, TN, NW, 0>::LDS_BYTES];
-  if ((int)blockIdx.x < nt0) gemm_glds_body<TM, TN, AKS, BKS, false, false, NW, 0, FAST>(p0, smem, blockIdx.x, nt0, 0, true);
-  else gemm_glds_body<TM, TN, AKS, BKS, false, false, NW, 0, FAST>(p1, smem, blockIdx.x - nt0, nt1, 0, true);
-}
-
-template <int TM, int TN, bool AKS, bool BKS>
-int launch_glds_pair(const GemmParams& p0, const GemmParams& p1, void* stream) {
-  constexpr int BM = 16 * TM * 2, BN = 32 * TN;
-  const long t0 = (long)((p0.M + BM - 1) / BM) * ((p0.N + BN - 1) / BN), t1 = (long)((p1.M + BM - 1) / BM) * ((p1.N + BN - 1) / BN);
-  if (t0 + t1 > 0x7fffffffL) return CMDA_ERR_SHAPE;
-  typedef DmaSrc<AKS, BM, false, 4, 0, 64, 1> FA;
-  typedef DmaSrc<BKS, BN, false, 4, 0, 64, 1> FB;
-  const bool fast = FA::mode_ok(p0.A, 1) && FB::mode_ok(p0.B, 1) && FA::mode_ok(p1.A, 1) && FB::mode_ok(p1.B, 1);
-  const dim3 grid((unsigned)(t0 + t1)), blk(256);
-  if (fast) CMDA_LAUNCH((gemm_glds_pair_kernel<TM, TN, AKS, BKS, 4, true>), grid, blk, 0, stream, p0, p1, (int)t0, (int)t1);
-  else CMDA_LAUNCH((gemm_glds_pair_kernel<TM, TN, AKS, BKS, 4, false>), grid, blk, 0, stream, p0, p1, (int)t0, (int)t1);
-  CMDA_CHECK_LAUNCH();
-}
-
 template <int TM, int TN, int NW, int NSV, bool AKS, bool BKS, bool ACONV, bool BCONV>
 int launch_glds_mode(const GemmParams& p, const dim3& grid, void* stream) {
   constexpr int BM = 16 * TM * (NW / 2), BN = 32 * TN;
@@ -1239,8 +1215,6 @@ int cmda_gemm_glds_t2_(const cmda_gemm_params_t& p, void* stream);        // gem
 int cmda_gemm_glds_t3_(const cmda_gemm_params_t& p, void* stream);        // gemm_t3.hip: 256x256 tile, 8 waves
 bool cmda_gemm_lean_ok_(const cmda_gemm_params_t& p, int tile);           // gemm_lean.hip: lean plain-operand instance (64x64 / 128x64)
 int cmda_gemm_lean_(const cmda_gemm_params_t& p, int tile, int four_stage, void* stream);
-int cmda_gemm_glds_pair_t2_(const cmda_gemm_params_t& p0, const cmda_gemm_params_t& p1, void* stream);  // gemm_t2.hip: 64x64 pair launch
-int cmda_gemm_glds_t4_(const cmda_gemm_params_t& p, void* stream);        // gemm_t4.hip: 64x320 ROW-PANEL tile (full rows of the C = 320 stage)
 int cmda_gemm_grouped_t2_(const cmda_gemm_params_t* tab, const void* blk, int nblocks, int bconv, void* stream);  // gemm_g2.hip: 64x64
 int cmda_gemm_grouped_t0_(const cmda_gemm_params_t* tab, const void* blk, int nblocks, int bconv, void* stream);  // gemm_g0.hip: 128x128
 int cmda_gemm_grouped_t1_(const cmda_gemm_params_t* tab, const void* blk, int nblocks, int bconv, void* stream);  // gemm_g1.hip: 128x64
@@ -1249,7 +1223,9 @@ int cmda_gemm_wg_grouped_(const cmda_gemm_params_t* tab, const void* blk, int nb
 int cmda_gemm_wg_(const cmda_gemm_params_t& p, void* stream);             // gemm_wg.hip: 256x256 weight-gradient kernel (32x32x16 MFMA, atomics)
 int cmda_gemm_pp_(const cmda_gemm_params_t& p, void* stream);             // gemm_pp.hip: 256x256 ping-pong kernel (32x32x16 MFMA)
 int cmda_gemm_reg_(const cmda_gemm_params_t& p, int tile, void* stream);  // gemm_reg.hip: register-staged kernels, dispatch
-int cmda_gemm_x3_(const cmda_gemm_params_t& p, int tile, void* stream);   // gemm_x3.hip: fp32 storage, split-bf16 (bf16 x 3) MFMA
+int cmda_gemm_x3_(const cmda_gemm_params_t& p, int tile, void* stream);
+bool cmda_gemm_x3_lean_ok_(const cmda_gemm_params_t& p);                   // gemm_x3_lean.hip: LDS-DMA split-bf16 kernel, plain operands
+int cmda_gemm_x3_lean_(const cmda_gemm_params_t& p, void* stream);   // gemm_x3.hip: fp32 storage, split-bf16 (bf16 x 3) MFMA
 // gemm_reg_{f32,bf16}_t{0,1,2}.hip: one (dtype, tile) each -- these are the slow units to compile (~50 s apiece)
 int cmda_gemm_reg_f32_t0_(const cmda_gemm_params_t& p, void* stream);
 int cmda_gemm_reg_f32_t1_(const cmda_gemm_params_t& p, void* stream);

@@ -1,0 +1,300 @@
+// gemm_x3_lean.hip -- the LEAN instance of the split-bf16 ("bf16 x 3") GEMM: the encoders' Linear layers and their data gradients in
+// the tolerance-meeting mode (fp32 storage, CMDA_F32X3; q / kv / proj / fc1 / fc2 of mix_transformer.py:31-44,62-66,80-102).
+//
+// Why: profiles/r04_x3_eager_kernel_stats.csv -- 2 265 launches per step of gemm_x3_kernel<2, 2, ...> at 37 - 46 us each (96 ms of
+// the step's 209) for problems the bf16 lean kernel runs in 8 - 10 us.  That kernel is register-staged (global -> VGPR -> split ->
+// LDS) on 32-deep k-tiles with four waves: ten exposed global-load latencies for K = 320.  Here the fp32 tiles come in through the
+// LDS-DMA (32-deep k-tiles, two tiles in flight while a third is consumed), are split ONCE per tile by all 512 threads
+// (x -> hi = bf16(x), lo = bf16(x - hi): one pass over the tile instead of once per fragment and wave) into bf16 hi / lo tiles laid
+// out exactly like the bf16 kernels' LDS images, and the k-loop is gemm_lean_kernel's with three MFMAs per fragment pair
+// (a_lo b_hi + a_hi b_lo + a_hi b_hi, fp32 accumulate: gemm_x3.hip).  The split of tile kt + 1 and the MFMAs of tile kt sit in the
+// same barrier interval (double-buffered hi / lo tiles), so the VALU pass hides under the matrix pipe.
+// Eligibility (host): CMDA_F32X3, plain operands, A K-contiguous, B K-contiguous or K-strided, K % 32 == 0, no batch / split-K /
+// atomic / column-sum / patch-store output; 64 x 64 tiles on eight waves, chosen where the general kernel would run its 64 x 64 or
+// 128 x 64 tile (the small grids of the encoders).
+#include "gemm_kernels.h"
+
+namespace {
+
+struct X3LeanParams {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  const float* res;
+  const float* rowscale;
+  long lda, ldb, ldc, ldres;
+  int M, N, nkt, tiles_n;
+  int ntile, rows_per_scale, act, flags;   // flags: 4 c_vec_ok
+  float alpha, beta;
+};
+
+// 64 x 64 tile on eight waves = 4 (rows of 16) x 2 (columns of 32); 32-deep k-tiles: three fp32 stages of 16 KiB (two in flight while
+// one is split) + two hi / lo sets of 16 KiB = 80 KiB, i.e. TWO workgroups per CU (a lone workgroup per CU left the k-loop waiting
+// on its own DMA: 64-deep tiles with one tile in flight measured 15.0 us for 4096 x 320 x 320 against 16.9 for the general kernel)
+template <bool BKS>
+__global__ __launch_bounds__(512, 2) void gemm_x3_lean_kernel(X3LeanParams q) {
+  constexpr int NW = 8, NT = 512, BM = 64, BN = 64, BK = 32, TN = 2, NSTG = 3;
+  constexpr int F_A = BM * BK, F_B = BN * BK;                 // fp32 elements of a stage (A | B)
+  constexpr int H_A = BM * BK, H_B = BN * BK;                 // bf16 elements of a hi (or lo) tile
+  constexpr int PITCH_C = BN + 4;
+  constexpr size_t FP_BYTES = (size_t)NSTG * (F_A + F_B) * 4;
+  constexpr size_t HL_BYTES = (size_t)2 * 2 * (H_A + H_B) * 2;   // two (hi, lo) tile sets
+  static_assert(FP_BYTES + HL_BYTES <= 81920, "two workgroups per CU");
+  __shared__ __attribute__((aligned(1024))) char smem[FP_BYTES + HL_BYTES];
+  float* const sF = reinterpret_cast<float*>(smem);           // [stage][A | B]
+  bf16_t* const sH = reinterpret_cast<bf16_t*>(smem + FP_BYTES);   // [set][A hi | A lo | B hi | B lo]
+  constexpr int SET = 2 * (H_A + H_B);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1, g = lane >> 4, l15 = lane & 15;
+  const int M = q.M, N = q.N, nkt = q.nkt, tiles_n = q.tiles_n, ntile = q.ntile;
+  int bt = blockIdx.x;
+  {   // XCD-contiguous tile ranges (gemm_lean_kernel)
+    const int qq = ntile >> 3, rr = ntile & 7, xcd = bt & 7, loc = bt >> 3;
+    bt = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + loc;
+  }
+  const int mt = (int)((unsigned)bt / (unsigned)tiles_n), nt = bt - mt * tiles_n;
+  const long m0 = (long)mt * BM, n0 = (long)nt * BN;
+
+  // ---- DMA: an fp32 stage is a LINEAR image of 16-byte positions; thread t owns position t of the A part and position t of the
+  //      B part, for the DMA (a wave instruction = 64 positions) and for the split pass alike.
+  //      K-contiguous operand: line = row, 8 positions (32 k) per line; K-strided B: line = k, 16 positions (64 columns) per line ----
+  const char* curA;
+  const char* curB;
+  int stepA, stepB;
+  const char* zero = reinterpret_cast<const char*>(g_zero16);
+  const int lnA = tid >> 3, chA = tid & 7;
+  {
+    const long r = m0 + lnA;
+    const bool ok = r < M;
+    curA = ok ? reinterpret_cast<const char*>(q.A + r * q.lda + chA * 4) : zero;
+    stepA = ok ? BK * 4 : 0;
+  }
+  const int lnB = BKS ? tid >> 4 : tid >> 3, chB = BKS ? tid & 15 : tid & 7;
+  if constexpr (!BKS) {
+    const long r = n0 + lnB;
+    const bool ok = r < N;
+    curB = ok ? reinterpret_cast<const char*>(q.B + r * q.ldb + chB * 4) : zero;
+    stepB = ok ? BK * 4 : 0;
+  } else {
+    const long c = n0 + chB * 4;
+    const bool ok = c + 4 <= N;
+    curB = ok ? reinterpret_cast<const char*>(q.B + (long)lnB * q.ldb + c) : zero;
+    stepB = ok ? (int)((long)BK * q.ldb * 4) : 0;
+  }
+  auto issue = [&](int stage) {
+    float* st = sF + stage * (F_A + F_B);
+    glds16_asm(curA, reinterpret_cast<char*>(st) + wid * 1024);
+    glds16_asm(curB, reinterpret_cast<char*>(st + F_A) + wid * 1024);
+    curA += stepA;
+    curB += stepB;
+  };
+  // ---- split pass: 16 bytes of fp32 -> 8 bytes of the hi tile + 8 bytes of the lo tile.  bf16 images: K-contiguous [line][32 k]
+  //      (64-byte lines of four 16-byte chunks, slot = chunk ^ ((line >> 2) & 3): lines r and r + 4 start on the same bank);
+  //      K-strided [32 k][64 columns] (128-byte lines, slot = chunk ^ (k & 7): the bf16 kernels' image) ----
+  const int offA = lnA * BK + ((((chA >> 1)) ^ ((lnA >> 2) & 3)) << 3) + ((chA & 1) << 2);
+  const int offB = BKS ? lnB * BN + ((((chB >> 1)) ^ (lnB & 7)) << 3) + ((chB & 1) << 2)
+                       : lnB * BK + ((((chB >> 1)) ^ ((lnB >> 2) & 3)) << 3) + ((chB & 1) << 2);
+  auto split = [&](int stage, int set) {
+    const float* st = sF + stage * (F_A + F_B);
+    bf16_t* ha = sH + set * SET;
+    bf16_t* hb = ha + 2 * H_A;
+    float va[4], vb[4], hi[4], lo[4];
+    ld4(st + tid * 4, va);
+    ld4(st + F_A + tid * 4, vb);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      hi[e] = bf2f(f2bf(va[e]));
+      lo[e] = va[e] - hi[e];
+    }
+    st4(ha + offA, hi);
+    st4(ha + H_A + offA, lo);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      hi[e] = bf2f(f2bf(vb[e]));
+      lo[e] = vb[e] - hi[e];
+    }
+    st4(hb + offB, hi);
+    st4(hb + H_B + offB, lo);
+  };
+#pragma unroll
+  for (int s = 0; s < NSTG; ++s)
+    if (s < nkt) issue(s);
+
+  // epilogue operands requested now (gemm_lean_kernel)
+  constexpr int QPR = BN / 4, RSTEP = NT / QPR, NIT = BM / RSTEP;
+  const int q4 = (tid % QPR) * 4, er0 = tid / QPR;
+  const long en = n0 + q4;
+  const bool ecol = en < N;
+  const bool full = (q.flags & 4) != 0 && en + 4 <= N;
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (q.bias && ecol) {
+    if (full) ld4(q.bias + en, bv);
+    else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (en + e < N) bv[e] = q.bias[en + e];
+    }
+  }
+
+  f32x4 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto mfma_tile = [&](int set) {
+    const bf16_t* aH = sH + set * SET;
+    const bf16_t* aL = aH + H_A;
+    const bf16_t* bH = aH + 2 * H_A;
+    const bf16_t* bL = bH + H_B;
+    u16x8 fah, fal, fbh[TN], fbl[TN];
+    {
+      const int row = wm * 16 + l15;
+      const int off = row * BK + ((g ^ ((row >> 2) & 3)) << 3);
+      fah = *reinterpret_cast<const u16x8*>(&aH[off]);
+      fal = *reinterpret_cast<const u16x8*>(&aL[off]);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int nr = wn * 16 * TN + j * 16;
+      if constexpr (!BKS) {
+        const int row = nr + l15;
+        const int off = row * BK + ((g ^ ((row >> 2) & 3)) << 3);
+        fbh[j] = *reinterpret_cast<const u16x8*>(&bH[off]);
+        fbl[j] = *reinterpret_cast<const u16x8*>(&bL[off]);
+      } else {
+        const int qd = l15 >> 2, pp = l15 & 3;
+        const int k0 = 8 * g + qd, k1 = k0 + 4;
+        const int cidx = (nr >> 3) + (pp >> 1), half = (pp & 1) << 2;
+        const int o0 = k0 * BN + ((cidx ^ (k0 & 7)) << 3) + half, o1 = k1 * BN + ((cidx ^ (k1 & 7)) << 3) + half;
+        const u16x4 h0 = lds_read_tr16(&bH[o0]), h1 = lds_read_tr16(&bH[o1]);
+        const u16x4 l0 = lds_read_tr16(&bL[o0]), l1 = lds_read_tr16(&bL[o1]);
+        fbh[j] = u16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+        fbl[j] = u16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {   // small terms first, then the leading product (gemm_x3.hip)
+      acc[j] = mfma_bf16_16x16x32(fal, fbh[j], acc[j]);
+      acc[j] = mfma_bf16_16x16x32(fah, fbl[j], acc[j]);
+      acc[j] = mfma_bf16_16x16x32(fah, fbh[j], acc[j]);
+    }
+  };
+
+  constexpr int LPT = 2;   // DMA instructions per wave per k-tile
+  // tile 0 has landed (tiles 1 and 2 may stay in flight) -> split into set 0
+  if (nkt > 2) pipe_barrier<2 * LPT>();
+  else if (nkt > 1) pipe_barrier<LPT>();
+  else pipe_barrier<0>();
+  split(0, 0);
+  int stg = 1, set = 0;    // stage of tile kt + 1, hi / lo set of tile kt
+  for (int kt = 0; kt < nkt; ++kt) {
+    // fp32 tile kt + 1 has landed (tile kt + 2 may stay in flight); every wave is done with the stage of tile kt (its split) and
+    // with hi / lo set (kt + 1) & 1 (the MFMAs of tile kt - 1); set kt & 1 is complete
+    if (kt + 2 < nkt) pipe_barrier<LPT>();
+    else pipe_barrier<0>();
+    if (kt + NSTG < nkt) issue(stg == 0 ? NSTG - 1 : stg - 1);   // the stage tile kt was split from
+    if (kt + 1 < nkt) split(stg, set ^ 1);
+    mfma_tile(set);
+    if (++stg == NSTG) stg = 0;
+    set ^= 1;
+  }
+  // residual rows of this thread: requested before the accumulators go through LDS
+  const bool has_res = q.res != nullptr;
+  float rv[NIT][4];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    rv[it][0] = rv[it][1] = rv[it][2] = rv[it][3] = 0.f;
+    const long m = m0 + er0 + it * RSTEP;
+    if (has_res && ecol && m < M) {
+      const long ri = m * q.ldres + en;
+      if (full) ld4(q.res + ri, rv[it]);
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (en + e < N) rv[it][e] = q.res[ri + e];
+      }
+    }
+  }
+  __syncthreads();
+  float* sC = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sC[(wm * 16 + 4 * g + r) * PITCH_C + wn * 16 * TN + j * 16 + l15] = acc[j][r];
+  __syncthreads();
+  if (!ecol) return;
+  const float alpha = q.alpha, beta = q.beta;
+  const bool has_beta = beta != 0.f, has_rs = q.rowscale != nullptr;
+  const int act = q.act;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int row = er0 + it * RSTEP;
+    const long m = m0 + row;
+    if (m >= M) break;
+    const float4 t = *reinterpret_cast<const float4*>(&sC[row * PITCH_C + q4]);
+    float v[4] = {t.x, t.y, t.z, t.w};
+    const long ci = m * q.ldc + en;
+    float ov[4] = {0.f, 0.f, 0.f, 0.f};
+    float rs = 1.f;
+    if (has_rs) rs = q.rowscale[(unsigned)m / (unsigned)q.rows_per_scale];
+    if (has_beta) {
+      if (full) ld4(q.C + ci, ov);
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (en + e < N) ov[e] = q.C[ci + e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float x = alpha * v[e] + bv[e];
+      const float a = act == 0 ? x : act == 1 ? epi_act<1>(x) : act == 2 ? epi_act<2>(x) : epi_act<3>(x);
+      v[e] = a * rs + rv[it][e] + beta * ov[e];
+    }
+    if (full) st4(q.C + ci, v);
+    else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (en + e < N) q.C[ci + e] = v[e];
+    }
+  }
+}
+
+int launch_x3_lean(const GemmParams& p, void* stream) {
+  constexpr int BM = 64, BN = 64;
+  X3LeanParams q;
+  q.A = reinterpret_cast<const float*>(p.A.ptr);
+  q.B = reinterpret_cast<const float*>(p.B.ptr);
+  q.C = reinterpret_cast<float*>(p.C);
+  q.bias = p.bias;
+  q.res = reinterpret_cast<const float*>(p.res);
+  q.rowscale = p.rowscale;
+  q.lda = p.A.ld; q.ldb = p.B.ld; q.ldc = p.ldc; q.ldres = p.ldres;
+  q.M = p.M; q.N = p.N; q.nkt = p.K / 32;
+  q.tiles_n = (p.N + BN - 1) / BN;
+  const long tiles = (long)((p.M + BM - 1) / BM) * q.tiles_n;
+  if (tiles > 0x7fffffffL) return CMDA_ERR_SHAPE;
+  q.ntile = (int)tiles;
+  q.rows_per_scale = p.rows_per_scale > 0 ? p.rows_per_scale : 1;
+  q.act = p.act;
+  q.flags = p.c_vec_ok ? 4 : 0;
+  q.alpha = p.alpha; q.beta = p.beta;
+  const dim3 grid((unsigned)tiles), blk(512);
+  if (p.b_kstrided) CMDA_LAUNCH((gemm_x3_lean_kernel<true>), grid, blk, 0, stream, q);
+  else CMDA_LAUNCH((gemm_x3_lean_kernel<false>), grid, blk, 0, stream, q);
+  CMDA_CHECK_LAUNCH();
+}
+
+}  // namespace
+
+// HOST: does the lean split-bf16 kernel take this problem?
+bool cmda_gemm_x3_lean_ok_(const cmda_gemm_params_t& p) {
+  auto plain = [](const GemmView& v) {
+    return v.conv == 0 && v.vec_ok && (v.ld % 4) == 0 && v.R < (1L << 31) && v.Cc < (1L << 31) && (reinterpret_cast<uintptr_t>(v.ptr) % 16) == 0;
+  };
+  return p.dtype == CMDA_F32X3 && !p.a_kstrided && plain(p.A) && plain(p.B) && (p.K % 32) == 0 && p.K >= 32 && p.batch == 1 && p.batch2 <= 1 &&
+         p.splits <= 1 && !p.atomic && !p.colsum && p.c_perm_ci == 0 && p.c_patch_ow == 0 && p.out_f32 && (p.N % 4) == 0 &&
+         (!p.b_kstrided || 32L * p.B.ld * 4 < (1L << 31)) && !(p.tile_hint > 0 && (p.tile_hint & 8192));   // (tile_hint bit 13: general kernel, tuning A/B)
+}
+
+int cmda_gemm_x3_lean_(const cmda_gemm_params_t& p, void* stream) { return launch_x3_lean(p, stream); }

@@ -90,6 +90,7 @@ class ResnetGenerator(nn.Module):
         """dacs.py:400-404: G(mean_c(img_time_res)) repeated to 3 channels; [B,3,H,W] -> [B,3,H,W]"""
         return self.forward(img_time_res.mean(dim=1, keepdim=True)).repeat(1, 3, 1, 1)
 
+    @ops.sited('generator')
     @torch.no_grad()
     def forward(self, inp):
         """inp fp32 NCHW [B,1,H,W] -> fp32 NCHW [B,1,H,W] (tanh)."""

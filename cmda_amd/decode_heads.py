@@ -321,12 +321,14 @@ class DAFormerHead(_HeadBase):
         super().__init__(input_transform='multiple_select', **kwargs)
         self.embed_layers, self.fuse_layer = self._make_branch()
 
+    @ops.sited('head')
     def fwd(self, feats, B):
         feat, sv_b = self._branch_fwd(self.embed_layers, self.fuse_layer, feats, B)
         H, W = sv_b[2], sv_b[3]
         logits, sv_c = self._cls_fwd(feat, B, H, W)
         return logits, (sv_b, sv_c, H, W)
 
+    @ops.sited('head')
     def bwd(self, saved, dlogits, B):
         sv_b, sv_c, H, W = saved
         dfeat = self._cls_bwd(sv_c, dlogits, B, H, W)
@@ -383,6 +385,7 @@ class DAFormerHeadFusion(_HeadBase):
     def _layers(self, which):
         return getattr(self, f'embed_layers_{which}'), getattr(self, f'fuse_layer_{which}')
 
+    @ops.sited('head')
     def fwd(self, inputs, B):
         """inputs: dict f_image / f_events / f_fusion / f_img_self_res -> list of (NLC tensor, H, W) or None."""
         out, saved = {}, {}
@@ -399,6 +402,7 @@ class DAFormerHeadFusion(_HeadBase):
             saved[key] = (sv_b, sv_c, H, W, which)
         return out, saved
 
+    @ops.sited('head')
     def bwd(self, saved, dlogits, B):
         """dlogits: dict key -> gradient (or None).  Returns dict f_* -> {level: d feat}."""
         dfeats = {}
@@ -423,6 +427,7 @@ class DAFormerHeadFusion(_HeadBase):
     def joint_ok(self):
         return self.share_decoder and isinstance(self.fuse_layer_image, ASPPWrapper)
 
+    @ops.sited('head')
     def fwd_joint(self, joint, names, B, passes=1):
         """joint: list of 4 (J_l [G*P*B*N_l, C_l], H_l, W_l); names: the G branch names in joint-buffer order, 'image' first.
         passes = P > 1: every branch block holds the B samples of P independent forward passes one after the other (the source
@@ -445,6 +450,7 @@ class DAFormerHeadFusion(_HeadBase):
             outs.append(out)
         return (outs[0] if P == 1 else outs), (sv_b, sv_c, H, W, tuple(names), logits, P)
 
+    @ops.sited('head')
     def bwd_joint(self, saved, dlogits_joint, B):
         """dlogits_joint fp32 [G*P*B,h,w,nc] -> {level: d joint features [G*P*B*N_l, C_l]}"""
         sv_b, sv_c, H, W, names, _, P = saved

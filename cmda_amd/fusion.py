@@ -31,6 +31,7 @@ class AttentionAvgFusion(nn.Module):
     def init_weights(self):
         pass  # the reference keeps torch's default initialisation for these blocks (init_cfg=None)
 
+    @ops.sited('fusion')
     def fwd(self, feats_i, feats_e, B, save=True, into=None):
         """into: optional list of 4 pre-allocated tensors the fused maps are written into"""
         outs, saved = [], []
@@ -43,6 +44,7 @@ class AttentionAvgFusion(nn.Module):
             saved.append((si, se, H, W))
         return outs, saved
 
+    @ops.sited('fusion')
     def bwd(self, saved, dfused, B):
         """dfused: list of 4 gradients (or None).  Returns (d image feats, d event feats) as lists."""
         di, de = [], []
@@ -81,6 +83,7 @@ class AttentionFusion(nn.Module):
     def init_weights(self):
         pass
 
+    @ops.sited('fusion')
     def fwd(self, feats_i, feats_e, B, save=True, into=None):
         outs, saved = [], []
         draw_drop_path(self, list(self.basic_block), B, feats_i[0][0].device)
@@ -98,6 +101,7 @@ class AttentionFusion(nn.Module):
             saved.append((sb, sm, H, W))
         return outs, saved
 
+    @ops.sited('fusion')
     def bwd(self, saved, dfused, B):
         di, de = [], []
         for i, (sb, sm, H, W) in enumerate(saved):

@@ -15,21 +15,19 @@ from .ops import conv_view, plain_view
 
 # ------------------------------------------------------------------ Linear
 def linear_fwd(x, weight, bias, M, K, *, act=None, res=None, rowscale=None, rows_per_scale=1, out=None, ldc=None,
-               c_offset=0, out_dtype=None, x_ld=None, x_off=0, hold=False):
-    """y[M,N] = act(x[M,K] @ W[N,K]^T + b) (* rowscale) (+ res).  hold=True: returns (out, handle) without launching (ops.gemm_pair)"""
+               c_offset=0, out_dtype=None, x_ld=None, x_off=0):
+    """y[M,N] = act(x[M,K] @ W[N,K]^T + b) (* rowscale) (+ res)"""
     N = weight.shape[0]
     if out is None:
         out = torch.empty(M, N, dtype=out_dtype or rt.compute_dtype(), device=x.device)
-    h = ops.gemm(plain_view(x, M, K, ld=x_ld, offset=x_off), plain_view(rt.w(weight), N, K), out, M, N, K, dtype=rt.tag(),
-                 bias=bias, act=act, res=res, rowscale=rowscale, rows_per_scale=rows_per_scale, ldc=ldc, c_offset=c_offset, hold=hold,
-                 keep=(x,) if hold else ())
-    return (out, h) if hold else out
+    ops.gemm(plain_view(x, M, K, ld=x_ld, offset=x_off), plain_view(rt.w(weight), N, K), out, M, N, K, dtype=rt.tag(),
+             bias=bias, act=act, res=res, rowscale=rowscale, rows_per_scale=rows_per_scale, ldc=ldc, c_offset=c_offset)
+    return out
 
 
 def linear_bwd(dy, x, weight, bias, M, K, *, need_dx=True, dx_out=None, dx_beta=0.0, dy_ld=None, dy_off=0, x_ld=None,
-               x_off=0, hold=False):
-    """dW += dy^T x, db += colsum(dy), returns dx = dy @ W (optionally accumulated into dx_out).  hold=True: the data-gradient GEMM is
-    not launched -- returns (dx, handle) for ops.gemm_pair (the weight gradient is queued / launched as usual)."""
+               x_off=0):
+    """dW += dy^T x, db += colsum(dy), returns dx = dy @ W (optionally accumulated into dx_out)"""
     N = weight.shape[0]
     dyv_k = plain_view(dy, M, N, ld=dy_ld, offset=dy_off)  # (r = token, c = n)
     xv = plain_view(x, M, K, ld=x_ld, offset=x_off)
@@ -45,9 +43,8 @@ def linear_bwd(dy, x, weight, bias, M, K, *, need_dx=True, dx_out=None, dx_beta=
     if not need_dx:
         return None
     dx = dx_out if dx_out is not None else torch.empty(M, K, dtype=rt.compute_dtype(), device=dy.device)
-    h = ops.gemm(dyv_k, plain_view(rt.w(weight), N, K), dx, M, K, N, b_kstrided=True, dtype=rt.tag(), beta=dx_beta, hold=hold,
-                 keep=(dy,) if hold else ())
-    return (dx, h) if hold else dx
+    ops.gemm(dyv_k, plain_view(rt.w(weight), N, K), dx, M, K, N, b_kstrided=True, dtype=rt.tag(), beta=dx_beta)
+    return dx
 
 
 # ------------------------------------------------------------------ Conv2d as implicit GEMM (NHWC)
@@ -55,19 +52,17 @@ def conv_out_size(H, W, k, stride, pad, dil=1):
     return (H + 2 * pad - dil * (k - 1) - 1) // stride + 1, (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
 
-def conv_fwd(x, weight, bias, B, H, W, stride, pad, dil=1, *, act=None, out=None, reflect=0, ci_pad=0, hold=False):
-    """ci_pad > Ci: x carries ci_pad channels per pixel (zeros past Ci) and the weight copy is padded alike (runtime.wconv).
-    hold=True: returns ((out, OH, OW), handle) without launching (ops.gemm_pair)"""
+def conv_fwd(x, weight, bias, B, H, W, stride, pad, dil=1, *, act=None, out=None, reflect=0, ci_pad=0):
+    """ci_pad > Ci: x carries ci_pad channels per pixel (zeros past Ci) and the weight copy is padded alike (runtime.wconv)"""
     Co, Ci, KH, KW = weight.shape
     Ci = max(Ci, ci_pad)
     OH, OW = conv_out_size(H, W, KH, stride, pad, dil)
     M, K = B * OH * OW, KH * KW * Ci
     if out is None:
         out = torch.empty(M, Co, dtype=rt.compute_dtype(), device=x.device)
-    h = ops.gemm(conv_view(x, B, H, W, Ci, KH, KW, stride, pad, dil, OH=OH, OW=OW, reflect=reflect),
-                 plain_view(rt.wconv(weight, ci_pad=ci_pad), Co, K), out, M, Co, K, dtype=rt.tag(), bias=bias, act=act, hold=hold,
-                 keep=(x,) if hold else ())
-    return ((out, OH, OW), h) if hold else (out, OH, OW)
+    ops.gemm(conv_view(x, B, H, W, Ci, KH, KW, stride, pad, dil, OH=OH, OW=OW, reflect=reflect),
+             plain_view(rt.wconv(weight, ci_pad=ci_pad), Co, K), out, M, Co, K, dtype=rt.tag(), bias=bias, act=act)
+    return out, OH, OW
 
 
 def conv_bwd(dy, x, weight, bias, B, H, W, stride, pad, dil=1, *, need_dx=True, dx_out=None, dx_beta=0.0, ci_pad=0):
@@ -192,31 +187,15 @@ def block_fwd(x, p, B, H, W, C, heads, sr, *, eps=1e-6, dp1=None, dp2=None, save
     a = p.attn
     cd = rt.compute_dtype()
     sd = x.dtype    # residual-stream storage: fp32 in the bf16 mode's fp32-stream option (runtime.residual_fp32), else the compute dtype
-    pair = rt.tag() == 1 and sr > 1 and ops.GEMM_PAIR
-    # norm1 -> q and attn.norm -> kv as ONE launch each (cmda_ln_gemm: the Linear's workgroups normalise their own rows) -- OFF by default
-    # (ops.LN_GEMM): measured no faster than the two launches on the step (58.0 - 58.6 against 58.1 - 58.4 ms, gpurun r04ln4)
-    lnq = rt.tag() == 1 and not pair and ops.LN_GEMM
-    if lnq:
-        xn = torch.empty(M, C, dtype=cd, device=x.device)
-        q, hq = linear_fwd(xn, a.q.weight, a.q.bias, M, C, hold=True)
-        m1, r1 = ops.ln_gemm(x, p.norm1.weight, p.norm1.bias, eps, hq)
-    else:
-        xn, m1, r1 = ops.layernorm_fwd(x, p.norm1.weight, p.norm1.bias, eps, out_dtype=cd)
+    # (round 4's two-problem launches (q + sr-conv) and the LayerNorm-prologue Linear measured no faster than the eight-wave lean kernel's
+    # separate launches on the step and were removed in round 5: DESIGN.md section 5)
+    xn, m1, r1 = ops.layernorm_fwd(x, p.norm1.weight, p.norm1.bias, eps, out_dtype=cd)
+    q = linear_fwd(xn, a.q.weight, a.q.bias, M, C)
     if sr > 1:
         OH, OW = conv_out_size(H, W, sr, sr, 0)
         Ksr = sr * sr * C
         splitk = rt.tag() == 1 and Ksr >= 1024 and ((B * OH * OW + 63) // 64) * ((C + 63) // 64) <= SR_SPLITK_TILES and C % 4 == 0
-        pair = pair and not splitk
-    if pair:   # q and the spatial-reduction convolution read the same xn and are independent: ONE launch (cmda_gemm_pair)
-        q, hq = linear_fwd(xn, a.q.weight, a.q.bias, M, C, hold=True)
-        (xs_pre, OH, OW), hs = conv_fwd(xn, a.sr.weight, a.sr.bias, B, H, W, sr, 0, hold=True)
-        ops.gemm_pair(hq, hs)
-    elif not lnq:
-        q = linear_fwd(xn, a.q.weight, a.q.bias, M, C)
-    if sr > 1:
-        if pair:
-            pass
-        elif splitk:
+        if splitk:
             # few output tiles, long contraction (stages 1 / 2: B*256 rows x 64 / 128 channels over K = 4096 / 2048): 8 - 32 workgroups
             # running 32 - 64 k-tiles one after the other (39 / 23 us).  Split K instead: the slices accumulate with fp32 atomics on
             # top of the bias, and the LayerNorm behind reads the fp32 sums (which it also keeps for its backward pass).
@@ -226,13 +205,8 @@ def block_fwd(x, p, B, H, W, C, heads, sr, *, eps=1e-6, dp1=None, dp2=None, save
         else:
             xs_pre, OH, OW = conv_fwd(xn, a.sr.weight, a.sr.bias, B, H, W, sr, 0)
         Nk = OH * OW
-        if rt.tag() == 1 and ops.LN_GEMM:
-            xs = torch.empty(B * Nk, C, dtype=cd, device=x.device)
-            kv, hkv = linear_fwd(xs, a.kv.weight, a.kv.bias, B * Nk, C, hold=True)
-            ms, rs = ops.ln_gemm(xs_pre, a.norm.weight, a.norm.bias, 1e-5, hkv, store_xn=save)
-        else:
-            xs, ms, rs = ops.layernorm_fwd(xs_pre, a.norm.weight, a.norm.bias, 1e-5, out_dtype=cd)
-            kv = linear_fwd(xs, a.kv.weight, a.kv.bias, B * Nk, C)
+        xs, ms, rs = ops.layernorm_fwd(xs_pre, a.norm.weight, a.norm.bias, 1e-5, out_dtype=cd)
+        kv = linear_fwd(xs, a.kv.weight, a.kv.bias, B * Nk, C)
     else:
         xs_pre, ms, rs, xs, Nk = None, None, None, xn, N
         kv = linear_fwd(xs, a.kv.weight, a.kv.bias, B * Nk, C)
@@ -281,22 +255,12 @@ def block_bwd(dy, p, saved, B, H, W, C, heads, sr, *, eps=1e-6, dy_scaled=None, 
                                      out_scale=dp1, rows_per_scale=N)
     do = linear_bwd(dps, o, a.proj.weight, a.proj.bias, M, C)
     dq, dkv = attention_bwd(do, q, kv, P, B, N, Nk, heads, C, hd ** -0.5)
-    if sr > 1 and rt.tag() == 1 and ops.GEMM_PAIR:
-        # the data gradients of kv and q are independent: ONE launch (cmda_gemm_pair); q's lands in dxn first, the spatial-reduction
-        # convolution's is accumulated on top of it
-        dxn = torch.empty(M, C, dtype=rt.compute_dtype(), device=dy.device)
-        dxs, hk = linear_bwd(dkv, xs, a.kv.weight, a.kv.bias, B * Nk, C, hold=True)
-        _, hq = linear_bwd(dq, xn, a.q.weight, a.q.bias, M, C, dx_out=dxn, dx_beta=0.0, hold=True)
-        ops.gemm_pair(hq, hk)
+    dxs = linear_bwd(dkv, xs, a.kv.weight, a.kv.bias, B * Nk, C)
+    if sr > 1:
         dxs_pre = ops.layernorm_bwd(dxs, xs_pre, a.norm.weight, ms, rs, rt.grad(a.norm.weight), rt.grad(a.norm.bias))
-        conv_bwd(dxs_pre, xn, a.sr.weight, a.sr.bias, B, H, W, sr, 0, dx_out=dxn, dx_beta=1.0)
+        dxn = conv_bwd(dxs_pre, xn, a.sr.weight, a.sr.bias, B, H, W, sr, 0)
     else:
-        dxs = linear_bwd(dkv, xs, a.kv.weight, a.kv.bias, B * Nk, C)
-        if sr > 1:
-            dxs_pre = ops.layernorm_bwd(dxs, xs_pre, a.norm.weight, ms, rs, rt.grad(a.norm.weight), rt.grad(a.norm.bias))
-            dxn = conv_bwd(dxs_pre, xn, a.sr.weight, a.sr.bias, B, H, W, sr, 0)
-        else:
-            dxn = dxs
-        linear_bwd(dq, xn, a.q.weight, a.q.bias, M, C, dx_out=dxn, dx_beta=1.0)
+        dxn = dxs
+    linear_bwd(dq, xn, a.q.weight, a.q.bias, M, C, dx_out=dxn, dx_beta=1.0)
     return ops.layernorm_bwd(dxn, x, p.norm1.weight, m1, r1, rt.grad(p.norm1.weight), rt.grad(p.norm1.bias), dres=dx1,
                              out_scale=next_scale, rows_per_scale=N)

@@ -46,6 +46,49 @@ ACT = {None: 0, 'none': 0, 'relu': 1, 'gelu': 2, 'tanh': 3}
 
 # bench.py's roofline leg: when a list is installed here every GEMM launch is bracketed by events on the launch stream
 GEMM_PROFILE = None
+# which part of the path is issuing work (set by the modules through `site(...)`): bench.py splits the MFMA roofline by it --
+# 'mit' (the MiT encoders: the blocks the 0.60 target is defined on), 'fusion', 'head', 'generator', 'other'
+GEMM_SITE = 'other'
+
+
+class site:
+    """with ops.site('mit'): ...  -- tags every GEMM / fused-attention launch (and every queued weight gradient) issued inside"""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        global GEMM_SITE
+        self.prev, GEMM_SITE = GEMM_SITE, self.name
+
+    def __exit__(self, *exc):
+        global GEMM_SITE
+        GEMM_SITE = self.prev
+
+
+def sited(name):
+    """decorator form of `site`"""
+    def deco(fn):
+        import functools
+
+        @functools.wraps(fn)
+        def wrapped(*a, **k):
+            with site(name):
+                return fn(*a, **k)
+        return wrapped
+    return deco
+
+
+def _attn_profile(flops, fn):
+    """bench.py's roofline leg: bracket a fused-attention launch like a GEMM launch (MFMA work of the MiT blocks)"""
+    if GEMM_PROFILE is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    GEMM_PROFILE.append((flops, e0, e1, 0, ('attention', GEMM_SITE)))
+    return r
 # cmda_gemm_params_t.tile_hint for every GEMM issued from here (0 = the library's heuristics); set by tuning sweeps / tests
 GEMM_TILE_HINT = int(os.environ.get('CMDA_GEMM_TILE_HINT', '0'))   # cmda_gemm_params_t.tile_hint of every launch (tuning sweeps, forced-tile tests)
 
@@ -58,7 +101,7 @@ def gemm(A, B, out, M, N, K, *, a_kstrided=False, b_kstrided=False, ldc=None, ba
     defer=True (weight gradients: nothing reads `out` before the pass ends): inside a deferral scope (`ln_deferral`) the launch is
     only QUEUED and goes out with the next `gemm_flush_deferred()` as part of a grouped launch; `keep` = the tensors behind the
     operand views (kept alive until then).
-    hold=True: build the problem but do NOT launch it -- returns a handle for `gemm_pair` (two independent problems, one launch)."""
+    hold=True: build the problem but do NOT launch it -- returns (params, meta, out, keep) for tools that time or inspect it."""
     check_dev(out, bias, res, rowscale)
     out_f32 = out.dtype == torch.float32
     p = GemmParams()
@@ -104,7 +147,7 @@ def gemm(A, B, out, M, N, K, *, a_kstrided=False, b_kstrided=False, ldc=None, ba
         es = 2 if dtype == 1 else 4
         nb = batch * batch2
         _GD['queues'].setdefault(GD_QUEUE_KEY or LN_LANE, []).append((p, (out, colsum) + tuple(keep), 2.0 * M * N * K * nb,
-                                                      (M * K + N * K) * nb * es + 2 * M * N * nb * 4))
+                                                      (M * K + N * K) * nb * es + 2 * M * N * nb * 4, GEMM_SITE))
         return out
     if hold or (GEMM_PROFILE is not None and out.is_cuda):
         es = 2 if dtype == 1 else 4
@@ -121,49 +164,10 @@ def gemm(A, B, out, M, N, K, *, a_kstrided=False, b_kstrided=False, ldc=None, ba
         e0.record()
         call('cmda_gemm', ctypes.byref(p), stream_of(out))
         e1.record()
-        GEMM_PROFILE.append((meta[0], e0, e1, meta[1], meta[2]))
+        GEMM_PROFILE.append((meta[0], e0, e1, meta[1], meta[2] + (GEMM_SITE,)))
         return out
     call('cmda_gemm', ctypes.byref(p), stream_of(out))
     return out
-
-
-# Pair launches (cmda_gemm_pair) are OFF by default since the lean kernel runs on eight waves and takes the patch view of the
-# spatial-reduction convolutions: two lean launches beat one four-wave pair grid (58.56 -> 58.37 ms, gpurun r04y; with the four-wave
-# lean kernel the pair had been worth 0.5 ms).  CMDA_GEMM_PAIR=1 turns them back on (tuning A/B; tests/test_gemm.py covers the kernel).
-GEMM_PAIR = os.environ.get('CMDA_GEMM_PAIR', '0') != '0'
-# LayerNorm-prologue Linear (cmda_ln_gemm, gemm_ln.hip) for norm1 -> q and attn.norm -> kv of the MiT blocks: OFF by default.  Measured
-# (tools/dbg/ln_gemm_bench.py, gpurun r04ln3/4): a fused launch beats LayerNorm + Linear where rows are short or the grid is at most one
-# workgroup per CU (65536 x 64 x 64: 9.9 against 16.6 us; 2048 x 320 x 320: 7.8 against 8.7) and loses at the student's stage-3 shape
-# (4096 x 320 x 320: 11.8 against 10.4); restricted to the winning shapes, the encoder's forward and the whole step did not move
-# (5.32 / 5.32 ms, 58.0 - 58.6 against 58.1 - 58.4 ms).  CMDA_LN_GEMM=1 turns it on (tests/test_gemm.py covers the kernel either way).
-LN_GEMM = os.environ.get('CMDA_LN_GEMM', '0') != '0'
-
-
-def ln_gemm(x, gamma, beta, eps, h, save_stats=True, store_xn=True):
-    """LayerNorm(x) followed by the held Linear `h` (gemm(..., hold=True) whose A view is the buffer xn the normalised rows go to) in ONE
-    launch (cmda_ln_gemm; the library runs the two kernels one after the other for problems its fused kernel does not take).
-    Returns (mean, rstd) -- fp32 [rows] or (None, None)."""
-    p, meta, out, keep = h
-    xn = keep[4]   # (bias, res, rowscale, colsum) + the caller's keep: the A operand's tensor first
-    check_dev(x, gamma, beta, xn)
-    rows = x.numel() // x.shape[-1]
-    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
-    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
-    prof = GEMM_PROFILE is not None and out.is_cuda
-    if prof:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    if LN_GEMM:
-        call('cmda_ln_gemm', ctypes.byref(p), ptr(x), dtype_tag(x), ptr(gamma), ptr(beta), c_f32(eps), ptr(mean), ptr(rstd),
-             c_i32(1 if store_xn else 0), stream_of(out))
-    else:
-        call('cmda_layernorm_fwd2', ptr(x), dtype_tag(x), ptr(gamma), ptr(beta), ptr(xn), dtype_tag(xn), ptr(mean), ptr(rstd), c_i64(rows),
-             c_i32(x.shape[-1]), c_f32(eps), stream_of(x))
-        call('cmda_gemm', ctypes.byref(p), stream_of(out))
-    if prof:
-        e1.record()
-        GEMM_PROFILE.append((meta[0], e0, e1, meta[1], meta[2]))
-    return mean, rstd
 
 
 # The MLP half of a MiT block as one launch (cmda_mixffn_fwd, csrc/mixffn.hip); CMDA_MIXFFN=0 keeps the four separate launches
@@ -199,25 +203,6 @@ def mixffn_fwd(x, gamma, beta, eps, w1, b1, wdw, bdw, w2, b2, rowscale, B, H, W,
     return out, (xn, mean, rstd, h, act)
 
 
-def gemm_pair(h0, h1):
-    """launch two held problems (gemm(..., hold=True)) that are INDEPENDENT of each other as one grid (cmda_gemm_pair); the library
-    falls back to two launches for problems its pair kernel does not take"""
-    (p0, m0, out0, _k0), (p1, m1, out1, _k1) = h0, h1
-    prof = GEMM_PROFILE is not None and out0.is_cuda
-    if prof:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    if GEMM_PAIR:
-        call('cmda_gemm_pair', ctypes.byref(p0), ctypes.byref(p1), stream_of(out0))
-    else:
-        call('cmda_gemm', ctypes.byref(p0), stream_of(out0))
-        call('cmda_gemm', ctypes.byref(p1), stream_of(out1))
-    if prof:
-        e1.record()
-        GEMM_PROFILE.append((m0[0] + m1[0], e0, e1, m0[1] + m1[1], ('pair',) + m0[2][1:]))
-    return out0, out1
-
-
 # ---- deferred weight gradients: queued by gemm(defer=True) inside a deferral scope, launched in groups (cmda_gemm_grouped) ----------
 import os as _os
 # queue key override for gemm(defer=True) (None: the current lane).  The decode head's weight gradients are queued under their own
@@ -229,38 +214,48 @@ _TAIL_FNS = []
 GEMM_DEFER = _os.environ.get('CMDA_GEMM_DEFER', '1') != '0'    # False: defer=True launches in place (A/B switch for tuning, tests of the single-launch path)
 _GD = {'queues': {}, 'plans': {}, 'arena': None, 'pinned_plans': False}
 _GD_ARENA_BYTES = 192 << 20
+_GD_EAGER_ARENA_BYTES = 64 << 20
 
 
 def _gd_arena(dev, nbytes):
-    """slice of the pinned host arena the grouped launches' tables are built in (a plain CPU tensor under the emulator).  Slices
-    are never reused while a plan lives: a captured graph re-runs the upload kernel of its plans on every replay."""
+    """slice of the pinned host arena the grouped launches' tables are built in (a plain CPU tensor under the emulator).
+    Two arenas: the MAIN one holds every plan made before or inside a capture -- a captured graph re-runs the upload kernel of its
+    plans on every replay, so its slices are never reused; once a capture has pinned plans, EAGER plans made afterwards (backward
+    passes whose operand pointers differ from the captured ones: allocator churn, another batch shape's warm-up) live in a second,
+    RECYCLABLE arena that is rewound (one sync, un-captured plans dropped) when it fills -- pinned host memory stays bounded at two
+    arenas whatever the training run does (one retired 192 MB arena per exhaustion before).  `_GD['recycles']` counts
+    the rewinds."""
     nbytes = (nbytes + 255) // 256 * 256
+    capturing = dev.type == 'cuda' and torch.cuda.is_current_stream_capturing()
+    pin = dev.type == 'cuda'
+    if _GD['pinned_plans'] and not capturing:
+        a = _GD.get('eager_arena')
+        if a is None or a[0].numel() < nbytes:
+            a = _GD['eager_arena'] = [torch.empty(max(_GD_EAGER_ARENA_BYTES, nbytes), dtype=torch.uint8, pin_memory=pin), 0]
+        if a[1] + nbytes > a[0].numel():
+            if pin:
+                torch.cuda.synchronize(dev)   # every upload that read the eager arena has run
+            _GD['plans'] = {k: v for k, v in _GD['plans'].items() if v[3]}
+            a[1] = 0
+            _GD['recycles'] = _GD.get('recycles', 0) + 1
+        lo = a[1]
+        a[1] = lo + nbytes
+        return a[0][lo:lo + nbytes], True
     a = _GD['arena']
     if a is None:
-        if dev.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+        if capturing:
             raise RuntimeError('grouped-GEMM arena: run one eager backward pass before capturing')
-        a = _GD['arena'] = [torch.empty(_GD_ARENA_BYTES, dtype=torch.uint8, pin_memory=(dev.type == 'cuda')), 0]
+        a = _GD['arena'] = [torch.empty(_GD_ARENA_BYTES, dtype=torch.uint8, pin_memory=pin), 0]
     if a[1] + nbytes > a[0].numel():
-        if dev.type == 'cuda' and torch.cuda.is_current_stream_capturing():
-            raise RuntimeError('grouped-GEMM arena exhausted inside a capture: run the eager warm-up iterations first')
-        if _GD['pinned_plans']:
-            # captured graphs replay uploads out of the current arena: it must stay as it is.  Open a fresh one for the plans to
-            # come (eager backward passes whose operand pointers differ from the captured ones -- allocator churn, a new batch
-            # shape's warm-up) instead of failing in the middle of training; un-captured plans are dropped with the old arena's
-            # bookkeeping, captured ones keep their slices alive through `retired`.
-            _GD.setdefault('retired', []).append(a[0])
-            if dev.type == 'cuda':
-                torch.cuda.synchronize(dev)
-            _GD['plans'] = {k: v for k, v in _GD['plans'].items() if v[3]}
-            a = _GD['arena'] = [torch.empty(max(_GD_ARENA_BYTES, nbytes), dtype=torch.uint8, pin_memory=(dev.type == 'cuda')), 0]
-        else:
-            if dev.type == 'cuda':
-                torch.cuda.synchronize(dev)   # eager plans only: every upload that read the arena has run
-            _GD['plans'].clear()
-            a[1] = 0
+        if capturing or _GD['pinned_plans']:
+            raise RuntimeError('grouped-GEMM arena exhausted by captured plans: raise ops._GD_ARENA_BYTES')
+        if pin:
+            torch.cuda.synchronize(dev)   # eager plans only: every upload that read the arena has run
+        _GD['plans'].clear()
+        a[1] = 0
     lo = a[1]
     a[1] = lo + nbytes
-    return a[0][lo:lo + nbytes]
+    return a[0][lo:lo + nbytes], False
 
 
 def tail_defer(fn):
@@ -306,12 +301,15 @@ def gemm_flush_deferred(all_lanes=False, from_lane=None):
         key = (str(dev), bytes(arr))
         plan = _GD['plans'].get(key)
         upload = 0
+        capturing = dev.type == 'cuda' and torch.cuda.is_current_stream_capturing()
+        if plan is not None and capturing and plan[4]:
+            plan = None   # made eagerly in the recyclable arena: a captured graph needs a slice that stays -> rebuild it in the main one
         if plan is None:
             nbytes = int(L.lib().cmda_gemm_grouped_ws_bytes(arr, c_i32(n)))
-            host = _gd_arena(dev, max(nbytes, 16))
-            plan = _GD['plans'][key] = [host, torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev), nbytes, False]
+            host, recyclable = _gd_arena(dev, max(nbytes, 16))
+            plan = _GD['plans'][key] = [host, torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev), nbytes, False, recyclable]
             upload = 1
-        if dev.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+        if capturing:
             _GD['pinned_plans'] = True
             plan[3] = True    # a captured graph replays this plan's upload + launch: its arena slice and device table stay
         host, devbuf, nbytes = plan[:3]
@@ -322,7 +320,10 @@ def gemm_flush_deferred(all_lanes=False, from_lane=None):
         call('cmda_gemm_grouped', arr, c_i32(n), ptr(host), ptr(devbuf), c_i64(nbytes), c_i32(upload), stream_of(out0))
         if prof:
             e1.record()
-            GEMM_PROFILE.append((sum(e[2] for e in q), e0, e1, sum(e[3] for e in q), ('grouped', n, 0, 0, 0, False, True, True, True, True)))
+            split = {}
+            for e in q:
+                split[e[4]] = split.get(e[4], 0.0) + e[2]
+            GEMM_PROFILE.append((sum(e[2] for e in q), e0, e1, sum(e[3] for e in q), ('grouped', n, 0, 0, 0, False, True, True, True, True, split)))
 
 
 def layernorm_fwd(x, gamma, beta, eps, save_stats=True, out=None, out_dtype=None):
@@ -692,8 +693,8 @@ def attention_fused_ok(q, Nk, heads, C, need_grad=True):
 def attention_fused_fwd(q, kv, B, N, Nk, heads, C, scale):
     check_dev(q, kv)
     o = torch.empty(B * N, C, dtype=q.dtype, device=q.device)
-    call('cmda_attention_fwd', ptr(q), ptr(kv), ptr(o), c_i32(B), c_i32(N), c_i32(Nk), c_i32(heads), c_i32(C),
-         c_f32(scale), dtype_tag(q), stream_of(q))
+    _attn_profile(4.0 * B * N * Nk * C, lambda: call('cmda_attention_fwd', ptr(q), ptr(kv), ptr(o), c_i32(B), c_i32(N), c_i32(Nk),
+                                                     c_i32(heads), c_i32(C), c_f32(scale), dtype_tag(q), stream_of(q)))
     return o
 
 
@@ -707,8 +708,9 @@ def attention_fused_bwd(q, kv, do, dkv32, B, N, Nk, heads, C, scale, dkv16=None)
     check_dev(q, kv, do, dkv32, dkv16)
     dq = torch.empty(B * N, C, dtype=q.dtype, device=q.device)
     stats = torch.empty(B * N * heads * 2, dtype=torch.float32, device=q.device)
-    call('cmda_attention_bwd', ptr(q), ptr(kv), ptr(do), ptr(dq), ptr(dkv32), ptr(dkv16), ptr(stats), c_i32(B), c_i32(N),
-         c_i32(Nk), c_i32(heads), c_i32(C), c_f32(scale), dtype_tag(q), stream_of(q))
+    _attn_profile(10.0 * B * N * Nk * C, lambda: call('cmda_attention_bwd', ptr(q), ptr(kv), ptr(do), ptr(dq), ptr(dkv32), ptr(dkv16),
+                                                      ptr(stats), c_i32(B), c_i32(N), c_i32(Nk), c_i32(heads), c_i32(C), c_f32(scale),
+                                                      dtype_tag(q), stream_of(q)))
     return dq
 
 

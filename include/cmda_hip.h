@@ -82,10 +82,10 @@ typedef struct cmda_gemm_params_t {
    * column buffer.  Off when c_patch_ow == 0; ldc / batch strides / residual are ignored in this mode. */
   int32_t c_patch_ow, c_patch_kh, c_patch_kwci;
   /* 0: the library's tile heuristics; -1: register-staged kernel instead of the LDS-DMA one.  > 0 (tuning sweeps, tests of the rarely
-   * chosen kernels): low 4 bits 1..5 force tile 128x128 / 128x64 / 64x64 / 256x256 / 64x320 row panel; bits 4-7 LDS stages (4 = four);
+   * chosen kernels): low 4 bits 1..4 force tile 128x128 / 128x64 / 64x64 / 256x256; bits 4-7 LDS stages (4 = four);
    * bit 8 no tile-group walk; bit 9 gemm_glds_kernel instead of the ping-pong / weight-gradient 256x256 kernels; bit 10 ping-pong
    * kernel; bit 11 general DMA address path; bit 12 (32, 4) weight-gradient configuration; bit 13 general kernel instead of the lean
-   * one; bit 14 lean kernel on four waves; bit 15 cmda_ln_gemm: fused kernel whatever the grid size. */
+   * one; bit 14 lean kernel on four waves. */
   int32_t tile_hint;
   /* atomic stores only, c_perm_ci > 0: GEMM column n = cell * c_perm_ci + ci (cell = kh*KW + kw, the im2col column order) is
    * stored at column ci * c_perm_cells + cell -- a convolution's weight gradient accumulated straight into the parameter's
@@ -99,21 +99,6 @@ typedef struct cmda_gemm_params_t {
 
 int cmda_gemm(const cmda_gemm_params_t* p, void* stream);
 
-/* Two INDEPENDENT GEMMs in one launch (neither reads the other's output): Attention's q projection and its spatial-reduction
- * convolution consume the same LayerNorm output (mix_transformer.py:86-92), and under autograd the data gradients of q and kv are
- * independent as well -- in chains bound by their launch count a pair costs one dependent launch.  Problems the pair kernel does not
- * take (fp32, split-K, batched, im2col views, different operand orientations) are launched one after the other through cmda_gemm. */
-int cmda_gemm_pair(const cmda_gemm_params_t* a, const cmda_gemm_params_t* b, void* stream);
-
-/* LayerNorm FOLLOWED BY a Linear in one launch: norm1 -> q and attn.norm -> kv of a MiT block (mix_transformer.py:86-92,123-139;
- * nn.LayerNorm + nn.Linear).  x [p->M, p->K] (x_dtype CMDA_F32 or CMDA_BF16, contiguous) is normalised over its K channels (gamma,
- * beta fp32 [K], eps inside the sqrt) and multiplied as the A operand of the problem `p`; p->A must be the plain view of the buffer
- * xn [M, K] that receives the normalised rows in the compute dtype when store_xn != 0 (the spatial-reduction convolution, the weight
- * gradient and the LayerNorm backward read them); mean / rstd fp32 [M] receive the statistics (both or neither may be null).
- * Same values as cmda_layernorm_fwd2 + cmda_gemm -- which is what runs for problems the fused kernel does not take (then xn is
- * written whatever store_xn says). */
-int cmda_ln_gemm(const cmda_gemm_params_t* p, const void* x, int x_dtype, const float* gamma, const float* beta, float eps,
-                 float* mean, float* rstd, int store_xn, void* stream);
 
 /* The MLP half of a MiT block as ONE launch -- mmseg/models/backbones/mix_transformer.py:141-146 (Block.forward: x = x +
  * drop_path(mlp(norm2(x)))), :31-44 (Mlp.forward: fc1 -> DWConv -> GELU -> fc2), :443-455 (DWConv: 3x3, pad 1, groups = hidden):

@@ -300,8 +300,9 @@ def test_stochastic_paths_with_injected_masks(tgt, mode):
     med, p90, worst = errs[len(errs) // 2], errs[int(len(errs) * 0.9)], errs[-1]
     print(f'[{mode}] injected masks: gradient rel err median {med:.2e}, 90th percentile {p90:.2e}, worst {worst:.2e}')
     if mode == 'f32':
-        check_le('gradient rel err 90th pct', p90, 1e-3, strict=True)    # (3.0e-4 measured)
-        check_le('gradient rel err worst', worst, 1.5e-2, strict=True)    # (4.4e-3 measured)
+        # (GPU, 128 x 128: 3.0e-4 / 4.4e-3 measured on three boxes; the emulator's 32 x 32 case: 1.9e-3 / 9e-3 -- fewer pixels per gradient)
+        check_le('gradient rel err 90th pct', p90, 1e-3 if tgt.kind == 'gpu' else 5e-3, strict=True)
+        check_le('gradient rel err worst', worst, 1.5e-2 if tgt.kind == 'gpu' else 3e-2, strict=True)
     else:   # bf16 activations: bounded in the bulk (tensors with tiny gradients carry large relative max-norm errors)
         check_le('bf16 gradient rel err median', med, 0.165, strict=True)   # (6.6e-2 worst of three boxes: 2.5x)
         check_le('bf16 gradient rel err 90th pct', p90, 0.26, strict=True)   # (0.101)

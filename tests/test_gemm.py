@@ -118,9 +118,9 @@ def _run_forced_tile(marker):
     # 4 | 1024: the ping-pong kernel (gemm_pp.hip) wherever its epilogue / operand modes allow; 4 | 512: gemm_glds_kernel's 8-wave tile
     for hint in ('1028', '516'):
         env = dict(os.environ, CMDA_TEST_GEMM_TILE=hint)
-        # (the tests of launches that ignore the forced tile -- pair / row-panel / deferred-grouped -- are left out: they run once, above)
+        # (the tests of launches that ignore the forced tile -- deferred-grouped -- are left out: they run once, above)
         r = subprocess.run([sys.executable, '-m', 'pytest', here, '-q', '-x', '-m', marker, '-k',
-                            'not forced_tile and not pair_launch and not row_panel and not deferred_grouped and not ln_gemm', '-p', 'no:cacheprovider'],
+                            'not forced_tile and not deferred_grouped', '-p', 'no:cacheprovider'],
                            env=env, capture_output=True, text=True, timeout=1500)
         assert r.returncode == 0, f'tile_hint {hint}: ' + r.stdout[-2000:] + r.stderr[-2000:]
 
@@ -200,7 +200,10 @@ def test_gemm_deferred_grouped_weight_gradients(tgt, dt, tag):
             lins.append((torch.randn(rows, n).to(dt), torch.randn(rows, k).to(dt), torch.nn.Parameter(tgt.to(torch.randn(n, k))),
                          torch.nn.Parameter(tgt.to(torch.randn(n)))))
         # a spatial-reduction conv (patch view) and a 3x3 conv (im2col view)
-        convs = [(2, 16, 16, 32, 24, 2, 2, 0), (1, 12, 20, 16, 16, 3, 1, 1), (1, 12, 20, 32, 272, 3, 1, 1), (2, 16, 16, 320, 320, 2, 2, 0)]
+        # (the last one: a patch view whose output rows are exactly one 64-deep k-tile (OW = 64) on the 256 x 256 tile's 32-deep kernel --
+        # classed 'fast' by a 64-deep eligibility test, its weight gradient came out wrong)
+        convs = [(2, 16, 16, 32, 24, 2, 2, 0), (1, 12, 20, 16, 16, 3, 1, 1), (1, 12, 20, 32, 272, 3, 1, 1), (2, 16, 16, 320, 320, 2, 2, 0),
+                 (1, 4, 128, 64, 256, 2, 2, 0)]
         cvs = []
         for Bc, H, W, Ci, Co, k, st, pd in convs:
             OH, OW = K.conv_out_size(H, W, k, st, pd)
@@ -248,118 +251,30 @@ def test_gemm_deferred_grouped_weight_gradients(tgt, dt, tag):
         rt.set_compute_dtype(torch.float32)
 
 
-@pytest.mark.parametrize('M,N,K', [(70, 320, 64), (200, 640, 320), (130, 300, 200), (64, 1280, 128), (257, 320, 1280)])
-def test_gemm_row_panel_tile(tgt, M, N, K):
-    """the 64 x 320 row-panel tile (gemm_t4.hip, tile_hint 5): whole rows of the C = 320 stage's Linear layers per workgroup, with
-    every epilogue the encoder blocks use on it (bias, GELU, per-sample drop-path scale, fp32 residual into an fp32 output)"""
-    old = ops.GEMM_TILE_HINT
-    ops.GEMM_TILE_HINT = 5
+def test_grouped_gemm_eager_arena_recycles_after_a_capture(tgt):
+    """ops._gd_arena: once a capture has pinned plans, eager grouped launches build their tables in a second, recyclable arena that is
+    rewound when it fills -- no new pinned arena per exhaustion.  Simulated here by marking plans pinned and shrinking
+    the eager arena: every flush still produces the right weight gradients and the rewinds are counted."""
+    from cmda_amd import nn as K
+    import cmda_amd.runtime as rt
+    rt.set_compute_dtype(torch.bfloat16)
+    saved = (ops._GD['pinned_plans'], ops._GD.get('eager_arena'), ops._GD_EAGER_ARENA_BYTES, ops._GD.get('recycles', 0), dict(ops._GD['plans']))
     try:
-        torch.manual_seed(M + N)
-        a, b = torch.randn(M, K).bfloat16(), (torch.randn(N, K) * 0.2).bfloat16()
-        bias, res = torch.randn(N), torch.randn(M, N)
-        ref = a.float() @ b.float().t()
-        ad, bd, biasd = tgt.to(a), tgt.to(b), tgt.to(bias)
-        out = torch.empty(M, N, dtype=torch.bfloat16, device=tgt.device)
-        ops.gemm(ops.plain_view(ad, M, K), ops.plain_view(bd, N, K), out, M, N, K, dtype=1, bias=biasd)
-        assert_close(out, ref + bias, 1.5e-2, name='row panel NT + bias')
-        out = torch.empty(M, N, dtype=torch.bfloat16, device=tgt.device)
-        ops.gemm(ops.plain_view(ad, M, K), ops.plain_view(bd, N, K), out, M, N, K, dtype=1, bias=biasd, act='gelu')
-        assert_close(out, F.gelu(ref + bias), 1.5e-2, name='row panel NT + bias + gelu')
-        sc = torch.tensor([0.0, 1.25, 1.25, 0.0])
-        rps = (M + 3) // 4
-        out = torch.empty(M, N, dtype=torch.float32, device=tgt.device)
-        ops.gemm(ops.plain_view(ad, M, K), ops.plain_view(bd, N, K), out, M, N, K, dtype=1, bias=biasd, res=tgt.to(res),
-                 rowscale=tgt.to(sc), rows_per_scale=rps)
-        assert_close(out, res + (ref + bias) * sc[torch.arange(M) // rps, None], 2e-3, atol=1e-3, name='row panel fp32 residual epilogue')
+        ops._GD['pinned_plans'], ops._GD['eager_arena'], ops._GD_EAGER_ARENA_BYTES = True, None, 1024
+        torch.manual_seed(9)
+        before = ops._GD.get('recycles', 0)
+        for rep in range(6):
+            rows, n, k = 256 + 64 * rep, 64, 64    # a new problem (and plan key) every time
+            dy, x = torch.randn(rows, n).bfloat16(), torch.randn(rows, k).bfloat16()
+            w, b = torch.nn.Parameter(tgt.to(torch.randn(n, k))), torch.nn.Parameter(tgt.to(torch.randn(n)))
+            w.grad, b.grad = torch.zeros_like(w.data), torch.zeros_like(b.data)
+            with ops.ln_deferral():
+                K.linear_bwd(tgt.to(dy), tgt.to(x), w, b, rows, k, need_dx=False)
+            assert_close(w.grad, dy.float().t() @ x.float(), 2e-2, name=f'dW after {rep} flushes')
+        assert ops._GD.get('recycles', 0) > before, 'the eager arena never filled: shrink it further'
+        assert ops._GD["eager_arena"][0].numel() <= 2048
     finally:
-        ops.GEMM_TILE_HINT = old
-
-
-@pytest.mark.parametrize('nn', [False, True], ids=['NT', 'NN'])
-def test_gemm_pair_launch(tgt, nn):
-    """cmda_gemm_pair: two independent problems in one grid -- a plain Linear next to a patch-view convolution (q and the
-    spatial-reduction conv of a MiT block: same input, different shapes and epilogues), and two data gradients (K-strided weights,
-    one accumulating into its output).  Must equal the two single launches bit for bit."""
-    torch.manual_seed(17)
-    Bc, H, W, C, s = 1, 8, 16, 32, 2          # tokens 128, channels 32; sr conv: kernel = stride = 2 -> 32 rows x K = 128
-    M = Bc * H * W
-    x = tgt.to(torch.randn(M, C).bfloat16())
-    if not nn:
-        wq, bq = tgt.to((torch.randn(96, C) * 0.2).bfloat16()), tgt.to(torch.randn(96))
-        ws, bs = tgt.to((torch.randn(C, s * s * C) * 0.1).bfloat16()), tgt.to(torch.randn(C))
-        OH, OW = H // s, W // s
-
-        def build(hold):
-            q = torch.empty(M, 96, dtype=torch.bfloat16, device=tgt.device)
-            xs = torch.empty(Bc * OH * OW, C, dtype=torch.bfloat16, device=tgt.device)
-            h0 = ops.gemm(ops.plain_view(x, M, C), ops.plain_view(wq, 96, C), q, M, 96, C, dtype=1, bias=bq, act='gelu', hold=hold)
-            h1 = ops.gemm(ops.conv_view(x, Bc, H, W, C, s, s, s, 0), ops.plain_view(ws, C, s * s * C), xs, Bc * OH * OW, C, s * s * C,
-                          dtype=1, bias=bs, hold=hold)
-            return q, xs, h0, h1
-    else:
-        dy0, dy1 = tgt.to(torch.randn(M, 64).bfloat16()), tgt.to(torch.randn(40, 128).bfloat16())
-        w0, w1 = tgt.to((torch.randn(64, C) * 0.2).bfloat16()), tgt.to((torch.randn(128, C) * 0.2).bfloat16())   # [N_out, K_in]
-        prev = tgt.to(torch.randn(40, C).bfloat16())
-
-        def build(hold):
-            d0 = torch.empty(M, C, dtype=torch.bfloat16, device=tgt.device)
-            d1 = prev.clone()
-            h0 = ops.gemm(ops.plain_view(dy0, M, 64), ops.plain_view(w0, 64, C), d0, M, C, 64, b_kstrided=True, dtype=1, hold=hold)
-            h1 = ops.gemm(ops.plain_view(dy1, 40, 128), ops.plain_view(w1, 128, C), d1, 40, C, 128, b_kstrided=True, dtype=1, beta=1.0, hold=hold)
-            return d0, d1, h0, h1
-    a0, a1, _, _ = build(False)
-    b0, b1, h0, h1 = build(True)
-    old = ops.GEMM_PAIR
-    ops.GEMM_PAIR = True   # (off by default in the step since round 4's eight-wave lean kernel: ops.GEMM_PAIR)
-    try:
-        ops.gemm_pair(h0, h1)
-    finally:
-        ops.GEMM_PAIR = old
-    assert torch.equal(a0.float().cpu(), b0.float().cpu()) and torch.equal(a1.float().cpu(), b1.float().cpu())
-    if not nn:
-        ref = torch.nn.functional.gelu(x.float().cpu() @ wq.float().cpu().t() + bq.cpu())
-        assert_close(b0, ref, 1.5e-2, name='pair: q')
-
-
-@pytest.mark.parametrize('M,N,K,xdt', [(130, 320, 320, torch.float32), (64, 64, 64, torch.float32), (200, 96, 128, torch.float32),
-                                       (257, 640, 320, torch.bfloat16), (70, 200, 256, torch.float32), (100, 64, 384, torch.float32),
-                                       (90, 128, 512, torch.float32)])
-def test_ln_gemm_matches_two_launches(tgt, M, N, K, xdt):
-    """cmda_ln_gemm (LayerNorm in the prologue of the Linear behind it: norm1 -> q, attn.norm -> kv) against the two separate launches:
-    statistics to fp32 round-off, normalised rows within one bf16 rounding step, the output within the bf16 GEMM tolerance; ragged
-    M / N included; K = 512 exceeds the resident panel and takes the library's two-launch path (bit-identical then)."""
-    torch.manual_seed(M + K)
-    x = tgt.to((torch.randn(M, K) * 2 + 0.5).to(xdt))
-    gamma, beta = tgt.to(torch.randn(K) * 0.5 + 1), tgt.to(torch.randn(K) * 0.1)
-    w, b = tgt.to((torch.randn(N, K) * 0.1).bfloat16()), tgt.to(torch.randn(N))
-    xn_ref, m_ref, r_ref = ops.layernorm_fwd(x, gamma, beta, 1e-6, out_dtype=torch.bfloat16)
-    y_ref = torch.empty(M, N, dtype=torch.bfloat16, device=tgt.device)
-    ops.gemm(ops.plain_view(xn_ref, M, K), ops.plain_view(w, N, K), y_ref, M, N, K, dtype=1, bias=b)
-    exact = K > 384
-    old = ops.LN_GEMM, ops.GEMM_TILE_HINT
-    # (off by default in the step: ops.LN_GEMM; tile_hint bit 15: the fused kernel whatever the grid size -- its shape rule, gemm_ln.hip)
-    ops.LN_GEMM, ops.GEMM_TILE_HINT = True, 32768
-    try:
-        for store in (True, False):
-            xn = torch.zeros(M, K, dtype=torch.bfloat16, device=tgt.device)
-            y = torch.empty(M, N, dtype=torch.bfloat16, device=tgt.device)
-            h = ops.gemm(ops.plain_view(xn, M, K), ops.plain_view(w, N, K), y, M, N, K, dtype=1, bias=b, hold=True, keep=(xn,))
-            m, r = ops.ln_gemm(x, gamma, beta, 1e-6, h, store_xn=store)
-            if exact:
-                assert torch.equal(y.float().cpu(), y_ref.float().cpu()) and torch.equal(xn.float().cpu(), xn_ref.float().cpu())
-                assert torch.equal(m.cpu(), m_ref.cpu()) and torch.equal(r.cpu(), r_ref.cpu())
-                continue
-            assert_close(m, m_ref, 1e-5, name='ln_gemm mean')
-            assert_close(r, r_ref, 1e-5, name='ln_gemm rstd')
-            assert_close(y, y_ref, 4e-3, name='ln_gemm output vs two launches')
-            if store:
-                assert_close(xn, xn_ref, 8e-3, name='ln_gemm normalised rows')   # one bf16 step (2^-8) of the largest entry at most
-                assert float((xn.float() != xn_ref.float()).float().mean()) < 0.01
-            else:
-                assert float(xn.float().abs().max()) == 0.0
-    finally:
-        ops.LN_GEMM, ops.GEMM_TILE_HINT = old
-    # against torch (fp32 LayerNorm, bf16-rounded operands)
-    ref = torch.nn.functional.layer_norm(x.float().cpu(), (K,), gamma.cpu(), beta.cpu(), 1e-6).bfloat16().float() @ w.float().cpu().t() + b.cpu()
-    assert_close(y, ref, 1.5e-2, name='ln_gemm vs torch')
+        ops._GD['pinned_plans'], ops._GD['eager_arena'], ops._GD_EAGER_ARENA_BYTES = saved[0], saved[1], saved[2]
+        ops._GD['recycles'] = saved[3]
+        ops._GD['plans'] = saved[4]
+        rt.set_compute_dtype(torch.float32)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""A/B of the 64 x 320 row-panel GEMM tile (tile_hint 5) against the library heuristics on the C = 320 stage's Linear shapes, and the
-split-bf16 (CMDA_F32X3) kernel against the exact-fp32 one on the step's large shapes.  GPU box: python tools/dbg/rp_bench.py"""
+"""Graph-timed GEMM tiles against the library heuristics on the C = 320 stage's Linear shapes, and the split-bf16 (CMDA_F32X3) kernel
+against the exact-fp32 one on the step's large shapes.  GPU box: python tools/dbg/rp_bench.py
+(round 4 also timed a 64 x 320 row-panel tile here -- measured slower than tile + LayerNorm launch, removed in round 5)"""
 import os
 import sys
 
@@ -54,16 +55,15 @@ if os.environ.get('RP_SHORT'):
     for M, N, K in ((2048, 320, 320), (8192, 320, 320), (8192, 1280, 320), (8192, 320, 1280)):
         print(f'  {M} x {N} x {K}: lean {nt(M, N, K, 0):.2f} us   general kernel {nt(M, N, K, 8192):.2f} us   general + general address path {nt(M, N, K, 8192 | 2048):.2f} us')
     sys.exit(0)
-print('row panel (hint 5) vs heuristics, bf16, us per launch (back-to-back launches)')
+print('tiles vs heuristics, bf16, us per launch (back-to-back launches)')
 for M in (2048, 4096, 8192, 16384):
     for N, K, res in ((320, 320, False), (320, 320, True), (640, 320, False), (1280, 320, False), (320, 1280, True)):
         t0 = nt(M, N, K, 0, res=res)
-        ts = [nt(M, N, K, 5, res=res)]
         tt = [nt(M, N, K, h, res=res) for h in (3, 3 | (4 << 4), 2, 2 | (4 << 4), 1, 1 | (4 << 4))]
         tg = [nt(M, N, K, h | 2048, res=res) for h in (3, 2, 1)]   # general address path
         fl = 2.0 * M * N * K
         print(f'  {M:6d} x {N:5d} x {K:5d} {"+res32" if res else "      "}: heuristics {t0:6.1f} us ({fl / t0 / 1e6:5.0f} TF) | 64x64 {tt[0]:5.1f} 4st {tt[1]:5.1f} | 128x64 {tt[2]:5.1f} 4st {tt[3]:5.1f} | '
-              f'128x128 {tt[4]:5.1f} 4st {tt[5]:5.1f} | general path 64x64 {tg[0]:5.1f} 128x64 {tg[1]:5.1f} 128x128 {tg[2]:5.1f} | row panel (8 waves, 2 stages) {ts[0]:5.1f}')
+              f'128x128 {tt[4]:5.1f} 4st {tt[5]:5.1f} | general path 64x64 {tg[0]:5.1f} 128x64 {tg[1]:5.1f} 128x128 {tg[2]:5.1f}')
 print('split-bf16 (dtype 2) vs exact fp32 (dtype 0), fp32 storage')
 for M, N, K in ((8192, 1280, 320), (8192, 320, 1280), (65536, 256, 1024), (16384, 1024, 1024), (4096, 4096, 4096)):
     t0 = nt(M, N, K, 0, torch.float32, 0)
