@@ -47,13 +47,6 @@ build/hip_pptiming/gemm_pp.o: $(CSRC)/gemm_pp.hip $(HDRS)
 pptiming: build/hip_pptiming/gemm_pp.o $(HIP_OBJS)
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o build/libcmda_hip_pptiming.so build/hip_pptiming/gemm_pp.o $(filter-out build/hip/gemm_pp.o,$(HIP_OBJS))
 
-# tuning build of the fused MixFFN kernel with per-phase s_memtime accumulators (tools/dbg/mixffn_phase.py)
-build/hip_mftiming/mixffn.o: $(CSRC)/mixffn.hip $(HDRS)
-	@mkdir -p build/hip_mftiming
-	$(HIPCC) $(HIPFLAGS) -DCMDA_MIXFFN_TIMING -c $< -o $@
-mftiming: build/hip_mftiming/mixffn.o $(HIP_OBJS)
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o build/libcmda_hip_mftiming.so build/hip_mftiming/mixffn.o $(filter-out build/hip/mixffn.o,$(HIP_OBJS))
-
 clean:
 	rm -rf build cmda_amd/libcmda_hip.so tests/emu/libcmda_emu.so
-.PHONY: all hip emu timing pptiming mftiming clean
+.PHONY: all hip emu timing pptiming clean

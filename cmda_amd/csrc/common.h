@@ -173,7 +173,7 @@ static inline void glds16(const void* gsrc, void* lds_wave_base) {
 // The same copy issued through inline asm, i.e. INVISIBLE to the compiler's wait-count bookkeeping.  With the builtin, hipcc puts
 // `s_waitcnt vmcnt(0)` in front of every LDS read it cannot prove disjoint from a pending DMA destination -- and it treats the
 // destination as "this address and everything above it", so a kernel that reads one LDS buffer while the DMA fills another one
-// BELOW it drains its whole vector-memory queue at every such read (csrc/mixffn.hip: each weight group's latency was exposed).
+// BELOW it drains its whole vector-memory queue at every such read (found on the fused-MixFFN experiment of round 5, DESIGN.md section 5: each weight group's latency was exposed).
 // The caller owns the completion: a counted vmcnt wait (pipe_barrier / dma_wait) and a barrier before the data is read.
 // M0 (the wave-uniform LDS destination) is compiler-reserved: saved and restored inside the statement.
 #ifndef CMDA_EMU

@@ -9,6 +9,7 @@
 // group, statistics in fp32.  Algorithmic bytes: fwd 2*rows*C*sizeof(T); bwd 3*rows*C*sizeof(T)
 // (+ rows*C*sizeof(T) when a residual gradient is fused in).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -51,11 +52,23 @@ __global__ void ln_fwd_kernel(const TX* __restrict__ x, const float* __restrict_
       const int vi = i * lpr + li;
       if (live && vi < nvec) {
         ld4(xr + vi * 4, v[i]);
-        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
       } else {
         v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
       }
     }
+    // gamma / beta requested WITH the row: behind the two reductions (where they are used) each row paid a second exposed L2 round
+    // trip in a kernel that holds one to four rows per wave (round 5; the same finding as the fused-MixFFN prologue)
+    float gv[NV][4], bvv[NV][4];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int vi = i * lpr + li;
+      if (vi < nvec) {
+        ld4(gamma + vi * 4, gv[i]);
+        ld4(beta + vi * 4, bvv[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     const float mean = group_sum(s, lpr) / (float)C;
     float q = 0.f;
 #pragma unroll
@@ -76,11 +89,9 @@ __global__ void ln_fwd_kernel(const TX* __restrict__ x, const float* __restrict_
     for (int i = 0; i < NV; ++i) {
       const int vi = i * lpr + li;
       if (vi < nvec) {
-        float g[4], b[4], o[4];
-        ld4(gamma + vi * 4, g);
-        ld4(beta + vi * 4, b);
+        float o[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
+        for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * gv[i][j] + bvv[i][j];
         st4(y + row * C + vi * 4, o);
       }
     }
@@ -261,7 +272,10 @@ extern "C" int cmda_layernorm_fwd2(const void* x, int x_dtype, const float* gamm
                                    float* rstd, int64_t rows, int C, float eps, void* stream) {
   if (rows <= 0) return CMDA_OK;
   if (C <= 0 || (C & 3) || C > kMaxVec * 256) return CMDA_ERR_SHAPE;
-  const int wpb = 4, lpr = lanes_per_row(C);
+  // C = 320 (80 vectors): 16 lanes x 5 vectors per row, four rows per wave -- every lane busy, four shuffle steps per reduction
+  // (64 lanes x 2 passes left 48 lanes idle in the second pass and took six steps).  Forward only: the backward's parameter-gradient
+  // fold measured slower on 16-lane groups (ln_bwd_grid).
+  const int wpb = 4, lpr = (C == 320 && !std::getenv("CMDA_LN_FWD_WIDE")) ? 16 : lanes_per_row(C);
   const long rpb = wpb * (64 / lpr);
   const int grid = (int)std::min<long>((rows + rpb - 1) / rpb, 8192);
   const int nv = ((C >> 2) + lpr - 1) / lpr;
@@ -278,6 +292,7 @@ extern "C" int cmda_layernorm_fwd2(const void* x, int x_dtype, const float* gamm
   } while (0)
   if (nv <= 1) { CMDA_LN_FWD(1); }
   else if (nv == 2) { CMDA_LN_FWD(2); }
+  else if (nv == 5) { CMDA_LN_FWD(5); }
   else { CMDA_LN_FWD(4); }
 #undef CMDA_LN_FWD
 #undef CMDA_LN_FWD_T
@@ -292,7 +307,8 @@ extern "C" int cmda_layernorm_fwd(const void* x, const float* gamma, const float
 static inline long ln_bwd_grid(long rows, int C) {
   const long rpb = 4 * (64 / lanes_per_row(C));
   // measured per shape (tools/ln_bench.py under rocprofv3): caps 256 / 512 / 2048 are all slower than 1024; so were 16-lane
-  // row groups for C = 320 with a shuffle fold of the parameter gradients (32-38 us against 21.5)
+  // row groups for C = 320 with a shuffle fold of the parameter gradients (32-38 us against 21.5) and, round 5, with the LDS fold of
+  // this kernel (graph-timed 4096 x 320: 23.2 us against 9.8 -- sixteen slots of 320 channels to fold per block)
   const long cap = 1024;
   return std::max<long>(1, std::min<long>((rows + rpb - 1) / rpb, cap));
 }

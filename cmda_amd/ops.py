@@ -170,39 +170,6 @@ def gemm(A, B, out, M, N, K, *, a_kstrided=False, b_kstrided=False, ldc=None, ba
     return out
 
 
-# The MLP half of a MiT block as one launch (cmda_mixffn_fwd, csrc/mixffn.hip); CMDA_MIXFFN=0 keeps the four separate launches
-MIXFFN = os.environ.get('CMDA_MIXFFN', '0') != '0'   # off until it beats the four launches side by side
-MIXFFN_LINES = int(os.environ.get('CMDA_MIXFFN_LINES', '0'))   # cap on image lines per workgroup (0: the library's choice)
-
-
-def mixffn_ok(x, B, H, W, C, hidden):
-    """does the fused MixFFN kernel take this pass?  (bf16 compute, fp32 residual stream, the shapes of cmda_mixffn_fwd_ok)"""
-    return (MIXFFN and x.dtype == torch.float32 and x.shape[1] == C
-            and bool(L.lib().cmda_mixffn_fwd_ok(c_i32(B), c_i32(H), c_i32(W), c_i32(C), c_i32(hidden))))
-
-
-def mixffn_fwd(x, gamma, beta, eps, w1, b1, wdw, bdw, w2, b2, rowscale, B, H, W, save=True, lines=None):
-    """x2 = x + rowscale * Mlp(LayerNorm(x)) in ONE launch.  x fp32 [B*H*W, C]; w1 [hidden, C] / w2 [C, hidden] bf16 mirrors; wdw
-    tap-major fp32 [9, hidden].  Returns (x2, (xn, mean, rstd, h, act)) -- the saves are None when save=False."""
-    check_dev(x, gamma, beta, w1, b1, wdw, bdw, w2, b2, rowscale)
-    M, C = x.shape
-    hidden = w1.shape[0]
-    assert w1.dtype == torch.bfloat16 and w2.dtype == torch.bfloat16 and x.dtype == torch.float32
-    out = torch.empty_like(x)
-    if save:
-        xn = torch.empty(M, C, dtype=torch.bfloat16, device=x.device)
-        mean = torch.empty(M, dtype=torch.float32, device=x.device)
-        rstd = torch.empty(M, dtype=torch.float32, device=x.device)
-        h = torch.empty(M, hidden, dtype=torch.bfloat16, device=x.device)
-        act = torch.empty(M, hidden, dtype=torch.bfloat16, device=x.device)
-    else:
-        xn = mean = rstd = h = act = None
-    call('cmda_mixffn_fwd', ptr(x), ptr(gamma), ptr(beta), c_f32(eps), ptr(w1), ptr(b1), ptr(wdw), ptr(bdw), ptr(w2), ptr(b2),
-         ptr(rowscale), ptr(out), ptr(xn), ptr(mean), ptr(rstd), ptr(h), ptr(act), c_i32(B), c_i32(H), c_i32(W), c_i32(C),
-         c_i32(hidden), c_i32(MIXFFN_LINES if lines is None else lines), stream_of(x))
-    return out, (xn, mean, rstd, h, act)
-
-
 # ---- deferred weight gradients: queued by gemm(defer=True) inside a deferral scope, launched in groups (cmda_gemm_grouped) ----------
 import os as _os
 # queue key override for gemm(defer=True) (None: the current lane).  The decode head's weight gradients are queued under their own

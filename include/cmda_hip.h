@@ -100,22 +100,6 @@ typedef struct cmda_gemm_params_t {
 int cmda_gemm(const cmda_gemm_params_t* p, void* stream);
 
 
-/* The MLP half of a MiT block as ONE launch -- mmseg/models/backbones/mix_transformer.py:141-146 (Block.forward: x = x +
- * drop_path(mlp(norm2(x)))), :31-44 (Mlp.forward: fc1 -> DWConv -> GELU -> fc2), :443-455 (DWConv: 3x3, pad 1, groups = hidden):
- *   out = x + rowscale[b] * (fc2(GELU(dw3x3(fc1(LayerNorm(x))) + bdw)) + b2)
- * x / out fp32 [B*H*W, C] (the fp32 residual stream of the bf16 mode, NLC rows of B images of H x W tokens); gamma / beta / eps = norm2;
- * w1 [Hd, C] and w2 [C, Hd] bf16 (the Linear weights as stored), b1 [Hd] / b2 [C] fp32; wdw tap-major fp32 [9][Hd], bdw [Hd];
- * rowscale fp32 [B] = the per-sample DropPath factor (null = 1).  A workgroup owns whole image lines of one sample (+ a recomputed
- * halo line on each side), the hidden activations never leave the CU.  Training saves, each written when non-null: xn bf16 [M, C]
- * (normalised rows), mean / rstd fp32 [M] (both or neither), h bf16 [M, Hd] (fc1 output), act bf16 [M, Hd] (GELU output) -- the
- * operands of the weight gradients and of the backward chain.  lines_hint > 0 caps the image lines per workgroup.
- * cmda_mixffn_fwd_ok returns 1 when the fused kernel takes the shape (C % 64 == 0, 128 <= C <= 320, Hd % 64 == 0, W even, W <= 42);
- * cmda_mixffn_fwd returns CMDA_ERR_UNSUPPORTED otherwise (the caller then runs the four separate entry points). */
-int cmda_mixffn_fwd_ok(int B, int H, int W, int C, int Hd);
-int cmda_mixffn_fwd(const float* x, const float* gamma, const float* beta, float eps, const void* w1, const float* b1,
-    const float* wdw, const float* bdw, const void* w2, const float* b2, const float* rowscale, float* out, void* xn, float* mean,
-    float* rstd, void* h, void* act, int B, int H, int W, int C, int Hd, int lines_hint, void* stream);
-
 /* K x K convolution with ONE output channel, stride 1, reflection (or zero) padding `pad`, NHWC x [B,H,W,C] and khwc weights
  * [K*K*C] in the activation dtype, out fp32 [B,H,W] = act(bias[0] + sum): the last layer of the Motion-Extractor generator
  * (ReflectionPad2d(3) + Conv2d(64,1,7) + Tanh, cyclegan/cyclegan_model.py:366-369).  Built for bf16, K = 7, C = 64, pad = 3;

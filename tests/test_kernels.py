@@ -439,64 +439,3 @@ def test_rows_fill_cast_pad_nchw_pad(tgt):
         want = torch.zeros(2, 7, 9, 8)
         want[..., :3] = img.permute(0, 2, 3, 1)
         assert torch.equal(dst.cpu().float(), want.view(-1, 8).to(dt).float())
-
-
-def _mixffn_reference(x, gamma, beta, eps, w1, b1, wdw9, bdw, w2, b2, rs, B, H, W):
-    """torch fp32 restatement of Block's MLP branch (mix_transformer.py:141-146, :31-44, :443-455) with the bf16 rounding points of
-    the kernels: normalised rows, fc1 output and GELU output are rounded to bf16, everything else fp32"""
-    M, C = x.shape
-    hidden = w1.shape[0]
-    xn = F.layer_norm(x, (C,), gamma, beta, eps).bfloat16().float()
-    h = (xn @ w1.float().t() + b1).bfloat16().float()
-    hc = h.view(B, H, W, hidden).permute(0, 3, 1, 2)
-    wk = wdw9.t().reshape(hidden, 1, 3, 3)
-    u = F.conv2d(hc, wk, bdw, padding=1, groups=hidden)
-    act = F.gelu(u).permute(0, 2, 3, 1).reshape(M, hidden).bfloat16().float()
-    y = act @ w2.float().t() + b2
-    scale = rs.repeat_interleave(H * W).unsqueeze(1) if rs is not None else 1.0
-    return x + scale * y, xn, h, act
-
-
-@pytest.mark.parametrize('B,H,W,C,hidden,lines,use_rs', [(2, 5, 32, 128, 256, 0, True), (1, 4, 16, 320, 128, 0, False),
-                                                         (1, 3, 40, 192, 128, 0, True), (2, 4, 8, 256, 192, 3, False),
-                                                         (1, 6, 32, 128, 128, 1, True)])
-def test_mixffn_fused_forward(tgt, B, H, W, C, hidden, lines, use_rs):
-    """cmda_mixffn_fwd (LayerNorm -> fc1 -> dw3x3 + GELU -> fc2 -> + residual in one launch) against torch and against the four
-    separate launches: ragged last panel (H not a multiple of the lines per workgroup), widths 8 ... 40, every C / 64 instance, the
-    lines_hint cap, the training saves."""
-    torch.manual_seed(B * 1000 + W + C)
-    M = B * H * W
-    x = torch.randn(M, C) * 1.5 + 0.3
-    gamma, beta = torch.randn(C) * 0.3 + 1, torch.randn(C) * 0.1
-    w1, b1 = (torch.randn(hidden, C) * C ** -0.5).bfloat16(), torch.randn(hidden) * 0.1
-    wdw = torch.randn(hidden, 1, 3, 3) * 0.3
-    bdw = torch.randn(hidden) * 0.1
-    w2, b2 = (torch.randn(C, hidden) * hidden ** -0.5).bfloat16(), torch.randn(C) * 0.1
-    rs = (torch.rand(B) > 0.3).float() / 0.7 if use_rs else None
-    wdw9 = wdw.view(hidden, 9).t().contiguous()
-    ref, xn_ref, h_ref, act_ref = _mixffn_reference(x, gamma, beta, 1e-6, w1, b1, wdw9, bdw, w2, b2, rs, B, H, W)
-    d = [tgt.to(t) for t in (x, gamma, beta, w1, b1, wdw9, bdw, w2, b2)]
-    rsd = tgt.to(rs)
-    old_mf, ops.MIXFFN = ops.MIXFFN, True
-    assert ops.mixffn_ok(d[0], B, H, W, C, hidden)
-    ops.MIXFFN = old_mf
-    for save in (True, False):
-        out, (xn, mean, rstd, h, act) = ops.mixffn_fwd(d[0], d[1], d[2], 1e-6, *d[3:], rsd, B, H, W, save=save, lines=lines)
-        assert_close(out, ref, 6e-3, name='mixffn fused vs torch')
-        if save:
-            assert_close(xn, xn_ref, 8e-3, name='mixffn saved normalised rows')
-            assert_close(h, h_ref, 8e-3, name='mixffn saved fc1 output')
-            assert_close(act, act_ref, 1.2e-2, name='mixffn saved activation')
-            mu = x.mean(1)
-            assert_close(mean, mu, 1e-5, atol=1e-6, name='mixffn saved mean')
-            assert_close(rstd, (x.var(1, unbiased=False) + 1e-6).rsqrt(), 1e-5, name='mixffn saved rstd')
-    # the four separate launches (the path the fused kernel replaces): same rounding points, other summation orders
-    xn2, m2, r2 = ops.layernorm_fwd(d[0], d[1], d[2], 1e-6, out_dtype=torch.bfloat16)
-    hh = torch.empty(M, hidden, dtype=torch.bfloat16, device=tgt.device)
-    ops.gemm(ops.plain_view(xn2, M, C), ops.plain_view(d[3], hidden, C), hh, M, hidden, C, dtype=1, bias=d[4])
-    aa = ops.dwconv_fwd(hh, d[5], d[6], B, H, W, hidden, 1, 'gelu')
-    y2 = torch.empty(M, C, dtype=torch.float32, device=tgt.device)
-    ops.gemm(ops.plain_view(aa, M, hidden), ops.plain_view(d[7], C, hidden), y2, M, C, hidden, dtype=1, bias=d[8], res=d[0],
-             rowscale=rsd, rows_per_scale=H * W)
-    assert_close(out, y2, 6e-3, name='mixffn fused vs separate launches')
-    assert_close(h, hh, 8e-3, name='mixffn h vs separate launches') if save else None
