@@ -33,12 +33,20 @@ class AttentionAvgFusion(nn.Module):
 
     @ops.sited('fusion')
     def fwd(self, feats_i, feats_e, B, save=True, into=None):
-        """into: optional list of 4 pre-allocated tensors the fused maps are written into"""
+        """into: optional list of 4 pre-allocated tensors the fused maps are written into.
+        The image-side blocks (basic_block[0, 2, 4, 6]) and the event-side blocks (1, 3, 5, 7) never see each other's data before
+        the average (attention_avg_fusion.py:45-50): with lanes on, the four event-side blocks run on the side lane next to the four
+        image-side ones -- the fusion module was ~4.5 ms of small dependent kernels on ONE lane of the step's single-lane phase."""
         outs, saved = [], []
         draw_drop_path(self, list(self.basic_block), B, feats_i[0][0].device)   # one RNG call for the eight blocks
-        for i, ((xi, H, W), (xe, _, _)) in enumerate(zip(feats_i, feats_e)):
-            yi, si = self.basic_block[2 * i].fwd(xi, B, H, W, save=save)
-            ye, se = self.basic_block[2 * i + 1].fwd(xe, B, H, W, save=save)
+        pools = [blk._dp_pool[0] for blk in self.basic_block if getattr(blk, '_dp_pool', None) is not None]
+        ev = []
+        with rt.lane('enc', *[x for x, _, _ in feats_e], *pools):
+            for i, (xe, H, W) in enumerate(feats_e):
+                ev.append(self.basic_block[2 * i + 1].fwd(xe, B, H, W, save=save))
+        im = [self.basic_block[2 * i].fwd(xi, B, H, W, save=save) for i, (xi, H, W) in enumerate(feats_i)]
+        rt.join_lanes('enc')
+        for i, ((yi, si), (ye, se), (_, H, W)) in enumerate(zip(im, ev, feats_i)):
             self.basic_block[2 * i]._dp_pool = self.basic_block[2 * i + 1]._dp_pool = None
             outs.append((ops.axpby(yi, ye, 0.5, 0.5, out=into[i] if into is not None else None), H, W))
             saved.append((si, se, H, W))
@@ -47,15 +55,17 @@ class AttentionAvgFusion(nn.Module):
     @ops.sited('fusion')
     def bwd(self, saved, dfused, B):
         """dfused: list of 4 gradients (or None).  Returns (d image feats, d event feats) as lists."""
-        di, de = [], []
-        for i, (si, se, H, W) in enumerate(saved):
-            d = dfused[i]
-            if d is None:
-                di.append(None), de.append(None)
-                continue
-            half = ops.axpby(d, None, 0.5, 0.0)
-            di.append(self.basic_block[2 * i].bwd(si, half, B, H, W))
-            de.append(self.basic_block[2 * i + 1].bwd(se, half, B, H, W))
+        halves = [ops.axpby(d, None, 0.5, 0.0) if d is not None else None for d in dfused]
+        de = [None] * len(saved)
+        with rt.lane('enc', *[h for h in halves if h is not None]):
+            for i, (si, se, H, W) in enumerate(saved):
+                if halves[i] is not None:
+                    de[i] = self.basic_block[2 * i + 1].bwd(se, halves[i], B, H, W)
+            if rt.concurrency():
+                ops.gemm_flush_deferred()   # the side lane's own queue of weight gradients (the caller flushes the current lane's)
+        di = [self.basic_block[2 * i].bwd(si, halves[i], B, H, W) if halves[i] is not None else None
+              for i, (si, se, H, W) in enumerate(saved)]
+        rt.join_lanes('enc')
         return di, de
 
     def forward(self, image_features, events_features):
