@@ -130,7 +130,8 @@ int launch_dtype(GemmParams& p, void* stream) {
       return cmda_gemm_glds_t2_(p, stream);
     }
   }
-  if (p.colsum) return CMDA_ERR_UNSUPPORTED;  // the fused bias gradient lives in the LDS-DMA kernel only
+  // the fused bias gradient lives in the LDS-DMA kernels only (bf16: above; split-bf16: the lean weight-gradient form)
+  if (p.colsum && !(p.dtype == CMDA_F32X3 && cmda_gemm_x3_lean_ok_(p))) return CMDA_ERR_UNSUPPORTED;
   return cmda_gemm_reg_(p, tile, stream);
 }
 

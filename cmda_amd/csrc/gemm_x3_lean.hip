@@ -9,8 +9,9 @@
 // out exactly like the bf16 kernels' LDS images, and the k-loop is gemm_lean_kernel's with three MFMAs per fragment pair
 // (a_lo b_hi + a_hi b_lo + a_hi b_hi, fp32 accumulate: gemm_x3.hip).  The split of tile kt + 1 and the MFMAs of tile kt sit in the
 // same barrier interval (double-buffered hi / lo tiles), so the VALU pass hides under the matrix pipe.
-// Eligibility (host): CMDA_F32X3, plain operands, A K-contiguous, B K-contiguous or K-strided, K % 32 == 0, no batch / split-K /
-// atomic / column-sum / patch-store output; 64 x 64 tiles on eight waves, chosen where the general kernel would run its 64 x 64 or
+// Eligibility (host): CMDA_F32X3, plain operands, K % 32 == 0, no batch / patch-store output; A K-contiguous with B K-contiguous or
+// K-strided (Linear forward / data gradient: no split-K, atomics or column sums), or BOTH K-strided with atomic output (weight
+// gradient: split-K chosen here, bias gradient fused); 64 x 64 tiles on eight waves, chosen where the general kernel would run its 64 x 64 or
 // 128 x 64 tile (the small grids of the encoders).
 #include "gemm_kernels.h"
 
@@ -27,13 +28,18 @@ struct X3LeanParams {
   int M, N, nkt, tiles_n;
   int ntile, rows_per_scale, act, flags;   // flags: 4 c_vec_ok
   float alpha, beta;
+  float* colsum;                           // weight-gradient form: bias gradient [M] += sum over k of A(k, m) (workgroups of n-tile 0)
+  int kt_per;                              // weight-gradient form: k-tiles per split (grid.z = splits)
 };
 
 // 64 x 64 tile on eight waves = 4 (rows of 16) x 2 (columns of 32); 32-deep k-tiles: three fp32 stages of 16 KiB (two in flight while
 // one is split) + two hi / lo sets of 16 KiB = 80 KiB, i.e. TWO workgroups per CU (a lone workgroup per CU left the k-loop waiting
 // on its own DMA: 64-deep tiles with one tile in flight measured 15.0 us for 4096 x 320 x 320 against 16.9 for the general kernel)
-template <bool BKS>
+// AKS (with BKS): the WEIGHT-GRADIENT form -- both operands K-strided ([tokens][channels] row-major: dW = dy^T x), split-K over the
+// tokens (grid.z), fp32 atomic accumulation into C, bias gradient (column sums of dy) fused
+template <bool AKS, bool BKS>
 __global__ __launch_bounds__(512, 2) void gemm_x3_lean_kernel(X3LeanParams q) {
+  static_assert(!AKS || BKS, "A K-strided: weight-gradient form only");
   constexpr int NW = 8, NT = 512, BM = 64, BN = 64, BK = 32, TN = 2, NSTG = 3;
   constexpr int F_A = BM * BK, F_B = BN * BK;                 // fp32 elements of a stage (A | B)
   constexpr int H_A = BM * BK, H_B = BN * BK;                 // bf16 elements of a hi (or lo) tile
@@ -47,7 +53,9 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_lean_kernel(X3LeanParams q) {
   constexpr int SET = 2 * (H_A + H_B);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1, g = lane >> 4, l15 = lane & 15;
-  const int M = q.M, N = q.N, nkt = q.nkt, tiles_n = q.tiles_n, ntile = q.ntile;
+  const int M = q.M, N = q.N, tiles_n = q.tiles_n, ntile = q.ntile;
+  const int kt0 = AKS ? blockIdx.z * q.kt_per : 0;
+  const int nkt = AKS ? min(q.nkt - kt0, q.kt_per) : q.nkt;   // k-tiles of THIS workgroup
   int bt = blockIdx.x;
   {   // XCD-contiguous tile ranges (gemm_lean_kernel)
     const int qq = ntile >> 3, rr = ntile & 7, xcd = bt & 7, loc = bt >> 3;
@@ -63,12 +71,17 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_lean_kernel(X3LeanParams q) {
   const char* curB;
   int stepA, stepB;
   const char* zero = reinterpret_cast<const char*>(g_zero16);
-  const int lnA = tid >> 3, chA = tid & 7;
-  {
+  const int lnA = AKS ? tid >> 4 : tid >> 3, chA = AKS ? tid & 15 : tid & 7;
+  if constexpr (!AKS) {
     const long r = m0 + lnA;
     const bool ok = r < M;
     curA = ok ? reinterpret_cast<const char*>(q.A + r * q.lda + chA * 4) : zero;
     stepA = ok ? BK * 4 : 0;
+  } else {                  // line = k (token), 64 consecutive output rows m
+    const long c = m0 + chA * 4;
+    const bool ok = c + 4 <= M;
+    curA = ok ? reinterpret_cast<const char*>(q.A + ((long)kt0 * BK + lnA) * q.lda + c) : zero;
+    stepA = ok ? (int)((long)BK * q.lda * 4) : 0;
   }
   const int lnB = BKS ? tid >> 4 : tid >> 3, chB = BKS ? tid & 15 : tid & 7;
   if constexpr (!BKS) {
@@ -79,7 +92,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_lean_kernel(X3LeanParams q) {
   } else {
     const long c = n0 + chB * 4;
     const bool ok = c + 4 <= N;
-    curB = ok ? reinterpret_cast<const char*>(q.B + (long)lnB * q.ldb + c) : zero;
+    curB = ok ? reinterpret_cast<const char*>(q.B + ((long)kt0 * BK + lnB) * q.ldb + c) : zero;
     stepB = ok ? (int)((long)BK * q.ldb * 4) : 0;
   }
   auto issue = [&](int stage) {
@@ -92,9 +105,11 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_lean_kernel(X3LeanParams q) {
   // ---- split pass: 16 bytes of fp32 -> 8 bytes of the hi tile + 8 bytes of the lo tile.  bf16 images: K-contiguous [line][32 k]
   //      (64-byte lines of four 16-byte chunks, slot = chunk ^ ((line >> 2) & 3): lines r and r + 4 start on the same bank);
   //      K-strided [32 k][64 columns] (128-byte lines, slot = chunk ^ (k & 7): the bf16 kernels' image) ----
-  const int offA = lnA * BK + ((((chA >> 1)) ^ ((lnA >> 2) & 3)) << 3) + ((chA & 1) << 2);
+  const int offA = AKS ? lnA * BM + ((((chA >> 1)) ^ (lnA & 7)) << 3) + ((chA & 1) << 2)
+                       : lnA * BK + ((((chA >> 1)) ^ ((lnA >> 2) & 3)) << 3) + ((chA & 1) << 2);
   const int offB = BKS ? lnB * BN + ((((chB >> 1)) ^ (lnB & 7)) << 3) + ((chB & 1) << 2)
                        : lnB * BK + ((((chB >> 1)) ^ ((lnB >> 2) & 3)) << 3) + ((chB & 1) << 2);
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
   auto split = [&](int stage, int set) {
     const float* st = sF + stage * (F_A + F_B);
     bf16_t* ha = sH + set * SET;
@@ -102,6 +117,10 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_lean_kernel(X3LeanParams q) {
     float va[4], vb[4], hi[4], lo[4];
     ld4(st + tid * 4, va);
     ld4(st + F_A + tid * 4, vb);
+    if constexpr (AKS) {   // bias gradient: this thread's four columns of dy, every token of its line index
+#pragma unroll
+      for (int e = 0; e < 4; ++e) csum[e] += va[e];
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       hi[e] = bf2f(f2bf(va[e]));
@@ -147,11 +166,20 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_lean_kernel(X3LeanParams q) {
     const bf16_t* bH = aH + 2 * H_A;
     const bf16_t* bL = bH + H_B;
     u16x8 fah, fal, fbh[TN], fbl[TN];
-    {
+    if constexpr (!AKS) {
       const int row = wm * 16 + l15;
       const int off = row * BK + ((g ^ ((row >> 2) & 3)) << 3);
       fah = *reinterpret_cast<const u16x8*>(&aH[off]);
       fal = *reinterpret_cast<const u16x8*>(&aL[off]);
+    } else {
+      const int mr = wm * 16, qd = l15 >> 2, pp = l15 & 3;
+      const int k0 = 8 * g + qd, k1 = k0 + 4;
+      const int cidx = (mr >> 3) + (pp >> 1), half = (pp & 1) << 2;
+      const int o0 = k0 * BM + ((cidx ^ (k0 & 7)) << 3) + half, o1 = k1 * BM + ((cidx ^ (k1 & 7)) << 3) + half;
+      const u16x4 h0 = lds_read_tr16(&aH[o0]), h1 = lds_read_tr16(&aH[o1]);
+      const u16x4 l0 = lds_read_tr16(&aL[o0]), l1 = lds_read_tr16(&aL[o1]);
+      fah = u16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+      fal = u16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -197,6 +225,33 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_lean_kernel(X3LeanParams q) {
     mfma_tile(set);
     if (++stg == NSTG) stg = 0;
     set ^= 1;
+  }
+  if constexpr (AKS) {
+    // ---- weight-gradient epilogue: fp32 atomics into C (split-K partial), bias gradient from the n-tile-0 workgroups ----
+    if (nkt <= 0) return;
+    const float alpha = q.alpha;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const long n = n0 + wn * 16 * TN + j * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long m = m0 + wm * 16 + 4 * g + r;
+        if (m < M && n < N) atomicAdd(q.C + m * q.ldc + n, alpha * acc[j][r]);
+      }
+    }
+    if (q.colsum && nt == 0) {   // 32 threads (lines) hold partial sums of the same four columns: fold through LDS
+      __syncthreads();
+      float* red = reinterpret_cast<float*>(smem);   // [32 lines][64 columns]
+      st4(red + lnA * 64 + chA * 4, csum);
+      __syncthreads();
+      if (tid < 64 && m0 + tid < M) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int l = 0; l < 32; ++l) s += red[l * 64 + tid];
+        atomicAdd(q.colsum + m0 + tid, s);
+      }
+    }
+    return;
   }
   // residual rows of this thread: requested before the accumulators go through LDS
   const bool has_res = q.res != nullptr;
@@ -279,9 +334,22 @@ int launch_x3_lean(const GemmParams& p, void* stream) {
   q.act = p.act;
   q.flags = p.c_vec_ok ? 4 : 0;
   q.alpha = p.alpha; q.beta = p.beta;
-  const dim3 grid((unsigned)tiles), blk(512);
-  if (p.b_kstrided) CMDA_LAUNCH((gemm_x3_lean_kernel<true>), grid, blk, 0, stream, q);
-  else CMDA_LAUNCH((gemm_x3_lean_kernel<false>), grid, blk, 0, stream, q);
+  q.colsum = p.colsum;
+  q.kt_per = q.nkt;
+  const dim3 blk(512);
+  if (p.a_kstrided) {
+    // split-K over the tokens: ~two workgroups per CU in all, at least four k-tiles per split (one fp32 atomic per output element
+    // per split)
+    int splits = (int)std::max<long>(1, std::min<long>(q.nkt / 4, (512 + tiles - 1) / tiles));
+    splits = std::min(splits, 1024);
+    q.kt_per = (q.nkt + splits - 1) / splits;
+    splits = (q.nkt + q.kt_per - 1) / q.kt_per;
+    CMDA_LAUNCH((gemm_x3_lean_kernel<true, true>), dim3((unsigned)tiles, 1, (unsigned)splits), blk, 0, stream, q);
+    CMDA_CHECK_LAUNCH();
+  }
+  const dim3 grid((unsigned)tiles);
+  if (p.b_kstrided) CMDA_LAUNCH((gemm_x3_lean_kernel<false, true>), grid, blk, 0, stream, q);
+  else CMDA_LAUNCH((gemm_x3_lean_kernel<false, false>), grid, blk, 0, stream, q);
   CMDA_CHECK_LAUNCH();
 }
 
@@ -292,9 +360,13 @@ bool cmda_gemm_x3_lean_ok_(const cmda_gemm_params_t& p) {
   auto plain = [](const GemmView& v) {
     return v.conv == 0 && v.vec_ok && (v.ld % 4) == 0 && v.R < (1L << 31) && v.Cc < (1L << 31) && (reinterpret_cast<uintptr_t>(v.ptr) % 16) == 0;
   };
-  return p.dtype == CMDA_F32X3 && !p.a_kstrided && plain(p.A) && plain(p.B) && (p.K % 32) == 0 && p.K >= 32 && p.batch == 1 && p.batch2 <= 1 &&
-         p.splits <= 1 && !p.atomic && !p.colsum && p.c_perm_ci == 0 && p.c_patch_ow == 0 && p.out_f32 && (p.N % 4) == 0 &&
-         (!p.b_kstrided || 32L * p.B.ld * 4 < (1L << 31)) && !(p.tile_hint > 0 && (p.tile_hint & 8192));   // (tile_hint bit 13: general kernel, tuning A/B)
+  if (!(p.dtype == CMDA_F32X3 && plain(p.A) && plain(p.B) && (p.K % 32) == 0 && p.K >= 32 && p.batch == 1 && p.batch2 <= 1 &&
+        p.c_perm_ci == 0 && p.c_patch_ow == 0 && p.out_f32 && (p.N % 4) == 0 && !(p.tile_hint > 0 && (p.tile_hint & 8192))))   // (bit 13: general kernel, tuning A/B)
+    return false;
+  if (p.a_kstrided)   // weight-gradient form: dW (+)= dy^T x with fp32 atomics, any split count (the kernel chooses its own)
+    return p.b_kstrided && p.atomic && (p.M % 4) == 0 && !p.bias && !p.res && !p.rowscale && p.act == 0 && p.beta == 0.f &&
+           32L * p.A.ld * 4 < (1L << 31) && 32L * p.B.ld * 4 < (1L << 31);
+  return p.splits <= 1 && !p.atomic && !p.colsum && (!p.b_kstrided || 32L * p.B.ld * 4 < (1L << 31));
 }
 
 int cmda_gemm_x3_lean_(const cmda_gemm_params_t& p, void* stream) { return launch_x3_lean(p, stream); }

@@ -33,6 +33,10 @@ def linear_bwd(dy, x, weight, bias, M, K, *, need_dx=True, dx_out=None, dx_beta=
     xv = plain_view(x, M, K, ld=x_ld, offset=x_off)
     fused = (bias is not None and rt.tag() == 1 and dyv_k.vec_ok and xv.vec_ok and N % 8 == 0 and K % 8 == 0
              and (dy_ld or N) % 8 == 0 and (x_ld or K) % 8 == 0)
+    # split-bf16 mode: the lean weight-gradient kernel (csrc/gemm_x3_lean.hip) folds the bias gradient as well -- its eligibility
+    # (cmda_gemm_x3_lean_ok_): plain fp32 operands, token count a multiple of the 32-deep k-tile, 16-byte rows
+    fused = fused or (bias is not None and rt.tag() == 2 and dyv_k.vec_ok and xv.vec_ok and M % 32 == 0 and N % 4 == 0 and K % 4 == 0
+                      and (dy_ld or N) % 4 == 0 and (x_ld or K) % 4 == 0 and ops.GEMM_TILE_HINT == 0)
     def wgrad():   # off the critical dgrad chain when a block-level batch is open (runtime.lane_batch)
         ops.gemm(dyv_k, xv, rt.grad(weight), N, K, M, a_kstrided=True, b_kstrided=True, dtype=rt.tag(), atomic=True,
                  splits=0, colsum=rt.grad(bias) if fused else None,   # bias gradient rides along in the wgrad kernel
