@@ -307,6 +307,8 @@ def gemm_roofline(step, workload):
     if os.environ.get('CMDA_BENCH_GEMM_HIST'):   # per-shape table for tuning (tools/gpu): where the GEMM time of a step goes
         hist = {}
         for f, e0, e1, _, key in prof:
+            key = tuple(v for v in key if isinstance(v, (int, bool, str)) and v not in ('mit', 'head', 'fusion', 'generator', 'other'))
+            key = tuple(-1 if isinstance(v, str) else v for v in key)   # ('grouped' / 'pair' markers)
             h = hist.setdefault(key, [0, 0.0, 0.0])
             h[0] += 1
             h[1] += e0.elapsed_time(e1)

@@ -86,14 +86,76 @@ __global__ __launch_bounds__(256) void conv_co1_kernel(const bf16_t* __restrict_
   }
 }
 
+// fp32 storage (the exact-fp32 and split-bf16 parity modes): plain FMAs, the channels in chunks of 16 so that the (16 + K - 1)^2
+// pixel tile fits LDS (pixel pitch 20 floats = 80 bytes: the 16 pixels a ds_read_b128 services together start 20 banks apart).  As an
+// N = 1 GEMM the layer cost the split-bf16 step 3.0 ms (524288 x 1 x 3136 at 1.1 TFLOP/s, round 5).
+template <int K, int C>
+__global__ __launch_bounds__(256) void conv_co1_f32_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ out, int H, int W,
+                                                           int pad, int reflect, int act) {
+  constexpr int T = 16, TW = T + K - 1, CC = 16, PITCH = CC + 4, NCH = C / CC;
+  __shared__ __attribute__((aligned(16))) float sX[TW * TW * PITCH];
+  __shared__ __attribute__((aligned(16))) float sW[K * K * C];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int ox0 = blockIdx.x * T, oy0 = blockIdx.y * T, b = blockIdx.z;
+  const float* xb = x + (long)b * H * W * C;
+  for (int i = tid; i < K * K * C / 4; i += 256) *reinterpret_cast<float4*>(&sW[i * 4]) = *reinterpret_cast<const float4*>(&w[i * 4]);
+  float acc[4] = {bias ? bias[0] : 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int cc = 0; cc < NCH; ++cc) {
+    __syncthreads();   // (the previous chunk's tile has been consumed; first pass: nothing to wait for)
+    for (int i = tid; i < TW * TW * (CC / 4); i += 256) {
+      const int p = i / (CC / 4), c4 = i - p * (CC / 4);
+      const int py = p / TW, px = p - py * TW;
+      int ih = oy0 + py - pad, iw = ox0 + px - pad;
+      if (reflect) {
+        ih = reflect1(ih, H);
+        iw = reflect1(iw, W);
+      }
+      const bool ok = ih >= 0 && ih < H && iw >= 0 && iw < W;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) v = *reinterpret_cast<const float4*>(&xb[((long)ih * W + iw) * C + cc * CC + c4 * 4]);
+      *reinterpret_cast<float4*>(&sX[p * PITCH + c4 * 4]) = v;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int kh = 0; kh < K; ++kh) {
+#pragma unroll
+      for (int kw = 0; kw < K; ++kw) {
+        const float* px = &sX[((ty + kh) * TW + tx + kw) * PITCH];
+        const float* pw = &sW[(kh * K + kw) * C + cc * CC];
+#pragma unroll
+        for (int c4 = 0; c4 < CC / 4; ++c4) {
+          const float4 a = *reinterpret_cast<const float4*>(px + c4 * 4), ww = *reinterpret_cast<const float4*>(pw + c4 * 4);
+          acc[0] = fmaf(a.x, ww.x, acc[0]);
+          acc[1] = fmaf(a.y, ww.y, acc[1]);
+          acc[2] = fmaf(a.z, ww.z, acc[2]);
+          acc[3] = fmaf(a.w, ww.w, acc[3]);
+        }
+      }
+    }
+  }
+  const int oy = oy0 + ty, ox = ox0 + tx;
+  if (oy < H && ox < W) {
+    float v = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    if (act == 1) v = fmaxf(v, 0.f);
+    else if (act == 3) v = tanhf(v);
+    out[((long)b * H + oy) * W + ox] = v;
+  }
+}
+
 }  // namespace
 
 extern "C" int cmda_conv_co1(const void* x, const void* w, const float* bias, float* out, int B, int H, int W, int C, int K,
                              int pad, int reflect, int act, int dtype, void* stream) {
   if (B <= 0 || H <= 0 || W <= 0) return CMDA_OK;
-  if (dtype != CMDA_BF16 || K != 7 || C != 64 || pad != 3 || (act != 0 && act != 1 && act != 3)) return CMDA_ERR_UNSUPPORTED;
+  if ((dtype != CMDA_BF16 && dtype != CMDA_F32) || K != 7 || C != 64 || pad != 3 || (act != 0 && act != 1 && act != 3)) return CMDA_ERR_UNSUPPORTED;
   if (reflect && (H <= pad || W <= pad)) return CMDA_ERR_SHAPE;
   const dim3 grid((W + 15) / 16, (H + 15) / 16, B);
+  if (dtype == CMDA_F32) {
+    CMDA_LAUNCH((conv_co1_f32_kernel<7, 64>), grid, dim3(256), 0, stream, (const float*)x, (const float*)w, bias, out, H, W, pad, reflect, act);
+    CMDA_CHECK_LAUNCH();
+  }
   CMDA_LAUNCH((conv_co1_kernel<7, 64>), grid, dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)w, bias, out, H, W, pad, reflect, act);
   CMDA_CHECK_LAUNCH();
 }

@@ -9,7 +9,7 @@
 // out exactly like the bf16 kernels' LDS images, and the k-loop is gemm_lean_kernel's with three MFMAs per fragment pair
 // (a_lo b_hi + a_hi b_lo + a_hi b_hi, fp32 accumulate: gemm_x3.hip).  The split of tile kt + 1 and the MFMAs of tile kt sit in the
 // same barrier interval (double-buffered hi / lo tiles), so the VALU pass hides under the matrix pipe.
-// Eligibility (host): CMDA_F32X3, plain operands, K % 32 == 0, no batch / patch-store output; A K-contiguous with B K-contiguous or
+// Eligibility (host): CMDA_F32X3, plain operands, K % 32 == 0, no patch-store output (batch x batch2 entries = grid.z: the unfused attention GEMMs); A K-contiguous with B K-contiguous or
 // K-strided (Linear forward / data gradient: no split-K, atomics or column sums), or BOTH K-strided with atomic output (weight
 // gradient: split-K chosen here, bias gradient fused); 64 x 64 tiles on eight waves, chosen where the general kernel would run its 64 x 64 or
 // 128 x 64 tile (the small grids of the encoders).
@@ -29,7 +29,9 @@ struct X3LeanParams {
   int ntile, rows_per_scale, act, flags;   // flags: 4 c_vec_ok
   float alpha, beta;
   float* colsum;                           // weight-gradient form: bias gradient [M] += sum over k of A(k, m) (workgroups of n-tile 0)
-  int kt_per;                              // weight-gradient form: k-tiles per split (grid.z = splits)
+  int kt_per;                              // weight-gradient form: k-tiles per split
+  int splits, batch2;                      // grid.z = batch * batch2 * splits (the attention GEMMs of the unfused fp32 path: batch x heads)
+  long a_bs, a_b2s, b_bs, b_b2s, c_bs, c_b2s, r_bs, r_b2s;   // element strides of the outer / inner batch index
 };
 
 // 64 x 64 tile on eight waves = 4 (rows of 16) x 2 (columns of 32); 32-deep k-tiles: three fp32 stages of 16 KiB (two in flight while
@@ -54,8 +56,16 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_lean_kernel(X3LeanParams q) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1, g = lane >> 4, l15 = lane & 15;
   const int M = q.M, N = q.N, tiles_n = q.tiles_n, ntile = q.ntile;
-  const int kt0 = AKS ? blockIdx.z * q.kt_per : 0;
+  const int bz = (int)blockIdx.z / q.splits, ksplit = (int)blockIdx.z - bz * q.splits;
+  const int kt0 = AKS ? ksplit * q.kt_per : 0;
   const int nkt = AKS ? min(q.nkt - kt0, q.kt_per) : q.nkt;   // k-tiles of THIS workgroup
+  {   // batch entry: operand / output bases move, everything else is per problem
+    const int b1 = bz / q.batch2, b2 = bz - b1 * q.batch2;
+    q.A += b1 * q.a_bs + b2 * q.a_b2s;
+    q.B += b1 * q.b_bs + b2 * q.b_b2s;
+    q.C += b1 * q.c_bs + b2 * q.c_b2s;
+    if (q.res) q.res += b1 * q.r_bs + b2 * q.r_b2s;
+  }
   int bt = blockIdx.x;
   {   // XCD-contiguous tile ranges (gemm_lean_kernel)
     const int qq = ntile >> 3, rr = ntile & 7, xcd = bt & 7, loc = bt >> 3;
@@ -336,18 +346,26 @@ int launch_x3_lean(const GemmParams& p, void* stream) {
   q.alpha = p.alpha; q.beta = p.beta;
   q.colsum = p.colsum;
   q.kt_per = q.nkt;
+  q.splits = 1;
+  q.batch2 = p.batch2 > 0 ? p.batch2 : 1;
+  q.a_bs = p.A.batch_stride; q.a_b2s = p.A.batch2_stride; q.b_bs = p.B.batch_stride; q.b_b2s = p.B.batch2_stride;
+  q.c_bs = p.c_batch_stride; q.c_b2s = p.c_batch2_stride; q.r_bs = p.res_batch_stride; q.r_b2s = p.res_batch2_stride;
+  const long nb = (long)p.batch * q.batch2;
   const dim3 blk(512);
   if (p.a_kstrided) {
     // split-K over the tokens: ~two workgroups per CU in all, at least four k-tiles per split (one fp32 atomic per output element
     // per split)
-    int splits = (int)std::max<long>(1, std::min<long>(q.nkt / 4, (512 + tiles - 1) / tiles));
+    int splits = (int)std::max<long>(1, std::min<long>(q.nkt / 4, (512 + tiles * nb - 1) / (tiles * nb)));
     splits = std::min(splits, 1024);
     q.kt_per = (q.nkt + splits - 1) / splits;
     splits = (q.nkt + q.kt_per - 1) / q.kt_per;
-    CMDA_LAUNCH((gemm_x3_lean_kernel<true, true>), dim3((unsigned)tiles, 1, (unsigned)splits), blk, 0, stream, q);
+    q.splits = splits;
+    if (nb * splits > 65535) return CMDA_ERR_SHAPE;
+    CMDA_LAUNCH((gemm_x3_lean_kernel<true, true>), dim3((unsigned)tiles, 1, (unsigned)(nb * splits)), blk, 0, stream, q);
     CMDA_CHECK_LAUNCH();
   }
-  const dim3 grid((unsigned)tiles);
+  if (nb > 65535) return CMDA_ERR_SHAPE;
+  const dim3 grid((unsigned)tiles, 1, (unsigned)nb);
   if (p.b_kstrided) CMDA_LAUNCH((gemm_x3_lean_kernel<false, true>), grid, blk, 0, stream, q);
   else CMDA_LAUNCH((gemm_x3_lean_kernel<false, false>), grid, blk, 0, stream, q);
   CMDA_CHECK_LAUNCH();
@@ -360,7 +378,10 @@ bool cmda_gemm_x3_lean_ok_(const cmda_gemm_params_t& p) {
   auto plain = [](const GemmView& v) {
     return v.conv == 0 && v.vec_ok && (v.ld % 4) == 0 && v.R < (1L << 31) && v.Cc < (1L << 31) && (reinterpret_cast<uintptr_t>(v.ptr) % 16) == 0;
   };
-  if (!(p.dtype == CMDA_F32X3 && plain(p.A) && plain(p.B) && (p.K % 32) == 0 && p.K >= 32 && p.batch == 1 && p.batch2 <= 1 &&
+  const long nb = (long)p.batch * (p.batch2 > 0 ? p.batch2 : 1);
+  auto bs_ok = [](const GemmView& v) { return (v.batch_stride % 4) == 0 && (v.batch2_stride % 4) == 0; };
+  if (!(p.dtype == CMDA_F32X3 && plain(p.A) && plain(p.B) && (p.K % 32) == 0 && p.K >= 32 && p.batch >= 1 && nb <= 65535 && bs_ok(p.A) && bs_ok(p.B) &&
+        (p.c_batch_stride % 4) == 0 && (p.c_batch2_stride % 4) == 0 && (nb == 1 || !p.colsum) &&
         p.c_perm_ci == 0 && p.c_patch_ow == 0 && p.out_f32 && (p.N % 4) == 0 && !(p.tile_hint > 0 && (p.tile_hint & 8192))))   // (bit 13: general kernel, tuning A/B)
     return false;
   if (p.a_kstrided)   // weight-gradient form: dW (+)= dy^T x with fp32 atomics, any split count (the kernel chooses its own)

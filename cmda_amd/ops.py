@@ -515,7 +515,7 @@ def permute4(src, dst, dims, perm, flipmask=0, accumulate=False):
 
 
 def conv_co1_ok(x, C, K, pad):
-    return x.dtype == torch.bfloat16 and C == 64 and K == 7 and pad == 3
+    return x.dtype in (torch.bfloat16, torch.float32) and C == 64 and K == 7 and pad == 3
 
 
 def conv_co1(x, w, bias, B, H, W, C, K, pad, reflect, act):

@@ -102,8 +102,8 @@ int cmda_gemm(const cmda_gemm_params_t* p, void* stream);
 
 /* K x K convolution with ONE output channel, stride 1, reflection (or zero) padding `pad`, NHWC x [B,H,W,C] and khwc weights
  * [K*K*C] in the activation dtype, out fp32 [B,H,W] = act(bias[0] + sum): the last layer of the Motion-Extractor generator
- * (ReflectionPad2d(3) + Conv2d(64,1,7) + Tanh, cyclegan/cyclegan_model.py:366-369).  Built for bf16, K = 7, C = 64, pad = 3;
- * CMDA_ERR_UNSUPPORTED otherwise (the caller then uses cmda_gemm). */
+ * (ReflectionPad2d(3) + Conv2d(64,1,7) + Tanh, cyclegan/cyclegan_model.py:366-369).  Built for K = 7, C = 64, pad = 3 in bf16 (packed
+ * dot products) and fp32 storage (both parity modes); CMDA_ERR_UNSUPPORTED otherwise (the caller then uses cmda_gemm). */
 int cmda_conv_co1(const void* x, const void* w, const float* bias, float* out, int B, int H, int W, int C, int K, int pad,
     int reflect, int act, int dtype, void* stream);
 

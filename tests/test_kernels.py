@@ -403,12 +403,14 @@ def test_gemm_fp32_residual_epilogue(tgt, M, N, K):
     check_le('fp32 residual epilogue: max abs err', err, 2e-3, strict=True)
 
 
-def test_conv_co1(tgt):
-    """the generator's last layer, Conv2d(64, 1, 7, padding 3 reflect) + tanh (cyclegan_model.py:372-374), as a dot-product stencil"""
+@pytest.mark.parametrize('dt,tol', [(torch.bfloat16, 2e-3), (torch.float32, 2e-5)])
+def test_conv_co1(tgt, dt, tol):
+    """the generator's last layer, Conv2d(64, 1, 7, padding 3 reflect) + tanh (cyclegan_model.py:372-374), as a dot-product stencil
+    (bf16: v_dot2; fp32 storage -- both parity modes --: plain FMAs over channel chunks)"""
     torch.manual_seed(3)
     B, H, W, C, K = 2, 19, 23, 64, 7
-    x = torch.randn(B, C, H, W).bfloat16()
-    w = (torch.randn(1, C, K, K) * 0.05).bfloat16()
+    x = torch.randn(B, C, H, W).to(dt)
+    w = (torch.randn(1, C, K, K) * 0.05).to(dt)
     bias = torch.randn(1)
     for reflect in (True, False):
         xp = F.pad(x.float(), (3, 3, 3, 3), mode='reflect') if reflect else F.pad(x.float(), (3, 3, 3, 3))
@@ -417,7 +419,7 @@ def test_conv_co1(tgt):
         wd = tgt.to(w.permute(0, 2, 3, 1).reshape(-1).contiguous())
         assert ops.conv_co1_ok(xd, C, K, 3)
         out = ops.conv_co1(xd, wd, tgt.to(bias), B, H, W, C, K, 3, reflect, 'tanh')
-        assert_close(out, ref, 2e-3, name=f'conv_co1 reflect={reflect}')
+        assert_close(out, ref, tol, name=f'conv_co1 reflect={reflect}')
 
 
 def test_rows_fill_cast_pad_nchw_pad(tgt):
