@@ -501,6 +501,31 @@ extern "C" int cmda_permute4(const void* src, void* dst, int d0, int d1, int d2,
   return CMDA_ERR_DTYPE;
 }
 
+// hi = bf16(x), lo = bf16(x - hi): the split-bf16 operand pair of a large GEMM in the tolerance-meeting mode, written ONCE to HBM so
+// that the bf16 LDS-DMA kernels can run the three products a_lo b_hi + a_hi b_lo + a_hi b_hi (8 bytes of traffic per element)
+namespace {
+__global__ void split_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, long n4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float v[4], h[4], l[4];
+    ld4(src + i * 4, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      h[e] = bf2f(f2bf(v[e]));
+      l[e] = v[e] - h[e];
+    }
+    st4(hi + i * 4, h);
+    st4(lo + i * 4, l);
+  }
+}
+}  // namespace
+
+extern "C" int cmda_split_bf16(const float* src, void* hi, void* lo, int64_t n, void* stream) {
+  if (n <= 0) return CMDA_OK;
+  if ((n & 3) || ((uintptr_t)src % 16) || ((uintptr_t)hi % 8) || ((uintptr_t)lo % 8)) return CMDA_ERR_SHAPE;
+  CMDA_LAUNCH(split_bf16_kernel, dim3(grid_for(n, 4)), dim3(256), 0, stream, src, (bf16_t*)hi, (bf16_t*)lo, (long)(n / 4));
+  CMDA_CHECK_LAUNCH();
+}
+
 extern "C" int cmda_cast_clear(float* src, void* dst, int64_t n, int dst_dtype, void* stream) {
   if (n <= 0) return CMDA_OK;
   if ((n & 3) || ((uintptr_t)src % 16) || ((uintptr_t)dst % 8)) return CMDA_ERR_SHAPE;

@@ -32,6 +32,11 @@ struct X3LeanParams {
   int kt_per;                              // weight-gradient form: k-tiles per split
   int splits, batch2;                      // grid.z = batch * batch2 * splits (the attention GEMMs of the unfused fp32 path: batch x heads)
   long a_bs, a_b2s, b_bs, b_b2s, c_bs, c_b2s, r_bs, r_b2s;   // element strides of the outer / inner batch index
+  // patch view of A (kernel == stride convolution, cmda_view_t.conv == 2: the spatial-reduction convolutions): row m = (b, oh, ow) starts
+  // at b * p_img + oh * p_row + ow * p_col elements; its K = KH * KW * C elements are KH segments of p_seg k-tiles (KW * C contiguous
+  // elements) p_jump bytes apart (gemm_lean.hip); p_seg == 0: plain operand
+  long p_img;
+  int p_ohw, p_ow, p_row, p_col, p_seg, p_jump;
 };
 
 // 64 x 64 tile on eight waves = 4 (rows of 16) x 2 (columns of 32); 32-deep k-tiles: three fp32 stages of 16 KiB (two in flight while
@@ -82,11 +87,19 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_lean_kernel(X3LeanParams q) {
   int stepA, stepB;
   const char* zero = reinterpret_cast<const char*>(g_zero16);
   const int lnA = AKS ? tid >> 4 : tid >> 3, chA = AKS ? tid & 15 : tid & 7;
+  int seg_left = q.p_seg;
   if constexpr (!AKS) {
     const long r = m0 + lnA;
     const bool ok = r < M;
-    curA = ok ? reinterpret_cast<const char*>(q.A + r * q.lda + chA * 4) : zero;
-    stepA = ok ? BK * 4 : 0;
+    if (q.p_seg > 0) {   // patch view: rows past M read row M - 1 (the segment jump stays uniform; the epilogue never stores them)
+      const unsigned rr = (unsigned)min(r, (long)M - 1);
+      const unsigned pb = rr / (unsigned)q.p_ohw, rem = rr - pb * (unsigned)q.p_ohw, oh = rem / (unsigned)q.p_ow, ow = rem - oh * (unsigned)q.p_ow;
+      curA = reinterpret_cast<const char*>(q.A + (long)pb * q.p_img + (long)oh * q.p_row + (long)ow * q.p_col + chA * 4);
+      stepA = BK * 4;
+    } else {
+      curA = ok ? reinterpret_cast<const char*>(q.A + r * q.lda + chA * 4) : zero;
+      stepA = ok ? BK * 4 : 0;
+    }
   } else {                  // line = k (token), 64 consecutive output rows m
     const long c = m0 + chA * 4;
     const bool ok = c + 4 <= M;
@@ -111,6 +124,12 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_lean_kernel(X3LeanParams q) {
     glds16_asm(curB, reinterpret_cast<char*>(st + F_A) + wid * 1024);
     curA += stepA;
     curB += stepB;
+    if constexpr (!AKS) {
+      if (seg_left > 0 && --seg_left == 0) {   // patch view: the next k-tile starts on the next input row of the patch
+        seg_left = q.p_seg;
+        curA += q.p_jump;
+      }
+    }
   };
   // ---- split pass: 16 bytes of fp32 -> 8 bytes of the hi tile + 8 bytes of the lo tile.  bf16 images: K-contiguous [line][32 k]
   //      (64-byte lines of four 16-byte chunks, slot = chunk ^ ((line >> 2) & 3): lines r and r + 4 start on the same bank);
@@ -347,6 +366,15 @@ int launch_x3_lean(const GemmParams& p, void* stream) {
   q.colsum = p.colsum;
   q.kt_per = q.nkt;
   q.splits = 1;
+  q.p_seg = 0; q.p_img = 0; q.p_ohw = q.p_ow = 1; q.p_row = q.p_col = q.p_jump = 0;
+  if (p.A.conv == 2) {
+    const GemmView& v = p.A;
+    q.p_img = (long)v.H * v.W * v.C;
+    q.p_ohw = v.OH * v.OW; q.p_ow = v.OW;
+    q.p_row = v.stride * v.W * v.C; q.p_col = v.stride * v.C;
+    q.p_seg = v.KW * v.C / 32;
+    q.p_jump = (v.W - v.KW) * v.C * 4;
+  }
   q.batch2 = p.batch2 > 0 ? p.batch2 : 1;
   q.a_bs = p.A.batch_stride; q.a_b2s = p.A.batch2_stride; q.b_bs = p.B.batch_stride; q.b_b2s = p.B.batch2_stride;
   q.c_bs = p.c_batch_stride; q.c_b2s = p.c_batch2_stride; q.r_bs = p.res_batch_stride; q.r_b2s = p.res_batch2_stride;
@@ -380,7 +408,14 @@ bool cmda_gemm_x3_lean_ok_(const cmda_gemm_params_t& p) {
   };
   const long nb = (long)p.batch * (p.batch2 > 0 ? p.batch2 : 1);
   auto bs_ok = [](const GemmView& v) { return (v.batch_stride % 4) == 0 && (v.batch2_stride % 4) == 0; };
-  if (!(p.dtype == CMDA_F32X3 && plain(p.A) && plain(p.B) && (p.K % 32) == 0 && p.K >= 32 && p.batch >= 1 && nb <= 65535 && bs_ok(p.A) && bs_ok(p.B) &&
+  // patch view of a kernel == stride convolution as A (K-contiguous B, no batch): KW * C a multiple of the k-tile, 32-bit row arithmetic
+  auto patch = [&](const GemmView& v) {
+    return v.conv == 2 && v.vec_ok && !p.a_kstrided && !p.b_kstrided && v.KH == v.stride && v.KW == v.stride && v.pad == 0 && v.dil == 1 &&
+           v.in_dil <= 1 && v.H == v.OH * v.stride && v.W == v.OW * v.stride && ((long)v.KW * v.C) % 32 == 0 && v.R < (1L << 31) &&
+           (long)v.stride * v.W * v.C * 4 < (1L << 31) && p.K == (long)v.KH * v.KW * v.C && nb == 1 && !p.atomic &&
+           (reinterpret_cast<uintptr_t>(v.ptr) % 16) == 0 && (v.C % 4) == 0;
+  };
+  if (!(p.dtype == CMDA_F32X3 && (plain(p.A) || patch(p.A)) && plain(p.B) && (p.K % 32) == 0 && p.K >= 32 && p.batch >= 1 && nb <= 65535 && bs_ok(p.A) && bs_ok(p.B) &&
         (p.c_batch_stride % 4) == 0 && (p.c_batch2_stride % 4) == 0 && (nb == 1 || !p.colsum) &&
         p.c_perm_ci == 0 && p.c_patch_ow == 0 && p.out_f32 && (p.N % 4) == 0 && !(p.tile_hint > 0 && (p.tile_hint & 8192))))   // (bit 13: general kernel, tuning A/B)
     return false;

@@ -201,7 +201,7 @@ def block_fwd(x, p, B, H, W, C, heads, sr, *, eps=1e-6, dp1=None, dp2=None, save
         # (split-bf16 mode as well, and there for every spatial-reduction convolution of few tiles: 512 x 320 x 1280 ran 80 us as one
         # launch of 40 workgroups -- 6.6 ms per step over the teacher's 82 calls)
         splitk = (rt.tag() in (1, 2) and Ksr >= 1024 and C % 4 == 0 and
-                  ((B * OH * OW + 63) // 64) * ((C + 63) // 64) <= (SR_SPLITK_TILES if rt.tag() == 1 else 4 * SR_SPLITK_TILES))
+                  ((B * OH * OW + 63) // 64) * ((C + 63) // 64) <= (SR_SPLITK_TILES if rt.tag() == 1 else 3 * SR_SPLITK_TILES))
         if splitk:
             # few output tiles, long contraction (stages 1 / 2: B*256 rows x 64 / 128 channels over K = 4096 / 2048): 8 - 32 workgroups
             # running 32 - 64 k-tiles one after the other (39 / 23 us).  Split K instead: the slices accumulate with fp32 atomics on

@@ -22,9 +22,11 @@ def plain_view(t, rows, cols, ld=None, batch_stride=0, offset=0, batch2_stride=0
     ch = 16 // es
     base = t.data_ptr() + offset * es
     vec_ok = int(base % 16 == 0 and ld % ch == 0 and batch_stride % ch == 0 and batch2_stride % ch == 0)
-    return View(ptr=base, ld=ld, R=rows, Cc=cols, batch_stride=batch_stride, batch2_stride=batch2_stride, conv=0,
-                vec_ok=vec_ok,
-                H=0, W=0, C=1, OH=1, OW=1, KH=1, KW=1, stride=1, pad=0, dil=1, in_dil=1, reflect=0)
+    v = View(ptr=base, ld=ld, R=rows, Cc=cols, batch_stride=batch_stride, batch2_stride=batch2_stride, conv=0,
+             vec_ok=vec_ok,
+             H=0, W=0, C=1, OH=1, OW=1, KH=1, KW=1, stride=1, pad=0, dil=1, in_dil=1, reflect=0)
+    v._t, v._off = t, offset    # (the tensor behind the view: `_gemm_x3_big` re-points the view at its bf16 hi / lo copies)
+    return v
 
 
 def conv_view(x, B, H, W, C, KH, KW, stride, pad, dil=1, OH=None, OW=None, in_dil=1, reflect=0):
@@ -37,9 +39,11 @@ def conv_view(x, B, H, W, C, KH, KW, stride, pad, dil=1, OH=None, OW=None, in_di
     # non-overlapping patches (the spatial-reduction convolutions): the same matrix, but its rows / K segments are contiguous
     # runs the kernels can fill like a plain operand (conv = 2)
     patch = (KH == KW == stride and pad == 0 and dil == 1 and in_dil == 1 and not reflect and H == OH * stride and W == OW * stride)
-    return View(ptr=x.data_ptr(), ld=0, R=B * OH * OW, Cc=KH * KW * C, batch_stride=0, batch2_stride=0, conv=2 if patch else 1, H=H, W=W, C=C,
-                OH=OH, OW=OW, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil, in_dil=in_dil, reflect=reflect,
-                vec_ok=vec_ok)
+    v = View(ptr=x.data_ptr(), ld=0, R=B * OH * OW, Cc=KH * KW * C, batch_stride=0, batch2_stride=0, conv=2 if patch else 1, H=H, W=W, C=C,
+             OH=OH, OW=OW, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil, in_dil=in_dil, reflect=reflect,
+             vec_ok=vec_ok)
+    v._t, v._off = x, 0
+    return v
 
 
 ACT = {None: 0, 'none': 0, 'relu': 1, 'gelu': 2, 'tanh': 3}
@@ -93,6 +97,71 @@ def _attn_profile(flops, fn):
 GEMM_TILE_HINT = int(os.environ.get('CMDA_GEMM_TILE_HINT', '0'))   # cmda_gemm_params_t.tile_hint of every launch (tuning sweeps, forced-tile tests)
 
 
+# ---- split-bf16 mode, LARGE problems: three launches of the bf16 kernels over operands split once in HBM -------------------------
+# The register-staged split kernel (csrc/gemm_x3.hip) runs the decode head's 3 x 3 bottleneck at ~170 TFLOP/s (7.3 ms per call at
+# 16 images) where the bf16 LDS-DMA kernel does 1.1 PFLOP/s; x = hi + lo with both halves stored as bf16 tensors of x's own layout
+# turns the contraction into a_lo b_hi + a_hi b_lo + a_hi b_hi on that kernel, accumulated in the fp32 output (beta = 1 / atomics):
+# same ~16 mantissa bits per product, 8 bytes of extra traffic per operand element.
+X3_BIG_FLOPS = float(os.environ.get('CMDA_X3_BIG_GFLOP', '15')) * 1e9   # (bench, ms per step at 40 / 20 / 10 / 5 / 2 GFLOP: 149.2 / 144.7 / 145.1 / 150.7 / 162.3)
+
+
+def split_bf16(t):
+    """(hi, lo) bf16 tensors of t's shape: hi = bf16(t), lo = bf16(t - hi).  Nothing is cached: a captured iteration replays the
+    split launch with that iteration's operand values (the weights of these problems are a few MB)."""
+    check_dev(t)
+    hi = torch.empty(t.shape, dtype=torch.bfloat16, device=t.device)
+    lo = torch.empty(t.shape, dtype=torch.bfloat16, device=t.device)
+    call('cmda_split_bf16', ptr(t), ptr(hi), ptr(lo), c_i64(t.numel()), stream_of(t))
+    return hi, lo
+
+
+def _x3_big_ok(A, B, out, M, N, K, nb, act, rowscale, hold, defer, splits, c_patch, c_perm):
+    if hold or act is not None or rowscale is not None or c_patch is not None or GEMM_TILE_HINT != 0:
+        return False
+    if 2.0 * M * N * K * nb < X3_BIG_FLOPS or out.dtype != torch.float32:
+        return False
+    for v in (A, B):
+        t = getattr(v, '_t', None)
+        if t is None or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() % 8 or t.data_ptr() % 16:
+            return False
+        if v.conv:
+            if v.C % 8:
+                return False
+        elif v.ld % 8 or v._off % 8 or v.batch_stride % 8 or v.batch2_stride % 8:
+            return False
+    return True
+
+
+def _x3_half_views(v):
+    hi, lo = split_bf16(v._t)
+    out = []
+    for h in (hi, lo):
+        w = View.from_buffer_copy(bytes(v))
+        w.ptr = h.data_ptr() + v._off * 2
+        w.vec_ok = 1
+        w._t, w._off = h, v._off
+        out.append(w)
+    return out[0], out[1], (hi, lo)
+
+
+def _gemm_x3_big(A, B, out, M, N, K, kw):
+    """out = a_lo b_hi + a_hi b_lo + a_hi b_hi (bias / residual / caller's beta in the first launch)"""
+    a_hi, a_lo, ka = _x3_half_views(A)
+    b_hi, b_lo, kb = _x3_half_views(B)
+    keep = tuple(kw.pop('keep', ())) + ka + kb
+    first = dict(kw)
+    rest = dict(kw, bias=None, res=None)
+    atomic = kw.get('atomic', False)
+    if not atomic:
+        rest['beta'] = 1.0
+    colsum = kw.get('colsum')
+    # the bias gradient (column sums of A = dy): sum of the two halves' column sums, taken in the launches that read them first
+    gemm(a_lo, b_hi, out, M, N, K, **dict(first, dtype=1, colsum=colsum, keep=keep))
+    gemm(a_hi, b_lo, out, M, N, K, **dict(rest, dtype=1, colsum=colsum, keep=keep))
+    gemm(a_hi, b_hi, out, M, N, K, **dict(rest, dtype=1, colsum=None, keep=keep))
+    return out
+
+
 def gemm(A, B, out, M, N, K, *, a_kstrided=False, b_kstrided=False, ldc=None, batch=1, c_batch_stride=0,
          batch2=1, c_batch2_stride=0, res_batch2_stride=0, splits=1, alpha=1.0, beta=0.0, bias=None, act=None, res=None, ldres=None, res_batch_stride=0,
          rowscale=None, rows_per_scale=1, atomic=False, dtype=None, c_offset=0, colsum=None, c_patch=None, c_perm=None, defer=False, keep=(),
@@ -103,6 +172,12 @@ def gemm(A, B, out, M, N, K, *, a_kstrided=False, b_kstrided=False, ldc=None, ba
     operand views (kept alive until then).
     hold=True: build the problem but do NOT launch it -- returns (params, meta, out, keep) for tools that time or inspect it."""
     check_dev(out, bias, res, rowscale)
+    if dtype == 2 and _x3_big_ok(A, B, out, M, N, K, batch * batch2, act, rowscale, hold, defer, splits, c_patch, c_perm):
+        return _gemm_x3_big(A, B, out, M, N, K, dict(a_kstrided=a_kstrided, b_kstrided=b_kstrided, ldc=ldc, batch=batch,
+                                                     c_batch_stride=c_batch_stride, batch2=batch2, c_batch2_stride=c_batch2_stride,
+                                                     res_batch2_stride=res_batch2_stride, splits=splits, alpha=alpha, beta=beta, bias=bias,
+                                                     res=res, ldres=ldres, res_batch_stride=res_batch_stride, atomic=atomic,
+                                                     c_offset=c_offset, colsum=colsum, c_perm=c_perm, defer=defer, keep=keep))
     out_f32 = out.dtype == torch.float32
     p = GemmParams()
     p.A, p.B = A, B

@@ -248,6 +248,11 @@ typedef struct cmda_permute_desc_t {
                          weight-gradient shadows in GEMM order -> the parameter's own [Co][Ci][KH][KW] layout */
   int64_t total;      /* d[0]*d[1]*d[2]*d[3] */
 } cmda_permute_desc_t;
+/* hi = bf16(src), lo = bf16(src - hi) (n % 4 == 0, bf16 outputs): the operand pair of the split-bf16 mode (CMDA_F32X3) written once, so that
+ * a LARGE contraction of that mode -- the decode head's 3x3 bottleneck and its gradients, the generator's convolutions
+ * (decode_heads/daformer_head.py:63-79, cyclegan/cyclegan_model.py:339-374) -- runs as three launches of the bf16 LDS-DMA kernels
+ * (a_lo b_hi + a_hi b_lo + a_hi b_hi, fp32 output accumulated with beta = 1) instead of the register-staged split kernel. */
+int cmda_split_bf16(const float* src, void* hi, void* lo, int64_t n, void* stream);
 /* dst (activation dtype) = src; src (fp32, n % 4 == 0) = 0: drains a persistent accumulation workspace and leaves it zeroed */
 int cmda_cast_clear(float* src, void* dst, int64_t n, int dst_dtype, void* stream);
 int cmda_permute4_batch(const void* desc, const int* blocks, int nblocks, void* stream);

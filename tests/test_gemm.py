@@ -278,3 +278,36 @@ def test_grouped_gemm_eager_arena_recycles_after_a_capture(tgt):
         ops._GD['recycles'] = saved[3]
         ops._GD['plans'] = saved[4]
         rt.set_compute_dtype(torch.float32)
+
+
+def test_gemm_x3_big_three_launch_path(tgt):
+    """split-bf16 mode, LARGE problems (ops._gemm_x3_big): operands split once into bf16 hi / lo tensors (cmda_split_bf16) and the
+    contraction run as three launches of the bf16 kernels accumulated in the fp32 output -- plain NT with bias + fp32 residual + beta,
+    the weight-gradient form with atomics and the fused bias gradient, an im2col view.  Forced here by lowering the FLOP threshold."""
+    old = ops.X3_BIG_FLOPS
+    ops.X3_BIG_FLOPS = 1e3
+    try:
+        torch.manual_seed(21)
+        M, N, K = 200, 72, 128
+        a, b = torch.randn(M, K), torch.randn(N, K)
+        bias, res, c0 = torch.randn(N), torch.randn(M, N), torch.randn(M, N)
+        ad, bd = tgt.to(a), tgt.to(b)
+        out = tgt.to(c0.clone())
+        ops.gemm(ops.plain_view(ad, M, K), ops.plain_view(bd, N, K), out, M, N, K, dtype=2, bias=tgt.to(bias), res=tgt.to(res), beta=0.5)
+        assert_close(out, a @ b.t() + bias + res + 0.5 * c0, 2e-5, name='x3 big NT + bias + res + beta')
+        hi, lo = ops.split_bf16(ad)
+        assert_close(hi.float() + lo.float(), a, 2e-5, name='hi + lo')
+        assert torch.equal(hi.cpu(), a.bfloat16())
+        atd, btd = tgt.to(a.t().contiguous()), tgt.to(b.t().contiguous())
+        dW, cs = torch.zeros(M, N, device=tgt.device), torch.zeros(M, device=tgt.device)
+        ops.gemm(ops.plain_view(atd, K, M), ops.plain_view(btd, K, N), dW, M, N, K, a_kstrided=True, b_kstrided=True, dtype=2, atomic=True,
+                 splits=0, colsum=cs)
+        assert_close(dW, a @ b.t(), 2e-5, name='x3 big weight-gradient form')
+        assert_close(cs, a.sum(1), 2e-5, name='x3 big fused bias gradient')
+        x, w = torch.randn(2, 12, 12, 16), torch.randn(24, 16, 3, 3)
+        wg = tgt.to(w.permute(0, 2, 3, 1).contiguous().view(24, -1))
+        o = torch.empty(2, 12, 12, 24, device=tgt.device)
+        ops.gemm(ops.conv_view(tgt.to(x), 2, 12, 12, 16, 3, 3, 1, 1, 1), ops.plain_view(wg, 24, 144), o, 288, 24, 144, dtype=2)
+        assert_close(o, F.conv2d(x.permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1), 2e-5, name='x3 big im2col view')
+    finally:
+        ops.X3_BIG_FLOPS = old
