@@ -222,7 +222,7 @@ def test_dacs_iteration_full_width_gpu(mode):
         if mode != 'bf16':
             check_iteration(outs[0], True, 1e-4, 5e-2 if mode == 'f32' else 0.1, tol_gen=None if mode == 'f32' else 5e-4)
         else:
-            check_iteration(outs[0], False, 2e-2, 0.6, label_agree=0.96)   # (worst gradient 0.19, labels 0.9876 measured, two runs)
+            check_iteration(outs[0], False, 2e-2, 0.5, label_agree=0.96)   # (worst gradient 0.19-0.24, labels 0.9876 measured, five runs: 2x)
     finally:
         rt.set_gemm_x3(False)
         rt.set_compute_dtype(torch.float32)
@@ -344,7 +344,7 @@ def test_dacs_iteration_full_depth_512_gpu(mode):
             check_le('bf16 generator output 99.9th pct rel err (512 x 512)', gen_p999, GEN_BF16_P999)
             check_le('bf16 generator output max rel err (512 x 512)', gen_max, GEN_BF16_MAX)
             check_le('bf16 teacher logits rel err', logit_err, 6e-2, strict=True)
-            check_ge('bf16 pseudo-label agreement', agree, float(os.environ.get('CMDA_TEST_BF16_LABEL_AGREE', 0.93)), strict=True)
+            check_ge('bf16 pseudo-label agreement', agree, float(os.environ.get('CMDA_TEST_BF16_LABEL_AGREE', 0.945)), strict=True)
             check_le('bf16 source loss abs err', abs(ls - rs), 2e-2 * max(1.0, abs(rs)), strict=True)
             check_le('bf16 mixed loss abs err', abs(lm - rm), 0.1 * max(1.0, abs(rm)), strict=True)
     finally:

@@ -490,3 +490,71 @@ def test_bn_buffers_broadcast_before_distributed_eval_world2():
         for r in range(world):
             assert out[r]['n'] == 2 and out[r]['differed'] and out[r]['same'] and out[r]['src'] and out[r]['params'], out[r]
             assert out[r]['nbt'] == [3, 3]
+
+
+class _TinySeg(torch.nn.Module):
+    """stand-in segmentor with the evaluation interface of the path (`simple_test(rescale, img=...)` -> list of label maps)"""
+
+    def __init__(self, classes=5):
+        super().__init__()
+        self.net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.BatchNorm2d(8), torch.nn.ReLU(),
+                                       torch.nn.Conv2d(8, classes, 1))
+
+    def simple_test(self, rescale=True, img=None):
+        return list(self.net(img).argmax(1).numpy())
+
+
+def _eval_samples(n, classes=5):
+    g = torch.Generator().manual_seed(31)
+    out = []
+    for i in range(n):
+        h, w = 12 + i, 16            # ragged heights: nothing of the exchange may depend on the image size
+        gt = torch.randint(0, classes, (h, w), generator=g)
+        gt[torch.rand(h, w, generator=g) < 0.1] = 255
+        out.append(dict(img=torch.randn(1, 3, h, w, generator=g), gt_semantic_seg=gt))
+    return out
+
+
+def _eval_worker(rank, world, port, out):
+    from cmda_amd.parallel import distributed_evaluate
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(11)
+    model = _TinySeg().train()
+    torch.manual_seed(200 + rank)                      # rank-local batches: running statistics differ at evaluation time
+    for _ in range(4):
+        model.net(torch.randn(2, 3, 8, 8) * (1 + 2 * rank) + rank)
+    res = distributed_evaluate(model, _eval_samples(5), 5)
+    out[rank] = {k: v.clone() for k, v in res.items()}
+    out[f'training{rank}'] = model.training
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_distributed_evaluate_matches_single_process_with_rank0_statistics(world):
+    """eval_hooks.py:86-121 + apis/test.py:216-274: the ranks score disjoint shares of the validation set with rank 0's BatchNorm
+    statistics and meet in one histogram all-reduce; result = one process scoring all samples with rank 0's model (the reference's
+    `multi_gpu_test` + `dataset.evaluate`), on every rank; 5 samples over 2 / 3 ranks = uneven shares"""
+    from cmda_amd import metrics
+    from cmda_amd.parallel import distributed_evaluate
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_eval_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        got = {r: out[r] for r in range(world)}
+        assert all(out[f'training{r}'] for r in range(world))        # the caller's train / eval state is restored
+    torch.manual_seed(11)
+    model = _TinySeg().train()
+    torch.manual_seed(200)
+    for _ in range(4):
+        model.net(torch.randn(2, 3, 8, 8))
+    samples = _eval_samples(5)
+    model.eval()
+    with torch.no_grad():
+        preds = [model.simple_test(True, img=s['img'])[0] for s in samples]
+    ref = metrics.mean_iou([torch.as_tensor(p) for p in preds], [s['gt_semantic_seg'] for s in samples], 5)
+    single = distributed_evaluate(model, samples, 5)                 # no process group: the same function, one rank
+    for r in range(world):
+        for k in ('aAcc', 'mIoU', 'mAcc', 'IoU', 'Acc'):
+            assert torch.equal(torch.nan_to_num(got[r][k], nan=-1.0), torch.nan_to_num(ref[k], nan=-1.0)), (r, k)
+    for k in ('aAcc', 'mIoU', 'IoU'):
+        assert torch.equal(torch.nan_to_num(single[k], nan=-1.0), torch.nan_to_num(ref[k], nan=-1.0))

@@ -1,7 +1,7 @@
 #!/bin/bash
-# copy the summaries of one tools/gpu/collect_r04.sh run from gpurun_out/<tag>/ into profiles/ (tracked)
-tag=${1:-r04final}
-R=${2:-r04}
+# copy the summaries of one tools/gpu/collect_r05.sh run from gpurun_out/<tag>/ into profiles/ (tracked)
+tag=${1:-r05final}
+R=${2:-r05}
 src=gpurun_out/$tag
 cp $src/bench.json profiles/${R}_dacs_bench.json
 cp "$(ls -t $src/stats_graph/*/*kernel_stats.csv | head -1)" profiles/${R}_dacs_graph_kernel_stats.csv   # (newest: a re-run into the same tag leaves the older PID's files)
@@ -16,4 +16,7 @@ grep -v amdgpu.ids $src/hbm_bench.txt > profiles/${R}_hbm_bench.txt
 grep -v amdgpu.ids $src/small_gemm.txt > profiles/${R}_small_gemm.txt 2>/dev/null
 cp $src/bench_force_reducer.json profiles/${R}_dacs_force_reducer.json 2>/dev/null
 cp $src/supervised.json profiles/${R}_supervised_bench.json 2>/dev/null
-ls -la profiles | tail -18
+cp $src/mfma_busy.txt profiles/${R}_dacs_mfma_busy.txt 2>/dev/null
+cp $src/x3_eager_kernel_stats.csv profiles/${R}_x3_eager_kernel_stats.csv 2>/dev/null
+grep -v amdgpu.ids $src/x3_gemm.txt > profiles/${R}_x3_gemm.txt 2>/dev/null
+ls -la profiles | tail -22
