@@ -35,7 +35,7 @@ class GemmParams(ctypes.Structure):
                 ('rowscale', c_vp), ('rows_per_scale', c_i32), ('out_f32', c_i32), ('atomic', c_i32),
                 ('dtype', c_i32), ('c_vec_ok', c_i32), ('colsum', c_vp),
                 ('c_patch_ow', c_i32), ('c_patch_kh', c_i32), ('c_patch_kwci', c_i32), ('tile_hint', c_i32), ('c_perm_ci', c_i32), ('c_perm_cells', c_i32),
-                ('res_f32', c_i32), ('reserved_', c_i32)]
+                ('res_f32', c_i32), ('colstats_rows', c_i32), ('colstats', c_vp)]
 
 
 class CmdaError(RuntimeError):
@@ -70,7 +70,7 @@ def _load():
             '(python -c "import __graft_entry__ as g; g.build()" or `make hip`). '
             'cmda_amd has no CPU fallback.')
     _lib = _declare(ctypes.CDLL(_LIB_PATH))
-    if _lib.cmda_abi_version() != 6:
+    if _lib.cmda_abi_version() != 7:
         raise CmdaError('libcmda_hip.so ABI version mismatch')
     return _lib
 

@@ -19,7 +19,7 @@ namespace {
 constexpr int kRowUnroll = 4;
 // Partial sums go to 32 workspace slots (block y % 32), not one: 1024 blocks adding into the same 2*C addresses
 // serialised in the atomic unit (~100 us of a 133 us reduction); a fold kernel / the finalize kernel sums the slots.
-constexpr int kBnSlots = 32;
+constexpr int kBnSlots = CMDA_BN_SLOTS;
 
 template <typename T>
 __global__ void bn_reduce_kernel(const T* __restrict__ x, float* __restrict__ ws, long M, int C, int rows_per_block) {
@@ -77,7 +77,7 @@ template <typename T>
 __global__ void bn_finalize_kernel(const T* __restrict__ x, const float* __restrict__ ws, float* __restrict__ mean,
                                    float* __restrict__ rstd, float* __restrict__ running_mean,
                                    float* __restrict__ running_var, long M, int C, float eps, float momentum, int G,
-                                   BnOrder order) {
+                                   BnOrder order, int fused_stats) {
   static_assert(kBnSlots == 32, "one lane per slot");
   const int k = threadIdx.x & 31;
   const int c = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
@@ -90,15 +90,19 @@ __global__ void bn_finalize_kernel(const T* __restrict__ x, const float* __restr
   }
   for (int i = 0; i < G; ++i) {
     const int g = order.g[i];
-    const float* wg = ws + (long)g * (kBnSlots + 1) * 2 * C;
+    float* wg = const_cast<float*>(ws) + (long)g * (kBnSlots + 1) * 2 * C;
     float s = wg[(long)k * 2 * C + cc], q = wg[(long)k * 2 * C + C + cc];
+    if (fused_stats && live) {   // sums from a GEMM epilogue (cmda_gemm colstats): the workspace is handed back zeroed
+      wg[(long)k * 2 * C + cc] = 0.f;
+      wg[(long)k * 2 * C + C + cc] = 0.f;
+    }
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) {
       s += __shfl_xor(s, o, 64);
       q += __shfl_xor(q, o, 64);
     }
     if (k != 0 || !live) continue;
-    const float shift = ldf(x + (long)g * M * C + c);
+    const float shift = fused_stats ? 0.f : ldf(x + (long)g * M * C + c);
     const float md = s / (float)M;
     const float mu = shift + md;
     float var = q / (float)M - md * md;
@@ -358,24 +362,24 @@ extern "C" int64_t cmda_bn_ws_floats(int C) { return (int64_t)(kBnSlots + 1) * 2
 
 extern "C" int cmda_bn_train_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                                  float* running_mean, float* running_var, float* ws, int64_t M, int C, float eps,
-                                 float momentum, int relu, int ldy, int coff, int groups, const int* order, int dtype,
-                                 void* stream) {
+                                 float momentum, int relu, int ldy, int coff, int groups, const int* order, int ws_has_stats,
+                                 int dtype, void* stream) {
   if (M <= 0 || C <= 0) return CMDA_OK;
   if ((C & 3) || (ldy & 3) || (coff & 3) || groups < 1 || groups > 8) return CMDA_ERR_SHAPE;
   BnOrder ord;
   for (int i = 0; i < 8; ++i) ord.g[i] = (order && i < groups) ? order[i] : i;
   for (int i = 0; i < groups; ++i)
     if (ord.g[i] < 0 || ord.g[i] >= groups) return CMDA_ERR_SHAPE;
-  cmda_zero_async(ws, sizeof(float) * (size_t)groups * (kBnSlots + 1) * 2 * C, stream);
+  if (!ws_has_stats) cmda_zero_async(ws, sizeof(float) * (size_t)groups * (kBnSlots + 1) * 2 * C, stream);
   const int gx = (C / 4 + 63) / 64;
   const int rpb = rows_per_block(M * groups, gx);
   dim3 rgrid(gx, (unsigned)((M + rpb - 1) / rpb), groups);
   const int arpb = rows_per_block_apply(M * groups, gx);
   dim3 agrid(gx, (unsigned)((M + arpb - 1) / arpb), groups);
   CMDA_DISPATCH_DTYPE(dtype, {
-    CMDA_LAUNCH((bn_reduce_kernel<T>), rgrid, dim3(256), 0, stream, (const T*)x, ws, (long)M, C, rpb);
+    if (!ws_has_stats) CMDA_LAUNCH((bn_reduce_kernel<T>), rgrid, dim3(256), 0, stream, (const T*)x, ws, (long)M, C, rpb);
     CMDA_LAUNCH((bn_finalize_kernel<T>), dim3((C + 7) / 8), dim3(256), 0, stream, (const T*)x, ws, mean, rstd,
-                running_mean, running_var, (long)M, C, eps, momentum, groups, ord);
+                running_mean, running_var, (long)M, C, eps, momentum, groups, ord, ws_has_stats);
     CMDA_LAUNCH((bn_apply_kernel<T>), agrid, dim3(256), 0, stream, (const T*)x, mean, rstd, gamma, beta, (T*)y + coff, (long)M,
                 C, relu, ldy, 0, arpb);
   });
@@ -387,7 +391,7 @@ extern "C" int cmda_bn_train_fwd(const void* x, const float* gamma, const float*
 extern "C" int cmda_bn_train_fwd2(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
                                   float* mean, float* rstd, float* running_mean, float* running_var, float* ws, int64_t M, int C,
                                   float eps, float momentum, int relu, int ldy, int coff, int groups, const int* order,
-                                  const float* res32, void* y2_bf16, void* stream) {
+                                  const float* res32, void* y2_bf16, int ws_has_stats, void* stream) {
   if (M <= 0 || C <= 0) return CMDA_OK;
   if ((C & 3) || (ldy & 3) || (coff & 3) || groups < 1 || groups > 8) return CMDA_ERR_SHAPE;
   if ((x_dtype != CMDA_F32 && x_dtype != CMDA_BF16) || (y_dtype != CMDA_F32 && y_dtype != CMDA_BF16)) return CMDA_ERR_DTYPE;
@@ -395,7 +399,7 @@ extern "C" int cmda_bn_train_fwd2(const void* x, int x_dtype, const float* gamma
   for (int i = 0; i < 8; ++i) ord.g[i] = (order && i < groups) ? order[i] : i;
   for (int i = 0; i < groups; ++i)
     if (ord.g[i] < 0 || ord.g[i] >= groups) return CMDA_ERR_SHAPE;
-  cmda_zero_async(ws, sizeof(float) * (size_t)groups * (kBnSlots + 1) * 2 * C, stream);
+  if (!ws_has_stats) cmda_zero_async(ws, sizeof(float) * (size_t)groups * (kBnSlots + 1) * 2 * C, stream);
   const int gx = (C / 4 + 63) / 64;
   const int rpb = rows_per_block(M * groups, gx);
   dim3 rgrid(gx, (unsigned)((M + rpb - 1) / rpb), groups);
@@ -405,9 +409,9 @@ extern "C" int cmda_bn_train_fwd2(const void* x, int x_dtype, const float* gamma
   CMDA_LAUNCH((bn_apply2_kernel<TX, TY>), agrid, dim3(256), 0, stream, (const TX*)x, mean, rstd, gamma, beta, (TY*)y + coff,      \
               res32, (bf16_t*)y2_bf16, (long)M, C, relu, ldy, arpb)
   CMDA_DISPATCH_DTYPE(x_dtype, {
-    CMDA_LAUNCH((bn_reduce_kernel<T>), rgrid, dim3(256), 0, stream, (const T*)x, ws, (long)M, C, rpb);
+    if (!ws_has_stats) CMDA_LAUNCH((bn_reduce_kernel<T>), rgrid, dim3(256), 0, stream, (const T*)x, ws, (long)M, C, rpb);
     CMDA_LAUNCH((bn_finalize_kernel<T>), dim3((C + 7) / 8), dim3(256), 0, stream, (const T*)x, ws, mean, rstd,
-                running_mean, running_var, (long)M, C, eps, momentum, groups, ord);
+                running_mean, running_var, (long)M, C, eps, momentum, groups, ord, ws_has_stats);
     if (y_dtype == CMDA_F32) CMDA_BN2_APPLY(T, float); else CMDA_BN2_APPLY(T, bf16_t);
   });
 #undef CMDA_BN2_APPLY

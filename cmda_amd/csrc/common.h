@@ -6,6 +6,8 @@
 // indexing of every kernel can be exercised on CPU by the test-suite; that build
 // is test infrastructure and is never linked into libcmda_hip.so.
 #pragma once
+// slots of the BatchNorm column-statistics workspace (batchnorm.hip; also filled by the GEMM epilogue, cmda_gemm_params_t.colstats)
+#define CMDA_BN_SLOTS 32
 #include <stdint.h>
 #include <algorithm>
 

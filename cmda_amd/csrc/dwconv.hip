@@ -195,7 +195,8 @@ struct DilGeom {
 template <typename T, int MODE, int CQ>
 __global__ __launch_bounds__(256) void dw_dilated_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, T* __restrict__ out, DilGeom g, int C,
-                                                         int act, int accumulate, int gx) {
+                                                         int act, int accumulate, int gx, float* __restrict__ stats,
+                                                         int imgs_per_group) {
   const int cx = threadIdx.x % CQ, py = threadIdx.x / CQ;
   const BlockXY blk = xcd_block(gx);
   const int c = (blk.bx * CQ + cx) * 4;
@@ -232,6 +233,10 @@ __global__ __launch_bounds__(256) void dw_dilated_kernel(const T* __restrict__ x
   float win[3][DRUN + 2][4];     // ... and is unpacked into win[r % 3]; sub-row -1 / nr = zero padding
   float pcur[DRUN][4];           // previous values of the sub-row being written
   const bool acc_mode = MODE == 2 && accumulate;
+  // MODE 0 with `stats`: column sums / sums of squares of the outputs this thread stores (the BatchNorm behind the dilated depthwise
+  // convolution of the sep-ASPP, sep_aspp_head.py:18-27), added to the BatchNorm workspace of the image's group when the walk is done
+  const bool do_stats = MODE == 0 && stats != nullptr;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
   // (no select on the loaded value here: it would pin the wait for the data right behind the request -- the padding columns are
   // zeroed when the row is unpacked)
   auto request = [&](int r, Raw<T> (&dst)[DRUN + 2], Raw<T> (&pdst)[DRUN]) {
@@ -290,11 +295,26 @@ __global__ __launch_bounds__(256) void dw_dilated_kernel(const T* __restrict__ x
               for (int q = 0; q < 4; ++q) acc[q] += win[(s + 2 + kh) % 3][i + kw][q] * wr[kh * 3 + kw][q];
           if (k0 + i < ncol) {
             st4(orow + coff[i + 1], acc);
+            if (do_stats) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                cs[q] += acc[q];
+                cq[q] += acc[q] * acc[q];
+              }
+            }
           }
         }
         unpack_prev(j + 1, praw[(s + 1) % 3]);
         request(j + 4, raw[(s + 1) % 3], praw[(s + 1) % 3]);
       }
+    }
+  }
+  if (do_stats) {   // one thread = one (image, sub-lattice, run) x 4 channels: eight atomics, spread over the 32 slots by the run index
+    float* wsl = stats + ((long)(b / imgs_per_group) * (CMDA_BN_SLOTS + 1) + (tu & (CMDA_BN_SLOTS - 1))) * 2 * (long)C + c;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      atomicAdd(wsl + q, cs[q]);
+      atomicAdd(wsl + C + q, cq[q]);
     }
   }
 }
@@ -491,7 +511,8 @@ static inline int run_len(int dtype) { return dtype == CMDA_BF16 ? RunLen<bf16_t
 
 template <int MODE>
 static int launch_stencil(const void* x, const float* w, const float* bias, const void* da, void* out, int B, int H, int W,
-                          int C, int dil, int act, int accumulate, int dtype, void* stream) {
+                          int C, int dil, int act, int accumulate, int dtype, void* stream, float* stats = nullptr,
+                          int imgs_per_group = 1) {
   const long npix = (long)B * H * W;
   if (npix * C <= 0) return CMDA_OK;
   if ((C & 3) || dil < 1) return CMDA_ERR_SHAPE;
@@ -506,9 +527,10 @@ static int launch_stencil(const void* x, const float* w, const float* bias, cons
     const long nb = (dg.nthreads + 256 / cq - 1) / (256 / cq) * gx;
     if (too_big(dg.nthreads) || nb > 0x7fffffffL) return CMDA_ERR_SHAPE;
     CMDA_DISPATCH_DTYPE(dtype, CMDA_LAUNCH((dw_dilated_kernel<T, MODE == 1 ? 0 : MODE, cq>), dim3((unsigned)nb), dim3(256), 0, stream,
-                                           (const T*)x, w, bias, (T*)out, dg, C, act, accumulate, gx));
+                                           (const T*)x, w, bias, (T*)out, dg, C, act, accumulate, gx, stats, imgs_per_group));
     CMDA_CHECK_LAUNCH();
   }
+  if (stats) return CMDA_ERR_UNSUPPORTED;   // the fused statistics exist on the dilated walk only
   const RunGeom g = run_geom(B, H, W, dil, run_len(dtype));
   if (too_big(g.nruns)) return CMDA_ERR_SHAPE;
   const long nblk = (g.nruns + 3) / 4 * gx;
@@ -523,6 +545,14 @@ static int launch_stencil(const void* x, const float* w, const float* bias, cons
 extern "C" int cmda_dwconv3x3_fwd(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C,
                                   int dil, int act, int dtype, void* stream) {
   return launch_stencil<0>(x, w, bias, nullptr, y, B, H, W, C, dil, act, 0, dtype, stream);
+}
+
+// ... with the column statistics of y (per group of imgs_per_group consecutive images) accumulated into the BatchNorm workspace
+// `colstats` (groups x cmda_bn_ws_floats(C) floats, zero on entry): cmda_gemm_params_t.colstats for the depthwise producer.  dil >= 2.
+extern "C" int cmda_dwconv3x3_fwd_stats(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C,
+                                        int dil, float* colstats, int imgs_per_group, int dtype, void* stream) {
+  if (!colstats || imgs_per_group < 1 || B % imgs_per_group || dil < 2) return CMDA_ERR_UNSUPPORTED;
+  return launch_stencil<0>(x, w, bias, nullptr, y, B, H, W, C, dil, 0, 0, dtype, stream, colstats, imgs_per_group);
 }
 
 extern "C" int cmda_dwconv3x3_gelu_bwd_prep(const void* x, const float* w, const float* bias, const void* da, void* dz,

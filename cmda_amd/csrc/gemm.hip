@@ -120,7 +120,7 @@ int launch_dtype(GemmParams& p, void* stream) {
       if (tile == 0) return cmda_gemm_glds_t0_(p, stream);
       // the encoders' Linear layers / data gradients on the two small tiles: the lean instance (gemm_lean.hip), in the 4-stage latency
       // configuration where launch_glds would choose it (>= 12 k-tiles on a grid that is resident at once)
-      if (cmda_gemm_lean_ok_(p, tile)) {
+      if (!p.colstats && cmda_gemm_lean_ok_(p, tile)) {   // (fused column statistics: the general epilogue)
         const long tl = tile == 1 ? blocks(128, 64) : blocks(64, 64);
         const int force = p.tile_hint > 0 ? ((p.tile_hint >> 4) & 15) : 0;
         const bool four_stage = force ? force == 4 : (tl <= 256L * (tile == 1 ? 1 : 2) && nkt >= 12);
@@ -146,6 +146,9 @@ extern "C" int cmda_gemm(const cmda_gemm_params_t* pp, void* stream) {
   if (p.atomic && !p.out_f32) return CMDA_ERR_UNSUPPORTED;
   if (p.splits > 1 && !p.atomic) return CMDA_ERR_UNSUPPORTED;
   if (p.atomic && (p.bias || p.act || p.res || p.rowscale)) return CMDA_ERR_UNSUPPORTED;
+  if (p.colstats && (p.atomic || p.splits > 1 || p.act || p.rowscale || p.c_patch_ow > 0 || p.a_kstrided || p.batch != 1 || p.batch2 != 1 || (p.N & 3) ||
+                     p.colstats_rows <= 0 || (p.colstats_rows & 255) || p.colsum))
+    return CMDA_ERR_UNSUPPORTED;
   if (p.c_patch_ow > 0 && (p.atomic || p.res || p.batch != 1 || p.batch2 != 1 || p.c_patch_kh <= 0 || p.c_patch_kwci <= 0 ||
                            p.N != p.c_patch_kh * p.c_patch_kwci || p.M % p.c_patch_ow != 0 || (p.c_patch_kwci & 3)))
     return CMDA_ERR_UNSUPPORTED;

@@ -219,13 +219,15 @@ static __device__ __forceinline__ float epi_act(float x) {
 
 template <typename T, int ACT, int BM, int BN, int PITCH_C, int NT>
 static __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* __restrict__ sC, long m0, long n,
-                                                     int q4, int r0, long cb, long rb_off, bool full, const float (&bv)[4]) {
+                                                     int q4, int r0, long cb, long rb_off, bool full, const float (&bv)[4],
+                                                     float (&cs)[4], float (&cq)[4]) {
   constexpr int QPR = BN / 4, RSTEP = NT / QPR, NIT = (BM + RSTEP - 1) / RSTEP;
   const bool has_res = p.res != nullptr, has_beta = p.beta != 0.f, has_rs = p.rowscale != nullptr, f32o = p.out_f32 != 0;
   const bool res32 = p.res_f32 != 0;
   const float alpha = p.alpha, beta = p.beta;
   const int patch_ow = p.c_patch_ow;
   const long patch_kh = patch_ow > 0 ? n / p.c_patch_kwci : 0, patch_rest = patch_ow > 0 ? n - patch_kh * p.c_patch_kwci : 0;
+  const bool stats = p.colstats != nullptr;
 #pragma unroll 4
   for (int it = 0; it < NIT; ++it) {
     const int row = r0 + it * RSTEP;
@@ -262,6 +264,13 @@ static __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const 
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = epi_act<ACT>(alpha * v[e] + bv[e]) * rs + rv[e] + beta * ov[e];
+    if (ACT == 0 && stats) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        cs[e] += v[e];
+        cq[e] += v[e] * v[e];
+      }
+    }
     if (full) {
       if (f32o) st4(reinterpret_cast<float*>(p.C) + ci, v);
       else st4(reinterpret_cast<T*>(p.C) + ci, v);
@@ -278,7 +287,7 @@ static __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const 
 
 template <typename T, int BM, int BN, int PITCH_C, int NT = 256>
 static __device__ __forceinline__ void epilogue_store(const GemmParams& p, const float* __restrict__ sC, long m0, long n0,
-                                                      long cb, long rb_off, int tid) {
+                                                      long cb, long rb_off, int tid, float (&cs)[4], float (&cq)[4]) {
   constexpr int QPR = BN / 4;  // quads per tile row
   static_assert(NT >= QPR, "tile shape");
   // (NT % QPR != 0 -- the 320-column row-panel tile: 80 quads per row, 3 rows per pass, 16 threads idle)
@@ -296,10 +305,51 @@ static __device__ __forceinline__ void epilogue_store(const GemmParams& p, const
         if (n + e < p.N) bv[e] = p.bias[n + e];
     }
   }
-  if (p.act == 0) epilogue_rows<T, 0, BM, BN, PITCH_C, NT>(p, sC, m0, n, q4, r0, cb, rb_off, full, bv);
-  else if (p.act == 1) epilogue_rows<T, 1, BM, BN, PITCH_C, NT>(p, sC, m0, n, q4, r0, cb, rb_off, full, bv);
-  else if (p.act == 2) epilogue_rows<T, 2, BM, BN, PITCH_C, NT>(p, sC, m0, n, q4, r0, cb, rb_off, full, bv);
-  else epilogue_rows<T, 3, BM, BN, PITCH_C, NT>(p, sC, m0, n, q4, r0, cb, rb_off, full, bv);
+  if (p.act == 0) epilogue_rows<T, 0, BM, BN, PITCH_C, NT>(p, sC, m0, n, q4, r0, cb, rb_off, full, bv, cs, cq);
+  else if (p.act == 1) epilogue_rows<T, 1, BM, BN, PITCH_C, NT>(p, sC, m0, n, q4, r0, cb, rb_off, full, bv, cs, cq);
+  else if (p.act == 2) epilogue_rows<T, 2, BM, BN, PITCH_C, NT>(p, sC, m0, n, q4, r0, cb, rb_off, full, bv, cs, cq);
+  else epilogue_rows<T, 3, BM, BN, PITCH_C, NT>(p, sC, m0, n, q4, r0, cb, rb_off, full, bv, cs, cq);
+}
+
+// Column statistics of the stored tile (cmda_gemm_params_t.colstats: the BatchNorm / InstanceNorm behind this convolution).  Every
+// thread arrives with the sums of ITS column quad over the rows it stored (all epilogue passes of the tile); the lanes of a wave that
+// share a quad fold with xor-shuffles, the waves meet in LDS (`scratch`: NT / 64 x 2 x BN floats, the tile staging area, free once
+// the last pass is stored -- the caller has a barrier behind it), and thread (statistic, column) issues ONE fp32 atomic into one of
+// the 32 slots of the row group's workspace: 2 x BN atomics per tile (a first version issued them per wave and pass -- one atomic per
+// four stored elements on the 256 x 256 tile: 255 against 159 us for the head's pointwise convolution).
+template <int BN, int NT>
+static __device__ __forceinline__ void colstats_flush(const GemmParams& p, float* scratch, long m0, long n0, int tid,
+                                                      float (&cs)[4], float (&cq)[4]) {
+  constexpr int QPR = BN / 4, NWV = NT / 64;
+#pragma unroll
+  for (int o = 32; o >= QPR; o >>= 1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      cs[e] += __shfl_xor(cs[e], o, 64);
+      cq[e] += __shfl_xor(cq[e], o, 64);
+    }
+  }
+  const int lane = tid & 63, wv = tid >> 6;
+  const int q4 = (tid % QPR) * 4;
+  if (lane < QPR || QPR >= 64) {
+    float* d = scratch + wv * 2 * BN;
+    st4(d + q4, cs);
+    st4(d + BN + q4, cq);
+  }
+  __syncthreads();
+  // (QPR > 64, the 256-wide tile on four waves, would leave quads unowned per wave -- not instantiated: NT >= QPR and the xor fold
+  // cover QPR <= 64; the static_assert below keeps it that way)
+  static_assert(QPR <= 64, "one wave owns every column quad");
+  for (int i = tid; i < 2 * BN; i += NT) {
+    const int col = i < BN ? i : i - BN;
+    if (n0 + col >= p.N) continue;
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) t += scratch[w * 2 * BN + i];
+    const long grp = (unsigned)m0 / (unsigned)p.colstats_rows;
+    const unsigned slot = (unsigned)(m0 >> 6) & (CMDA_BN_SLOTS - 1);
+    atomicAdd(p.colstats + (grp * (CMDA_BN_SLOTS + 1) + slot) * 2 * (long)p.N + (i < BN ? 0 : p.N) + n0 + col, t);
+  }
 }
 
 template <typename T, int TM, int TN, bool AKS, bool BKS>
@@ -509,7 +559,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
       for (int r = 0; r < 4; ++r)
         sC[(wm * 16 * TM + i * 16 + 4 * g + r) * PITCH_C + wn * 16 * TN + j * 16 + l15] = acc[i][j][r];
   __syncthreads();
-  epilogue_store<T, BM, BN, PITCH_C>(p, sC, m0, n0, cb, rb_off, tid);
+  float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
+  epilogue_store<T, BM, BN, PITCH_C>(p, sC, m0, n0, cb, rb_off, tid, cs, cq);
+  if (p.colstats) {
+    __syncthreads();
+    colstats_flush<BN, 256>(p, sC, m0, n0, tid, cs, cq);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1076,8 +1131,14 @@ static __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, char*
           sC[(wm * 16 * TM + i * 16 + 4 * g + r) * PITCH_C + wn * 16 * TN + j * 16 + l15] = acc[i][j][r];
     __syncthreads();
     CMDA_STAMP(4);
-    epilogue_store<T, BM, BN, PITCH_C, NTHR>(p, sC, m0, n0, cb, rb_off, tid);
+    float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
+    epilogue_store<T, BM, BN, PITCH_C, NTHR>(p, sC, m0, n0, cb, rb_off, tid, cs, cq);
+    if (p.colstats) {
+      __syncthreads();
+      colstats_flush<BN, NTHR>(p, sC, m0, n0, tid, cs, cq);
+    }
   } else {
+    float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
     for (int wr = 0; wr < WM; ++wr) {  // one wave-row (16*TM rows) per pass: its two waves stage, everyone stores
       if (wm == wr) {
 #pragma unroll
@@ -1090,9 +1151,10 @@ static __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, char*
       }
       __syncthreads();
       if (m0 + wr * EPI_ROWS < p.M)
-        epilogue_store<T, EPI_ROWS, BN, PITCH_C, NTHR>(p, sC, m0 + wr * EPI_ROWS, n0, cb, rb_off, tid);
+        epilogue_store<T, EPI_ROWS, BN, PITCH_C, NTHR>(p, sC, m0 + wr * EPI_ROWS, n0, cb, rb_off, tid, cs, cq);
       __syncthreads();
     }
+    if (p.colstats) colstats_flush<BN, NTHR>(p, sC, m0, n0, tid, cs, cq);
     CMDA_STAMP(4);
   }
   CMDA_STAMP(5);

@@ -280,6 +280,10 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(GemmParams p) {
   const long cb = (long)batch * p.c_batch_stride + (long)batch2 * p.c_batch2_stride;
   T* C = reinterpret_cast<T*>(p.C) + cb;
   const bool vec = p.c_vec_ok != 0 && (p.ldc & 7) == 0 && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+  // fused column statistics (cmda_gemm_params_t.colstats): a thread stores the same 8-column chunk of every row it handles, so the
+  // sums of the STORED (bf16) values ride along in 16 registers -- the accumulators are dead by now
+  const bool stats = p.colstats != nullptr;
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, cq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
   for (int it = 0; it < (PP_BM * PP_BN / 8) / 512; ++it) {
     const int idx = it * 512 + tid;
@@ -287,6 +291,16 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(GemmParams p) {
     const long m = m0 + row, n = n0 + ch * 8;
     if (m >= p.M || n >= p.N) continue;
     const uint4 val = *reinterpret_cast<const uint4*>(&sC[row * PP_PITCH_C + ch * 8]);
+    if (stats) {
+      T tv[8];
+      __builtin_memcpy(tv, &val, 16);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float f = bf2f(tv[e]);
+        cs[e] += f;
+        cq[e] += f * f;
+      }
+    }
     if (vec && n + 8 <= p.N) {
       *reinterpret_cast<uint4*>(&C[m * p.ldc + n]) = val;
     } else {
@@ -295,6 +309,34 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(GemmParams p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e)
         if (n + e < p.N) C[m * p.ldc + n + e] = tmp[e];
+    }
+  }
+  if (stats) {   // lanes l and l ^ 32 hold the same chunk; the eight waves meet in LDS; 2 x 256 atomics per tile (gemm_kernels.h colstats_flush)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      cs[e] += __shfl_xor(cs[e], 32, 64);
+      cq[e] += __shfl_xor(cq[e], 32, 64);
+    }
+    __syncthreads();   // everyone is done with the image
+    float* scr = reinterpret_cast<float*>(smem);
+    const int wv = tid >> 6, ln = tid & 63;
+    if (ln < 32) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        scr[wv * 2 * PP_BN + ln * 8 + e] = cs[e];
+        scr[wv * 2 * PP_BN + PP_BN + ln * 8 + e] = cq[e];
+      }
+    }
+    __syncthreads();
+    static_assert(2 * PP_BN == 512, "one thread per (statistic, column)");
+    const int col = tid & (PP_BN - 1);
+    if (n0 + col < p.N) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) t += scr[w * 2 * PP_BN + tid];
+      const long gidx = (unsigned)m0 / (unsigned)p.colstats_rows;
+      const unsigned slot = (unsigned)(m0 >> 6) & (CMDA_BN_SLOTS - 1);
+      atomicAdd(p.colstats + (gidx * (CMDA_BN_SLOTS + 1) + slot) * 2 * (long)p.N + (tid < PP_BN ? 0 : p.N) + n0 + col, t);
     }
   }
 }

@@ -8,7 +8,7 @@ int cmda_gemm_reg_(const cmda_gemm_params_t& p, int tile, void* stream) {
   if (p.dtype == CMDA_F32X3) {
     // the encoders' Linear layers / data gradients (small grids: the 64 x 64 and 128 x 64 tile choices): the LDS-DMA instance
     // ... and every weight gradient it takes (split-K over the tokens chosen by the kernel's launcher, bias gradient fused)
-    if ((tile == 1 || tile == 2 || tile == 4 || p.a_kstrided || (p.tile_hint > 0 && (p.tile_hint & 65536))) && cmda_gemm_x3_lean_ok_(p))
+    if ((tile == 1 || tile == 2 || tile == 4 || p.a_kstrided || (p.tile_hint > 0 && (p.tile_hint & 65536))) && !p.colstats && cmda_gemm_x3_lean_ok_(p))
       return cmda_gemm_x3_lean_(p, stream);   // (tile_hint bit 16: the lean kernel whatever the tile choice -- tuning A/B)
     return cmda_gemm_x3_(p, tile, stream);
   }

@@ -201,7 +201,12 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmParams p) {
       for (int r = 0; r < 4; ++r)
         sC[(wm * 16 * TM + i * 16 + 4 * g + r) * PITCH_C + wn * 16 * TN + j * 16 + l15] = acc[i][j][r];
   __syncthreads();
-  epilogue_store<T, BM, BN, PITCH_C>(p, sC, m0, n0, cb, rb_off, tid);
+  float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
+  epilogue_store<T, BM, BN, PITCH_C>(p, sC, m0, n0, cb, rb_off, tid, cs, cq);
+  if (p.colstats) {
+    __syncthreads();
+    colstats_flush<BN, 256>(p, sC, m0, n0, tid, cs, cq);
+  }
 }
 
 template <int TM, int TN>

@@ -37,6 +37,15 @@ struct X3LeanParams {
   // elements) p_jump bytes apart (gemm_lean.hip); p_seg == 0: plain operand
   long p_img;
   int p_ohw, p_ow, p_row, p_col, p_seg, p_jump;
+  // forward form with atomic != 0: split-K over grid.z (kt_per k-tiles per split), fp32 atomics into C (the spatial-reduction
+  // convolutions of small token counts: bias rows pre-filled by cmda_rows_fill)
+  int atomic;
+  // patch-store epilogue (cmda_gemm_params_t.c_patch_*: the data gradient of a kernel == stride convolution stored straight into NHWC)
+  int c_patch_ow, c_patch_kh, c_patch_kwci;
+  // weight-gradient form with a PATCH view as B (dW of a kernel == stride convolution: B(k = token, n = (kh, kw, ci))): token
+  // (b, oh, ow) starts at b * pb_img + oh * pb_row + ow * pb_col elements; column n = kh * pb_kwc + rest lies at kh * pb_line + rest
+  long pb_img;
+  int pb_ohw, pb_ow, pb_row, pb_col, pb_kwc, pb_line;   // pb_kwc == 0: plain B
 };
 
 // 64 x 64 tile on eight waves = 4 (rows of 16) x 2 (columns of 32); 32-deep k-tiles: three fp32 stages of 16 KiB (two in flight while
@@ -62,8 +71,8 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_lean_kernel(X3LeanParams q) {
   const int wm = wid >> 1, wn = wid & 1, g = lane >> 4, l15 = lane & 15;
   const int M = q.M, N = q.N, tiles_n = q.tiles_n, ntile = q.ntile;
   const int bz = (int)blockIdx.z / q.splits, ksplit = (int)blockIdx.z - bz * q.splits;
-  const int kt0 = AKS ? ksplit * q.kt_per : 0;
-  const int nkt = AKS ? min(q.nkt - kt0, q.kt_per) : q.nkt;   // k-tiles of THIS workgroup
+  const int kt0 = ksplit * q.kt_per;                   // (kt_per = all k-tiles and one split unless the launcher split K)
+  const int nkt = min(q.nkt - kt0, q.kt_per);          // k-tiles of THIS workgroup
   {   // batch entry: operand / output bases move, everything else is per problem
     const int b1 = bz / q.batch2, b2 = bz - b1 * q.batch2;
     q.A += b1 * q.a_bs + b2 * q.a_b2s;
@@ -96,8 +105,13 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_lean_kernel(X3LeanParams q) {
       const unsigned pb = rr / (unsigned)q.p_ohw, rem = rr - pb * (unsigned)q.p_ohw, oh = rem / (unsigned)q.p_ow, ow = rem - oh * (unsigned)q.p_ow;
       curA = reinterpret_cast<const char*>(q.A + (long)pb * q.p_img + (long)oh * q.p_row + (long)ow * q.p_col + chA * 4);
       stepA = BK * 4;
+      if (kt0 > 0) {   // split-K: this workgroup starts in segment kt0 / p_seg, kt0 % p_seg k-tiles into it
+        const int sg = kt0 / q.p_seg, within = kt0 - sg * q.p_seg;
+        curA += (long)sg * ((long)q.p_seg * BK * 4 + q.p_jump) + (long)within * BK * 4;
+        seg_left = q.p_seg - within;
+      }
     } else {
-      curA = ok ? reinterpret_cast<const char*>(q.A + r * q.lda + chA * 4) : zero;
+      curA = ok ? reinterpret_cast<const char*>(q.A + r * q.lda + (long)kt0 * BK + chA * 4) : zero;
       stepA = ok ? BK * 4 : 0;
     }
   } else {                  // line = k (token), 64 consecutive output rows m
@@ -110,7 +124,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_lean_kernel(X3LeanParams q) {
   if constexpr (!BKS) {
     const long r = n0 + lnB;
     const bool ok = r < N;
-    curB = ok ? reinterpret_cast<const char*>(q.B + r * q.ldb + chB * 4) : zero;
+    curB = ok ? reinterpret_cast<const char*>(q.B + r * q.ldb + (long)kt0 * BK + chB * 4) : zero;
     stepB = ok ? BK * 4 : 0;
   } else {
     const long c = n0 + chB * 4;
@@ -118,9 +132,28 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_lean_kernel(X3LeanParams q) {
     curB = ok ? reinterpret_cast<const char*>(q.B + ((long)kt0 * BK + lnB) * q.ldb + c) : zero;
     stepB = ok ? (int)((long)BK * q.ldb * 4) : 0;
   }
+  // patch view as the K-strided B of the weight-gradient form: the thread's token moves 32 rows per k-tile, its column offset
+  // (kh segment + rest: a 64-column tile never straddles a segment, KW * C % 64 == 0) is fixed
+  unsigned tokB = 0;
+  long colB = 0;
+  if constexpr (AKS) {
+    if (q.pb_kwc > 0) {
+      const unsigned c = (unsigned)(n0 + chB * 4), kh = c / (unsigned)q.pb_kwc;
+      colB = (long)kh * q.pb_line + (c - kh * (unsigned)q.pb_kwc);
+      tokB = (unsigned)(kt0 * BK + lnB);
+    }
+  }
+  auto patch_b = [&]() {
+    const unsigned pb = tokB / (unsigned)q.pb_ohw, rem = tokB - pb * (unsigned)q.pb_ohw, oh = rem / (unsigned)q.pb_ow, ow = rem - oh * (unsigned)q.pb_ow;
+    tokB += BK;
+    return reinterpret_cast<const char*>(q.B + (long)pb * q.pb_img + (long)oh * q.pb_row + (long)ow * q.pb_col + colB);
+  };
   auto issue = [&](int stage) {
     float* st = sF + stage * (F_A + F_B);
     glds16_asm(curA, reinterpret_cast<char*>(st) + wid * 1024);
+    if constexpr (AKS) {
+      if (q.pb_kwc > 0) curB = patch_b();
+    }
     glds16_asm(curB, reinterpret_cast<char*>(st + F_A) + wid * 1024);
     curA += stepA;
     curB += stepB;
@@ -255,8 +288,9 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_lean_kernel(X3LeanParams q) {
     if (++stg == NSTG) stg = 0;
     set ^= 1;
   }
-  if constexpr (AKS) {
-    // ---- weight-gradient epilogue: fp32 atomics into C (split-K partial), bias gradient from the n-tile-0 workgroups ----
+  if (AKS || q.atomic) {
+    // ---- split-K epilogue (weight-gradient form; forward form with atomic output): fp32 atomics into C, bias gradient from the
+    //      n-tile-0 workgroups ----
     if (nkt <= 0) return;
     const float alpha = q.alpha;
 #pragma unroll
@@ -268,7 +302,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_lean_kernel(X3LeanParams q) {
         if (m < M && n < N) atomicAdd(q.C + m * q.ldc + n, alpha * acc[j][r]);
       }
     }
-    if (q.colsum && nt == 0) {   // 32 threads (lines) hold partial sums of the same four columns: fold through LDS
+    if (AKS && q.colsum && nt == 0) {   // 32 threads (lines) hold partial sums of the same four columns: fold through LDS
       __syncthreads();
       float* red = reinterpret_cast<float*>(smem);   // [32 lines][64 columns]
       st4(red + lnA * 64 + chA * 4, csum);
@@ -317,7 +351,12 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_lean_kernel(X3LeanParams q) {
     if (m >= M) break;
     const float4 t = *reinterpret_cast<const float4*>(&sC[row * PITCH_C + q4]);
     float v[4] = {t.x, t.y, t.z, t.w};
-    const long ci = m * q.ldc + en;
+    long ci = m * q.ldc + en;
+    if (q.c_patch_ow > 0) {   // un-patchify (gemm_kernels.h epilogue_rows): ((boh*KH + kh) * OW + ow) * KW*Ci + (kw*Ci + ci)
+      const unsigned boh = (unsigned)m / (unsigned)q.c_patch_ow, ow = (unsigned)m - boh * (unsigned)q.c_patch_ow;
+      const unsigned kh = (unsigned)en / (unsigned)q.c_patch_kwci, rest = (unsigned)en - kh * (unsigned)q.c_patch_kwci;
+      ci = (((long)boh * q.c_patch_kh + kh) * q.c_patch_ow + ow) * q.c_patch_kwci + rest;
+    }
     float ov[4] = {0.f, 0.f, 0.f, 0.f};
     float rs = 1.f;
     if (has_rs) rs = q.rowscale[(unsigned)m / (unsigned)q.rows_per_scale];
@@ -375,6 +414,16 @@ int launch_x3_lean(const GemmParams& p, void* stream) {
     q.p_seg = v.KW * v.C / 32;
     q.p_jump = (v.W - v.KW) * v.C * 4;
   }
+  q.atomic = 0;
+  q.c_patch_ow = p.c_patch_ow; q.c_patch_kh = p.c_patch_kh; q.c_patch_kwci = p.c_patch_kwci;
+  q.pb_kwc = 0; q.pb_img = 0; q.pb_ohw = q.pb_ow = 1; q.pb_row = q.pb_col = q.pb_line = 0;
+  if (p.B.conv == 2) {
+    const GemmView& v = p.B;
+    q.pb_img = (long)v.H * v.W * v.C;
+    q.pb_ohw = v.OH * v.OW; q.pb_ow = v.OW;
+    q.pb_row = v.stride * v.W * v.C; q.pb_col = v.stride * v.C;
+    q.pb_kwc = v.KW * v.C; q.pb_line = v.W * v.C;
+  }
   q.batch2 = p.batch2 > 0 ? p.batch2 : 1;
   q.a_bs = p.A.batch_stride; q.a_b2s = p.A.batch2_stride; q.b_bs = p.B.batch_stride; q.b_b2s = p.B.batch2_stride;
   q.c_bs = p.c_batch_stride; q.c_b2s = p.c_batch2_stride; q.r_bs = p.res_batch_stride; q.r_b2s = p.res_batch2_stride;
@@ -392,8 +441,14 @@ int launch_x3_lean(const GemmParams& p, void* stream) {
     CMDA_LAUNCH((gemm_x3_lean_kernel<true, true>), dim3((unsigned)tiles, 1, (unsigned)(nb * splits)), blk, 0, stream, q);
     CMDA_CHECK_LAUNCH();
   }
-  if (nb > 65535) return CMDA_ERR_SHAPE;
-  const dim3 grid((unsigned)tiles, 1, (unsigned)nb);
+  if (p.atomic) {   // forward form, split-K with the caller's / dispatcher's split count
+    int splits = std::max(1, std::min(p.splits, q.nkt));
+    q.kt_per = (q.nkt + splits - 1) / splits;
+    q.splits = (q.nkt + q.kt_per - 1) / q.kt_per;
+    q.atomic = 1;
+  }
+  if (nb * q.splits > 65535) return CMDA_ERR_SHAPE;
+  const dim3 grid((unsigned)tiles, 1, (unsigned)(nb * q.splits));
   if (p.b_kstrided) CMDA_LAUNCH((gemm_x3_lean_kernel<false, true>), grid, blk, 0, stream, q);
   else CMDA_LAUNCH((gemm_x3_lean_kernel<false, false>), grid, blk, 0, stream, q);
   CMDA_CHECK_LAUNCH();
@@ -408,21 +463,33 @@ bool cmda_gemm_x3_lean_ok_(const cmda_gemm_params_t& p) {
   };
   const long nb = (long)p.batch * (p.batch2 > 0 ? p.batch2 : 1);
   auto bs_ok = [](const GemmView& v) { return (v.batch_stride % 4) == 0 && (v.batch2_stride % 4) == 0; };
-  // patch view of a kernel == stride convolution as A (K-contiguous B, no batch): KW * C a multiple of the k-tile, 32-bit row arithmetic
-  auto patch = [&](const GemmView& v) {
-    return v.conv == 2 && v.vec_ok && !p.a_kstrided && !p.b_kstrided && v.KH == v.stride && v.KW == v.stride && v.pad == 0 && v.dil == 1 &&
-           v.in_dil <= 1 && v.H == v.OH * v.stride && v.W == v.OW * v.stride && ((long)v.KW * v.C) % 32 == 0 && v.R < (1L << 31) &&
-           (long)v.stride * v.W * v.C * 4 < (1L << 31) && p.K == (long)v.KH * v.KW * v.C && nb == 1 && !p.atomic &&
-           (reinterpret_cast<uintptr_t>(v.ptr) % 16) == 0 && (v.C % 4) == 0;
+  // patch view of a kernel == stride convolution (no batch): 32-bit row arithmetic, 16-byte pieces
+  auto patch_geom = [&](const GemmView& v) {
+    return v.conv == 2 && v.vec_ok && v.KH == v.stride && v.KW == v.stride && v.pad == 0 && v.dil == 1 && v.in_dil <= 1 &&
+           v.H == v.OH * v.stride && v.W == v.OW * v.stride && v.R < (1L << 31) && (long)v.stride * v.W * v.C * 4 < (1L << 31) &&
+           p.K > 0 && nb == 1 && (reinterpret_cast<uintptr_t>(v.ptr) % 16) == 0 && (v.C % 4) == 0;
   };
-  if (!(p.dtype == CMDA_F32X3 && (plain(p.A) || patch(p.A)) && plain(p.B) && (p.K % 32) == 0 && p.K >= 32 && p.batch >= 1 && nb <= 65535 && bs_ok(p.A) && bs_ok(p.B) &&
-        (p.c_batch_stride % 4) == 0 && (p.c_batch2_stride % 4) == 0 && (nb == 1 || !p.colsum) &&
-        p.c_perm_ci == 0 && p.c_patch_ow == 0 && p.out_f32 && (p.N % 4) == 0 && !(p.tile_hint > 0 && (p.tile_hint & 8192))))   // (bit 13: general kernel, tuning A/B)
+  // ... as A of the forward form (K-contiguous B): KW * C a multiple of the k-tile
+  auto patch_a = [&](const GemmView& v) {
+    return patch_geom(v) && !p.a_kstrided && !p.b_kstrided && ((long)v.KW * v.C) % 32 == 0 && p.K == (long)v.KH * v.KW * v.C;
+  };
+  // ... as the K-strided B of the weight-gradient form (dW of the convolution): a 64-column tile inside one kernel row
+  auto patch_b = [&](const GemmView& v) {
+    return patch_geom(v) && p.a_kstrided && p.b_kstrided && ((long)v.KW * v.C) % 64 == 0 && p.N == (long)v.KH * v.KW * v.C && p.K == v.R;
+  };
+  if (!(p.dtype == CMDA_F32X3 && (plain(p.A) || patch_a(p.A)) && (plain(p.B) || patch_b(p.B)) && (p.K % 32) == 0 && p.K >= 32 && p.batch >= 1 && nb <= 65535 &&
+        bs_ok(p.A) && bs_ok(p.B) && (p.c_batch_stride % 4) == 0 && (p.c_batch2_stride % 4) == 0 && (nb == 1 || !p.colsum) &&
+        p.c_perm_ci == 0 && p.out_f32 && (p.N % 4) == 0 && !(p.tile_hint > 0 && (p.tile_hint & 8192))))   // (bit 13: general kernel, tuning A/B)
     return false;
   if (p.a_kstrided)   // weight-gradient form: dW (+)= dy^T x with fp32 atomics, any split count (the kernel chooses its own)
-    return p.b_kstrided && p.atomic && (p.M % 4) == 0 && !p.bias && !p.res && !p.rowscale && p.act == 0 && p.beta == 0.f &&
-           32L * p.A.ld * 4 < (1L << 31) && 32L * p.B.ld * 4 < (1L << 31);
-  return p.splits <= 1 && !p.atomic && !p.colsum && (!p.b_kstrided || 32L * p.B.ld * 4 < (1L << 31));
+    return p.b_kstrided && p.atomic && (p.M % 4) == 0 && !p.bias && !p.res && !p.rowscale && p.act == 0 && p.beta == 0.f && p.c_patch_ow == 0 &&
+           32L * p.A.ld * 4 < (1L << 31) && (p.B.conv == 2 || 32L * p.B.ld * 4 < (1L << 31));
+  if (p.colsum || (p.b_kstrided && 32L * p.B.ld * 4 >= (1L << 31))) return false;
+  if (p.atomic)       // forward form with split-K: atomics into pre-filled rows (plain epilogue only; the caller's split count)
+    return nb == 1 && p.c_patch_ow == 0 && !p.bias && !p.res && !p.rowscale && p.act == 0 && p.beta == 0.f && p.splits >= 1;
+  if (p.c_patch_ow > 0)   // patch-store epilogue (spatial-reduction data gradients): 32-bit row / column arithmetic
+    return nb == 1 && !p.res && p.c_vec_ok;
+  return p.splits <= 1;
 }
 
 int cmda_gemm_x3_lean_(const cmda_gemm_params_t& p, void* stream) { return launch_x3_lean(p, stream); }

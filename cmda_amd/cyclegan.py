@@ -45,7 +45,7 @@ class ResnetGenerator(nn.Module):
         self.n_blocks = n_blocks
         self._ident = {}
 
-    def _inorm(self, x, B, HW, C, relu, res=None, out_dtype=None, copy=False):
+    def _inorm(self, x, B, HW, C, relu, res=None, out_dtype=None, copy=False, stats=None):
         """InstanceNorm2d(affine=False, eps 1e-5) (+ReLU) (+ fp32 residual) on NHWC-flat x [B*HW, C]: the grouped column-statistics
         kernels with one group per sample (up to 8 samples per launch).  x is the convolution's fp32 output in both modes; the
         result is stored as `out_dtype` (default: the compute dtype, the next convolution's operand).  copy=True (the residual
@@ -64,26 +64,35 @@ class ResnetGenerator(nn.Module):
             g = min(8, B - b0)
             sl = slice(b0 * HW, (b0 + g) * HW)
             ops.bn_train_fwd2(x[sl], one, zero, y[sl], HW, C, 1e-5, relu, groups=g, res32=None if res is None else res[sl],
-                              y2=None if y2 is None else y2[sl])
+                              y2=None if y2 is None else y2[sl], stats_ws=stats if B <= 8 else None)
         return (y, y if y2 is None else y2) if copy else y
 
-    def _conv(self, x, conv, B, H, W, stride, pad, reflect, act=None):
-        """fp32 output in both modes: the InstanceNorm behind every convolution takes its statistics from the unrounded sums"""
+    @staticmethod
+    def _stats_ws(dev, B, HW, C):
+        """the workspace the convolution's epilogue leaves the InstanceNorm statistics in (one group per sample), or None"""
+        return ops.bn_stats_ws(dev, B, C) if (B <= 8 and ops.colstats_ok(HW, C)) else None
+
+    def _conv(self, x, conv, B, H, W, stride, pad, reflect, act=None, stats=False):
+        """fp32 output in both modes: the InstanceNorm behind every convolution takes its statistics from the unrounded sums.
+        stats=True: ... in the epilogue of this very launch where the shapes allow; returns (y, OH, OW, workspace or None)"""
         Co, _, KH, _ = conv.weight.shape
         OH, OW = K.conv_out_size(H, W, KH, stride, pad)
         out = torch.empty(B * OH * OW, Co, dtype=torch.float32, device=x.device)
-        y, OH, OW = K.conv_fwd(x, conv.weight, conv.bias, B, H, W, stride, pad, 1, act=act, reflect=reflect, out=out)
-        return y, OH, OW
+        ws = self._stats_ws(x.device, B, OH * OW, Co) if stats else None
+        y, OH, OW = K.conv_fwd(x, conv.weight, conv.bias, B, H, W, stride, pad, 1, act=act, reflect=reflect, out=out,
+                               colstats=None if ws is None else (ws, OH * OW))
+        return (y, OH, OW, ws) if stats else (y, OH, OW)
 
     def _convT(self, x, ct, B, H, W):
         """ConvTranspose2d(k3, s2, p1, output_padding 1) = conv of the zero-inserted input with the flipped kernel."""
         Ci, Co, KH, KW = ct.weight.shape
         OH, OW = 2 * H, 2 * W
         y = torch.empty(B * OH * OW, Co, dtype=torch.float32, device=x.device)
+        ws = self._stats_ws(x.device, B, OH * OW, Co)
         ops.gemm(conv_view(x, B, H, W, Ci, KH, KW, 1, KH - 1 - 1, 1, OH=OH, OW=OW, in_dil=2),
                  plain_view(rt.wconv(ct.weight, 'dgrad'), Co, KH * KW * Ci), y, B * OH * OW, Co, KH * KW * Ci,
-                 dtype=rt.tag(), bias=ct.bias)
-        return y, OH, OW
+                 dtype=rt.tag(), bias=ct.bias, colstats=None if ws is None else (ws, OH * OW))
+        return y, OH, OW, ws
 
     @torch.no_grad()
     def forward_mean3(self, img_time_res):
@@ -102,29 +111,32 @@ class ResnetGenerator(nn.Module):
             ops.nchw_to_nhwc_pad(inp.contiguous(), x, B, Cin, H * W, cp)
             H1, W1 = K.conv_out_size(H + 6, W + 6, 7, 1, 0)
             c = torch.empty(B * H1 * W1, m[1].out_channels, dtype=torch.float32, device=inp.device)
-            K.conv_fwd(x, m[1].weight, m[1].bias, B, H, W, 1, 3, 1, reflect=1, ci_pad=cp, out=c)
+            ws = self._stats_ws(inp.device, B, H1 * W1, m[1].out_channels)
+            K.conv_fwd(x, m[1].weight, m[1].bias, B, H, W, 1, 3, 1, reflect=1, ci_pad=cp, out=c,
+                       colstats=None if ws is None else (ws, H1 * W1))
         else:
             ops.permute4(inp.contiguous(), x, (B, Cin, H, W), (0, 2, 3, 1))
-            c, H1, W1 = self._conv(x, m[1], B, H, W, 1, 3, 1)
-        x = self._inorm(c, B, H1 * W1, m[1].out_channels, True)
-        c, H2, W2 = self._conv(x, m[4], B, H1, W1, 2, 1, 0)
-        x = self._inorm(c, B, H2 * W2, m[4].out_channels, True)
-        c, H3, W3 = self._conv(x, m[7], B, H2, W2, 2, 1, 0)
+            c, H1, W1, ws = self._conv(x, m[1], B, H, W, 1, 3, 1, stats=True)
+        # every InstanceNorm below takes its statistics from the epilogue of the convolution in front of it (`ws`)
+        x = self._inorm(c, B, H1 * W1, m[1].out_channels, True, stats=ws)
+        c, H2, W2, ws = self._conv(x, m[4], B, H1, W1, 2, 1, 0, stats=True)
+        x = self._inorm(c, B, H2 * W2, m[4].out_channels, True, stats=ws)
+        c, H3, W3, ws = self._conv(x, m[7], B, H2, W2, 2, 1, 0, stats=True)
         C = m[7].out_channels
         # the residual stream of the nine ResNet blocks stays fp32 (xs); xb = its compute-dtype copy, the convolutions' operand
-        xs, xb = self._inorm(c, B, H3 * W3, C, True, out_dtype=torch.float32, copy=True)
+        xs, xb = self._inorm(c, B, H3 * W3, C, True, out_dtype=torch.float32, copy=True, stats=ws)
         for i in range(self.n_blocks):
             cb = m[10 + i].conv_block
-            c, _, _ = self._conv(xb, cb[1], B, H3, W3, 1, 1, 1)
-            y = self._inorm(c, B, H3 * W3, C, True)
-            c, _, _ = self._conv(y, cb[5], B, H3, W3, 1, 1, 1)
-            xs, xb = self._inorm(c, B, H3 * W3, C, False, res=xs, out_dtype=torch.float32, copy=True)
+            c, _, _, ws = self._conv(xb, cb[1], B, H3, W3, 1, 1, 1, stats=True)
+            y = self._inorm(c, B, H3 * W3, C, True, stats=ws)
+            c, _, _, ws = self._conv(y, cb[5], B, H3, W3, 1, 1, 1, stats=True)
+            xs, xb = self._inorm(c, B, H3 * W3, C, False, res=xs, out_dtype=torch.float32, copy=True, stats=ws)
         x = xb
         k = 10 + self.n_blocks
-        c, H4, W4 = self._convT(x, m[k], B, H3, W3)
-        x = self._inorm(c, B, H4 * W4, m[k].out_channels, True)
-        c, H5, W5 = self._convT(x, m[k + 3], B, H4, W4)
-        x = self._inorm(c, B, H5 * W5, m[k + 3].out_channels, True)
+        c, H4, W4, ws = self._convT(x, m[k], B, H3, W3)
+        x = self._inorm(c, B, H4 * W4, m[k].out_channels, True, stats=ws)
+        c, H5, W5, ws = self._convT(x, m[k + 3], B, H4, W4)
+        x = self._inorm(c, B, H5 * W5, m[k + 3].out_channels, True, stats=ws)
         last = m[k + 7]
         Co = last.out_channels
         Ci = last.in_channels

@@ -45,13 +45,21 @@ class MLP(nn.Module):
         self.proj = nn.Linear(input_dim, embed_dim)
 
 
-def _bn_fwd(bn, x, y, M, C, relu, ldy=None, coff=0, groups=1, order=None):
+def _bn_stats_ws(bn, dev, M, C, groups):
+    """the workspace in which the convolution in front of `bn` leaves the batch statistics (its GEMM epilogue, ops.gemm colstats), or
+    None: evaluation mode, groups that are not whole 256-row tiles, fused statistics switched off"""
+    if not bn.training or M % groups or not ops.colstats_ok(M // groups, C):
+        return None
+    return ops.bn_stats_ws(dev, groups, C)
+
+
+def _bn_fwd(bn, x, y, M, C, relu, ldy=None, coff=0, groups=1, order=None, stats_ws=None):
     """train: batch stats + running-stat update; eval: running stats.  Returns what the backward needs.  M = ALL rows of x;
     groups > 1: x is `groups` consecutive blocks of M/groups rows, each with its own batch statistics (one decoder pass over
-    several feature sets, running statistics updated in `order`)."""
+    several feature sets, running statistics updated in `order`).  stats_ws: `_bn_stats_ws` filled by the producer of x."""
     if bn.training:
         mean, rstd = ops.bn_train_fwd(x, bn.weight, bn.bias, y, bn.running_mean, bn.running_var, M // groups, C, bn.eps,
-                                      bn.momentum, relu, ldy, coff, groups, order)
+                                      bn.momentum, relu, ldy, coff, groups, order, stats_ws=stats_ws)
     else:
         mean, rstd = bn.running_mean, torch.rsqrt(bn.running_var + bn.eps)
         ops.bn_apply(x, mean, rstd, bn.weight, bn.bias, y, M, C, relu, ldy, coff)
@@ -91,20 +99,24 @@ class ASPPWrapper(nn.Module):
         g = dict(groups=groups, order=order)
         for j, (d, m) in enumerate(zip(self.dilations, self.aspp_modules)):
             if d == 1:
-                z = K.linear_fwd(x, m.conv.weight, None, M, Cin)
-                st = _bn_fwd(m.bn, z, cat, M, Ch, True, nb * Ch, j * Ch, **g)
+                ws = _bn_stats_ws(m.bn, x.device, M, Ch, groups)
+                z = K.linear_fwd(x, m.conv.weight, None, M, Cin, colstats=None if ws is None else (ws, M // groups))
+                st = _bn_fwd(m.bn, z, cat, M, Ch, True, nb * Ch, j * Ch, stats_ws=ws, **g)
                 saved.append((z, st))
             else:
                 dwm, pwm = m.depthwise_conv, m.pointwise_conv
-                u = ops.dwconv_fwd(x, rt.wdw(dwm.conv.weight), None, B, H, W, Cin, d, None)
+                ws = _bn_stats_ws(dwm.bn, x.device, M, Cin, groups) if (d >= 2 and B % groups == 0) else None
+                u = ops.dwconv_fwd(x, rt.wdw(dwm.conv.weight), None, B, H, W, Cin, d, None, colstats=None if ws is None else (ws, B // groups))
                 ub = torch.empty_like(u)
-                st_u = _bn_fwd(dwm.bn, u, ub, M, Cin, True, **g)
-                z = K.linear_fwd(ub, pwm.conv.weight, None, M, Cin)
-                st_z = _bn_fwd(pwm.bn, z, cat, M, Ch, True, nb * Ch, j * Ch, **g)
+                st_u = _bn_fwd(dwm.bn, u, ub, M, Cin, True, stats_ws=ws, **g)
+                ws = _bn_stats_ws(pwm.bn, x.device, M, Ch, groups)
+                z = K.linear_fwd(ub, pwm.conv.weight, None, M, Cin, colstats=None if ws is None else (ws, M // groups))
+                st_z = _bn_fwd(pwm.bn, z, cat, M, Ch, True, nb * Ch, j * Ch, stats_ws=ws, **g)
                 saved.append((u, st_u, ub, z, st_z))
-        zb, _, _ = K.conv_fwd(cat, self.bottleneck.conv.weight, None, B, H, W, 1, 1)
+        ws = _bn_stats_ws(self.bottleneck.bn, x.device, M, Ch, groups)
+        zb, _, _ = K.conv_fwd(cat, self.bottleneck.conv.weight, None, B, H, W, 1, 1, colstats=None if ws is None else (ws, M // groups))
         feat = torch.empty_like(zb)
-        st_b = _bn_fwd(self.bottleneck.bn, zb, feat, M, Ch, True, **g)
+        st_b = _bn_fwd(self.bottleneck.bn, zb, feat, M, Ch, True, stats_ws=ws, **g)
         return feat, (x, cat, saved, zb, st_b, groups)
 
     def bwd(self, sv, dfeat, B, H, W):

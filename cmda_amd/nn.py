@@ -15,13 +15,13 @@ from .ops import conv_view, plain_view
 
 # ------------------------------------------------------------------ Linear
 def linear_fwd(x, weight, bias, M, K, *, act=None, res=None, rowscale=None, rows_per_scale=1, out=None, ldc=None,
-               c_offset=0, out_dtype=None, x_ld=None, x_off=0):
-    """y[M,N] = act(x[M,K] @ W[N,K]^T + b) (* rowscale) (+ res)"""
+               c_offset=0, out_dtype=None, x_ld=None, x_off=0, colstats=None):
+    """y[M,N] = act(x[M,K] @ W[N,K]^T + b) (* rowscale) (+ res); colstats: ops.gemm"""
     N = weight.shape[0]
     if out is None:
         out = torch.empty(M, N, dtype=out_dtype or rt.compute_dtype(), device=x.device)
     ops.gemm(plain_view(x, M, K, ld=x_ld, offset=x_off), plain_view(rt.w(weight), N, K), out, M, N, K, dtype=rt.tag(),
-             bias=bias, act=act, res=res, rowscale=rowscale, rows_per_scale=rows_per_scale, ldc=ldc, c_offset=c_offset)
+             bias=bias, act=act, res=res, rowscale=rowscale, rows_per_scale=rows_per_scale, ldc=ldc, c_offset=c_offset, colstats=colstats)
     return out
 
 
@@ -56,7 +56,7 @@ def conv_out_size(H, W, k, stride, pad, dil=1):
     return (H + 2 * pad - dil * (k - 1) - 1) // stride + 1, (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
 
-def conv_fwd(x, weight, bias, B, H, W, stride, pad, dil=1, *, act=None, out=None, reflect=0, ci_pad=0):
+def conv_fwd(x, weight, bias, B, H, W, stride, pad, dil=1, *, act=None, out=None, reflect=0, ci_pad=0, colstats=None):
     """ci_pad > Ci: x carries ci_pad channels per pixel (zeros past Ci) and the weight copy is padded alike (runtime.wconv)"""
     Co, Ci, KH, KW = weight.shape
     Ci = max(Ci, ci_pad)
@@ -65,7 +65,7 @@ def conv_fwd(x, weight, bias, B, H, W, stride, pad, dil=1, *, act=None, out=None
     if out is None:
         out = torch.empty(M, Co, dtype=rt.compute_dtype(), device=x.device)
     ops.gemm(conv_view(x, B, H, W, Ci, KH, KW, stride, pad, dil, OH=OH, OW=OW, reflect=reflect),
-             plain_view(rt.wconv(weight, ci_pad=ci_pad), Co, K), out, M, Co, K, dtype=rt.tag(), bias=bias, act=act)
+             plain_view(rt.wconv(weight, ci_pad=ci_pad), Co, K), out, M, Co, K, dtype=rt.tag(), bias=bias, act=act, colstats=colstats)
     return out, OH, OW
 
 

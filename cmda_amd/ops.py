@@ -144,8 +144,9 @@ def _x3_half_views(v):
     return out[0], out[1], (hi, lo)
 
 
-def _gemm_x3_big(A, B, out, M, N, K, kw):
-    """out = a_lo b_hi + a_hi b_lo + a_hi b_hi (bias / residual / caller's beta in the first launch)"""
+def _gemm_x3_big(A, B, out, M, N, K, kw, colstats=None):
+    """out = a_lo b_hi + a_hi b_lo + a_hi b_hi (bias / residual / caller's beta in the first launch; fused column statistics in the
+    last one, whose epilogue stores the final values)"""
     a_hi, a_lo, ka = _x3_half_views(A)
     b_hi, b_lo, kb = _x3_half_views(B)
     keep = tuple(kw.pop('keep', ())) + ka + kb
@@ -158,26 +159,29 @@ def _gemm_x3_big(A, B, out, M, N, K, kw):
     # the bias gradient (column sums of A = dy): sum of the two halves' column sums, taken in the launches that read them first
     gemm(a_lo, b_hi, out, M, N, K, **dict(first, dtype=1, colsum=colsum, keep=keep))
     gemm(a_hi, b_lo, out, M, N, K, **dict(rest, dtype=1, colsum=colsum, keep=keep))
-    gemm(a_hi, b_hi, out, M, N, K, **dict(rest, dtype=1, colsum=None, keep=keep))
+    gemm(a_hi, b_hi, out, M, N, K, **dict(rest, dtype=1, colsum=None, keep=keep, colstats=colstats))
     return out
 
 
 def gemm(A, B, out, M, N, K, *, a_kstrided=False, b_kstrided=False, ldc=None, batch=1, c_batch_stride=0,
          batch2=1, c_batch2_stride=0, res_batch2_stride=0, splits=1, alpha=1.0, beta=0.0, bias=None, act=None, res=None, ldres=None, res_batch_stride=0,
          rowscale=None, rows_per_scale=1, atomic=False, dtype=None, c_offset=0, colsum=None, c_patch=None, c_perm=None, defer=False, keep=(),
-         hold=False):
+         hold=False, colstats=None):
     """out[m,n] = epi(alpha * sum_k A(m,k) B(n,k)); A/B are `View`s built by plain_view / conv_view.
     defer=True (weight gradients: nothing reads `out` before the pass ends): inside a deferral scope (`ln_deferral`) the launch is
     only QUEUED and goes out with the next `gemm_flush_deferred()` as part of a grouped launch; `keep` = the tensors behind the
     operand views (kept alive until then).
-    hold=True: build the problem but do NOT launch it -- returns (params, meta, out, keep) for tools that time or inspect it."""
+    hold=True: build the problem but do NOT launch it -- returns (params, meta, out, keep) for tools that time or inspect it.
+    colstats=(ws, rows_per_group): column sums / sums of squares of the stored output accumulated into the BatchNorm workspace `ws`
+    (`bn_stats_ws`: zero on entry) by the epilogue -- the statistics pass of the BatchNorm / InstanceNorm behind this convolution
+    (`colstats_ok` says whether a problem qualifies)."""
     check_dev(out, bias, res, rowscale)
     if dtype == 2 and _x3_big_ok(A, B, out, M, N, K, batch * batch2, act, rowscale, hold, defer, splits, c_patch, c_perm):
         return _gemm_x3_big(A, B, out, M, N, K, dict(a_kstrided=a_kstrided, b_kstrided=b_kstrided, ldc=ldc, batch=batch,
                                                      c_batch_stride=c_batch_stride, batch2=batch2, c_batch2_stride=c_batch2_stride,
                                                      res_batch2_stride=res_batch2_stride, splits=splits, alpha=alpha, beta=beta, bias=bias,
                                                      res=res, ldres=ldres, res_batch_stride=res_batch_stride, atomic=atomic,
-                                                     c_offset=c_offset, colsum=colsum, c_perm=c_perm, defer=defer, keep=keep))
+                                                     c_offset=c_offset, colsum=colsum, c_perm=c_perm, defer=defer, keep=keep), colstats=colstats)
     out_f32 = out.dtype == torch.float32
     p = GemmParams()
     p.A, p.B = A, B
@@ -206,6 +210,10 @@ def gemm(A, B, out, M, N, K, *, a_kstrided=False, b_kstrided=False, ldc=None, ba
         ok = ok and bias.data_ptr() % 16 == 0
     p.c_vec_ok = int(ok)
     p.colsum = colsum.data_ptr() if colsum is not None else None
+    if colstats is not None:
+        check_dev(colstats[0])
+        assert colstats[0].dtype == torch.float32 and not defer and not atomic
+        p.colstats, p.colstats_rows = colstats[0].data_ptr(), colstats[1]
     p.tile_hint = GEMM_TILE_HINT
     if c_perm is not None:   # (Ci, KH*KW): atomic store of a conv weight gradient in the parameter's [Co,Ci,KH,KW] layout
         assert atomic and batch == 1 and batch2 == 1
@@ -756,9 +764,16 @@ def attention_fused_bwd(q, kv, do, dkv32, B, N, Nk, heads, C, scale, dkv16=None)
     return dq
 
 
-def dwconv_fwd(x, w, bias, B, H, W, C, dil=1, act=None):
+def dwconv_fwd(x, w, bias, B, H, W, C, dil=1, act=None, colstats=None):
+    """colstats=(ws, images_per_group): the BatchNorm statistics of y on the way (dilated walk, no activation: cmda_dwconv3x3_fwd_stats)"""
     check_dev(x, w, bias)
     y = torch.empty_like(x)
+    if colstats is not None:
+        assert act is None and dil >= 2
+        check_dev(colstats[0])
+        call('cmda_dwconv3x3_fwd_stats', ptr(x), ptr(w), ptr(bias), ptr(y), c_i32(B), c_i32(H), c_i32(W), c_i32(C), c_i32(dil),
+             ptr(colstats[0]), c_i32(colstats[1]), dtype_tag(x), stream_of(x))
+        return y
     call('cmda_dwconv3x3_fwd', ptr(x), ptr(w), ptr(bias), ptr(y), c_i32(B), c_i32(H), c_i32(W), c_i32(C), c_i32(dil),
          c_i32(ACT[act]), dtype_tag(x), stream_of(x))
     return y
@@ -809,31 +824,67 @@ def bilinear_bwd(dy, dx, B, IH, IW, OH, OW, C, ldy=None, coff=0):
     return dx
 
 
-def bn_train_fwd(x, gamma, beta, y, running_mean, running_var, M, C, eps, momentum, relu, ldy=None, coff=0, groups=1, order=None):
-    """M = rows PER GROUP; x / y hold `groups` consecutive blocks of M rows (own statistics each); returns mean, rstd [groups, C]"""
-    check_dev(x, gamma, beta, y, running_mean, running_var)
+BN_FUSED_STATS = os.environ.get('CMDA_BN_FUSED_STATS', '1') != '0'   # statistics of conv -> BN / IN pairs in the GEMM epilogue (A/B switch)
+_BN_WS = {}
+
+
+def bn_stats_ws(device, groups, C):
+    """the persistent ZERO workspace a GEMM epilogue accumulates BatchNorm statistics into (gemm(colstats=...)); bn_train_fwd /
+    bn_train_fwd2 with stats_ws hand it back zeroed, so one buffer per device and concurrency lane serves every layer (calls on one
+    stream are ordered).  None where the fused statistics are switched off."""
+    if not BN_FUSED_STATS:
+        return None
+    n = 8 * int(L.lib().cmda_bn_ws_floats(2048))
+    need = groups * int(L.lib().cmda_bn_ws_floats(C))
+    key = (device.type, device.index, LN_LANE)
+    ws = _BN_WS.get(key)
+    if ws is None or ws.numel() < need:
+        if device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+            return None   # (a lane nobody pre-allocated for, met inside a capture: the separate statistics pass)
+        ws = _BN_WS[key] = torch.zeros(max(n, need), dtype=torch.float32, device=device)
+    return ws[:need]
+
+
+def bn_ws_prealloc(device, lanes):
+    for ln in lanes:
+        key = (device.type, device.index, ln)
+        if key not in _BN_WS:
+            _BN_WS[key] = torch.zeros(8 * int(L.lib().cmda_bn_ws_floats(2048)), dtype=torch.float32, device=device)
+
+
+def colstats_ok(rows_per_group, N):
+    """may the convolution in front of a BatchNorm / InstanceNorm over groups of `rows_per_group` rows and N channels take the
+    statistics in its epilogue (cmda_gemm_params_t.colstats: whole 256-row tiles per group, 16-byte column quads)"""
+    return BN_FUSED_STATS and rows_per_group > 0 and rows_per_group % 256 == 0 and N % 4 == 0
+
+
+def bn_train_fwd(x, gamma, beta, y, running_mean, running_var, M, C, eps, momentum, relu, ldy=None, coff=0, groups=1, order=None,
+                 stats_ws=None):
+    """M = rows PER GROUP; x / y hold `groups` consecutive blocks of M rows (own statistics each); returns mean, rstd [groups, C].
+    stats_ws: the workspace the producing GEMM's epilogue filled (gemm(colstats=(ws, M))): no statistics pass over x"""
+    check_dev(x, gamma, beta, y, running_mean, running_var, stats_ws)
     mean = torch.empty(groups, C, dtype=torch.float32, device=x.device)
     rstd = torch.empty(groups, C, dtype=torch.float32, device=x.device)
-    ws = torch.empty(groups * L.lib().cmda_bn_ws_floats(C), dtype=torch.float32, device=x.device)
+    ws = stats_ws if stats_ws is not None else torch.empty(groups * L.lib().cmda_bn_ws_floats(C), dtype=torch.float32, device=x.device)
     order_c = (ctypes.c_int * groups)(*order) if order is not None else None
     call('cmda_bn_train_fwd', ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), ptr(running_mean),
          ptr(running_var), ptr(ws), c_i64(M), c_i32(C), c_f32(eps), c_f32(momentum), c_i32(int(relu)),
-         c_i32(C if ldy is None else ldy), c_i32(coff), c_i32(groups), order_c, dtype_tag(x), stream_of(x))
+         c_i32(C if ldy is None else ldy), c_i32(coff), c_i32(groups), order_c, c_i32(int(stats_ws is not None)), dtype_tag(x), stream_of(x))
     return mean, rstd
 
 
-def bn_train_fwd2(x, gamma, beta, y, M, C, eps, relu, groups=1, res32=None, y2=None, ldy=None, coff=0):
+def bn_train_fwd2(x, gamma, beta, y, M, C, eps, relu, groups=1, res32=None, y2=None, ldy=None, coff=0, stats_ws=None):
     """cmda_bn_train_fwd2: x and y of independent storage types, no running statistics; res32 (fp32 [groups*M, C]) is added after
-    the normalisation, y2 (bf16 [groups*M, C]) receives a copy of the result.  Returns mean, rstd [groups, C]."""
-    check_dev(x, gamma, beta, y, res32, y2)
+    the normalisation, y2 (bf16 [groups*M, C]) receives a copy of the result.  Returns mean, rstd [groups, C].  stats_ws: bn_train_fwd"""
+    check_dev(x, gamma, beta, y, res32, y2, stats_ws)
     assert res32 is None or res32.dtype == torch.float32
     assert y2 is None or y2.dtype == torch.bfloat16
     mean = torch.empty(groups, C, dtype=torch.float32, device=x.device)
     rstd = torch.empty(groups, C, dtype=torch.float32, device=x.device)
-    ws = torch.empty(groups * L.lib().cmda_bn_ws_floats(C), dtype=torch.float32, device=x.device)
+    ws = stats_ws if stats_ws is not None else torch.empty(groups * L.lib().cmda_bn_ws_floats(C), dtype=torch.float32, device=x.device)
     call('cmda_bn_train_fwd2', ptr(x), dtype_tag(x), ptr(gamma), ptr(beta), ptr(y), dtype_tag(y), ptr(mean), ptr(rstd), None, None,
          ptr(ws), c_i64(M), c_i32(C), c_f32(eps), c_f32(0.0), c_i32(int(relu)), c_i32(C if ldy is None else ldy), c_i32(coff),
-         c_i32(groups), None, ptr(res32), ptr(y2), stream_of(x))
+         c_i32(groups), None, ptr(res32), ptr(y2), c_i32(int(stats_ws is not None)), stream_of(x))
     return mean, rstd
 
 

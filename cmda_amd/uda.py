@@ -492,6 +492,7 @@ class DACS(nn.Module):
         second = torch.empty_like(st_src['image'])
         ops.ln_ws_prealloc(dev, ('main', 'main/enc'))
         ops.zero_ws_prealloc(dev, ('main', 'main/enc'))
+        ops.bn_ws_prealloc(dev, ('main', 'main/enc'))
         torch.cuda.synchronize(dev)
         rt.refresh(force=True)   # every copy exists and is current before the capture starts
         lanes = getattr(self, 'graph_lane_set', None)

@@ -94,7 +94,16 @@ typedef struct cmda_gemm_params_t {
   /* the residual `res` is fp32 whatever `dtype` says (with out_f32: the fp32 residual stream of the bf16 mode, see
    * cmda_layernorm_fwd2) */
   int32_t res_f32;
-  int32_t reserved_;
+  /* colstats != NULL: column statistics of the OUTPUT fused into the epilogue -- the BatchNorm / InstanceNorm behind a convolution
+   * (mmcv ConvModule conv -> norm, daformer_head.py:46-62, sep_aspp_head.py:18-27; cyclegan_model.py:339-434) no longer re-reads the
+   * activation for its batch statistics.  For every stored element v = C[m][n] (as computed, before rounding to the storage type):
+   * colstats[g][slot][0][n] += v and colstats[g][slot][1][n] += v * v with g = m / colstats_rows and an arbitrary slot < 32, i.e. the
+   * layout of the BatchNorm workspace (groups x cmda_bn_ws_floats(N) floats, ZERO on entry); cmda_bn_train_fwd / fwd2 with
+   * ws_has_stats = 1 finish the normalisation from it.  Requires: forward form (A, B not K-strided outputs of atomics: atomic == 0,
+   * splits <= 1), act == 0, no rowscale, no c_patch_*, batch == batch2 == 1, N % 4 == 0, colstats_rows % 256 == 0.  The library then
+   * runs a kernel with the general epilogue (CMDA_ERR_UNSUPPORTED where none takes the problem). */
+  int32_t colstats_rows;
+  float* colstats;
 } cmda_gemm_params_t;
 
 int cmda_gemm(const cmda_gemm_params_t* p, void* stream);
@@ -170,6 +179,12 @@ int cmda_attention_bwd(const void* q, const void* kv, const void* d_o, void* dq,
  * half of the sep-ASPP decode_heads/sep_aspp_head.py:18-27.  `w` is tap-major fp32 [9][C]; dw (gradient) is [C][9]. */
 int cmda_dwconv3x3_fwd(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int dil,
     int act, int dtype, void* stream);
+/* cmda_dwconv3x3_fwd (no activation, dil >= 2: the sep-ASPP's dilated depthwise convolutions, sep_aspp_head.py:18-27) with the batch
+ * statistics of the BatchNorm behind it taken on the way: column sums / sums of squares of y per group of `imgs_per_group`
+ * consecutive images are added to `colstats`, the BatchNorm workspace (groups x cmda_bn_ws_floats(C) floats, zero on entry;
+ * cmda_bn_train_fwd with ws_has_stats = 1 finishes from it).  CMDA_ERR_UNSUPPORTED for dil < 2. */
+int cmda_dwconv3x3_fwd_stats(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int dil,
+    float* colstats, int imgs_per_group, int dtype, void* stream);
 int cmda_dwconv3x3_gelu_bwd_prep(const void* x, const float* w, const float* bias, const void* da, void* dz, int B,
     int H, int W, int C, int dil, int dtype, void* stream);
 int cmda_dwconv3x3_bwd_data(const void* dy, const float* w, void* dx, int B, int H, int W, int C, int dil, int
@@ -195,18 +210,20 @@ int cmda_bilinear_bwd(const void* dy, void* dx, int B, int IH, int IW, int OH, i
  * array of `groups` entries, NULL = 0,1,2,..) -- the shared decoder of daformer_head.py:254-258,305-319 run once over the
  * image / events / fusion / ISR features instead of four times.  Also used with groups = samples (no running statistics)
  * as InstanceNorm2d for cyclegan/cyclegan_model.py:339-374.  ws: groups * cmda_bn_ws_floats(C) floats of scratch.
- * groups <= 8. */
+ * groups <= 8.  ws_has_stats = 1: ws already holds the column sums of x, accumulated by cmda_gemm's `colstats` epilogue of the
+ * convolution that produced x (no reduction pass over x; the sums are taken without the per-channel shift of the reduction kernel);
+ * ws is left ZERO again, so one zero-initialised workspace per stream serves every such layer. */
 int64_t cmda_bn_ws_floats(int C);
 int cmda_bn_train_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, float*
     running_mean, float* running_var, float* ws, int64_t M, int C, float eps, float momentum, int relu, int ldy, int
-    coff, int groups, const int* order, int dtype, void* stream);
+    coff, int groups, const int* order, int ws_has_stats, int dtype, void* stream);
 /* Mixed storage types: x in x_dtype, y in y_dtype; res32 (optional fp32 [groups*M, C]) is added AFTER the normalisation (+ReLU) and
  * y2_bf16 (optional bf16 [groups*M, C]) receives a second copy of the result -- ResnetBlock of the Motion-Extractor generator in the
  * bf16 mode (cyclegan/cyclegan_model.py:377-434: out = x + conv_block(x)): the convolution output and the residual stream stay fp32,
  * the bf16 copy is the next convolution's operand. */
 int cmda_bn_train_fwd2(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype, float* mean,
     float* rstd, float* running_mean, float* running_var, float* ws, int64_t M, int C, float eps, float momentum, int relu, int ldy,
-    int coff, int groups, const int* order, const float* res32, void* y2_bf16, void* stream);
+    int coff, int groups, const int* order, const float* res32, void* y2_bf16, int ws_has_stats, void* stream);
 int cmda_bn_apply(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, void* y,
     int64_t M, int C, int relu, int ldy, int coff, int dtype, void* stream);
 int cmda_bn_train_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const

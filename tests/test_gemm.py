@@ -107,6 +107,80 @@ def test_conv_implicit_gemm(tgt, dt, tag, tol, Bc, H, W, Ci, Co, KH, st, pd, dl)
         assert_close(dx, xr.grad.permute(0, 2, 3, 1), tol * 2, name='conv dgrad')
 
 
+@pytest.mark.parametrize('Bc,H,W,Ci,Co,k,splits', [(2, 16, 16, 32, 40, 2, 3), (1, 32, 16, 16, 64, 4, 4), (3, 8, 8, 64, 24, 2, 5)])
+def test_x3_patch_conv_split_k_forward(tgt, Bc, H, W, Ci, Co, k, splits):
+    """split-bf16 mode, kernel == stride convolution of a small token count (the spatial-reduction convolutions of the deep stages,
+    mix_transformer.py:70-75): bias rows pre-filled, the K range split over workgroups, fp32 atomics -- the lean split kernel's forward
+    form with a split count (patch view as A: a split starts inside a kernel row), and the same with a plain A operand"""
+    torch.manual_seed(Ci + k)
+    x, w, bias = torch.randn(Bc, H, W, Ci), torch.randn(Co, Ci, k, k), torch.randn(Co)
+    yref = F.conv2d(x.permute(0, 3, 1, 2), w, bias, stride=k).permute(0, 2, 3, 1)
+    OH, OW = H // k, W // k
+    M, K = Bc * OH * OW, k * k * Ci
+    xd, wg = tgt.to(x), tgt.to(w.permute(0, 2, 3, 1).contiguous().view(Co, -1))
+    prev = ops.GEMM_TILE_HINT
+    try:
+        for hint in (0, 65536, 8192):   # the library's choice, the lean split kernel whatever the tile choice, the register-staged kernel
+            ops.GEMM_TILE_HINT = hint
+            out = tgt.to(bias.expand(M, Co).contiguous())
+            ops.gemm(ops.conv_view(xd, Bc, H, W, Ci, k, k, k, 0, 1), ops.plain_view(wg, Co, K), out, M, Co, K, dtype=2, atomic=True, splits=splits)
+            assert_close(out.view(Bc, OH, OW, Co), yref, 1e-4, name=f'x3 patch conv, split-K atomics (hint {hint})')
+    finally:
+        ops.GEMM_TILE_HINT = prev
+    cols = tgt.to(F.unfold(x.permute(0, 3, 1, 2), k, stride=k).view(Bc, Ci, k * k, OH * OW).permute(0, 3, 2, 1).reshape(M, K).contiguous())
+    out2 = tgt.to(bias.expand(M, Co).contiguous())
+    ops.gemm(ops.plain_view(cols, M, K), ops.plain_view(wg, Co, K), out2, M, Co, K, dtype=2, atomic=True, splits=splits)
+    assert_close(out2.view(Bc, OH, OW, Co), yref, 1e-4, name='x3 plain A, split-K atomics')
+
+
+@pytest.mark.parametrize('dt,tag,tol', DT)
+@pytest.mark.parametrize('hint', [0, 1, 2, 3, 4, 516, 1028])
+def test_gemm_fused_column_statistics(tgt, dt, tag, tol, hint):
+    """cmda_gemm_params_t.colstats: the batch statistics of the BatchNorm / InstanceNorm behind a convolution (mmcv ConvModule conv -> norm,
+    daformer_head.py:46-62; cyclegan_model.py:339-434) accumulated by the GEMM epilogue into the BatchNorm workspace -- sums of the
+    stored values per row group, on every tile of the general kernels; then cmda_bn_train_fwd(ws_has_stats) against the BatchNorm that
+    takes its own statistics pass, and the workspace handed back zeroed"""
+    from cmda_amd import _lib as L
+    torch.manual_seed(3 + hint)
+    groups, rpg, N, K = 3, 512, 72, 96
+    M = groups * rpg
+    a, b, bias = torch.randn(M, K).to(dt), torch.randn(N, K).to(dt), torch.randn(N) * 2 + 0.5
+    res = torch.randn(M, N).to(dt) if hint != 1028 else None      # (1028: the ping-pong kernel, which takes no residual)
+    ref = a.float() @ b.float().t() + bias + (res.float() if res is not None else 0.0)
+    ad, bd, bsd, rd = tgt.to(a), tgt.to(b), tgt.to(bias), (tgt.to(res) if res is not None else None)
+    wsn = int(L.lib().cmda_bn_ws_floats(N))
+    prev = ops.GEMM_TILE_HINT
+    try:
+        ops.GEMM_TILE_HINT = hint
+        for out_dt in (dt, torch.float32):
+            ws = torch.zeros(groups * wsn, device=tgt.device)
+            out = torch.empty(M, N, dtype=out_dt, device=tgt.device)
+            ops.gemm(ops.plain_view(ad, M, K), ops.plain_view(bd, N, K), out, M, N, K, dtype=tag, bias=bsd, res=rd, colstats=(ws, rpg))
+            assert_close(out, ref, tol, name='output')
+            st = ws.view(groups, 33, 2, N)[:, :32].sum(1).cpu()          # [group][sum | sum of squares][channel]
+            # (the ping-pong kernel sums the bf16 values it stores, the general epilogue the unrounded ones)
+            rg = (out.float().cpu() if (hint == 1028 and tag == 1 and out_dt == dt) else ref).view(groups, rpg, N)
+            assert_close(st[:, 0], rg.sum(1), tol, atol=tol * rpg ** 0.5 * 4, name='column sums')
+            assert_close(st[:, 1], (rg * rg).sum(1), tol * 2, name='column sums of squares')
+            assert ws.view(groups, 33, 2, N)[:, 32].abs().max().item() == 0.0
+            # BatchNorm from the workspace == BatchNorm with its own statistics pass over the stored activation
+            g, be = tgt.to(torch.rand(N) + 0.5), tgt.to(torch.randn(N))
+            outs = []
+            for fused in (True, False):
+                rm, rv = torch.zeros(N, device=tgt.device), torch.ones(N, device=tgt.device)
+                y = torch.empty_like(out)
+                mean, rstd = ops.bn_train_fwd(out, g, be, y, rm, rv, rpg, N, 1e-5, 0.1, True, groups=groups, order=[2, 0, 1],
+                                              stats_ws=ws if fused else None)
+                outs.append((y, mean, rstd, rm, rv))
+            # (bf16 storage: the fused statistics are those of the unrounded values, the separate pass sees the rounded ones)
+            st_tol = 2e-5 if out_dt == torch.float32 else 4e-3
+            for i, nm in enumerate(('y', 'mean', 'rstd', 'running_mean', 'running_var')):
+                assert_close(outs[0][i], outs[1][i], st_tol if i else max(st_tol, tol), atol=st_tol, name=f'BatchNorm from epilogue statistics: {nm}')
+            assert ws.abs().max().item() == 0.0, 'the workspace comes back zeroed'
+    finally:
+        ops.GEMM_TILE_HINT = prev
+
+
 def _run_forced_tile(marker):
     """the tile heuristics only pick the 256x256 (8-wave) kernel for very large problems: force it through
     cmda_gemm_params_t.tile_hint (tests/conftest.py sets ops.GEMM_TILE_HINT from CMDA_TEST_GEMM_TILE) and run the whole GEMM
@@ -137,7 +211,10 @@ def test_forced_tile_256_gpu():
 @pytest.mark.parametrize('dt,tag,tol,B,OH,OW,Co,Ci,k', [(torch.float32, 0, 2e-5, 2, 3, 5, 24, 8, 2),
                                                         # bf16 with Co % 64 == 0: the lean kernel's patch-store epilogue (K-strided weights)
                                                         (torch.bfloat16, 1, 2e-2, 2, 3, 5, 64, 32, 2), (torch.bfloat16, 1, 2e-2, 3, 4, 8, 128, 64, 4),
-                                                        (torch.bfloat16, 1, 2e-2, 1, 9, 7, 192, 8, 2)])
+                                                        (torch.bfloat16, 1, 2e-2, 1, 9, 7, 192, 8, 2),
+                                                        # split-bf16 with Co % 32 == 0: the lean split kernel's patch-store epilogue
+                                                        (torch.float32, 2, 1e-4, 2, 3, 5, 64, 32, 2), (torch.float32, 2, 1e-4, 3, 4, 8, 128, 64, 4),
+                                                        (torch.float32, 2, 1e-4, 1, 9, 7, 96, 8, 2)])
 def test_gemm_unpatchify_store(tgt, dt, tag, tol, B, OH, OW, Co, Ci, k):
     """c_patch: the data gradient of a kernel == stride convolution is stored straight in NHWC (mix_transformer.py:70-75's sr
     conv backward), compared with conv_transpose2d; also with beta accumulation."""

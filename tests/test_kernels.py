@@ -92,6 +92,17 @@ def test_dwconv(tgt, dt, tol, dil, act, shape):
     xd, wd, bd, dyd = tgt.to(x), tgt.to(w.view(C, 9).t().contiguous()), tgt.to(b) if act else None, tgt.to(dy)  # tap-major [9,C]
     y = ops.dwconv_fwd(xd, wd, bd, B, H, W, C, dil, act)
     assert_close(y, ref.permute(0, 2, 3, 1), tol, name='dw fwd')
+    if dil >= 2 and act is None:   # the BatchNorm statistics of the output taken on the way (groups of images: cmda_dwconv3x3_fwd_stats)
+        from cmda_amd import _lib as L
+        for ipg in (1, B):
+            G = B // ipg
+            ws = torch.zeros(G * int(L.lib().cmda_bn_ws_floats(C)), device=tgt.device)
+            y2 = ops.dwconv_fwd(xd, wd, None, B, H, W, C, dil, None, colstats=(ws, ipg))
+            assert torch.equal(y2, y)
+            st = ws.view(G, 33, 2, C)[:, :32].sum(1).cpu()
+            zr = z.detach().permute(0, 2, 3, 1).reshape(G, ipg * H * W, C)
+            assert_close(st[:, 0], zr.sum(1), tol, atol=tol * (ipg * H * W) ** 0.5 * 4, name='dw output column sums')
+            assert_close(st[:, 1], (zr * zr).sum(1), tol * 2, name='dw output column sums of squares')
     dz = ops.dwconv_gelu_bwd_prep(xd, wd, bd, dyd, B, H, W, C, dil) if act == 'gelu' else dyd
     dx = ops.dwconv_bwd_data(dz, wd, B, H, W, C, dil)
     assert_close(dx, xr.grad.permute(0, 2, 3, 1), tol * 2, name='dw dx')

@@ -261,6 +261,40 @@ def test_generator_golden(tgt, mode):
     assert_close(y, g['y'], 1e-4 if mode == torch.float32 else 0.1, name='generator')  # bf16: 23 conv+InstanceNorm layers, random weights
 
 
+@pytest.mark.parametrize('mode', [torch.float32, torch.bfloat16], indirect=True)
+def test_generator_fused_instance_norm_statistics(tgt, mode):
+    """every InstanceNorm of the generator taking its statistics from the epilogue of the convolution in front of it
+    (cmda_gemm_params_t.colstats; 64 x 64 input: all 23 conv / norm pairs have whole 256-row tiles per sample) against the same
+    model with the separate statistics pass, and against the oracle"""
+    from cmda_amd import cyclegan as cg, ops
+    from oracle import cyclegan as ocg
+    G = seeded_fill(cg.ResnetGenerator(), 83).eval().to(tgt.device)
+    x = seeded_randn((2, 1, 64, 64), 83, 'x')
+    calls = []
+    orig = ops.bn_train_fwd2
+
+    def spy(*a, **k):
+        calls.append(k.get('stats_ws') is not None)
+        return orig(*a, **k)
+    prev = ops.BN_FUSED_STATS
+    ops.bn_train_fwd2 = spy
+    try:
+        ops.BN_FUSED_STATS = True
+        y_fused = G(tgt.to(x)).float().cpu()
+        n_fused = sum(calls)
+        ops.BN_FUSED_STATS = False
+        y_sep = G(tgt.to(x)).float().cpu()
+    finally:
+        ops.BN_FUSED_STATS, ops.bn_train_fwd2 = prev, orig
+    assert n_fused == 23 and sum(calls) == 23, calls
+    ref = seeded_fill(ocg.ResnetGenerator(), 83).eval()
+    with torch.no_grad():
+        want = ref(x)
+    tol = 1e-4 if mode == torch.float32 else 0.1
+    assert_close(y_fused, want, tol, name='generator, fused statistics vs oracle')
+    assert_close(y_fused, y_sep, 2e-5 if mode == torch.float32 else 0.05, name='generator, fused vs separate statistics pass')
+
+
 @pytest.mark.gpu
 def test_eval_path_440x640_matches_oracle():
     """SURVEY 8f (next row): whole-image inference at the DSEC evaluation size 440x640 -- token grids that are not powers

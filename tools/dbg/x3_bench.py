@@ -45,6 +45,54 @@ def run(M, N, K, nn, hint, dt, tag):
     return t, o.clone(), (a, b, bias, res)
 
 
+def sr_forms():
+    """the spatial-reduction convolution of stage 3 (2 x 2 / stride 2 on 32 x 32 tokens, C = 320) at B = 2 / 4 / 8 samples: forward with
+    split-K atomics (patch view as A), weight gradient (patch view as K-strided B), data gradient with the patch-store epilogue"""
+    print('spatial-reduction convolution forms, us per launch: library choice | register-staged general kernel (tile_hint bit 13)')
+    C, k, HW = 320, 2, 32
+    for B in (2, 4, 8):
+        x = torch.randn(B, HW, HW, C, device=dev)
+        w = torch.randn(C, k * k * C, device=dev)
+        M, K = B * (HW // k) ** 2, k * k * C
+        out = torch.zeros(M, C, device=dev)
+        dy = torch.randn(M, C, device=dev)
+        dW = torch.zeros(C, K, device=dev)
+        dx = torch.empty(B * HW * HW, C, device=dev)
+        forms = {
+            'fwd split-K 5': lambda: ops.gemm(ops.conv_view(x, B, HW, HW, C, k, k, k, 0, 1), ops.plain_view(w, C, K), out, M, C, K, dtype=2, atomic=True, splits=5),
+            'wgrad (patch B)': lambda: ops.gemm(ops.plain_view(dy, M, C), ops.conv_view(x, B, HW, HW, C, k, k, k, 0, 1), dW, C, K, M, a_kstrided=True, b_kstrided=True,
+                                                dtype=2, atomic=True, splits=4),
+            'dgrad patch-store': lambda: ops.gemm(ops.plain_view(dy, M, C), ops.plain_view(w, C, K), dx, M, K, C, b_kstrided=True, dtype=2, c_patch=(HW // k, k, k * C)),
+        }
+        for name, f in forms.items():
+            ts = []
+            for hint in (0, 8192):
+                ops.GEMM_TILE_HINT = hint
+                ts.append(timeit(f))
+            ops.GEMM_TILE_HINT = 0
+            print(f'  B = {B}  {name:18s} {ts[0]:7.1f} | {ts[1]:7.1f}', flush=True)
+
+
+def short_k():
+    """shapes where the tile heuristics choose 128 x 128 (register-staged kernel) although the lean kernel takes them: stage-1 / 2 Linears
+    and the unfused attention's batched products; library choice | lean forced (bit 16) | general forced (bit 13)"""
+    print('short-K shapes, us per launch: library choice | lean forced | general forced')
+    for M, N, K, nb in ((32768, 256, 64, 1), (65536, 256, 64, 1), (131072, 256, 64, 1), (16384, 512, 128, 1), (32768, 512, 128, 1), (65536, 128, 256, 1),
+                        (4096, 256, 64, 16), (16384, 256, 64, 4), (16384, 256, 64, 8)):
+        a = torch.randn(nb, M, K, device=dev)
+        b = torch.randn(nb, N, K, device=dev)
+        o = torch.empty(nb, M, N, device=dev)
+        ts = []
+        for hint in (0, 65536, 8192):
+            ops.GEMM_TILE_HINT = hint
+            ts.append(timeit(lambda: ops.gemm(ops.plain_view(a, M, K, batch_stride=M * K), ops.plain_view(b, N, K, batch_stride=N * K), o, M, N, K, batch=nb,
+                                              c_batch_stride=M * N, dtype=2), iters=20))
+        ops.GEMM_TILE_HINT = 0
+        print(f'  {M:6d} x {N:4d} x {K:4d} batch {nb:2d}: {ts[0]:7.1f} | {ts[1]:7.1f} | {ts[2]:7.1f}', flush=True)
+
+
+sr_forms()
+short_k()
 print('split-bf16 GEMMs, us per launch: lean (LDS-DMA) | general (register-staged) | bf16 lean kernel;  max |lean - general| / max|general|')
 for nn in (False, True):
     for M, N, K in ((2048, 320, 320), (4096, 320, 320), (8192, 320, 320), (8192, 1280, 320), (8192, 320, 1280), (4096, 640, 320),
