@@ -115,11 +115,15 @@ def split_bf16(t):
     return hi, lo
 
 
+X3_BIG_INTENSITY = float(os.environ.get('CMDA_X3_BIG_INTENSITY', 100))   # FLOP per byte moved by the split / accumulate passes
+
+
 def _x3_big_ok(A, B, out, M, N, K, nb, act, rowscale, hold, defer, splits, c_patch, c_perm):
     if hold or act is not None or rowscale is not None or c_patch is not None or GEMM_TILE_HINT != 0:
         return False
     if 2.0 * M * N * K * nb < X3_BIG_FLOPS or out.dtype != torch.float32:
         return False
+    moved = 16.0 * M * N * nb   # two more read + write passes over the fp32 output (beta = 1 launches)
     for v in (A, B):
         t = getattr(v, '_t', None)
         if t is None or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() % 8 or t.data_ptr() % 16:
@@ -129,7 +133,11 @@ def _x3_big_ok(A, B, out, M, N, K, nb, act, rowscale, hold, defer, splits, c_pat
                 return False
         elif v.ld % 8 or v._off % 8 or v.batch_stride % 8 or v.batch2_stride % 8:
             return False
-    return True
+        moved += 12.0 * t.numel()   # the split pass: 4 bytes read, 2 x 2 written, the halves read again
+    # the three launches pay for themselves where the contraction outweighs those passes (profiles/r05_x3_gemm.txt: 4096^3 at 204 FLOP
+    # per moved byte 460 against 728 us on the register-staged split kernel; the head's pointwise convolution 262144 x 256 x 1024 at 32:
+    # 1438 against 1119)
+    return 2.0 * M * N * K * nb >= X3_BIG_INTENSITY * moved
 
 
 def _x3_half_views(v):

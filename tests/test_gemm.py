@@ -361,8 +361,8 @@ def test_gemm_x3_big_three_launch_path(tgt):
     """split-bf16 mode, LARGE problems (ops._gemm_x3_big): operands split once into bf16 hi / lo tensors (cmda_split_bf16) and the
     contraction run as three launches of the bf16 kernels accumulated in the fp32 output -- plain NT with bias + fp32 residual + beta,
     the weight-gradient form with atomics and the fused bias gradient, an im2col view.  Forced here by lowering the FLOP threshold."""
-    old = ops.X3_BIG_FLOPS
-    ops.X3_BIG_FLOPS = 1e3
+    old, old_i = ops.X3_BIG_FLOPS, ops.X3_BIG_INTENSITY
+    ops.X3_BIG_FLOPS, ops.X3_BIG_INTENSITY = 1e3, 0.0
     try:
         torch.manual_seed(21)
         M, N, K = 200, 72, 128
@@ -387,4 +387,4 @@ def test_gemm_x3_big_three_launch_path(tgt):
         ops.gemm(ops.conv_view(tgt.to(x), 2, 12, 12, 16, 3, 3, 1, 1, 1), ops.plain_view(wg, 24, 144), o, 288, 24, 144, dtype=2)
         assert_close(o, F.conv2d(x.permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1), 2e-5, name='x3 big im2col view')
     finally:
-        ops.X3_BIG_FLOPS = old
+        ops.X3_BIG_FLOPS, ops.X3_BIG_INTENSITY = old, old_i
