@@ -430,9 +430,10 @@ int launch_x3_lean(const GemmParams& p, void* stream) {
   const long nb = (long)p.batch * q.batch2;
   const dim3 blk(512);
   if (p.a_kstrided) {
-    // split-K over the tokens: ~two workgroups per CU in all, at least four k-tiles per split (one fp32 atomic per output element
+    // split-K over the tokens: ~two workgroups per CU in all, at least eight k-tiles per split (one fp32 atomic per output element
     // per split)
-    int splits = (int)std::max<long>(1, std::min<long>(q.nkt / 4, (512 + tiles * nb - 1) / (tiles * nb)));
+    // (tools/dbg/x3_wgrad_bench.py: 256 / 384 / 1024 workgroups and 4 / 16 k-tiles per split measured within +-10 % of this choice)
+    int splits = (int)std::max<long>(1, std::min<long>(q.nkt / 8, (512 + tiles * nb - 1) / (tiles * nb)));
     splits = std::min(splits, 1024);
     q.kt_per = (q.nkt + splits - 1) / splits;
     splits = (q.nkt + q.kt_per - 1) / q.kt_per;

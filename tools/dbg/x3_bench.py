@@ -91,17 +91,18 @@ def short_k():
         print(f'  {M:6d} x {N:4d} x {K:4d} batch {nb:2d}: {ts[0]:7.1f} | {ts[1]:7.1f} | {ts[2]:7.1f}', flush=True)
 
 
-sr_forms()
-short_k()
-print('split-bf16 GEMMs, us per launch: lean (LDS-DMA) | general (register-staged) | bf16 lean kernel;  max |lean - general| / max|general|')
-for nn in (False, True):
-    for M, N, K in ((2048, 320, 320), (4096, 320, 320), (8192, 320, 320), (8192, 1280, 320), (8192, 320, 1280), (4096, 640, 320),
-                    (16384, 128, 128), (16384, 512, 128), (65536, 64, 64), (1024, 512, 512), (1024, 2048, 512),
-                    (262144, 256, 1024), (262144, 1024, 256), (131072, 256, 256), (65536, 256, 512), (4096, 4096, 4096))[int(os.environ.get('X3_FROM', 0)):]:
-        torch.manual_seed(M + N)
-        t_lean, o_lean, _ = run(M, N, K, nn, int(os.environ.get('X3_LEAN_HINT', 0)), torch.float32, 2)
-        torch.manual_seed(M + N)
-        t_gen, o_gen, _ = run(M, N, K, nn, 8192, torch.float32, 2)
-        t_bf, _, _ = run(M, N, K, nn, 0, torch.bfloat16, 1)
-        err = (o_lean - o_gen).abs().max().item() / o_gen.abs().max().item()
-        print(f'  {"NN" if nn else "NT"} {M:6d} x {N:5d} x {K:5d}: {t_lean:7.1f} | {t_gen:7.1f} | {t_bf:6.1f}   err {err:.1e}', flush=True)
+if __name__ == "__main__":
+    sr_forms()
+    short_k()
+    print('split-bf16 GEMMs, us per launch: lean (LDS-DMA) | general (register-staged) | bf16 lean kernel;  max |lean - general| / max|general|')
+    for nn in (False, True):
+        for M, N, K in ((2048, 320, 320), (4096, 320, 320), (8192, 320, 320), (8192, 1280, 320), (8192, 320, 1280), (4096, 640, 320),
+                        (16384, 128, 128), (16384, 512, 128), (65536, 64, 64), (1024, 512, 512), (1024, 2048, 512),
+                        (262144, 256, 1024), (262144, 1024, 256), (131072, 256, 256), (65536, 256, 512), (4096, 4096, 4096))[int(os.environ.get('X3_FROM', 0)):]:
+            torch.manual_seed(M + N)
+            t_lean, o_lean, _ = run(M, N, K, nn, int(os.environ.get('X3_LEAN_HINT', 0)), torch.float32, 2)
+            torch.manual_seed(M + N)
+            t_gen, o_gen, _ = run(M, N, K, nn, 8192, torch.float32, 2)
+            t_bf, _, _ = run(M, N, K, nn, 0, torch.bfloat16, 1)
+            err = (o_lean - o_gen).abs().max().item() / o_gen.abs().max().item()
+            print(f'  {"NN" if nn else "NT"} {M:6d} x {N:5d} x {K:5d}: {t_lean:7.1f} | {t_gen:7.1f} | {t_bf:6.1f}   err {err:.1e}', flush=True)
