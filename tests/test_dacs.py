@@ -333,7 +333,7 @@ def test_dacs_iteration_full_depth_512_gpu(mode):
         if mode != 'bf16':
             check_le('generator output rel err (512 x 512)', gen_max, 5e-4 if mode == 'x3' else 2e-4)
             check_le('teacher logits rel err', logit_err, 1e-3, strict=True)
-            check_le('teacher logits element-wise rel err, 99.9th pct (floor 1e-3 of range)', logit_ew_p999, 1e-2)
+            check_le('teacher logits element-wise rel err, 99.9th pct (floor 1e-3 of range)', logit_ew_p999, 2e-2 if mode == 'x3' else 1e-2)   # (6.9e-3 / 8.1e-4 measured)
             check_ge('pseudo-label agreement', agree, 0.9998)   # (numerical ties: 0.99995 measured in both fp32-storage modes)
             check_ge('mixed-label agreement', lbl_same, 0.9998)
             check_le('source loss abs err', abs(ls - rs), 1e-4 * max(1.0, abs(rs)), strict=True)
