@@ -18,10 +18,12 @@ namespace {
 // tile kinds of the grouped kernels: {BM, BN, resident blocks per CU (LDS 2 stages x (BM + BN) x 128 B)}
 // kind 4 = gemm_wg.hip's 256x256 tile (8 waves, 32x32x16 MFMA): outputs of at least 256 x 256 -- both operands of these contractions
 // stream from beyond L2, so operand bytes per FLOP decide
-constexpr int kTileBM[5] = {64, 128, 64, 128, 256}, kTileBN[5] = {64, 64, 128, 128, 256}, kTileRes[5] = {4, 3, 3, 2, 1};
+// kind 5 = the lean split-bf16 kernel's weight-gradient form (gemm_x3_lean.hip: CMDA_F32X3, 64 x 64 tiles on eight waves, 32-deep k-tiles,
+// two workgroups per CU)
+constexpr int kTileBM[6] = {64, 128, 64, 128, 256, 64}, kTileBN[6] = {64, 64, 128, 128, 256, 64}, kTileRes[6] = {4, 3, 3, 2, 1, 2};
 // bucket = tile kind * 3 + operand class: 0 = both operands plain with K a multiple of 64 (the kernels' running-pointer DMA sources,
 // gemm_kernels.h DmaSrc mode 1), 1 = plain / patch views in general, 2 = B is an im2col view
-constexpr int kBuckets = 15;
+constexpr int kBuckets = 18;   // (kind 5 uses its first bucket only)
 
 struct Plan {
   int bucket;       // -1 = single launch through cmda_gemm
@@ -42,6 +44,16 @@ static bool dma_view_ok(const GemmView& v) {
 // 16 KB through L2 -> LDS per 0.5 MFLOP, 128x128 32 KB per 2.1 MFLOP: the k-loop is bound by that per-CU rate)
 static Plan classify(const GemmParams& p) {
   Plan pl{-1, 1, 0, 0, 0};
+  if (p.dtype == CMDA_F32X3) {   // split-bf16 mode: the weight gradients the lean split kernel takes (its own eligibility test)
+    const int b2 = p.batch2 > 0 ? p.batch2 : 1;
+    if (!(p.atomic && p.out_f32 && p.a_kstrided && p.b_kstrided && p.tile_hint == 0 && p.splits <= 0 && p.batch == 1 && b2 == 1 && p.M > 0 && p.N > 0 &&
+          cmda_gemm_x3_lean_ok_(p)) || 2.0 * p.M * p.N * (double)p.K > 30e9)
+      return pl;
+    pl.bucket = 5 * 3;
+    pl.tiles = ((p.M + 63) / 64) * ((p.N + 63) / 64);
+    pl.nkt = p.K / 32;
+    return pl;
+  }
   const bool ok = p.dtype == CMDA_BF16 && p.atomic && p.out_f32 && p.a_kstrided && p.b_kstrided && p.A.conv != 1 && p.batch >= 1 &&
                   p.M > 0 && p.N > 0 && p.K > 0 && dma_view_ok(p.A) && dma_view_ok(p.B) && p.tile_hint == 0 && p.splits <= 0 &&
                   !p.bias && !p.act && !p.res && !p.rowscale && p.c_patch_ow == 0;
@@ -210,7 +222,8 @@ extern "C" int cmda_gemm_grouped(const cmda_gemm_params_t* params, int n, void* 
                    : kind == 1 ? cmda_gemm_grouped_t1_(dtab, bptr, (int)cnt, bc, stream)
                    : kind == 2 ? cmda_gemm_grouped_t3_(dtab, bptr, (int)cnt, bc, stream)
                    : kind == 3 ? cmda_gemm_grouped_t0_(dtab, bptr, (int)cnt, bc, stream)
-                               : cmda_gemm_wg_grouped_(dtab, bptr, (int)cnt, bc, stream);
+                   : kind == 4 ? cmda_gemm_wg_grouped_(dtab, bptr, (int)cnt, bc, stream)
+                               : cmda_gemm_x3_lean_grouped_(dtab, bptr, (int)cnt, stream);
       if (rc != CMDA_OK) return rc;
     }
   }

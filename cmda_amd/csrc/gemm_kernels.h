@@ -1287,7 +1287,8 @@ int cmda_gemm_pp_(const cmda_gemm_params_t& p, void* stream);             // gem
 int cmda_gemm_reg_(const cmda_gemm_params_t& p, int tile, void* stream);  // gemm_reg.hip: register-staged kernels, dispatch
 int cmda_gemm_x3_(const cmda_gemm_params_t& p, int tile, void* stream);
 bool cmda_gemm_x3_lean_ok_(const cmda_gemm_params_t& p);                   // gemm_x3_lean.hip: LDS-DMA split-bf16 kernel, plain operands
-int cmda_gemm_x3_lean_(const cmda_gemm_params_t& p, void* stream);   // gemm_x3.hip: fp32 storage, split-bf16 (bf16 x 3) MFMA
+int cmda_gemm_x3_lean_(const cmda_gemm_params_t& p, void* stream);
+int cmda_gemm_x3_lean_grouped_(const cmda_gemm_params_t* tab, const void* blk, int nblocks, void* stream);   // grouped weight-gradient form   // gemm_x3.hip: fp32 storage, split-bf16 (bf16 x 3) MFMA
 // gemm_reg_{f32,bf16}_t{0,1,2}.hip: one (dtype, tile) each -- these are the slow units to compile (~50 s apiece)
 int cmda_gemm_reg_f32_t0_(const cmda_gemm_params_t& p, void* stream);
 int cmda_gemm_reg_f32_t1_(const cmda_gemm_params_t& p, void* stream);

@@ -53,8 +53,9 @@ struct X3LeanParams {
 // on its own DMA: 64-deep tiles with one tile in flight measured 15.0 us for 4096 x 320 x 320 against 16.9 for the general kernel)
 // AKS (with BKS): the WEIGHT-GRADIENT form -- both operands K-strided ([tokens][channels] row-major: dW = dy^T x), split-K over the
 // tokens (grid.z), fp32 atomic accumulation into C, bias gradient (column sums of dy) fused
+// bt_in: output tile of the problem (hardware order; remapped to XCD-contiguous ranges when `remap`), zidx: (batch entry, split)
 template <bool AKS, bool BKS>
-__global__ __launch_bounds__(512, 2) void gemm_x3_lean_kernel(X3LeanParams q) {
+static __device__ __forceinline__ void x3_lean_body(X3LeanParams& q, int bt_in, int zidx, bool remap) {
   static_assert(!AKS || BKS, "A K-strided: weight-gradient form only");
   constexpr int NW = 8, NT = 512, BM = 64, BN = 64, BK = 32, TN = 2, NSTG = 3;
   constexpr int F_A = BM * BK, F_B = BN * BK;                 // fp32 elements of a stage (A | B)
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_lean_kernel(X3LeanParams q) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1, g = lane >> 4, l15 = lane & 15;
   const int M = q.M, N = q.N, tiles_n = q.tiles_n, ntile = q.ntile;
-  const int bz = (int)blockIdx.z / q.splits, ksplit = (int)blockIdx.z - bz * q.splits;
+  const int bz = zidx / q.splits, ksplit = zidx - bz * q.splits;
   const int kt0 = ksplit * q.kt_per;                   // (kt_per = all k-tiles and one split unless the launcher split K)
   const int nkt = min(q.nkt - kt0, q.kt_per);          // k-tiles of THIS workgroup
   {   // batch entry: operand / output bases move, everything else is per problem
@@ -80,8 +81,8 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_lean_kernel(X3LeanParams q) {
     q.C += b1 * q.c_bs + b2 * q.c_b2s;
     if (q.res) q.res += b1 * q.r_bs + b2 * q.r_b2s;
   }
-  int bt = blockIdx.x;
-  {   // XCD-contiguous tile ranges (gemm_lean_kernel)
+  int bt = bt_in;
+  if (remap) {   // XCD-contiguous tile ranges (gemm_lean_kernel)
     const int qq = ntile >> 3, rr = ntile & 7, xcd = bt & 7, loc = bt >> 3;
     bt = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + loc;
   }
@@ -383,9 +384,15 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_lean_kernel(X3LeanParams q) {
   }
 }
 
-int launch_x3_lean(const GemmParams& p, void* stream) {
+template <bool AKS, bool BKS>
+__global__ __launch_bounds__(512, 2) void gemm_x3_lean_kernel(X3LeanParams q) {
+  x3_lean_body<AKS, BKS>(q, (int)blockIdx.x, (int)blockIdx.z, true);
+}
+
+// everything of X3LeanParams that follows from the problem alone (host launcher and the grouped kernel alike); the split fields
+// (kt_per, splits, atomic) are the caller's
+static __host__ __device__ inline void x3_fill(const GemmParams& p, X3LeanParams& q) {
   constexpr int BM = 64, BN = 64;
-  X3LeanParams q;
   q.A = reinterpret_cast<const float*>(p.A.ptr);
   q.B = reinterpret_cast<const float*>(p.B.ptr);
   q.C = reinterpret_cast<float*>(p.C);
@@ -395,9 +402,7 @@ int launch_x3_lean(const GemmParams& p, void* stream) {
   q.lda = p.A.ld; q.ldb = p.B.ld; q.ldc = p.ldc; q.ldres = p.ldres;
   q.M = p.M; q.N = p.N; q.nkt = p.K / 32;
   q.tiles_n = (p.N + BN - 1) / BN;
-  const long tiles = (long)((p.M + BM - 1) / BM) * q.tiles_n;
-  if (tiles > 0x7fffffffL) return CMDA_ERR_SHAPE;
-  q.ntile = (int)tiles;
+  q.ntile = (int)((long)((p.M + BM - 1) / BM) * q.tiles_n);
   q.rows_per_scale = p.rows_per_scale > 0 ? p.rows_per_scale : 1;
   q.act = p.act;
   q.flags = p.c_vec_ok ? 4 : 0;
@@ -427,6 +432,29 @@ int launch_x3_lean(const GemmParams& p, void* stream) {
   q.batch2 = p.batch2 > 0 ? p.batch2 : 1;
   q.a_bs = p.A.batch_stride; q.a_b2s = p.A.batch2_stride; q.b_bs = p.B.batch_stride; q.b_b2s = p.B.batch2_stride;
   q.c_bs = p.c_batch_stride; q.c_b2s = p.c_batch2_stride; q.r_bs = p.res_batch_stride; q.r_b2s = p.res_batch2_stride;
+}
+
+// GROUPED weight-gradient form: the deferred weight gradients of a backward phase in the split-bf16 mode as ONE grid (cmda_gemm_grouped:
+// in round 5's first version each of the ~900 per step was its own 29-us launch, 17 % of that mode's kernel time).  tab: the
+// problems (splits resolved by the planner); map: {problem, split * tiles + tile} per workgroup, -1 = padding (gemm_grouped.hip)
+__global__ __launch_bounds__(512, 2) void gemm_x3_lean_grouped_kernel(const GemmParams* __restrict__ tab, const int* __restrict__ map) {
+  const int prob = map[2 * blockIdx.x], blk = map[2 * blockIdx.x + 1];
+  if (prob < 0) return;
+  const GemmParams& p = tab[prob];
+  X3LeanParams q;
+  x3_fill(p, q);
+  const int splits = p.splits > 0 ? p.splits : 1;
+  q.kt_per = (q.nkt + splits - 1) / splits;
+  q.splits = splits;
+  x3_lean_body<true, true>(q, blk % q.ntile, blk / q.ntile, false);
+}
+
+int launch_x3_lean(const GemmParams& p, void* stream) {
+  constexpr int BM = 64, BN = 64;
+  X3LeanParams q;
+  const long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  if (tiles > 0x7fffffffL) return CMDA_ERR_SHAPE;
+  x3_fill(p, q);
   const long nb = (long)p.batch * q.batch2;
   const dim3 blk(512);
   if (p.a_kstrided) {
@@ -494,3 +522,10 @@ bool cmda_gemm_x3_lean_ok_(const cmda_gemm_params_t& p) {
 }
 
 int cmda_gemm_x3_lean_(const cmda_gemm_params_t& p, void* stream) { return launch_x3_lean(p, stream); }
+
+// grouped weight-gradient launch (gemm_grouped.hip plans the splits and the block map; tab / blk are DEVICE pointers)
+int cmda_gemm_x3_lean_grouped_(const cmda_gemm_params_t* tab, const void* blk, int nblocks, void* stream) {
+  if (nblocks <= 0) return CMDA_OK;
+  CMDA_LAUNCH(gemm_x3_lean_grouped_kernel, dim3((unsigned)nblocks), dim3(512), 0, stream, tab, reinterpret_cast<const int*>(blk));
+  CMDA_CHECK_LAUNCH();
+}

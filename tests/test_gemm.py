@@ -258,7 +258,7 @@ def test_gemm_grouped_tile_walk(tgt, hint, M, N):
         ops.GEMM_TILE_HINT = 0
 
 
-@pytest.mark.parametrize('dt,tag', [(torch.bfloat16, 1), (torch.float32, 0)])
+@pytest.mark.parametrize('dt,tag', [(torch.bfloat16, 1), (torch.float32, 0), (torch.float32, 2)])
 def test_gemm_deferred_grouped_weight_gradients(tgt, dt, tag):
     """ops.gemm(defer=True) inside a deferral scope queues the weight gradients of a backward pass and gemm_flush_deferred()
     launches them as grouped grids (cmda_gemm_grouped: 64x64 ... 128x128 tiles and gemm_wg.hip's 256x256 tile, plain / patch / im2col B views, fused bias
@@ -269,9 +269,11 @@ def test_gemm_deferred_grouped_weight_gradients(tgt, dt, tag):
     import cmda_amd.runtime as rt
     torch.manual_seed(5)
     rt.set_compute_dtype(dt)
+    rt.set_gemm_x3(tag == 2)   # split-bf16 mode: the lean split kernel's grouped weight-gradient form (token counts that are whole 32-deep k-tiles)
     try:
         shapes = [(520, 64, 64), (4200, 320, 128), (3300, 128, 256), (700, 72, 40), (130, 256, 128), (64, 8, 24), (2000, 256, 64), (9000, 128, 320),
-                  (3000, 320, 320), (2100, 640, 320), (1500, 1280, 320), (1100, 320, 1280)]   # (rows M, out N, in K); the last four: 256x256 tiles
+                  (3000, 320, 320), (2100, 640, 320), (1500, 1280, 320), (1100, 320, 1280),   # (rows M, out N, in K); these four: 256x256 tiles
+                 (4096, 320, 320), (2048, 1280, 320), (1024, 64, 512), (8192, 64, 64), (96, 128, 128)]   # whole 32-deep k-tiles
         lins = []
         for rows, n, k in shapes:
             lins.append((torch.randn(rows, n).to(dt), torch.randn(rows, k).to(dt), torch.nn.Parameter(tgt.to(torch.randn(n, k))),
@@ -311,6 +313,14 @@ def test_gemm_deferred_grouped_weight_gradients(tgt, dt, tag):
         finally:
             ops.GEMM_DEFER = True
         tol = 2e-2 if dt == torch.bfloat16 else 1e-4
+        if tag == 2:   # the planner does put an eligible problem into the grouped launch of the split kernel (a block map exists)
+            import ctypes
+            from cmda_amd import _lib as L
+            dy, x = tgt.to(lins[-5][0]), tgt.to(lins[-5][1])
+            pr = ops.gemm(ops.plain_view(dy, 4096, 320), ops.plain_view(x, 4096, 320), torch.zeros(320, 320, device=tgt.device), 320, 320, 4096,
+                          a_kstrided=True, b_kstrided=True, dtype=2, atomic=True, splits=0, hold=True)[0]
+            arr = (L.GemmParams * 1)(pr)
+            assert int(L.lib().cmda_gemm_grouped_ws_bytes(arr, ctypes.c_int32(1))) > (ctypes.sizeof(L.GemmParams) + 15) // 16 * 16
         for i, (a, b) in enumerate(zip(single, grouped)):
             assert_close(b, a, 1e-5, name=f'grouped vs single {i}')
         # and against torch
@@ -325,6 +335,7 @@ def test_gemm_deferred_grouped_weight_gradients(tgt, dt, tag):
             y.backward(g)
             assert_close(grouped[2 * len(lins) + 2 * j], wr.grad, tol, name=f'conv dW {j}')
     finally:
+        rt.set_gemm_x3(False)
         rt.set_compute_dtype(torch.float32)
 
 
