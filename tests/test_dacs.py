@@ -32,7 +32,7 @@ DEPTHS = [1, 1, 1, 1]
 # fp32 conv outputs + fp32 residual stream (round 3, bf16 everywhere: 5.1e-2 / 3.8e-2); only split-bf16 operands remove it (7e-5).
 # The max over 32 k pixels depends on the atomic summation order of the InstanceNorm statistics, so the gate is the 99.9th
 # percentile with a loose hard max (VERDICT r03 #1b).
-GEN_BF16_P999, GEN_BF16_MAX = 8e-2, 0.2
+GEN_BF16_P999, GEN_BF16_MAX = 6.5e-2, 0.12   # (3.0e-2 / 4.8e-2 worst of the audited runs: profiles/r05_test_margins.txt)
 SMALL = dict(dims=[32, 64, 160, 256], ch=64)   # reduced widths (head dim 32) keep the emulator run short
 FULLW = dict(dims=[64, 128, 320, 512], ch=256)  # MiT-B5 widths: head dim 64, the bench's kernel selection
 ISR = dict(val_range=[0.01, 1.01], _threshold=0.005, _clip_range=0.1, shift_pixel=1)
@@ -547,7 +547,7 @@ def test_dacs_train_step_against_reference_fixture_gpu(mode):
                 assert_close(sample_grad(p.data.cpu(), 24), g[f'it{it}.ema.{k}'], 2e-5, atol=8e-4 * it if it else 1e-6, name=f'it{it} ema {k}')
             for k, b in dacs.model.named_buffers():
                 if f'it{it}.bn.{k}' in g:
-                    assert_close(b.cpu(), g[f'it{it}.bn.{k}'], 5e-4 if it == 0 else 3e-3, atol=1e-5, name=f'it{it} {k}')
+                    assert_close(b.cpu(), g[f'it{it}.bn.{k}'], 5e-4 if it == 0 else 8e-3, atol=1e-5, name=f'it{it} {k}')   # (behind the optimizer steps: 3.2e-3 worst of two runs)
             print(f'iteration {it}: losses {got.tolist()} vs reference {ref_l[[0, 2]].tolist()}, pseudo-labels {agree:.5f}, worst gradient {worst:.2e}')
         assert dacs.local_iter == 3
         dacs._update_ema(1500)

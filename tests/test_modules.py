@@ -21,13 +21,13 @@ def gold(name):
     return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(HERE, 'golden', name + '.npz')).items()}
 
 
-def check_grads(module, g, rtol, n=2048, atol=1e-6, outlier_frac=0.0):
+def check_grads(module, g, rtol, n=2048, atol=1e-6, outlier_frac=0.0, outlier_rtol=0.05):
     seen = 0
     for name, p in module.named_parameters():
         key = 'grad.' + name
         if key in g:
             assert p.grad is not None, name
-            assert_close_fingerprint(sample_grad(p.grad, n), g[key], rtol, atol=atol, name=key, outlier_frac=outlier_frac)
+            assert_close_fingerprint(sample_grad(p.grad, n), g[key], rtol, atol=atol, name=key, outlier_frac=outlier_frac, outlier_rtol=outlier_rtol)
             seen += 1
     assert seen == sum(k.startswith('grad.') for k in g)
 
@@ -172,8 +172,8 @@ def test_head_fusion_train_golden(tgt, mode, joint):
             assert_close_robust(d[i], ref, 6e-2, 0.15, name=f'd{k}{i}')   # (2.1e-2 / 3.9e-2 measured on the flip-affected branch)
             worst = max(worst, (d[i].float().cpu() - ref).abs().max().item() / ref.abs().max().item())
         tight += worst < 3e-4
-    check_ge('branches with every input gradient within 3e-4', tight, 1)
-    check_grads(head, g, 5e-4, outlier_frac=1.0, atol=2e-6)
+    check_ge('branches with every input gradient within 3e-4', tight, 2)   # (3 of 4 measured on the GPU and the emulator)
+    check_grads(head, g, 5e-4, outlier_frac=1.0, atol=2e-6, outlier_rtol=0.08)   # (flipped BN + ReLU masks: 3.0e-2 of the tensor's largest element, two runs)
     for k, v in head.state_dict().items():
         if 'running' in k and ('bn.' + k) in g:
             assert_close(v, g['bn.' + k], 1e-4, name=k)
@@ -292,7 +292,7 @@ def test_generator_fused_instance_norm_statistics(tgt, mode):
         want = ref(x)
     tol = 1e-4 if mode == torch.float32 else 0.1
     assert_close(y_fused, want, tol, name='generator, fused statistics vs oracle')
-    assert_close(y_fused, y_sep, 2e-5 if mode == torch.float32 else 0.05, name='generator, fused vs separate statistics pass')
+    assert_close(y_fused, y_sep, 4e-5 if mode == torch.float32 else 0.05, name='generator, fused vs separate statistics pass')   # (1.0e-5 measured)
 
 
 @pytest.mark.gpu
