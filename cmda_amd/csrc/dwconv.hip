@@ -193,17 +193,10 @@ struct DilGeom {
   long nthreads;        // B * dil * dil * rpc
 };
 template <typename T, int MODE, int CQ>
-__global__ __launch_bounds__(256) void dw_dilated_kernel(const T* __restrict__ x, const float* __restrict__ w,
-                                                         const float* __restrict__ bias, T* __restrict__ out, DilGeom g, int C,
-                                                         int act, int accumulate, int gx, float* __restrict__ stats,
-                                                         int imgs_per_group) {
-  const int cx = threadIdx.x % CQ, py = threadIdx.x / CQ;
-  const BlockXY blk = xcd_block(gx);
-  const int c = (blk.bx * CQ + cx) * 4;
-  const long t = blk.by * (256 / CQ) + py;
-  if (c >= C || t >= g.nthreads) return;
+static __device__ __forceinline__ void dw_dilated_walk(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                       T* __restrict__ out, const DilGeom& g, int C, int accumulate, int c, unsigned tu,
+                                                       bool do_stats, int imgs_per_group, float (&cs)[4], float (&cq)[4], int& grp) {
   // t -> (b, rho_h, rho_w, k): k fastest, so the runs of one sub-row sit in the same / the next workgroup
-  const unsigned tu = (unsigned)t;
   const int k = (int)(tu % (unsigned)g.rpc);
   const unsigned t1 = tu / (unsigned)g.rpc;
   const int rho_w = (int)(t1 % (unsigned)g.dil);
@@ -213,6 +206,7 @@ __global__ __launch_bounds__(256) void dw_dilated_kernel(const T* __restrict__ x
   const int ncol = (g.W - rho_w + g.dil - 1) / g.dil;
   const int k0 = k * DRUN;
   if (nr <= 0 || k0 >= ncol) return;
+  if (do_stats) grp = b / imgs_per_group;
   const long img = (long)b * g.H * g.W;
   // window column ci <-> sub-column k0 - 1 + ci; out-of-image columns read a clamped address and are zeroed by a select
   long coff[DRUN + 2];
@@ -235,8 +229,6 @@ __global__ __launch_bounds__(256) void dw_dilated_kernel(const T* __restrict__ x
   const bool acc_mode = MODE == 2 && accumulate;
   // MODE 0 with `stats`: column sums / sums of squares of the outputs this thread stores (the BatchNorm behind the dilated depthwise
   // convolution of the sep-ASPP, sep_aspp_head.py:18-27), added to the BatchNorm workspace of the image's group when the walk is done
-  const bool do_stats = MODE == 0 && stats != nullptr;
-  float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
   // (no select on the loaded value here: it would pin the wait for the data right behind the request -- the padding columns are
   // zeroed when the row is unpacked)
   auto request = [&](int r, Raw<T> (&dst)[DRUN + 2], Raw<T> (&pdst)[DRUN]) {
@@ -309,8 +301,66 @@ __global__ __launch_bounds__(256) void dw_dilated_kernel(const T* __restrict__ x
       }
     }
   }
-  if (do_stats) {   // one thread = one (image, sub-lattice, run) x 4 channels: eight atomics, spread over the 32 slots by the run index
-    float* wsl = stats + ((long)(b / imgs_per_group) * (CMDA_BN_SLOTS + 1) + (tu & (CMDA_BN_SLOTS - 1))) * 2 * (long)C + c;
+}
+
+template <typename T, int MODE, int CQ>
+__global__ __launch_bounds__(256) void dw_dilated_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, T* __restrict__ out, DilGeom g, int C,
+                                                         int act, int accumulate, int gx, float* __restrict__ stats,
+                                                         int imgs_per_group) {
+  const int cx = threadIdx.x % CQ, py = threadIdx.x / CQ;
+  const BlockXY blk = xcd_block(gx);
+  const int c = (blk.bx * CQ + cx) * 4;
+  const long t = blk.by * (256 / CQ) + py;
+  // MODE 0 with `stats` (the BatchNorm statistics of the outputs, below): the workgroup's run lanes meet in LDS at the end, so a
+  // thread without work stays for the barrier instead of leaving
+  const bool do_stats = MODE == 0 && stats != nullptr;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
+  int grp = -1;
+  if (c < C && t < g.nthreads) dw_dilated_walk<T, MODE, CQ>(x, w, bias, out, g, C, accumulate, c, (unsigned)t, do_stats, imgs_per_group, cs, cq, grp);
+  if (!do_stats) return;
+  // one (image, sub-lattice, run) x 4 channels per thread; the 256 / CQ run lanes of a channel quad fold through LDS when they belong
+  // to the same statistics group (always, except across an image-group boundary), then ONE thread per quad adds eight sums to one of
+  // the 32 slots of the group's workspace (per-thread atomics -- 7 M per launch at the decode head's size -- cost 37 us of a 190-us kernel)
+  constexpr int RL = 256 / CQ;
+  __shared__ float red[RL][CQ][8];
+  __shared__ int rgrp[RL];
+  if (cx == 0) rgrp[py] = grp;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    red[py][cx][q] = cs[q];
+    red[py][cx][4 + q] = cq[q];
+  }
+  __syncthreads();
+  if (c >= C) return;
+  bool uniform = true;   // (threads past the end of the problem carry group -1 and zero sums)
+  int g0 = -1;
+#pragma unroll
+  for (int r = 0; r < RL; ++r) {
+    const int gr = rgrp[r];
+    if (gr >= 0) {
+      if (g0 < 0) g0 = gr;
+      else if (gr != g0) uniform = false;
+    }
+  }
+  if (g0 < 0) return;
+  const unsigned slot = (unsigned)blk.by & (CMDA_BN_SLOTS - 1);
+  if (uniform) {
+    if (py != 0) return;
+    float* wsl = stats + ((long)g0 * (CMDA_BN_SLOTS + 1) + slot) * 2 * (long)C + c;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float a = 0.f, b2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < RL; ++r) {
+        a += red[r][cx][q];
+        b2 += red[r][cx][4 + q];
+      }
+      atomicAdd(wsl + q, a);
+      atomicAdd(wsl + C + q, b2);
+    }
+  } else if (grp >= 0) {
+    float* wsl = stats + ((long)grp * (CMDA_BN_SLOTS + 1) + slot) * 2 * (long)C + c;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       atomicAdd(wsl + q, cs[q]);
