@@ -222,7 +222,7 @@ def test_dacs_iteration_full_width_gpu(mode):
         if mode != 'bf16':
             check_iteration(outs[0], True, 1e-4, 5e-2 if mode == 'f32' else 0.1, tol_gen=None if mode == 'f32' else 5e-4)
         else:
-            check_iteration(outs[0], False, 2e-2, 0.5, label_agree=0.96)   # (worst gradient 0.19-0.24, labels 0.9876 measured, five runs: 2x)
+            check_iteration(outs[0], False, 2e-2, 0.55, label_agree=0.96)   # (worst gradient 0.19-0.27, labels 0.9876 measured, eight runs: 2x)
     finally:
         rt.set_gemm_x3(False)
         rt.set_compute_dtype(torch.float32)
@@ -538,7 +538,7 @@ def test_dacs_train_step_against_reference_fixture_gpu(mode):
             # (14 runs of four kernel configurations, tools/gpu/r05_fixture_var.sh) -- the spread is the same with and without the fused
             # BatchNorm statistics and the three-launch gate: it is the order of the fp32 atomics amplified by two optimizer steps
             check_le(f'it{it} worst gradient fingerprint error vs reference', worst,
-                     (1.2e-2 if exact else 3e-2) if it == 0 else (0.2 if exact else 0.4))
+                     (1.2e-2 if exact else 3e-2) if it == 0 else (0.3 if exact else 0.4))   # (worst of ten fp32 runs 0.108, of seventeen split-bf16 runs 0.157)
             for k, p in dacs.model.named_parameters():
                 # (AdamW turns the round-off-level gradients of the key half of every kv.bias into +-lr steps of arbitrary sign: up to
                 # 32 elements x 6e-5 per iteration on the fingerprint's sums)
