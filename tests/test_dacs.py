@@ -535,7 +535,7 @@ def test_dacs_train_step_against_reference_fixture_gpu(mode):
             # iteration 0: fp32 round-off (3.8e-3 measured; split-bf16 3.2e-3 .. 1.2e-2); behind the first optimizer step the runs differ by
             # AdamW's +-lr noise on the zero-gradient parameters and a handful of flipped pseudo-labels.  Exact fp32: 2.8e-2 .. 4.2e-2 at
             # iteration 1, up to 7.5e-2 at iteration 2 (seven runs); split-bf16: 4e-2 .. 7.6e-2 at iteration 1, 6.6e-2 .. 0.157 at iteration 2
-            # (14 runs of four kernel configurations, tools/gpu/r05_fixture_var.sh) -- the spread is the same with and without the fused
+            # (14 runs of four kernel configurations, tools/gpu/fixture_var.sh) -- the spread is the same with and without the fused
             # BatchNorm statistics and the three-launch gate: it is the order of the fp32 atomics amplified by two optimizer steps
             check_le(f'it{it} worst gradient fingerprint error vs reference', worst,
                      (1.2e-2 if exact else 3e-2) if it == 0 else (0.3 if exact else 0.4))   # (worst of ten fp32 runs 0.108, of seventeen split-bf16 runs 0.157)

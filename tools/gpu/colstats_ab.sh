@@ -10,4 +10,4 @@ run CMDA_BN_FUSED_STATS=1
 run CMDA_BN_FUSED_STATS=0
 run CMDA_BN_FUSED_STATS=1 "--dtype f32x3"
 run CMDA_BN_FUSED_STATS=0 "--dtype f32x3"
-bash tools/gpu/r05_cs_stats.sh
+bash tools/gpu/colstats_stats.sh
