@@ -378,6 +378,15 @@ def test_fusion_simple_test_440x640_vs_oracle():
     want2 = torch.softmax(ohd.resize(want, (480, 700)), 1).flip(dims=(3,)).argmax(1)[0].numpy()
     assert pred2.shape == (480, 700)
     check_ge('rescaled + flipped label agreement', float((pred2 == want2).mean()), 0.9995, strict=True)
+    # the validation pass as the distributed entry point runs it (parallel.distributed_evaluate: BatchNorm-buffer broadcast, sharded
+    # scoring, one histogram exchange; here one rank, no process group): same mIoU as scoring simple_test's label map directly
+    from cmda_amd import parallel
+    sample = dict(warp_image=tgt.to(img), events_vg=tgt.to(ev), img_metas=meta, gt_semantic_seg=torch.from_numpy(gt))
+    res = parallel.distributed_evaluate(model, [sample], 19, 255)
+    pred1 = model.simple_test(True, warp_image=tgt.to(img), events_vg=tgt.to(ev), img_metas=meta)[0]
+    m1 = metrics.mean_iou([torch.from_numpy(pred1)], [torch.from_numpy(gt)], 19, 255)
+    assert abs(res['mIoU'].item() - m1['mIoU'].item()) < 1e-12 and abs(res['aAcc'].item() - m1['aAcc'].item()) < 1e-12
+    assert not model.training
 
 
 @pytest.mark.gpu
