@@ -166,12 +166,12 @@ static __device__ __forceinline__ void x3_lean_body(X3LeanParams& q, int bt_in, 
     }
   };
   // ---- split pass: 16 bytes of fp32 -> 8 bytes of the hi tile + 8 bytes of the lo tile.  bf16 images: K-contiguous [line][32 k]
-  //      (64-byte lines of four 16-byte chunks, slot = chunk ^ ((line >> 2) & 3): lines r and r + 4 start on the same bank);
+  //      (64-byte lines of four 16-byte chunks, slot = chunk ^ ((line >> 1) & 3): eight consecutive lines of one k-chunk cover all 32 banks once);
   //      K-strided [32 k][64 columns] (128-byte lines, slot = chunk ^ (k & 7): the bf16 kernels' image) ----
   const int offA = AKS ? lnA * BM + ((((chA >> 1)) ^ (lnA & 7)) << 3) + ((chA & 1) << 2)
-                       : lnA * BK + ((((chA >> 1)) ^ ((lnA >> 2) & 3)) << 3) + ((chA & 1) << 2);
+                       : lnA * BK + ((((chA >> 1)) ^ ((lnA >> 1) & 3)) << 3) + ((chA & 1) << 2);
   const int offB = BKS ? lnB * BN + ((((chB >> 1)) ^ (lnB & 7)) << 3) + ((chB & 1) << 2)
-                       : lnB * BK + ((((chB >> 1)) ^ ((lnB >> 2) & 3)) << 3) + ((chB & 1) << 2);
+                       : lnB * BK + ((((chB >> 1)) ^ ((lnB >> 1) & 3)) << 3) + ((chB & 1) << 2);
   float csum[4] = {0.f, 0.f, 0.f, 0.f};
   auto split = [&](int stage, int set) {
     const float* st = sF + stage * (F_A + F_B);
@@ -231,7 +231,7 @@ static __device__ __forceinline__ void x3_lean_body(X3LeanParams& q, int bt_in, 
     u16x8 fah, fal, fbh[TN], fbl[TN];
     if constexpr (!AKS) {
       const int row = wm * 16 + l15;
-      const int off = row * BK + ((g ^ ((row >> 2) & 3)) << 3);
+      const int off = row * BK + ((g ^ ((row >> 1) & 3)) << 3);
       fah = *reinterpret_cast<const u16x8*>(&aH[off]);
       fal = *reinterpret_cast<const u16x8*>(&aL[off]);
     } else {
@@ -249,7 +249,7 @@ static __device__ __forceinline__ void x3_lean_body(X3LeanParams& q, int bt_in, 
       const int nr = wn * 16 * TN + j * 16;
       if constexpr (!BKS) {
         const int row = nr + l15;
-        const int off = row * BK + ((g ^ ((row >> 2) & 3)) << 3);
+        const int off = row * BK + ((g ^ ((row >> 1) & 3)) << 3);
         fbh[j] = *reinterpret_cast<const u16x8*>(&bH[off]);
         fbl[j] = *reinterpret_cast<const u16x8*>(&bL[off]);
       } else {
