@@ -47,6 +47,12 @@ build/hip_pptiming/gemm_pp.o: $(CSRC)/gemm_pp.hip $(HDRS)
 pptiming: build/hip_pptiming/gemm_pp.o $(HIP_OBJS)
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o build/libcmda_hip_pptiming.so build/hip_pptiming/gemm_pp.o $(filter-out build/hip/gemm_pp.o,$(HIP_OBJS))
 
+build/hip_x3timing/gemm_x3_lean.o: $(CSRC)/gemm_x3_lean.hip $(HDRS)
+	@mkdir -p build/hip_x3timing
+	$(HIPCC) $(HIPFLAGS) -DCMDA_X3_TIMING -c $< -o $@
+x3timing: build/hip_x3timing/gemm_x3_lean.o $(HIP_OBJS)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o build/libcmda_hip_x3timing.so build/hip_x3timing/gemm_x3_lean.o $(filter-out build/hip/gemm_x3_lean.o,$(HIP_OBJS))
+
 clean:
 	rm -rf build cmda_amd/libcmda_hip.so tests/emu/libcmda_emu.so
-.PHONY: all hip emu timing pptiming clean
+.PHONY: all hip emu timing pptiming x3timing clean

@@ -17,6 +17,16 @@
 
 namespace {
 
+// -DCMDA_X3_TIMING (tuning build `make x3timing`, tools/dbg/x3_phase.py): lane 0 of wave 0 of workgroup 0 stamps s_memtime at entry (0),
+// after the prologue's DMA issue (1), when tile 0 has landed (2), after the first split (3), at the top of k-tile kt (4 + kt, kt < 40),
+// at the end of the k-loop (50), after the accumulators went through LDS (51), at the end of the epilogue (52)
+#ifdef CMDA_X3_TIMING
+__device__ unsigned long long g_x3_stamps[64];
+#define X3_STAMP(i) do { if (threadIdx.x == 0 && bt_in == 0 && zidx == 0) g_x3_stamps[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define X3_STAMP(i) do { } while (0)
+#endif
+
 struct X3LeanParams {
   const float* A;
   const float* B;
@@ -48,25 +58,22 @@ struct X3LeanParams {
   int pb_ohw, pb_ow, pb_row, pb_col, pb_kwc, pb_line;   // pb_kwc == 0: plain B
 };
 
-// 64 x 64 tile on eight waves = 4 (rows of 16) x 2 (columns of 32); 32-deep k-tiles: three fp32 stages of 16 KiB (two in flight while
-// one is split) + two hi / lo sets of 16 KiB = 80 KiB, i.e. TWO workgroups per CU (a lone workgroup per CU left the k-loop waiting
-// on its own DMA: 64-deep tiles with one tile in flight measured 15.0 us for 4096 x 320 x 320 against 16.9 for the general kernel)
+// 64 x 64 tile on eight waves = 4 (rows of 16) x 2 (columns of 32); 32-deep k-tiles: the fp32 values of two tiles wait in registers
+// (16 bytes of A and of B per thread and tile), two hi / lo sets of 16 KiB in LDS
 // AKS (with BKS): the WEIGHT-GRADIENT form -- both operands K-strided ([tokens][channels] row-major: dW = dy^T x), split-K over the
 // tokens (grid.z), fp32 atomic accumulation into C, bias gradient (column sums of dy) fused
 // bt_in: output tile of the problem (hardware order; remapped to XCD-contiguous ranges when `remap`), zidx: (batch entry, split)
 template <bool AKS, bool BKS>
 static __device__ __forceinline__ void x3_lean_body(X3LeanParams& q, int bt_in, int zidx, bool remap) {
   static_assert(!AKS || BKS, "A K-strided: weight-gradient form only");
-  constexpr int NW = 8, NT = 512, BM = 64, BN = 64, BK = 32, TN = 2, NSTG = 3;
-  constexpr int F_A = BM * BK, F_B = BN * BK;                 // fp32 elements of a stage (A | B)
+  X3_STAMP(0);
+  constexpr int NW = 8, NT = 512, BM = 64, BN = 64, BK = 32, TN = 2;
   constexpr int H_A = BM * BK, H_B = BN * BK;                 // bf16 elements of a hi (or lo) tile
   constexpr int PITCH_C = BN + 4;
-  constexpr size_t FP_BYTES = (size_t)NSTG * (F_A + F_B) * 4;
   constexpr size_t HL_BYTES = (size_t)2 * 2 * (H_A + H_B) * 2;   // two (hi, lo) tile sets
-  static_assert(FP_BYTES + HL_BYTES <= 81920, "two workgroups per CU");
-  __shared__ __attribute__((aligned(1024))) char smem[FP_BYTES + HL_BYTES];
-  float* const sF = reinterpret_cast<float*>(smem);           // [stage][A | B]
-  bf16_t* const sH = reinterpret_cast<bf16_t*>(smem + FP_BYTES);   // [set][A hi | A lo | B hi | B lo]
+  static_assert(HL_BYTES >= (size_t)BM * PITCH_C * 4 && HL_BYTES >= 32 * 64 * 4, "the epilogue's tile / the bias-gradient fold alias the sets");
+  __shared__ __attribute__((aligned(1024))) char smem[HL_BYTES];
+  bf16_t* const sH = reinterpret_cast<bf16_t*>(smem);         // [set][A hi | A lo | B hi | B lo]
   constexpr int SET = 2 * (H_A + H_B);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1, g = lane >> 4, l15 = lane & 15;
@@ -149,13 +156,17 @@ static __device__ __forceinline__ void x3_lean_body(X3LeanParams& q, int bt_in, 
     tokB += BK;
     return reinterpret_cast<const char*>(q.B + (long)pb * q.pb_img + (long)oh * q.pb_row + (long)ow * q.pb_col + colB);
   };
-  auto issue = [&](int stage) {
-    float* st = sF + stage * (F_A + F_B);
-    glds16_asm(curA, reinterpret_cast<char*>(st) + wid * 1024);
+  // ---- loads: thread t owns 16-byte position t of the A part and of the B part of every k-tile; the fp32 values travel through
+  //      REGISTERS (two tiles in flight: one being converted, one on its way), not through LDS stages -- the first version of this
+  //      kernel brought them in by LDS-DMA and split them in a second pass: 16 KiB written + 16 KiB read per k-tile on top of the
+  //      16 KiB of hi / lo writes and the 48 KiB of fragment reads, and the phase stamps (`make x3timing`) showed the k-tile bound by
+  //      exactly that LDS traffic (96 KiB at 128 B per cycle = 768 of its 1200 cycles) ----
+  auto fetch = [&](f32x4& ra, f32x4& rb) {
+    ra = *reinterpret_cast<const f32x4*>(curA);
     if constexpr (AKS) {
       if (q.pb_kwc > 0) curB = patch_b();
     }
-    glds16_asm(curB, reinterpret_cast<char*>(st + F_A) + wid * 1024);
+    rb = *reinterpret_cast<const f32x4*>(curB);
     curA += stepA;
     curB += stepB;
     if constexpr (!AKS) {
@@ -173,13 +184,11 @@ static __device__ __forceinline__ void x3_lean_body(X3LeanParams& q, int bt_in, 
   const int offB = BKS ? lnB * BN + ((((chB >> 1)) ^ (lnB & 7)) << 3) + ((chB & 1) << 2)
                        : lnB * BK + ((((chB >> 1)) ^ ((lnB >> 1) & 3)) << 3) + ((chB & 1) << 2);
   float csum[4] = {0.f, 0.f, 0.f, 0.f};
-  auto split = [&](int stage, int set) {
-    const float* st = sF + stage * (F_A + F_B);
+  auto convert = [&](const f32x4& ra, const f32x4& rb, int set) {
     bf16_t* ha = sH + set * SET;
     bf16_t* hb = ha + 2 * H_A;
-    float va[4], vb[4], hi[4], lo[4];
-    ld4(st + tid * 4, va);
-    ld4(st + F_A + tid * 4, vb);
+    const float va[4] = {ra[0], ra[1], ra[2], ra[3]}, vb[4] = {rb[0], rb[1], rb[2], rb[3]};
+    float hi[4], lo[4];
     if constexpr (AKS) {   // bias gradient: this thread's four columns of dy, every token of its line index
 #pragma unroll
       for (int e = 0; e < 4; ++e) csum[e] += va[e];
@@ -199,9 +208,10 @@ static __device__ __forceinline__ void x3_lean_body(X3LeanParams& q, int bt_in, 
     st4(hb + offB, hi);
     st4(hb + H_B + offB, lo);
   };
-#pragma unroll
-  for (int s = 0; s < NSTG; ++s)
-    if (s < nkt) issue(s);
+  f32x4 ra0 = f32x4{0.f, 0.f, 0.f, 0.f}, rb0 = ra0, ra1 = ra0, rb1 = ra0;   // tile kt in slot kt & 1
+  if (nkt > 0) fetch(ra0, rb0);
+  if (nkt > 1) fetch(ra1, rb1);
+  X3_STAMP(1);
 
   // epilogue operands requested now (gemm_lean_kernel)
   constexpr int QPR = BN / 4, RSTEP = NT / QPR, NIT = BM / RSTEP;
@@ -223,12 +233,14 @@ static __device__ __forceinline__ void x3_lean_body(X3LeanParams& q, int bt_in, 
 #pragma unroll
   for (int j = 0; j < TN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  auto mfma_tile = [&](int set) {
+  // fragments of hi / lo set `set` (requested FIRST in a k-tile: their LDS latency passes under the split pass of the next tile, which
+  // the compiler cannot prove disjoint and would otherwise keep strictly in front -- phase stamps of `make x3timing`: 1200 cycles per
+  // k-tile of which 730 were this read -> MFMA chain on its own)
+  auto load_frags = [&](int set, u16x8& fah, u16x8& fal, u16x8 (&fbh)[TN], u16x8 (&fbl)[TN]) {
     const bf16_t* aH = sH + set * SET;
     const bf16_t* aL = aH + H_A;
     const bf16_t* bH = aH + 2 * H_A;
     const bf16_t* bL = bH + H_B;
-    u16x8 fah, fal, fbh[TN], fbl[TN];
     if constexpr (!AKS) {
       const int row = wm * 16 + l15;
       const int off = row * BK + ((g ^ ((row >> 1) & 3)) << 3);
@@ -263,32 +275,40 @@ static __device__ __forceinline__ void x3_lean_body(X3LeanParams& q, int bt_in, 
         fbl[j] = u16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
       }
     }
+  };
+  // small terms first, then the leading product (gemm_x3.hip); the two accumulators alternate, so no matrix instruction waits for
+  // the one issued right before it
+  auto do_mfma = [&](const u16x8& fah, const u16x8& fal, const u16x8 (&fbh)[TN], const u16x8 (&fbl)[TN]) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {   // small terms first, then the leading product (gemm_x3.hip)
-      acc[j] = mfma_bf16_16x16x32(fal, fbh[j], acc[j]);
-      acc[j] = mfma_bf16_16x16x32(fah, fbl[j], acc[j]);
-      acc[j] = mfma_bf16_16x16x32(fah, fbh[j], acc[j]);
-    }
+    for (int j = 0; j < TN; ++j) acc[j] = mfma_bf16_16x16x32(fal, fbh[j], acc[j]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[j] = mfma_bf16_16x16x32(fah, fbl[j], acc[j]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[j] = mfma_bf16_16x16x32(fah, fbh[j], acc[j]);
   };
 
-  constexpr int LPT = 2;   // DMA instructions per wave per k-tile
-  // tile 0 has landed (tiles 1 and 2 may stay in flight) -> split into set 0
-  if (nkt > 2) pipe_barrier<2 * LPT>();
-  else if (nkt > 1) pipe_barrier<LPT>();
-  else pipe_barrier<0>();
-  split(0, 0);
-  int stg = 1, set = 0;    // stage of tile kt + 1, hi / lo set of tile kt
-  for (int kt = 0; kt < nkt; ++kt) {
-    // fp32 tile kt + 1 has landed (tile kt + 2 may stay in flight); every wave is done with the stage of tile kt (its split) and
-    // with hi / lo set (kt + 1) & 1 (the MFMAs of tile kt - 1); set kt & 1 is complete
-    if (kt + 2 < nkt) pipe_barrier<LPT>();
-    else pipe_barrier<0>();
-    if (kt + NSTG < nkt) issue(stg == 0 ? NSTG - 1 : stg - 1);   // the stage tile kt was split from
-    if (kt + 1 < nkt) split(stg, set ^ 1);
-    mfma_tile(set);
-    if (++stg == NSTG) stg = 0;
-    set ^= 1;
+  // tile 0 -> set 0; its register slot takes tile 2
+  convert(ra0, rb0, 0);
+  X3_STAMP(2);
+  if (nkt > 2) fetch(ra0, rb0);
+  lds_barrier();
+  X3_STAMP(3);
+  // one k-tile: fragments of set `kt & 1` requested first, then tile kt + 1 converted into the other set (its register slot refilled
+  // with tile kt + 3), then the matrix instructions; ONE barrier: every wave is done reading this set and writing the other one
+  auto ktile = [&](int kt, int set, f32x4& ra, f32x4& rb) {   // (ra, rb): the slot of tile kt + 1
+    if (kt < 40) X3_STAMP(4 + kt);
+    u16x8 fah, fal, fbh[TN], fbl[TN];
+    load_frags(set, fah, fal, fbh, fbl);
+    if (kt + 1 < nkt) convert(ra, rb, set ^ 1);
+    if (kt + 3 < nkt) fetch(ra, rb);
+    do_mfma(fah, fal, fbh, fbl);
+    lds_barrier();
+  };
+  for (int kt = 0; kt < nkt; kt += 2) {
+    ktile(kt, 0, ra1, rb1);
+    if (kt + 1 < nkt) ktile(kt + 1, 1, ra0, rb0);
   }
+  X3_STAMP(50);
   if (AKS || q.atomic) {
     // ---- split-K epilogue (weight-gradient form; forward form with atomic output): fp32 atomics into C, bias gradient from the
     //      n-tile-0 workgroups ----
@@ -341,6 +361,7 @@ static __device__ __forceinline__ void x3_lean_body(X3LeanParams& q, int bt_in, 
 #pragma unroll
     for (int r = 0; r < 4; ++r) sC[(wm * 16 + 4 * g + r) * PITCH_C + wn * 16 * TN + j * 16 + l15] = acc[j][r];
   __syncthreads();
+  X3_STAMP(51);
   if (!ecol) return;
   const float alpha = q.alpha, beta = q.beta;
   const bool has_beta = beta != 0.f, has_rs = q.rowscale != nullptr;
@@ -382,6 +403,7 @@ static __device__ __forceinline__ void x3_lean_body(X3LeanParams& q, int bt_in, 
         if (en + e < N) q.C[ci + e] = v[e];
     }
   }
+  X3_STAMP(52);
 }
 
 template <bool AKS, bool BKS>
@@ -484,6 +506,12 @@ int launch_x3_lean(const GemmParams& p, void* stream) {
 }
 
 }  // namespace
+
+#ifdef CMDA_X3_TIMING
+extern "C" int cmda_debug_x3_stamps(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_x3_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -3;
+}
+#endif
 
 // HOST: does the lean split-bf16 kernel take this problem?
 bool cmda_gemm_x3_lean_ok_(const cmda_gemm_params_t& p) {
