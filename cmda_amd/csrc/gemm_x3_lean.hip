@@ -78,10 +78,16 @@ static __device__ __forceinline__ void x3_lean_body(X3LeanParams& q, int bt_in, 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1, g = lane >> 4, l15 = lane & 15;
   const int M = q.M, N = q.N, tiles_n = q.tiles_n, ntile = q.ntile;
-  const int bz = zidx / q.splits, ksplit = zidx - bz * q.splits;
+  // flags bit 4: batched (grid.z carries batch entries), bit 5: K split -- the plain Linear / data-gradient launch has neither and
+  // skips their divisions and the cold half of the parameter block (a scalar-load round trip of the prologue)
+  int bz = 0, ksplit = 0;
+  if (q.flags & 48) {
+    bz = zidx / q.splits;
+    ksplit = zidx - bz * q.splits;
+  }
   const int kt0 = ksplit * q.kt_per;                   // (kt_per = all k-tiles and one split unless the launcher split K)
   const int nkt = min(q.nkt - kt0, q.kt_per);          // k-tiles of THIS workgroup
-  {   // batch entry: operand / output bases move, everything else is per problem
+  if (q.flags & 16) {   // batch entry: operand / output bases move, everything else is per problem
     const int b1 = bz / q.batch2, b2 = bz - b1 * q.batch2;
     q.A += b1 * q.a_bs + b2 * q.a_b2s;
     q.B += b1 * q.b_bs + b2 * q.b_b2s;
@@ -468,6 +474,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_lean_grouped_kernel(const Gemm
   const int splits = p.splits > 0 ? p.splits : 1;
   q.kt_per = (q.nkt + splits - 1) / splits;
   q.splits = splits;
+  q.flags |= splits > 1 ? 32 : 0;
   x3_lean_body<true, true>(q, blk % q.ntile, blk / q.ntile, false);
 }
 
@@ -488,6 +495,7 @@ int launch_x3_lean(const GemmParams& p, void* stream) {
     q.kt_per = (q.nkt + splits - 1) / splits;
     splits = (q.nkt + q.kt_per - 1) / q.kt_per;
     q.splits = splits;
+    q.flags |= (nb > 1 ? 16 : 0) | (splits > 1 ? 32 : 0);
     if (nb * splits > 65535) return CMDA_ERR_SHAPE;
     CMDA_LAUNCH((gemm_x3_lean_kernel<true, true>), dim3((unsigned)tiles, 1, (unsigned)(nb * splits)), blk, 0, stream, q);
     CMDA_CHECK_LAUNCH();
@@ -499,6 +507,7 @@ int launch_x3_lean(const GemmParams& p, void* stream) {
     q.atomic = 1;
   }
   if (nb * q.splits > 65535) return CMDA_ERR_SHAPE;
+  q.flags |= (nb > 1 ? 16 : 0) | (q.splits > 1 ? 32 : 0);
   const dim3 grid((unsigned)tiles, 1, (unsigned)(nb * q.splits));
   if (p.b_kstrided) CMDA_LAUNCH((gemm_x3_lean_kernel<false, true>), grid, blk, 0, stream, q);
   else CMDA_LAUNCH((gemm_x3_lean_kernel<false, false>), grid, blk, 0, stream, q);
