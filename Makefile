@@ -53,6 +53,12 @@ build/hip_x3timing/gemm_x3_lean.o: $(CSRC)/gemm_x3_lean.hip $(HDRS)
 x3timing: build/hip_x3timing/gemm_x3_lean.o $(HIP_OBJS)
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o build/libcmda_hip_x3timing.so build/hip_x3timing/gemm_x3_lean.o $(filter-out build/hip/gemm_x3_lean.o,$(HIP_OBJS))
 
+build/hip_leantiming/gemm_lean.o: $(CSRC)/gemm_lean.hip $(HDRS)
+	@mkdir -p build/hip_leantiming
+	$(HIPCC) $(HIPFLAGS) -DCMDA_LEAN_TIMING -c $< -o $@
+leantiming: build/hip_leantiming/gemm_lean.o $(HIP_OBJS)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o build/libcmda_hip_leantiming.so build/hip_leantiming/gemm_lean.o $(filter-out build/hip/gemm_lean.o,$(HIP_OBJS))
+
 clean:
 	rm -rf build cmda_amd/libcmda_hip.so tests/emu/libcmda_emu.so
-.PHONY: all hip emu timing pptiming x3timing clean
+.PHONY: all hip emu timing pptiming x3timing leantiming clean

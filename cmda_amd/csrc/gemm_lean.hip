@@ -36,8 +36,19 @@ struct LeanParams {
 // >= 12 k-tiles per block (fc2 / its data gradient at K = 1280 ... 2048: three k-tiles in flight) -- launch_glds's rule
 // PATCH: A is the patch view of a kernel == stride convolution (the spatial-reduction convolutions of the MiT attention,
 // mix_transformer.py:73-75,86-90): the running pointer jumps to the next input row at the end of every KW * C segment
+// -DCMDA_LEAN_TIMING (tuning build `make leantiming`, tools/dbg/lean_phase.py): lane 0 of wave 0 of workgroup 0 stamps s_memtime at entry (0),
+// after the prologue's DMA issue (1), at the top of k-tile kt (4 + kt, kt < 40), at the end of the k-loop (50), when the accumulators went
+// through LDS (51), at the end of the epilogue (52)
+#ifdef CMDA_LEAN_TIMING
+__device__ unsigned long long g_lean_stamps[64];
+#define LEAN_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.z == 0) g_lean_stamps[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LEAN_STAMP(i) do { } while (0)
+#endif
+
 template <int TM, int TN, bool BKS, int NSV = 0, int NW = 4, bool PATCH = false>
 __global__ __launch_bounds__(64 * NW, (GldsCfg<TM, TN, NW, NSV>::MIN_WAVES)) void gemm_lean_kernel(LeanParams q) {
+  LEAN_STAMP(0);
   typedef bf16_t T;
   typedef GldsCfg<TM, TN, NW, NSV> Cfg;
   constexpr int NT = 64 * NW;
@@ -122,6 +133,7 @@ __global__ __launch_bounds__(64 * NW, (GldsCfg<TM, TN, NW, NSV>::MIN_WAVES)) voi
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s)
     if (s < nkt) issue(s);
+  LEAN_STAMP(1);
 
   // epilogue operands requested NOW: the thread's bias quad (and, below, its residual rows before the last barrier)
   constexpr int QPR = BN / 4, RSTEP = NT / QPR, NIT = BM / RSTEP;
@@ -148,6 +160,7 @@ __global__ __launch_bounds__(64 * NW, (GldsCfg<TM, TN, NW, NSV>::MIN_WAVES)) voi
   constexpr int LPT = JA + JB;           // DMA instructions per wave per k-tile
   int st = 0;
   for (int kt = 0; kt < nkt; ++kt) {
+    if (kt < 40) LEAN_STAMP(4 + kt);
     // tile kt has landed (NS - 2 younger tiles may stay in flight; the tail drains); every wave is done reading stage st - 1
     if (kt + NS - 2 < nkt) pipe_barrier<(NS - 2) * LPT>();
     else pipe_barrier<0>();
@@ -191,6 +204,7 @@ __global__ __launch_bounds__(64 * NW, (GldsCfg<TM, TN, NW, NSV>::MIN_WAVES)) voi
   // residual rows of this thread: requested before the accumulators go through LDS (their latency hides behind the staging)
   const bool has_res = q.res != nullptr, res32 = (q.flags & 2) != 0, f32o = (q.flags & 1) != 0;
   float rv[NIT][4];
+LEAN_STAMP(50);
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     rv[it][0] = rv[it][1] = rv[it][2] = rv[it][3] = 0.f;
@@ -217,6 +231,7 @@ __global__ __launch_bounds__(64 * NW, (GldsCfg<TM, TN, NW, NSV>::MIN_WAVES)) voi
       for (int r = 0; r < 4; ++r)
         sC[(wm * 16 * TM + i * 16 + 4 * g + r) * PITCH_C + wn * 16 * TN + j * 16 + l15] = acc[i][j][r];
   __syncthreads();
+  LEAN_STAMP(51);
   if (!ecol) return;
   const float alpha = q.alpha, beta = q.beta;
   const bool has_beta = beta != 0.f, has_rs = q.rowscale != nullptr;
@@ -272,6 +287,7 @@ __global__ __launch_bounds__(64 * NW, (GldsCfg<TM, TN, NW, NSV>::MIN_WAVES)) voi
       }
     }
   }
+  LEAN_STAMP(52);
 }
 
 template <int TM, int TN, int NSV = 0, int NW = 4>
@@ -345,3 +361,9 @@ int cmda_gemm_lean_(const cmda_gemm_params_t& p, int tile, int four_stage, void*
   if (four_stage) return tile == 1 ? launch_lean<4, 2, 4>(p, stream) : launch_lean<2, 2, 4>(p, stream);
   return tile == 1 ? launch_lean<4, 2>(p, stream) : launch_lean<2, 2>(p, stream);
 }
+
+#ifdef CMDA_LEAN_TIMING
+extern "C" int cmda_debug_lean_stamps(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_lean_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -3;
+}
+#endif

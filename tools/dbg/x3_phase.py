@@ -21,7 +21,7 @@ t = list(buf)
 nkt = min(K // 32, 40)
 t0 = t[0]
 cyc = lambda i: t[i] - t0   # s_memtime ticks = shader cycles
-print(f'{M} x {N} x {K} {"NN" if nn else "NT"}: workgroup 0 / wave 0, cycles from kernel entry (100 MHz-independent: shader clock)')
+print(f'{M} x {N} x {K} {"NN" if nn else "NT"}: workgroup 0 / wave 0, cycles from kernel entry')
 print(f'  prologue issue done {cyc(1)}, tile 0 landed {cyc(2)}, first split done {cyc(3)}')
 tops = [cyc(4 + i) for i in range(nkt)]
 print('  k-tile tops:', tops)
