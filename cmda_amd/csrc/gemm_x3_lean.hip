@@ -372,6 +372,20 @@ static __device__ __forceinline__ void x3_lean_body(X3LeanParams& q, int bt_in, 
   const float alpha = q.alpha, beta = q.beta;
   const bool has_beta = beta != 0.f, has_rs = q.rowscale != nullptr;
   const int act = q.act;
+  // the common epilogue (gemm_lean.hip): whole column quads, plain store, bias (+ residual), nothing else
+  if (full && q.c_patch_ow == 0 && !has_rs && !has_beta && act == 0) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = er0 + it * RSTEP;
+      const long m = m0 + row;
+      if (m >= M) break;
+      const float4 t = *reinterpret_cast<const float4*>(&sC[row * PITCH_C + q4]);
+      float v[4] = {alpha * t.x + bv[0] + rv[it][0], alpha * t.y + bv[1] + rv[it][1], alpha * t.z + bv[2] + rv[it][2], alpha * t.w + bv[3] + rv[it][3]};
+      st4(q.C + m * q.ldc + en, v);
+    }
+    X3_STAMP(52);
+    return;
+  }
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int row = er0 + it * RSTEP;

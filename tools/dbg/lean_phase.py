@@ -25,4 +25,4 @@ cyc = lambda i: t[i] - t[0]
 tops = [cyc(4 + i) for i in range(nkt)]
 print(f'{M} x {N} x {K} {"NN" if nn else "NT"}{" + fp32 residual" if res is not None else ""}: workgroup 0 / wave 0, shader cycles from kernel entry')
 print(f'  prologue issue done {cyc(1)}; k-tile tops {tops}; durations {[tops[i + 1] - tops[i] for i in range(nkt - 1)]} + last {cyc(50) - tops[-1]}')
-print(f'  loop end {cyc(50)}, accumulators staged {cyc(51)}, rows stored {cyc(52)}')
+print(f'  loop end {cyc(50)}, accumulators staged {cyc(51)}, row-loop iteration tops {cyc(53)} {cyc(55)}, rows stored {cyc(52)}')
