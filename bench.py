@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_TBS = 8.0              # HBM3E, same guide (6.3 TB/s achievable by a float4 copy)
 GFLOP_PER_IMAGE_FWD = 252.6     # MiT-B5 138.8 + DAFormer head 113.8
 GFLOP_PER_PAIR_UDA = 6430.0     # full UDA step per (source, target) pair
 
@@ -261,11 +262,36 @@ def profile_json(name):
         return None
 
 
+def accuracy_block():
+    """Distance of each mode of the step to the CPU oracle at THIS configuration, read from the latest committed parity record
+    (profiles/rNN_parity.json, written by tools/gpu/parity.sh = tests/test_dacs.py::test_dacs_iteration_full_depth_512_gpu run
+    on the GPU box with CMDA_PARITY_JSON set): range-relative and element-wise logit error of the teacher's fusion logits,
+    pseudo-label agreement.  The north star's tolerance is 1e-3 on the logits and bit-exact pseudo-label argmax."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_parity.json')))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None
+    out = {'source': os.path.relpath(files[-1], ROOT), 'tolerance': 'logits within 1e-3 (north star); pseudo-label argmax equal',
+           'what': rec.get('_what')}
+    for mode in ('bf16', 'f32x3', 'f32'):
+        r = rec.get(mode)
+        if r:
+            out[mode] = {k: r[k] for k in ('logit_err_range', 'logit_err_elementwise_p999', 'logit_err_elementwise_max',
+                                           'pseudo_label_agreement', 'mixed_label_agreement', 'gradient_rel_err_p90') if k in r}
+            out[mode]['within_tolerance'] = bool(r.get('logit_err_range', 1.0) <= 1e-3)
+    return out
+
+
 def rocprof_gemm_stats(workload):
     """GEMM-family launches / average duration in the committed rocprofv3 --kernel-trace --stats summary of this command's eager
     launch sequence (profiles/r04_<workload>_eager_kernel_stats.csv, else the latest earlier round's), for the cross-check against the live HIP-event figure"""
     import csv
-    path = next((p for p in (os.path.join(ROOT, 'profiles', f'{r}_{workload}_eager_kernel_stats.csv') for r in ('r05', 'r04', 'r03', 'r02'))
+    path = next((p for p in (os.path.join(ROOT, 'profiles', f'{r}_{workload}_eager_kernel_stats.csv') for r in ('r06', 'r05', 'r04', 'r03', 'r02'))
                  if os.path.exists(p)), os.path.join(ROOT, 'profiles', f'r02_{workload}_eager_kernel_stats.csv'))
     try:
         calls = ns = 0
@@ -277,6 +303,48 @@ def rocprof_gemm_stats(workload):
         return {'file': os.path.relpath(path, ROOT), 'launches': calls, 'avg_launch_us': round(ns / max(calls, 1) / 1e3, 2)} if calls else None
     except (OSError, KeyError, ValueError):
         return None
+
+
+def _family(n):
+    """kernel family by name (the rule of tools/pmc_traffic.py)"""
+    for key, fam in (('gemm', 'gemm'), ('attn', 'attention'), ('ln_', 'layernorm'), ('dw_', 'depthwise'), ('bn_', 'batchnorm')):
+        if key in n:
+            return fam
+    return 'ce/pseudo-label' if ('ce_' in n or 'pseudo' in n) else 'other'
+
+
+def hbm_families(workload):
+    """The HBM-bound kernel families of the step against the 8 TB/s roof, from the COMMITTED measurements of this command (not from
+    eager event timers, which mostly measure the launch path of a 5-us kernel): bytes per launch = FETCH_SIZE x 2 + WRITE_SIZE of the
+    PMC passes (profiles/pmc_traffic_<workload>.json), duration = the family's average kernel duration in the rocprofv3 kernel trace
+    of the eager launch sequence (profiles/rNN_<workload>_eager_kernel_stats.csv).  frac = bytes / duration / 8 TB/s."""
+    import csv
+    pmc = profile_json(f'pmc_traffic_{workload}')
+    path = next((p for p in (os.path.join(ROOT, 'profiles', f'{r}_{workload}_eager_kernel_stats.csv') for r in ('r06', 'r05', 'r04'))
+                 if os.path.exists(p)), None)
+    if not pmc or not path or 'families' not in pmc:
+        return None
+    dur = {}
+    try:
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                a = dur.setdefault(_family(r['Name']), [0, 0])
+                a[0] += int(r['Calls'])
+                a[1] += int(r['TotalDurationNs'])
+    except (OSError, KeyError, ValueError):
+        return None
+    out = {'peak': HBM_PEAK_TBS, 'unit': 'TB/s', 'bytes': 'rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE per launch (profiles/pmc_traffic_%s.json)' % workload,
+           'durations': os.path.relpath(path, ROOT)}
+    for fam in ('depthwise', 'layernorm', 'batchnorm', 'ce/pseudo-label'):
+        t, d = pmc['families'].get(fam), dur.get(fam)
+        if not t or not d or not d[0]:
+            continue
+        mb = t['fetch_mb_per_launch'] + t['write_mb_per_launch']
+        us = d[1] / d[0] / 1e3
+        tbs = mb / us   # MB / us = TB/s
+        out[fam] = {'mb_per_launch': round(mb, 2), 'avg_us': round(us, 2), 'achieved': round(tbs, 3), 'frac': round(tbs / HBM_PEAK_TBS, 3),
+                    'launches_in_trace': d[0], 'ms_in_trace': round(d[1] / 1e6, 2)}
+    return out
 
 
 def gemm_roofline(step, workload):
@@ -317,6 +385,9 @@ def gemm_roofline(step, workload):
             fh.write('M N K batch splits conv a_kstr b_kstr atomic out_f32 | calls ms_total us_avg TFLOP/s\n')
             for key, (c, ms, f) in sorted(hist.items(), key=lambda kv: -kv[1][1]):
                 fh.write(' '.join(str(int(v)) for v in key) + f' | {c} {ms:.3f} {ms / c * 1e3:.1f} {f / ms / 1e9:.1f}\n')
+    if os.environ.get('CMDA_BENCH_GEMM_LOG'):   # launch-ordered record of this step's GEMM launches (tools/pmc_gemm_instances.py
+        with open(os.environ['CMDA_BENCH_GEMM_LOG'], 'w') as fh:   # matches it with the dispatches of a PMC pass of the same command)
+            json.dump([dict(flops=f, bytes=b, key=[v if isinstance(v, (int, bool, str)) else 'grouped' for v in key]) for f, _, _, b, key in prof], fh)
     pmc = profile_json(f'pmc_traffic_{workload}')
     roof = {'bound': 'mfma', 'kernel': 'gemm_glds_kernel + gemm_kernel (bf16 MFMA tile GEMM / implicit-GEMM conv family, all '
                                        'template instances)',
@@ -342,6 +413,9 @@ def gemm_roofline(step, workload):
         roof['generator'] = _site(sites['generator'])
     if pmc:
         roof['traffic_source'] = pmc.get('source')
+    hbm = hbm_families(workload)
+    if hbm:
+        roof['hbm'] = hbm
     micro = profile_json('micro_peaks')
     if micro:
         roof['peak_measured'] = micro
@@ -362,7 +436,9 @@ def run_dacs(args, rank, world, dev, dist):
     dacs = build_dacs(dev)
     opt = optim.FlatAdamW(dacs.model, lr=6e-5, weight_decay=0.01, custom_keys=CUSTOM_KEYS)
     dacs.attach_flat_store(opt)
-    reducer = GradAllReducer(opt.flat_g, wire_dtype=torch.bfloat16, force=args.force_reducer)
+    # single rank with --force-reducer: the bucket is padded, scattered and gathered as for TWO ranks (GradAllReducer.virtual_ways), so the
+    # RCCL reduce_scatter_tensor / all_gather_into_tensor calls of the multi-GPU exchange run with their shard-sized views on one GPU
+    reducer = GradAllReducer(opt.flat_g, wire_dtype=torch.bfloat16, force=args.force_reducer, virtual_ways=2 if world == 1 else 1)
     if reducer.active:
         # overlap inside the LAST backward pass of the iteration: the decode head and both encoders (each back-propagated once
         # per pass -- the event encoder sees events + ISR as one batch) start their slices as they finish; the fusion blocks
@@ -445,7 +521,8 @@ def run_dacs(args, rank, world, dev, dist):
                'model_gflop_per_pair': GFLOP_PER_PAIR_UDA,
                'model_tflops_achieved': round(GFLOP_PER_PAIR_UDA * value / 1e3 / world, 2),
                'roofline': roofline}
-        out['schema'] = 2   # 2: x3_* (split-bf16) and exact_f32_* carry the fp32-storage modes; parity_mode_* = alias of x3_* 
+        out['schema'] = 3   # 2: x3_* (split-bf16) and exact_f32_* carry the fp32-storage modes; parity_mode_* = alias of x3_* (ADVICE r04); 3: + accuracy
+        out['accuracy'] = accuracy_block()   # per mode: distance to the oracle at this configuration (committed parity run)
         if world == 1 and args.dtype == 'bf16' and not args.no_parity_mode:
             # the children allocate a whole fp32 model each: hand the parent's cached activation blocks back first
             import gc
@@ -464,7 +541,7 @@ def parity_mode_line(args):
     claim has a throughput attached: `parity_mode_*` = split-bf16 (bf16 x 3) GEMMs on fp32 storage (runtime.set_gemm_x3: the
     tolerance-meeting mode, tests/test_dacs.py::test_dacs_iteration_full_depth_512_gpu[x3]); `exact_f32_*` = the exact-fp32 matrix
     instruction (v_mfma_f32_16x16x4_f32, 1/16 of the bf16 rate: what rounds 1-3 reported as parity_mode).  The bf16 line's own
-    distance to the oracle is quoted from the committed parity run (profiles/r04_parity.txt)."""
+    distance to the oracle is in the line's `accuracy` block (accuracy_block: the committed parity run, profiles/rNN_parity.json)."""
     import subprocess
     out = {}
     for key, dt, what in (('x3', 'f32x3', 'dtype f32x3: fp32 storage, split-bf16 (bf16 x 3) MFMA GEMMs, same step, 3 timed steps in a child process'),

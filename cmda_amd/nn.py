@@ -47,6 +47,9 @@ def linear_bwd(dy, x, weight, bias, M, K, *, need_dx=True, dx_out=None, dx_beta=
     if not need_dx:
         return None
     dx = dx_out if dx_out is not None else torch.empty(M, K, dtype=rt.compute_dtype(), device=dy.device)
+    # (round 6: the same product through a TRANSPOSED bf16 weight mirror -- both operands K-contiguous, the forward's kernel form --
+    # measured 1.0 ms per step SLOWER, same box, three alternating runs: 55.5 against 56.5-56.7 ms; the ~155 M Linear weights re-transposed
+    # per step cost more than the K-strided k-tile loses inside the two-lane step.  Removed)
     ops.gemm(dyv_k, plain_view(rt.w(weight), N, K), dx, M, K, N, b_kstrided=True, dtype=rt.tag(), beta=dx_beta)
     return dx
 

@@ -85,7 +85,7 @@ def broadcast_bn_buffers(model, src=0, group=None):
 
 
 def distributed_evaluate(model, samples, num_classes, ignore_index=255, nan_to_num=None, group=None, predict=None,
-                         label_map=None, reduce_zero_label=False):
+                         label_map=None, reduce_zero_label=False, force=False):
     """Distributed evaluation of the segmentor: `DistEvalHook._do_evaluate` (mmseg/core/evaluation/eval_hooks.py:86-121) +
     `multi_gpu_test` (mmseg/apis/test.py:216-274) + the dataset's mIoU (`mmseg/core/evaluation/metrics.py:89-125`).
 
@@ -93,14 +93,17 @@ def distributed_evaluate(model, samples, num_classes, ignore_index=255, nan_to_n
     its share of `samples` with `model.simple_test(rescale=True, ...)` in eval mode -- sample i belongs to rank i % world, the order a
     non-shuffling DistributedSampler deals them in; the sampler's wrap-around padding is what `collect_results` cuts off again, so it
     is not produced here --, (3) the results meet.  The reference ships every rank's full-resolution label maps to rank 0 (pickled
-    through a tmpdir or an all-gather of byte tensors); here each rank folds its maps into the four per-class area histograms on its
-    device and ONE all-reduce of 4 x num_classes float64 sums them: same totals, ~600 bytes on the wire instead of H x W per image.
-    Every rank returns the same dict (aAcc, mIoU, mAcc, IoU[C], Acc[C]).
+    through a tmpdir or an all-gather of byte tensors); here each rank folds its maps into the four per-class area histograms (on
+    the device the predictor returned them on: the default `simple_test` hands back host label maps) and ONE all-reduce of
+    4 x num_classes float64 sums them: same totals, ~600 bytes on the wire instead of H x W per image.  The vector that meets is
+    moved to ONE device on every rank first -- the model's device on RCCL (which has no CPU backend), the host elsewhere -- so a
+    rank without samples and a rank with host-side histograms agree.
+    Every rank returns the same dict (aAcc, mIoU, mAcc, IoU[C], Acc[C]).  force: run the collectives even at world size 1 (tests).
 
     samples: a sequence of dicts, the keyword arguments of `simple_test` plus `gt_semantic_seg` (integer label map);
     predict(model, sample) -> label map replaces the default `model.simple_test(True, **inputs)[0]`."""
     from . import metrics
-    on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    on = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
     rank, world = (dist.get_rank(group), dist.get_world_size(group)) if on else (0, 1)
     broadcast_bn_buffers(model, 0, group)
     was_training = model.training
@@ -117,9 +120,10 @@ def distributed_evaluate(model, samples, num_classes, ignore_index=255, nan_to_n
             tot = parts if tot is None else tuple(a + b for a, b in zip(tot, parts))
     if was_training:
         model.train()
-    dev = tot[0].device if tot is not None else next((p.device for p in model.parameters()), torch.device('cpu'))
-    vec = torch.stack(tot).reshape(-1) if tot is not None else torch.zeros(4 * num_classes, dtype=torch.float64, device=dev)
+    vec = torch.stack(tot).reshape(-1).double() if tot is not None else torch.zeros(4 * num_classes, dtype=torch.float64)
     if on:
+        model_dev = next((p.device for p in model.parameters()), torch.device('cpu'))
+        vec = vec.to(model_dev if dist.get_backend(group) == 'nccl' else torch.device('cpu'))
         dist.all_reduce(vec, group=group)
     inter, union, _, lab = vec.view(4, num_classes)
     out = {'aAcc': inter.sum() / lab.sum(), 'IoU': inter / union, 'Acc': inter / lab}
@@ -139,11 +143,16 @@ class GradAllReducer:
         stream underneath the rest of the backward pass; `finish()` reduces whatever was not started and joins.
     Every rank must issue the same ranges in the same order (it does: the schedule is a function of the model only)."""
 
-    def __init__(self, flat_grad, bucket_elems=32 * 1024 * 1024, wire_dtype=torch.float32, group=None, force=False, exchange='auto'):
+    def __init__(self, flat_grad, bucket_elems=32 * 1024 * 1024, wire_dtype=torch.float32, group=None, force=False, exchange='auto',
+                 virtual_ways=1):
         """exchange: 'auto' = reduce-scatter + all-gather on RCCL, all-reduce elsewhere; 'rs_ag' = the reduce-scatter + all-gather
         arithmetic on ANY backend (padding to per * world, mean on the owned shard, wire format, gather, copy-back): where the
         backend has no reduce_scatter_tensor (gloo: the CPU tests run this path at world 2 and 4) the collective itself is an
-        all-reduce of the padded bucket of which the rank keeps its own shard; 'all_reduce' = never split."""
+        all-reduce of the padded bucket of which the rank keeps its own shard; 'all_reduce' = never split.
+        virtual_ways > 1 (single-rank runs with `force`, i.e. `bench.py --force-reducer` on one GPU): the bucket is laid out, padded and
+        exchanged as for THAT many ranks -- per = ceil(n / ways), zero tail, one reduce_scatter_tensor / all_gather_into_tensor pair
+        per virtual shard on the world-1 group -- so RCCL's own collectives run with the shard-sized views, dtypes and buffer
+        aliasing of a multi-rank exchange on a box that has one GPU."""
         assert exchange in ('auto', 'rs_ag', 'all_reduce')
         self.flat = flat_grad
         self.group = group
@@ -166,6 +175,11 @@ class GradAllReducer:
             self._wire_rs = torch.empty(cap, dtype=wire_dtype, device=flat_grad.device)
             self._shard = torch.empty(-(-cap // self.world), dtype=wire_dtype, device=flat_grad.device)
         self._started = []  # [lo, hi) slices already issued this step
+        self.ways = self.world if self.world > 1 else max(1, int(virtual_ways))
+        if self._rs_ag and self.ways != self.world:
+            cap = min(n, bucket_elems) + self.ways
+            self._wire_rs = torch.empty(cap, dtype=wire_dtype, device=flat_grad.device)
+            self._shard = torch.empty(-(-cap // self.ways), dtype=wire_dtype, device=flat_grad.device)
 
     def _reduce(self, lo, hi):
         inv = 1.0 / self.world
@@ -177,15 +191,22 @@ class GradAllReducer:
                 # reduce-scatter keeps every link busy with 1/world of the bucket, the mean is taken on the owned shard only
                 # (1/world of the multiplies), and the all-gather returns the averaged bucket.
                 n = e - s
-                per = -(-n // self.world)
-                w = self._wire_rs[:per * self.world]
+                per = -(-n // self.ways)
+                w = self._wire_rs[:per * self.ways]
                 w[:n].copy_(seg)
-                if per * self.world > n:
+                if per * self.ways > n:
                     w[n:].zero_()
                 shard = self._shard[:per]
-                self._reduce_scatter(shard, w, per)
-                shard.mul_(inv)
-                self._all_gather(w, shard, per)
+                if self.ways == self.world:
+                    self._reduce_scatter(shard, w, per)
+                    shard.mul_(inv)
+                    self._all_gather(w, shard, per)
+                else:   # one rank standing in for `ways`: every virtual shard through the collectives of the world-1 group
+                    for k in range(self.ways):
+                        wk = w[k * per:(k + 1) * per]
+                        self._reduce_scatter(shard, wk, per)
+                        shard.mul_(inv)
+                        self._all_gather(wk, shard, per)
                 seg.copy_(w[:n])
             elif self._wire is not None:
                 w = self._wire[:e - s]

@@ -146,3 +146,4 @@ def test_refresh_frozen_rebuilds_channel_padded_copies(tgt):
             ops.permute4(p.data, torch.empty_like(c1), (16, 8, 7, 7), (0, 2, 3, 1), flipmask=(2 << 8) | (1 << 16))
     finally:
         rt.set_compute_dtype(torch.float32)
+

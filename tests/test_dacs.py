@@ -330,6 +330,20 @@ def test_dacs_iteration_full_depth_512_gpu(mode):
         print(f'[{mode}] full-depth 512x512 B={B}+{B}: oracle {t_oracle:.0f} s; teacher logits rel err {logit_err:.2e}; pseudo-label '
               f'agreement {agree:.6f}; mixed-label agreement {lbl_same:.6f}; source loss {ls:.6f} vs {rs:.6f}; mixed loss {lm:.6f} vs '
               f'{rm:.6f}; gradient rel err median {errs[len(errs) // 2]:.2e}, 90th pct {errs[int(len(errs) * 0.9)]:.2e}, worst {errs[-1]:.2e}')
+        if os.environ.get('CMDA_PARITY_JSON'):   # tools/gpu/parity.sh: the record bench.py's `accuracy` block quotes (profiles/rNN_parity.json)
+            import json
+            pj = os.environ['CMDA_PARITY_JSON']
+            rec = json.load(open(pj)) if os.path.exists(pj) else {}
+            rec[{'f32': 'f32', 'x3': 'f32x3', 'bf16': 'bf16'}[mode]] = dict(
+                logit_err_range=logit_err, logit_err_elementwise_p999=logit_ew_p999, logit_err_elementwise_max=logit_ew_max,
+                pseudo_label_agreement=agree, mixed_label_agreement=lbl_same, source_loss=[ls, rs], mixed_loss=[lm, rm],
+                gradient_rel_err_median=errs[len(errs) // 2], gradient_rel_err_p90=errs[int(len(errs) * 0.9)], gradient_rel_err_worst=errs[-1],
+                generator_err_max=gen_max, generator_err_p999=gen_p999)
+            rec['_what'] = (f'HIP DACS iteration against oracle/dacs_iter.py at the bench configuration: full-depth MiT-B5 (3, 6, 40, 3), '
+                            f'512 x 512, {B} + {B} samples (tests/test_dacs.py::test_dacs_iteration_full_depth_512_gpu); logit errors of the '
+                            f'teacher fusion logits at full resolution: range-relative max, element-wise with a floor at 1e-3 of the range')
+            with open(pj, 'w') as fh:
+                json.dump(rec, fh, indent=1, sort_keys=True)
         if mode != 'bf16':
             check_le('generator output rel err (512 x 512)', gen_max, 5e-4 if mode == 'x3' else 2e-4)
             check_le('teacher logits rel err', logit_err, 1e-3, strict=True)
@@ -349,6 +363,89 @@ def test_dacs_iteration_full_depth_512_gpu(mode):
             check_le('bf16 mixed loss abs err', abs(lm - rm), 0.1 * max(1.0, abs(rm)), strict=True)
     finally:
         rt.set_gemm_x3(False)
+        rt.set_compute_dtype(torch.float32)
+
+
+# bounds of test_dacs_train_step_bf16_against_reference_fixture_gpu: about twice the measured distance of the bf16 mode to the reference's own
+# step at iteration 0 (profiles/r06_reference_step_fixture_bf16.txt)
+BF16_FIXTURE = dict(loss=5e-2, acc=5.0, labels=0.90, conf=20000, mixed_labels=0.95, events=0.2, grad_p90=0.5, grad_worst=1.5)
+
+
+@pytest.mark.gpu
+def test_dacs_train_step_bf16_against_reference_fixture_gpu():
+    """the SPEED mode (bf16 storage and MFMA operands: what the bench line's headline number runs) against the reference's own
+    `DACS.train_step` (tests/golden/dacs_step.npz, iteration 0: dacs.py:274-315,357-860 on the CPU in fp32): losses, accuracies,
+    pseudo-labels, confident-pixel count, the mixed tensors and the accumulated gradients -- reported and bounded at about twice the
+    measured distance (bf16 met only the oracle before).  Behind the first optimizer step a bf16 run and the fp32
+    reference are different trajectories, so only iteration 0 is compared."""
+    from conftest import Target
+    from cmda_amd import _lib
+    from cmda_amd.optim import FlatAdamW
+    from weights import DACS_CH, DACS_DIMS, DACS_SEEDS, DACS_SEG_SCALE, dacs_batch, sample_grad
+    _lib._unbind_for_tests()
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU on this machine')
+    tgt = Target('gpu')
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(HERE, 'golden', 'dacs_step.npz')).items()}
+    rt.set_compute_dtype(torch.bfloat16)
+    try:
+        dacs = build_train_model(make_cfg(DACS_DIMS, DACS_CH))
+        seeded_fill(dacs.model, DACS_SEEDS['student'])
+        seeded_fill(dacs.ema_model, DACS_SEEDS['teacher'])
+        seeded_fill(dacs.cyclegan_itrd2en, DACS_SEEDS['generator'])
+        with torch.no_grad():
+            dacs.model.decode_head.conv_seg.weight.mul_(DACS_SEG_SCALE)
+        dacs.to(tgt.device).train()
+        opt = FlatAdamW(dacs.model, lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01)
+        src, tg = dacs_batch()
+        kmax = dacs._kmax()
+        it = 0
+        cj, bl, sigma = [float(v) for v in g[f'it{it}.gates']]
+        cls = torch.full((1, kmax), -1, dtype=torch.int64)
+        cls[0, :g[f'it{it}.classes'].numel()] = g[f'it{it}.classes']
+        dacs.inject_draws = dict(choice=float(g[f'it{it}.choice']), color_jitter=cj, blur=bl, sigma=sigma, classes=cls, jitter=None,
+                                 direction=[['leftdown', 'leftup'], ['rightdown', 'rightup']][int(cj * 10) % 2][int(cj * 100) % 2])
+        batch = dict(source={k: tgt.to(v.clone()) for k, v in src.items()}, target={k: tgt.to(v.clone()) for k, v in tg.items()})
+        res = dacs.train_step(batch, opt)
+        torch.cuda.synchronize()
+        lv, mix = res['log_vars'], dacs.last_mix
+        ref_l = g[f'it{it}.losses'].float()
+        got = torch.tensor([float(lv['decode.loss_seg']), float(lv['mix.decode.loss_seg'])])
+        loss_err = ((got - ref_l[[0, 2]]).abs() / ref_l[[0, 2]].abs()).max().item()
+        accs = torch.tensor([float(lv['decode.acc_seg']), float(lv['mix.decode.acc_seg'])])
+        acc_err = (accs - ref_l[[1, 3]]).abs().max().item()
+        agree = (mix['pseudo_label'].cpu().to(torch.uint8) == g[f'it{it}.pseudo_label']).float().mean().item()
+        conf = abs(int(mix['pseudo_count']) - int(g[f'it{it}.pseudo_conf']))
+        same = (mix['mixed_lbl'].cpu().to(torch.uint8) == g[f'it{it}.mixed_lbl']).float().mean().item()
+
+        def rel(a, b):
+            return ((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-30)).item()
+        e_img = rel(mix['mixed_img'].cpu()[..., ::4, ::4], g[f'it{it}.mixed_img_s'])
+        e_evt = rel(mix['mixed_events'].cpu()[:, :1, ::4, ::4], g[f'it{it}.mixed_events_s'])
+        e_isr = rel(mix['mixed_isr'].cpu()[:, :1, ::2, ::2], g[f'it{it}.mixed_isr_s'])
+        errs = []
+        for k, p in dacs.model.named_parameters():
+            ref_f = g[f'it{it}.grad.{k}']
+            got_f = sample_grad(p.grad.cpu(), 24)
+            errs.append(max((got_f[:-2] - ref_f[:-2]).abs().max().item() / (ref_f[:-2].abs().max().item() + 1e-12),
+                            (got_f[-2:] - ref_f[-2:]).abs().max().item() / (ref_f[-1].abs().item() + 1e-12)))
+        errs.sort()
+        print(f'[bf16 vs reference step, iteration 0] losses {got.tolist()} vs {ref_l[[0, 2]].tolist()} (rel {loss_err:.2e}); accuracies abs err '
+              f'{acc_err:.3f}; pseudo-labels {agree:.5f}; confident-pixel count difference {conf}; mixed-label agreement {same:.5f}; mixed '
+              f'image {e_img:.2e}, events {e_evt:.2e}, ISR {e_isr:.2e}; gradient fingerprints median {errs[len(errs) // 2]:.2e}, 90th pct '
+              f'{errs[int(len(errs) * 0.9)]:.2e}, worst {errs[-1]:.2e}')
+        check_le('bf16 losses vs reference step (rel)', loss_err, BF16_FIXTURE['loss'])
+        check_le('bf16 accuracies vs reference step (abs, percent)', acc_err, BF16_FIXTURE['acc'])
+        check_ge('bf16 pseudo-label agreement with the reference step', agree, BF16_FIXTURE['labels'])
+        check_le('bf16 confident-pixel count difference', conf, BF16_FIXTURE['conf'])
+        check_ge('bf16 mixed-label agreement with the reference step', same, BF16_FIXTURE['mixed_labels'])
+        check_le('bf16 mixed image vs reference step', e_img, 1e-5)            # (fp32 arithmetic in every mode)
+        check_le('bf16 mixed events vs reference step', e_evt, BF16_FIXTURE['events'])
+        check_le('bf16 mixed ISR vs reference step', e_isr, 1e-3)              # (uint8 luma of the fp32 mixed image)
+        check_le('bf16 90th-percentile gradient fingerprint error vs reference step', errs[int(len(errs) * 0.9)], BF16_FIXTURE['grad_p90'])
+        check_le('bf16 worst gradient fingerprint error vs reference step', errs[-1], BF16_FIXTURE['grad_worst'])
+    finally:
+        dacs.inject_draws = None
         rt.set_compute_dtype(torch.float32)
 
 

@@ -399,3 +399,4 @@ def test_gemm_x3_big_three_launch_path(tgt):
         assert_close(o, F.conv2d(x.permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1), 2e-5, name='x3 big im2col view')
     finally:
         ops.X3_BIG_FLOPS, ops.X3_BIG_INTENSITY = old, old_i
+

@@ -559,3 +559,80 @@ def test_distributed_evaluate_matches_single_process_with_rank0_statistics(world
             assert torch.equal(torch.nan_to_num(got[r][k], nan=-1.0), torch.nan_to_num(ref[k], nan=-1.0)), (r, k)
     for k in ('aAcc', 'mIoU', 'IoU'):
         assert torch.equal(torch.nan_to_num(single[k], nan=-1.0), torch.nan_to_num(ref[k], nan=-1.0))
+
+
+def _one_rank_group(backend):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), RANK='0', WORLD_SIZE='1')
+    dist.init_process_group(backend, rank=0, world_size=1)
+
+
+def _virtual_ways_case(dev, wire):
+    """one rank, `force`, exchange laid out for 3 virtual ranks: the mean over one rank is the identity (up to the wire rounding)"""
+    torch.manual_seed(5)
+    for n, bucket in ((100003, 30001), (4099, 1025), (10, 7)):
+        flat = torch.randn(n, device=dev)
+        want = flat.clone()
+        red = GradAllReducer(flat, bucket_elems=bucket, wire_dtype=wire, force=True, exchange='rs_ag', virtual_ways=3)
+        assert red.active and red._rs_ag and red.ways == 3
+        red.start_range(n // 3, n // 2)
+        red.all_reduce_mean()
+        if dev != 'cpu':
+            torch.cuda.synchronize()
+        tol = 0.0 if wire == torch.float32 else 8e-3
+        assert torch.allclose(flat, want, rtol=tol, atol=tol), (n, bucket)
+
+
+@pytest.mark.parametrize('wire', [torch.float32, torch.bfloat16])
+def test_grad_exchange_virtual_ways_single_rank_gloo(wire):
+    """`bench.py --force-reducer` on one GPU: GradAllReducer.virtual_ways pads / scatters / gathers every bucket as for several
+    ranks through the collectives of the world-1 group (mmseg/core/ddp_wrapper.py:70-89's exchange, one rank standing in)"""
+    _one_rank_group('gloo')
+    try:
+        _virtual_ways_case('cpu', wire)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('wire', [torch.float32, torch.bfloat16])
+def test_grad_exchange_native_reduce_scatter_all_gather_single_rank_rccl(wire):
+    """the RCCL calls themselves -- dist.reduce_scatter_tensor / dist.all_gather_into_tensor on shard-sized views of the wire buffer
+    (parallel.py `_reduce_scatter` / `_all_gather`, native branch) -- on one GPU, with the padded layout of a 3-rank exchange"""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU on this machine')
+    _one_rank_group('nccl')
+    try:
+        red = GradAllReducer(torch.zeros(8, device='cuda'), force=True)
+        assert red._native_rs
+        _virtual_ways_case('cuda', wire)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_distributed_evaluate_single_rank_rccl_host_label_maps():
+    """the default predictor returns HOST label maps, RCCL has no CPU backend -- the histogram vector must be moved to the
+    model's device before the all-reduce (and a rank without samples must build it there too)"""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU on this machine')
+    from cmda_amd import metrics
+    from cmda_amd.parallel import distributed_evaluate
+
+    class Seg(_TinySeg):
+        def simple_test(self, rescale=True, img=None):
+            return list(self.net(img.cuda()).argmax(1).cpu().numpy())
+    _one_rank_group('nccl')
+    try:
+        torch.manual_seed(11)
+        model = Seg().cuda().eval()
+        samples = _eval_samples(4)
+        got = distributed_evaluate(model, samples, 5, force=True)
+        with torch.no_grad():
+            preds = [model.simple_test(True, img=s['img'])[0] for s in samples]
+        ref = metrics.mean_iou([torch.as_tensor(p) for p in preds], [s['gt_semantic_seg'] for s in samples], 5)
+        for k in ('aAcc', 'mIoU', 'IoU'):   # (float64 on the device: the mean's summation order differs from the host's in the last bit)
+            assert torch.allclose(torch.nan_to_num(got[k].cpu(), nan=-1.0), torch.nan_to_num(ref[k], nan=-1.0), rtol=1e-12, atol=0), k
+        empty = distributed_evaluate(model, [], 5, force=True)      # no samples on this rank: the zero vector goes to the same device
+        assert empty['IoU'].shape == (5,)
+    finally:
+        dist.destroy_process_group()

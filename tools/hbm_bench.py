@@ -13,17 +13,28 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cmda_amd import ops  # noqa: E402
 
 
-def timeit(fn, iters=20):
+def timeit(fn, iters=20, reps=5):
+    """us per launch of `iters` dependent launches REPLAYED FROM A hipGraph (as tools/dbg/rp_bench.py does): eager launches from Python
+    are host-bound at ~8 us each, so event-bracketed eager loops measured the launch path, not the kernel, for everything under ~10 us
+    (VERDICT r05 weak #5).  The figure still includes the ~1.9-us dependent-launch boundary of a replayed graph."""
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(iters):
-        fn()
-    e.record()
-    torch.cuda.synchronize()
-    return s.elapsed_time(e) / iters * 1e3  # us
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            for _ in range(iters):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            g.replay()
+        e.record()
+        torch.cuda.synchronize()
+    return s.elapsed_time(e) / (iters * reps) * 1e3  # us
 
 
 def main():
@@ -52,6 +63,8 @@ def main():
         rec(f'dw gelu-bwd-prep {tag}', timeit(lambda: ops.dwconv_gelu_bwd_prep(x, w, bias, dy, B, H, H, C, dil)), 3 * n * 2)
         rec(f'dw bwd-data {tag}', timeit(lambda: ops.dwconv_bwd_data(dy, w, B, H, H, C, dil)), 2 * n * 2)
         rec(f'dw bwd-weight {tag}', timeit(lambda: ops.dwconv_bwd_weight(dy, x, dw, db, B, H, H, C, dil)), 2 * n * 2)
+        if dil == 1:   # the MixFFN backward's fused pass (GELU backward + depthwise weight / bias gradient): what the step runs
+            rec(f'dw gelu-bwd FUSED {tag}', timeit(lambda: ops.dwconv_gelu_bwd_fused(x, w, bias, dy, dw, db, B, H, H, C, dil)), 3 * n * 2)
         del x, dy
     # LayerNorm per stage
     for (H, C) in ((128, 64), (64, 128), (32, 320), (16, 512)):
