@@ -304,8 +304,18 @@ class MixVisionTransformer(nn.Module):
                 if nxt is not None:
                     dx, dxs = dx
             dnext = getattr(self, f'patch_embed{s}').bwd(sv_pe, dx, B, need_dx=(s > 1))
-            ops.gemm_flush_deferred()   # the stage's queued weight gradients: one grouped launch per (tile, operand mode)
+            # the stage's queued weight gradients: one grouped launch per (tile, operand mode).  Lane 'wq' (uda.DACS, single GPU): they
+            # leave this lane's dependent dgrad chain and run on a side queue underneath the next stage's chain -- the queues the teacher
+            # used in the first part of the iteration are idle by now (runtime.LANE_ALIAS).  With a gradient exchange armed the stage's
+            # gradients must be final here: flushed in place.
+            if rt.grad_ready_hook is None:
+                src_lane = ops.LN_LANE
+                with rt.lane('wq', *ops.gemm_deferred_tensors()):
+                    ops.gemm_flush_deferred(from_lane=src_lane)
+            else:
+                ops.gemm_flush_deferred()
             rt.notify_grads_ready(f'backbone.stage{s}', self)
+        rt.join_lanes('wq')
         return None
 
     def forward(self, x):

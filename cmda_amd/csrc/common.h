@@ -172,25 +172,9 @@ static inline void glds16(const void* gsrc, void* lds_wave_base) {
 }
 #endif
 
-// The same copy issued through inline asm, i.e. INVISIBLE to the compiler's wait-count bookkeeping.  With the builtin, hipcc puts
-// `s_waitcnt vmcnt(0)` in front of every LDS read it cannot prove disjoint from a pending DMA destination -- and it treats the
-// destination as "this address and everything above it", so a kernel that reads one LDS buffer while the DMA fills another one
-// BELOW it drains its whole vector-memory queue at every such read (found on the fused-MixFFN experiment of round 5, DESIGN.md section 5: each weight group's latency was exposed).
-// The caller owns the completion: a counted vmcnt wait (pipe_barrier / dma_wait) and a barrier before the data is read.
-// M0 (the wave-uniform LDS destination) is compiler-reserved: saved and restored inside the statement.
-#ifndef CMDA_EMU
-static __device__ __forceinline__ void glds16_asm(const void* gsrc, void* lds_wave_base) {
-  const unsigned dst = __builtin_amdgcn_readfirstlane(
-      (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)lds_wave_base));
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(dst)
-               : "memory");
-}
-#else
-static inline void glds16_asm(const void* gsrc, void* lds_wave_base) { glds16(gsrc, lds_wave_base); }
-#endif
+// (An inline-asm form of the same copy -- invisible to the compiler's wait-count bookkeeping: with the builtin hipcc puts
+// `s_waitcnt vmcnt(0)` in front of LDS reads it cannot prove disjoint from a pending DMA destination -- was tried on the round-5
+// fused-MixFFN experiment and removed with it: no kernel of the tree needs it)
 
 // Barrier of a multi-stage LDS-DMA pipeline: wait until at most N of this wave's DMA loads are still in flight (the older
 // ones -- the stage about to be read -- have landed), then s_barrier WITHOUT the vmcnt(0) drain __syncthreads() implies,

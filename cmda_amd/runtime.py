@@ -307,6 +307,13 @@ def ones1(device):
 # encoder's two input sets as separate passes on a second side lane (3 queues, +50 % event-encoder launches): 95.6 against 79.6;
 # the four ASPP branches of the decode head split over the two lanes (HBM-bound stencils / BatchNorm next to the pointwise GEMMs): the
 # branches take twice as long side by side -- no gain, and the generator loses its slot next to the teacher's decoder.
+# Round 6 (segmented replay, ms per step, same box, three alternating runs each; profiles/r06_lanes_ab.txt): {enc} 55.4-55.9;
+# {enc, T} in the EARLY-STUDENT form (uda.DACS._iteration: the teacher on lane T from the start of the iteration, its encoders one after
+# the other, joined in front of the decode head's loss) 54.3-54.8; + 'Tenc' (the teacher's event encoder on a FOURTH queue, main/T/enc)
+# 52.3-52.7; + 'wq' (the encoders' grouped weight gradients on the teacher's two queues, idle by then: LANE_ALIAS) 52.05-52.3 -- the
+# default of the captured DACS iteration (uda.GRAPH_LANES).  Four streams = HIP's four hardware queues: every lane stream is chosen so
+# that it really runs beside the others (prepare_lane_streams; two torch streams may share a queue), and GPU_MAX_HW_QUEUES=8 ran the
+# same four-lane step at 82-85 ms.
 _conc = {'on': False, 'streams': {}, 'stack': ['main'], 'sstack': [], 'used': {}, 'keep': {}, 'enabled': {'enc'}, 'seg': None, 'seen': set()}
 
 
@@ -378,6 +385,50 @@ class SegmentedCapture:
         cur.wait_stream(self.main)
 
 
+def _runs_beside(a, b, device):
+    """does work queued on stream `a` overtake a long run of kernels queued earlier on stream `b`?  (False: the two HIP streams share
+    a hardware queue -- HIP maps its streams onto a few of them (GPU_MAX_HW_QUEUES, default 4) in creation order -- and serialise)"""
+    import time
+    x = torch.empty(64 << 20, dtype=torch.float32, device=device)
+    torch.cuda.synchronize(device)
+    with torch.cuda.stream(b):
+        for _ in range(40):          # ~4 ms of HBM-bound kernels
+            x.mul_(1.0)
+    t0 = time.perf_counter()
+    with torch.cuda.stream(a):
+        y = torch.zeros(64, dtype=torch.float32, device=device)
+        y.add_(1.0)
+    a.synchronize()
+    dt = time.perf_counter() - t0
+    torch.cuda.synchronize(device)
+    del x, y
+    return dt < 1.5e-3
+
+
+def prepare_lane_streams(device, main_stream, lanes):
+    """Create the side streams of the named lanes (full names: 'main/enc', 'main/T') BEFORE a capture, each on a hardware queue of
+    its own: a lane whose stream shares a queue with another lane's only runs when that one is idle (measured, round 6: the
+    generator on 'main/enc' started when the teacher on 'main/T' had finished, 12.5 ms into the iteration, tools/lanes_timeline.py).
+    Candidates are drawn from torch's stream pool until one overtakes long-running work on the main stream and on every lane
+    stream chosen so far (`_runs_beside`); without such a candidate the last one drawn is kept."""
+    if device.type != 'cuda':
+        return
+    chosen = [main_stream]
+    for full in lanes:
+        key = (full, str(device))   # (the key of lane.__enter__)
+        s = _conc['streams'].get(key)
+        if s is not None and all(_runs_beside(s, o, device) and _runs_beside(o, s, device) for o in chosen):
+            chosen.append(s)
+            continue
+        cand = None
+        for _ in range(24):
+            cand = torch.cuda.Stream(device)
+            if all(c is not cand for c in chosen) and all(_runs_beside(cand, o, device) and _runs_beside(o, cand, device) for o in chosen):
+                break
+        _conc['streams'][key] = cand
+        chosen.append(cand)
+
+
 def set_concurrency(flag, lanes=None, seg=None):
     """lanes: subset of {'enc', 'wgrad', 'T'} to use (default: enc, see above); seg: a SegmentedCapture whose main segment
     is already open -- lanes then cut segments instead of forking streams inside one capture"""
@@ -398,6 +449,12 @@ def lane_enabled(name):
     return _conc['on'] and name in _conc['enabled'] and _conc['stack'][-1] == 'main'
 
 
+# Lanes that REUSE another lane's stream (and with it its hardware queue: HIP has four by default and more cost dearly -- GPU_MAX_HW_QUEUES=8
+# ran the step at 82 ms against 53): the weight-gradient queues of the encoders' backward passes run on the streams the teacher's two
+# encoders used at the head of the iteration, which are joined and idle by then.
+LANE_ALIAS = {'main/wq': 'main/T', 'main/enc/wq': 'main/T/enc'}
+
+
 class lane:
     """`with lane('enc', t1, t2...)`: run the body on the side stream `<current lane>/enc`, ordered after everything enqueued
     so far on the current lane (re-entering a lane therefore adds exactly that dependency).  Lanes nest.  The tensors
@@ -415,12 +472,12 @@ class lane:
         if not _conc['on'] or self.name not in _conc['enabled']:
             return self
         parent = _conc['stack'][-1]
-        if self.name == 'enc' and parent != 'main':
-            return self   # lane T is off the critical path: its encoders run one after the other
+        if self.name == 'enc' and parent != 'main' and 'Tenc' not in _conc['enabled']:
+            return self   # the teacher's encoders on lane T run one after the other ('Tenc': side by side on a fourth queue, main/T/enc)
         seg = _conc['seg']
         full = parent + '/' + self.name
         dev = seg.device if seg is not None else torch.cuda.current_device()
-        key = (full, str(dev))
+        key = (LANE_ALIAS.get(full, full), str(dev))
         s = _conc['streams'].get(key)
         if s is None:
             s = _conc['streams'][key] = torch.cuda.Stream(dev)

@@ -319,17 +319,20 @@ class FusionEncoderDecoder(nn.Module):
         losses, logits, sv_h = self.decode_head.fwd_train(feats, B, gt, seg_weight, cfg)
         return losses['loss_seg'], (losses, logits, feats), (sv, sv_h, B)
 
-    def train_fwd_passes(self, passes, cfg):
+    def train_fwd_passes(self, passes, cfg, before_head=None):
         """P training passes with the same weights as ONE pass over P*B samples (passes: list of (inputs, gt, seg_weight)): the
         source and the mixed step of a DACS iteration (dacs.py:489-523, :820-860) differ only in their inputs and targets, and
         the reference's `backward()` calls just add their gradients up.  Per-pass state -- BatchNorm batch statistics and the
         order of the running-statistic updates, the loss normalisation -- is kept per pass (DAFormerHeadFusion.fwd_joint).
-        Returns ([(loss, losses)] per pass, saved); `train_bwd(saved, gscale)` back-propagates the SUM of the pass losses."""
+        Returns ([(loss, losses)] per pass, saved); `train_bwd(saved, gscale)` back-propagates the SUM of the pass losses.
+        before_head: called between the encoders / fusion blocks and the decode head -- the first use of the targets."""
         first = passes[0][0]
         assert self._joint_ok(first['image'], first['events'], cfg)
         P = len(passes)
         isr = [p[0]['img_self_res'] for p in passes] if first.get('img_self_res') is not None else None
         feats, names, sv, Bt = self._extract_joint([p[0]['image'] for p in passes], [p[0]['events'] for p in passes], isr, True)
+        if before_head is not None:   # the targets (gt, seg_weight) may come from another lane: joined here, behind the encoders (uda.DACS)
+            before_head()
         losses, logits, sv_h = self.decode_head.fwd_train_joint(feats, names, Bt // P, [p[1] for p in passes],
                                                                 [p[2] for p in passes], cfg, passes=P)
         return [(l['loss_seg'], l) for l in losses], ('joint', sv, sv_h, Bt, P)

@@ -49,6 +49,10 @@ def log_vars_to_float(log_vars):
     return {k: (v.item() if isinstance(v, torch.Tensor) else v) for k, v in log_vars.items()}
 
 
+# concurrency lanes of the captured iteration (DACS._capture; CMDA_GRAPH_LANES / DACS.graph_lane_set override): runtime.py documents them
+GRAPH_LANES = tuple(x for x in os.environ.get('CMDA_GRAPH_LANES', 'enc,T,Tenc,wq').split(',') if x)
+
+
 @UDA.register_module()
 class DACS(nn.Module):
     SUPPORTED = {'cs2dsec_image+events', 'cs2dz_image+raw-isr', 'cs2dsec_image+events_together'}
@@ -373,8 +377,8 @@ class DACS(nn.Module):
         # source + mixed samples (lane 'T' -- the teacher on its own lane -- exists as an option and is off: runtime.py).
         # With the lanes switched off (eager launches) the same code simply runs in program order.
 
-        # ---- teacher pseudo-labels (dacs.py:653-711) -----------------------------------------------------------------------------
-        with rt.lane('T', night_image, teacher_second, *[v for v in tgt.values() if isinstance(v, torch.Tensor)]):
+        def teacher_labels():
+            """teacher forward -> pseudo-labels -> ClassMix'd labels / weights (dacs.py:653-711, :716-771 for the targets)"""
             if tt != 'cs2dz_image+raw-isr' and self.fuse_both_ice_and_e:
                 ema = teacher.encode_decode_lowres(night_image, night_events, tgt['warp_img_self_res'], dict(self.forward_cfg, fusion_all=True))
             elif tt != 'cs2dz_image+raw-isr' and self.isr_another_fusion and not use_events:
@@ -386,8 +390,11 @@ class DACS(nn.Module):
             gt_pixel_weight = torch.ones(B, H, W, dtype=torch.float32, device=dev)
             mixed_lbl = ops.class_mix_label(lab, pseudo_label, lab, classes).view(B, 1, H, W)
             mixed_weight = ops.class_mix(gt_pixel_weight.view(B, 1, H, W), pseudo_weight.view(B, 1, H, W), lab, classes).view(B, H, W)
-            # ClassMix + strong augmentation + ISR of the mixed image (dacs.py:716-771; dacs_transforms.py:64-98, kornia
-            # semantics): the on/off gates and the per-sample parameters are read from the control block by the kernels
+            return ema, pseudo_label, count, mixed_lbl, mixed_weight
+
+        def mixed_inputs():
+            """ClassMix + strong augmentation + ISR of the mixed image (dacs.py:716-771; dacs_transforms.py:64-98, kornia
+            semantics): the on/off gates and the per-sample parameters are read from the control block by the kernels"""
             mixed_img = ops.class_mix(day_image, night_image, lab, classes)
             if self.color_jitter_p < 1.0:
                 ops.color_jitter_(mixed_img, ctl['jitter'], ctl['jitter_on'])
@@ -396,6 +403,25 @@ class DACS(nn.Module):
             gray = ops.isr_gray(mixed_img)
             mixed_isr = ops.isr_from_gray(gray, self.isr_parms['val_range'], self.isr_parms['_threshold'],
                                           self.isr_parms['_clip_range'], self.isr_parms['shift_pixel'], direction, dirs_dev=ctl['dirs'])
+            return mixed_img, mixed_isr
+
+        # EARLY-STUDENT schedule (lane 'T' enabled): the student's forward pass needs the MIXED INPUTS, which depend on the source labels,
+        # the class draw and the generator only -- the teacher's pseudo-labels enter at the loss (mixed label / weight).  So the teacher
+        # runs on its own lane from the start of the iteration (its two encoders one after the other), the mixed image / ISR are built
+        # on this lane at once, the generator on the side lane, and the student's encoders start as soon as the generator is done; lane
+        # 'T' is joined in front of the decode head's loss (train_fwd_passes before_head).  The reference's order (teacher before the
+        # mixed step, dacs.py:653-860) only matters through these data dependencies.
+        early = (getattr(self, 'early_student', True) and rt.lane_enabled('T') and getattr(self, 'fused_student_passes', True)
+                 and hasattr(student, 'train_fwd_passes'))
+        if early:
+            with rt.lane('T', night_image, teacher_second, lab, classes, *[v for v in tgt.values() if isinstance(v, torch.Tensor)]):
+                ema, pseudo_label, count, mixed_lbl, mixed_weight = teacher_labels()
+            mixed_img, mixed_isr = mixed_inputs()
+        else:
+            # ---- teacher pseudo-labels (dacs.py:653-711) -------------------------------------------------------------------------
+            with rt.lane('T', night_image, teacher_second, *[v for v in tgt.values() if isinstance(v, torch.Tensor)]):
+                ema, pseudo_label, count, mixed_lbl, mixed_weight = teacher_labels()
+                mixed_img, mixed_isr = mixed_inputs()
 
         # ---- Image Motion-Extractor (dacs.py:400-404), frozen, no grad ------------------------------------------------------------
         if tt != 'cs2dz_image+raw-isr':
@@ -409,8 +435,11 @@ class DACS(nn.Module):
                 day_events = src['img_time_res']
         mixed_events = None
         if day_events is not None:
-            with rt.lane('T', day_events):
+            if early:
                 mixed_events = ops.class_mix(day_events, night_events, lab, classes)
+            else:
+                with rt.lane('T', day_events):
+                    mixed_events = ops.class_mix(day_events, night_events, lab, classes)
 
         # ---- student inputs: source (dacs.py:489-523) and mixed (dacs.py:820-860) ---------------------------------------------------
         if tt == 'cs2dz_image+raw-isr':
@@ -433,9 +462,11 @@ class DACS(nn.Module):
             # both, dacs.py:523 / :860 only accumulate gradients), so the 2B samples travel as one batch -- half the launches,
             # twice the rows per GEMM.  What is per step in the reference stays per step: BatchNorm batch statistics and the order
             # of the running-statistic updates (source first), the loss normalisation, DropPath / Dropout2d draws per sample.
-            rt.join_lanes('T')
+            if not early:
+                rt.join_lanes('T')
             ((l_src, d_src), (l_mix, d_mix)), saved = student.train_fwd_passes(
-                [(in_src, day_label, None), (in_mix, mixed_lbl, mixed_weight)], cfg_s)
+                [(in_src, day_label, None), (in_mix, mixed_lbl, mixed_weight)], cfg_s,
+                before_head=(lambda: rt.join_lanes('T')) if early else None)
             log_vars['decode.loss_seg'], log_vars['decode.acc_seg'] = l_src, d_src['acc_seg']
             log_vars['mix.decode.loss_seg'], log_vars['mix.decode.acc_seg'] = l_mix, d_mix['acc_seg']
             log_vars['loss'] = l_mix   # _parse_losses of the mixed step overwrites 'loss' (dacs.py:851-857)
@@ -490,16 +521,26 @@ class DACS(nn.Module):
         st_src = {k: v.clone() for k, v in src.items() if isinstance(v, torch.Tensor)}
         st_tgt = {k: v.clone() for k, v in tgt.items() if isinstance(v, torch.Tensor)}
         second = torch.empty_like(st_src['image'])
-        ops.ln_ws_prealloc(dev, ('main', 'main/enc'))
-        ops.zero_ws_prealloc(dev, ('main', 'main/enc'))
-        ops.bn_ws_prealloc(dev, ('main', 'main/enc'))
+        ws_lanes = ('main', 'main/enc', 'main/T', 'main/T/enc')   # (the per-lane persistent workspaces exist before the capture starts)
+        ops.ln_ws_prealloc(dev, ws_lanes)
+        ops.zero_ws_prealloc(dev, ws_lanes)
+        ops.bn_ws_prealloc(dev, ws_lanes)
         torch.cuda.synchronize(dev)
         rt.refresh(force=True)   # every copy exists and is current before the capture starts
         lanes = getattr(self, 'graph_lane_set', None)
         if lanes is None and os.environ.get('CMDA_LANES'):   # tuning: comma-separated lane set (runtime.set_concurrency)
             lanes = set(os.environ['CMDA_LANES'].split(','))
+        if lanes is None:
+            # the default set of the captured iteration (round 6, same-box A/B 55.4-55.9 -> 52.1-52.3 ms): 'enc' the two encoders side by
+            # side; 'T' + 'Tenc' the EARLY-STUDENT schedule -- the teacher on two queues of its own from the start of the iteration, joined
+            # in front of the decode head's loss; 'wq' the encoders' grouped weight gradients on those queues once the teacher is done
+            lanes = set(GRAPH_LANES)
         seg = rt.SegmentedCapture(dev)
         g = seg
+        if os.environ.get('CMDA_LANE_QUEUES', '1') != '0':   # every lane stream on a hardware queue of its own (runtime.prepare_lane_streams)
+            en = lanes if lanes is not None else rt._conc['enabled']
+            rt.prepare_lane_streams(dev, seg.main, ['main/' + n for n in sorted(en) if n in ('enc', 'T', 'hw')] +
+                                    (['main/T/enc'] if 'T' in en and 'Tenc' in en else []))
         import gc
         gc.collect()
         torch.cuda.empty_cache()

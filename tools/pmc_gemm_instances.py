@@ -36,16 +36,45 @@ def main():
     lines = ['rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python3 bench.py --steps 1 --warmup 1 --no-graph '
              '--no-cpu-baseline --no-parity-mode`, last step; per GEMM kernel instance: measured HBM-side bytes (FETCH x 2 + WRITE) against the',
              'algorithmic bytes (operand tensors once + output) of the launches that ran on it (bench.py CMDA_BENCH_GEMM_LOG, matched in launch order)', '']
-    matched = len(fe) == len(wr) == len(rec) and all(a[0] == b[0] for a, b in zip(fe, wr))
-    lines.append(f'dispatches: fetch pass {len(fe)}, write pass {len(wr)}, bench record {len(rec)} -> {"matched" if matched else "NOT matched: instance totals only"}')
+    # a GROUPED record of the bench (one cmda_gemm_grouped flush = the deferred weight gradients of a backward phase) is several
+    # dispatches: the grouped kernels of each tile kind + the problems the planner launches by themselves (weight-gradient form:
+    # both operands K-strided).  Walk both sequences: a plain record takes one dispatch, a grouped record takes the following run of
+    # grouped / weight-gradient-form dispatches; the match counts only if both sequences end together.
+    def wgrad_form(n):
+        return 'grouped' in n or 'gemm_wg_kernel' in n or re.search(r'gemm_glds_kernel<\d+, \d+, true, true', n) is not None
+    same = len(fe) == len(wr) and all(a[0] == b[0] for a, b in zip(fe, wr))
+    owner, i = [None] * len(fe), 0      # dispatch -> (record index, share of the record's bytes)
+    ok = same
+    for ri, r in enumerate(rec):
+        if not ok or i >= len(fe):
+            ok = False
+            break
+        if 'grouped' in [str(x) for x in r['key']]:
+            j = i
+            while j < len(fe) and wgrad_form(fe[j][0]):
+                j += 1
+            if j == i:
+                ok = False
+                break
+            tot = sum(fe[k][1] for k in range(i, j)) or 1.0
+            for k in range(i, j):   # the flush's algorithmic bytes split over its dispatches by their measured fetch share
+                owner[k] = (ri, fe[k][1] / tot)
+            i = j
+        else:
+            owner[i] = (ri, 1.0)
+            i += 1
+    matched = ok and i == len(fe)
+    lines.append(f'dispatches: fetch pass {len(fe)}, write pass {len(wr)}, bench records {len(rec)} ({sum(1 for r in rec if "grouped" in [str(x) for x in r["key"]])} '
+                 f'grouped flushes) -> {"matched" if matched else "NOT matched: instance totals only"}')
     acc = collections.defaultdict(lambda: [0, 0.0, 0.0, 0.0, collections.Counter()])
     for i, (n, v) in enumerate(fe):
         a = acc[n]
         a[0] += 1
         a[1] += v * 1024 * 2
         if matched:
-            a[3] += rec[i]['bytes']
-            k = rec[i]['key']
+            ri, share = owner[i]
+            a[3] += rec[ri]['bytes'] * share
+            k = rec[ri]['key']
             a[4][' '.join(str(int(x)) if not isinstance(x, str) else x for x in k[:4])] += 1
     for n, v in wr:
         acc[n][2] += v * 1024
