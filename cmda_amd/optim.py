@@ -113,15 +113,43 @@ class FlatAdamW:
                 out.append([lo, hi])
         return [(lo, hi) for lo, hi in out if hi - lo >= min_elems]
 
+    # -- overlapped update (opt-in: `overlap = True`) ------------------------------------------------------------------------------------
+    # The update, the gradient clear behind it and (uda.DACS) the EMA teacher update run on a stream of their own, ordered after
+    # everything the calling stream has enqueued.  Whoever reads the parameters next must order itself behind that stream:
+    # `synchronize()` on an ordinary stream, or -- the captured DACS iteration -- a `runtime.wait_external` step placed behind the
+    # part of the iteration that needs no trainable weight (mixing, the frozen generator), which then runs underneath the update.
+    overlap = False
+
+    def update_stream(self):
+        s = getattr(self, '_update_stream', None)
+        if s is None:
+            s = self._update_stream = torch.cuda.Stream(self.flat_p.device)
+        return s
+
+    def _on_update_stream(self):
+        import contextlib
+        if not (self.overlap and self.flat_p.is_cuda) or torch.cuda.is_current_stream_capturing():
+            return contextlib.nullcontext()
+        s = self.update_stream()
+        s.wait_stream(torch.cuda.current_stream(self.flat_p.device))
+        return torch.cuda.stream(s)
+
+    def synchronize(self):
+        """order the current stream behind the overlapped update (no-op otherwise)"""
+        if self.overlap and self.flat_p.is_cuda and getattr(self, '_update_stream', None) is not None:
+            torch.cuda.current_stream(self.flat_p.device).wait_stream(self._update_stream)
+
     def zero_grad(self):
-        self.flat_g.zero_()
+        with self._on_update_stream():
+            self.flat_g.zero_()
 
     def step(self, lr_scale=1.0):
         self.step_count += 1
-        for start, end, lm, dm in self.segments:
-            ops.adamw_step(self.flat_p[start:end], self.flat_g[start:end], self.flat_m[start:end], self.flat_v[start:end],
-                           self.lr * lm * lr_scale, self.betas[0], self.betas[1], self.eps, self.weight_decay * dm,
-                           self.step_count, p_bf16=self.flat_bf16[start:end] if self.flat_bf16 is not None else None)
+        with self._on_update_stream():
+            for start, end, lm, dm in self.segments:
+                ops.adamw_step(self.flat_p[start:end], self.flat_g[start:end], self.flat_m[start:end], self.flat_v[start:end],
+                               self.lr * lm * lr_scale, self.betas[0], self.betas[1], self.eps, self.weight_decay * dm,
+                               self.step_count, p_bf16=self.flat_bf16[start:end] if self.flat_bf16 is not None else None)
         rt.invalidate()
 
 
@@ -131,6 +159,10 @@ class FlatAdamW:
         return o, o + p.numel()
 
     def state_dict(self):
+        self.synchronize()
+        return self._state_dict()
+
+    def _state_dict(self):
         """{'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [...]} keyed by parameter index in
         model.named_parameters() order, one group per parameter (mmcv's DefaultOptimizerConstructor with paramwise_cfg builds
         one group per parameter), tensors on the CPU."""

@@ -380,6 +380,10 @@ class SegmentedCapture:
             elif op == 'call':
                 with torch.cuda.stream(b):
                     a()
+            elif op == 'wait_ext':   # a stream outside the program (the overlapped optimizer update), looked up at replay time
+                ext = b()
+                if ext is not None:
+                    a.wait_stream(ext)
             else:
                 a.wait_stream(b)
         cur.wait_stream(self.main)
@@ -544,6 +548,22 @@ def side(name, fn, *keep):
         b[2].extend(keep)
     else:
         fn()
+
+
+def wait_external(fn):
+    """order the current lane behind a stream that is not part of the iteration: fn() -> torch.cuda.Stream or None, evaluated NOW in
+    eager mode and at every replay of a segmented capture (the overlapped optimizer / EMA update of uda.DACS: what the iteration has
+    enqueued on its lanes before this point runs underneath that update)"""
+    seg = _conc['seg']
+    if seg is not None and seg.active is not None:
+        stream = seg.active[1]
+        seg.end()
+        seg.program.append(('wait_ext', stream, fn))
+        seg.begin(stream)
+        return
+    ext = fn()
+    if ext is not None and not torch.cuda.is_current_stream_capturing():
+        torch.cuda.current_stream().wait_stream(ext)
 
 
 def keep_alive(*tensors):

@@ -49,6 +49,11 @@ def log_vars_to_float(log_vars):
     return {k: (v.item() if isinstance(v, torch.Tensor) else v) for k, v in log_vars.items()}
 
 
+def _null_ctx():
+    import contextlib
+    return contextlib.nullcontext()
+
+
 # concurrency lanes of the captured iteration (DACS._capture; CMDA_GRAPH_LANES / DACS.graph_lane_set override): runtime.py documents them
 GRAPH_LANES = tuple(x for x in os.environ.get('CMDA_GRAPH_LANES', 'enc,T,Tenc,wq').split(',') if x)
 
@@ -154,6 +159,7 @@ class DACS(nn.Module):
                 view.copy_(p.data)
                 p.data = view
         self._flat = (flat_p, ema_flat)
+        self._opt = opt   # (an overlapped update -- FlatAdamW.overlap -- is waited for inside the iteration, see _iteration)
         # bf16 compute copies of the teacher in one flat mirror too, refreshed by ONE cast after each EMA update (without
         # it every teacher Linear weight is cast on its own: ~1100 extra launches per iteration)
         self._ema_bf16 = None
@@ -351,7 +357,8 @@ class DACS(nn.Module):
         the control block; `teacher_second` = the teacher's second input (events or ISR, already chosen); `use_events` /
         `direction` only select code paths that are fixed per configuration (student inputs of 'cs2dsec_image+events')."""
         tt = self.train_type
-        rt.refresh(force=True)   # first node of the iteration: all re-laid-out weight copies follow this iteration's masters
+        opt = getattr(self, '_opt', None)
+        ext_wait = (lambda: getattr(opt, '_update_stream', None)) if (opt is not None and getattr(opt, 'overlap', False)) else None
         day_image, day_isr, day_label = src['image'], src['img_self_res'], src['label']
         day_events = night_events = None
         if tt == 'cs2dz_image+raw-isr':
@@ -413,10 +420,23 @@ class DACS(nn.Module):
         # mixed step, dacs.py:653-860) only matters through these data dependencies.
         early = (getattr(self, 'early_student', True) and rt.lane_enabled('T') and getattr(self, 'fused_student_passes', True)
                  and hasattr(student, 'train_fwd_passes'))
+        # OVERLAPPED UPDATE (FlatAdamW.overlap): AdamW, the gradient clear and the EMA update of the step boundary run on the optimizer's
+        # own stream; the part of the iteration that reads no trainable weight -- the mixed inputs and the frozen generator -- is enqueued
+        # FIRST and runs underneath them, then this lane waits for that stream (`wait_external`), refreshes the weight copies and goes on.
+        pre = early and ext_wait is not None and tt != 'cs2dz_image+raw-isr' and self.cyclegan_itrd2en is not None
+        day_events_pre = None
+        if pre:
+            mixed_img, mixed_isr = mixed_inputs()
+            with rt.lane('enc', src['img_time_res'], independent=True):
+                day_events_pre = self.cyclegan_itrd2en.forward_mean3(src['img_time_res'])
+        if ext_wait is not None:
+            rt.wait_external(ext_wait)
+        rt.refresh(force=True)   # all re-laid-out weight copies follow this iteration's masters (first node without the overlapped update)
         if early:
             with rt.lane('T', night_image, teacher_second, lab, classes, *[v for v in tgt.values() if isinstance(v, torch.Tensor)]):
                 ema, pseudo_label, count, mixed_lbl, mixed_weight = teacher_labels()
-            mixed_img, mixed_isr = mixed_inputs()
+            if not pre:
+                mixed_img, mixed_isr = mixed_inputs()
         else:
             # ---- teacher pseudo-labels (dacs.py:653-711) -------------------------------------------------------------------------
             with rt.lane('T', night_image, teacher_second, *[v for v in tgt.values() if isinstance(v, torch.Tensor)]):
@@ -430,8 +450,11 @@ class DACS(nn.Module):
                 # teacher's fusion / decoder / pseudo-label / mixing work on this one
                 # (EARLY-STUDENT: letting the image encoder start before the generator is done -- generator, event mix and event encoder on
                 # the side lane without the join -- measured the same, 52.22 against 52.25 ms over three alternating runs: not kept)
-                with rt.lane('enc', src['img_time_res'], independent=True):
-                    day_events = self.cyclegan_itrd2en.forward_mean3(src['img_time_res'])
+                if day_events_pre is not None:
+                    day_events = day_events_pre
+                else:
+                    with rt.lane('enc', src['img_time_res'], independent=True):
+                        day_events = self.cyclegan_itrd2en.forward_mean3(src['img_time_res'])
                 rt.join_lanes('enc')
             else:
                 day_events = src['img_time_res']
@@ -572,10 +595,12 @@ class DACS(nn.Module):
         use_events = tt != 'cs2dz_image+raw-isr' and draws['choice'] > self.random_choice_thres
         cb = self._control_block(dev, B, H, W)
         self._stage(cb, draws)
-        if self.local_iter == 0:
-            self._init_ema_weights()
-        if self.local_iter > 0:
-            self._update_ema(self.local_iter)
+        opt = getattr(self, '_opt', None)
+        with (opt._on_update_stream() if opt is not None else _null_ctx()):   # overlapped update: the EMA follows AdamW on ITS stream
+            if self.local_iter == 0:
+                self._init_ema_weights()
+            if self.local_iter > 0:
+                self._update_ema(self.local_iter)
         if tt == 'cs2dz_image+raw-isr':
             second = tgt['warp_img_self_res'] if 'warp_image' in tgt else tgt['night_isr']
         else:
@@ -604,6 +629,8 @@ class DACS(nn.Module):
             G['graph'].replay()
             log_vars, extras = G['out']
         else:
+            if opt is not None:
+                opt.synchronize()   # eager launches: everything behind the (possibly overlapped) update
             log_vars, extras = self._iteration(src, tgt, cb['d'], struct_events, second, ndir_key)
         self.local_iter += 1
         self.last_mix = extras
