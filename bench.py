@@ -435,6 +435,9 @@ def run_dacs(args, rank, world, dev, dist):
     torch.manual_seed(1234)                   # identical initial weights on every rank
     dacs = build_dacs(dev)
     opt = optim.FlatAdamW(dacs.model, lr=6e-5, weight_decay=0.01, custom_keys=CUSTOM_KEYS)
+    # the step boundary (AdamW, gradient clear, EMA) on the optimizer's own stream, underneath the weight-free head of the next captured
+    # iteration (optim.FlatAdamW.overlap, uda.DACS._iteration); CMDA_OPT_OVERLAP=0: in stream order (same-box A/B)
+    opt.overlap = (not args.no_graph) and os.environ.get('CMDA_OPT_OVERLAP', '1') != '0'
     dacs.attach_flat_store(opt)
     # single rank with --force-reducer: the bucket is padded, scattered and gathered as for TWO ranks (GradAllReducer.virtual_ways), so the
     # RCCL reduce_scatter_tensor / all_gather_into_tensor calls of the multi-GPU exchange run with their shard-sized views on one GPU

@@ -451,6 +451,57 @@ def test_dacs_train_step_bf16_against_reference_fixture_gpu():
         rt.set_compute_dtype(torch.float32)
 
 
+@pytest.mark.gpu
+def test_dacs_overlapped_optimizer_update_matches_in_order_update_gpu():
+    """FlatAdamW.overlap: AdamW, the gradient clear and the EMA update of the step boundary (dacs.py:250-315) on the optimizer's own
+    stream, the weight-free head of the next captured iteration (mixing, frozen generator) underneath them, `runtime.wait_external` in
+    front of the first use of a trainable weight.  Five train steps (one eager, four replayed) with the update in stream order and
+    overlapped must give the same trajectory: same draws, losses and pseudo-labels; parameters / EMA weights / Adam moments equal up to
+    the order of the fp32 atomics in the weight gradients."""
+    from conftest import Target
+    from cmda_amd import _lib
+    from cmda_amd.optim import FlatAdamW
+    _lib._unbind_for_tests()
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU on this machine')
+    tgt = Target('gpu')
+    rt.set_compute_dtype(torch.float32)
+    try:
+        res = {}
+        for overlap in (False, True):
+            dacs = build_train_model(make_cfg(SMALL['dims'], SMALL['ch']))
+            seeded_fill(dacs.model, 7)
+            seeded_fill(dacs.ema_model, 8)
+            seeded_fill(dacs.cyclegan_itrd2en, 9)
+            dacs.to(tgt.device).train()
+            opt = FlatAdamW(dacs.model, lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01)
+            opt.overlap = overlap
+            dacs.attach_flat_store(opt)
+            src, tg = make_batch(2, 64, 64)
+            batch = dict(source={k: tgt.to(v) for k, v in src.items()}, target={k: tgt.to(v) for k, v in tg.items()})
+            torch.manual_seed(11), random.seed(11), np.random.seed(11)
+            dacs.enable_graph(warmup_iters=1)
+            losses, labels = [], []
+            for it in range(5):
+                out = dacs.train_step(batch, opt)
+                losses.append([float(out['log_vars']['decode.loss_seg']), float(out['log_vars']['mix.decode.loss_seg'])])
+                labels.append(dacs.last_mix['pseudo_label'].clone())
+            opt.synchronize()
+            torch.cuda.synchronize()
+            assert dacs._graph is not None
+            res[overlap] = dict(losses=torch.tensor(losses), labels=[t.cpu() for t in labels], p=opt.flat_p.cpu().clone(),
+                                m=opt.flat_m.cpu().clone(), ema=dacs._flat[1].cpu().clone(), g=opt.flat_g.cpu().clone())
+        a, b = res[False], res[True]
+        assert_close(b['losses'], a['losses'], 2e-4, name='losses, overlapped update vs in-order update')
+        for it, (x, y) in enumerate(zip(a['labels'], b['labels'])):
+            check_ge(f'it{it} pseudo-label agreement, overlapped vs in-order update', (x == y).float().mean().item(), 0.999)
+        assert_close(b['p'], a['p'], 1e-5, atol=5 * 6e-5 * 1.5, name='parameters after five steps')   # (AdamW: +-lr per step on round-off-level gradients)
+        assert_close(b['ema'], a['ema'], 1e-5, atol=5 * 6e-5 * 1.5, name='EMA teacher after five steps')
+        assert_close(b['g'], a['g'], 5e-3, name='gradients of the last step')
+    finally:
+        rt.set_compute_dtype(torch.float32)
+
+
 class _MaskFeed(torch.nn.Module):
     """stands in for an oracle DropPath: pops the next per-sample keep factors (already divided by keep)"""
 
