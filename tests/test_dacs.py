@@ -468,14 +468,14 @@ def test_dacs_overlapped_optimizer_update_matches_in_order_update_gpu():
     rt.set_compute_dtype(torch.float32)
     try:
         res = {}
-        for overlap in (False, True):
+        for overlap in (False, 'again', True):   # 'again': a second in-order run -- the run-to-run spread of the fp32 atomics, amplified by AdamW
             dacs = build_train_model(make_cfg(SMALL['dims'], SMALL['ch']))
             seeded_fill(dacs.model, 7)
             seeded_fill(dacs.ema_model, 8)
             seeded_fill(dacs.cyclegan_itrd2en, 9)
             dacs.to(tgt.device).train()
             opt = FlatAdamW(dacs.model, lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01)
-            opt.overlap = overlap
+            opt.overlap = overlap is True
             dacs.attach_flat_store(opt)
             src, tg = make_batch(2, 64, 64)
             batch = dict(source={k: tgt.to(v) for k, v in src.items()}, target={k: tgt.to(v) for k, v in tg.items()})
@@ -491,13 +491,20 @@ def test_dacs_overlapped_optimizer_update_matches_in_order_update_gpu():
             assert dacs._graph is not None
             res[overlap] = dict(losses=torch.tensor(losses), labels=[t.cpu() for t in labels], p=opt.flat_p.cpu().clone(),
                                 m=opt.flat_m.cpu().clone(), ema=dacs._flat[1].cpu().clone(), g=opt.flat_g.cpu().clone())
-        a, b = res[False], res[True]
+        a, a2, b = res[False], res['again'], res[True]
         assert_close(b['losses'], a['losses'], 2e-4, name='losses, overlapped update vs in-order update')
         for it, (x, y) in enumerate(zip(a['labels'], b['labels'])):
             check_ge(f'it{it} pseudo-label agreement, overlapped vs in-order update', (x == y).float().mean().item(), 0.999)
         assert_close(b['p'], a['p'], 1e-5, atol=5 * 6e-5 * 1.5, name='parameters after five steps')   # (AdamW: +-lr per step on round-off-level gradients)
         assert_close(b['ema'], a['ema'], 1e-5, atol=5 * 6e-5 * 1.5, name='EMA teacher after five steps')
-        assert_close(b['g'], a['g'], 5e-3, name='gradients of the last step')
+        # the last step's gradients: two in-order runs already differ (atomic order -> +-lr steps of AdamW on round-off-level gradients ->
+        # four steps of drift, the effect tests/test_dacs.py documents for the reference fixture); the overlapped run must sit inside
+        # three times that spread
+        scale = a['g'].abs().max().item()
+        spread = (a2['g'] - a['g']).abs().max().item() / scale
+        got = (b['g'] - a['g']).abs().max().item() / scale
+        print(f'last-step gradients: overlapped vs in-order {got:.2e}, in-order vs in-order {spread:.2e} (of the largest gradient)')
+        check_le('last-step gradients, overlapped vs in-order update (rel. to 3 x the in-order run-to-run spread + 2e-3)', got, 3 * spread + 2e-3)
     finally:
         rt.set_compute_dtype(torch.float32)
 
