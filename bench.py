@@ -474,6 +474,7 @@ def run_dacs(args, rank, world, dev, dist):
         return log_vars
 
     def fence():
+        opt.synchronize()                     # an overlapped update that is still postponed is LAUNCHED here: the timed region holds exactly K optimizer steps
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

@@ -434,15 +434,423 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_dkv_kernel(
   }
 }
 
+
+// ===============================================================================================================================
+// SPLIT-bf16 instances (cmda dtype CMDA_F32X3: fp32 storage, every product as three bf16 MFMAs a_hi b_hi + a_hi b_lo + a_lo b_hi with
+// fp32 accumulation, ~16 mantissa bits per product -- the arithmetic of gemm_x3_lean.hip): the tolerance-meeting mode's attention ran
+// as batched Q K^T / softmax / P V GEMMs + four backward products + two softmax launches with the [N, Nk] probabilities in HBM
+// (mix_transformer.py:97-101; ~20 ms of that mode's kernel time per UDA step).  Same orientation, same three kernels as above; what
+// differs: q / kv / d_o arrive as fp32 and are split ONCE -- K and V into hi / lo bf16 images in LDS (4 x 32 KB: one workgroup per CU),
+// the query-side fragments in registers --, the probabilities and dS are split in registers right where the bf16 kernels pack them, and
+// the outputs are stored as fp32.
+struct AttnX3Params {
+  const float* q;
+  const float* kv;
+  float* o;
+  int B, N, Nk, heads, C;
+  float scale;
+  int q_per_block;
+};
+
+static __device__ __forceinline__ void split4(const float (&x)[4], u16x4& hi, u16x4& lo) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const bf16_t h = f2bf(x[e]);
+    hi[e] = h;
+    lo[e] = f2bf(x[e] - bf2f(h));
+  }
+}
+
+// this wave's LDS stores are visible to its own later LDS reads (cross-lane hand-off inside ONE wave: DS operations of a wave execute in
+// order; the statement also keeps the compiler from moving the reads up)
+#ifndef CMDA_EMU
+static __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#else
+static inline void wave_lds_sync() { emu::wave_barrier(); }
+#endif
+
+// rows [0, rows) of an fp32 [*, ld] matrix (64 columns at src) -> hi / lo images [rows][64] bf16 in the swizzled layout of load_kv_tile
+// (16-byte chunk c of line r at slot c ^ (r & 7)); rows >= nvalid are zero.  Thread t of nthr converts one float4 per step.
+static __device__ __forceinline__ void load_split_tile(const float* __restrict__ src, long ld, int nvalid, int rows, bf16_t* hi, bf16_t* lo,
+                                                       int t, int nthr) {
+  for (int i = t; i < rows * 16; i += nthr) {
+    const int row = i >> 4, c4 = i & 15;
+    float x[4] = {0.f, 0.f, 0.f, 0.f};
+    if (row < nvalid) ld4(src + (long)row * ld + 4 * c4, x);
+    u16x4 h, l;
+    split4(x, h, l);
+    const int off = row * kHD + ((((c4 >> 1) ^ (row & 7))) << 3) + ((c4 & 1) << 2);
+    *reinterpret_cast<u16x4*>(hi + off) = h;
+    *reinterpret_cast<u16x4*>(lo + off) = l;
+  }
+}
+
+// B operand b[k = d][col = query] of 16 consecutive rows of an fp32 [rows, ld] matrix, split: lane (l15, g) reads d = 32 kk + 8 g .. + 7
+static __device__ __forceinline__ void load_qfrag_x3(const float* __restrict__ base, long row0, long nrows, int ld, int g, int l15,
+                                                     u16x8 (&fh)[2], u16x8 (&fl)[2]) {
+  long row = row0 + l15;
+  if (row >= nrows) row = nrows - 1;
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    float a[4], b[4];
+    ld4(base + row * ld + 32 * kk + 8 * g, a);
+    ld4(base + row * ld + 32 * kk + 8 * g + 4, b);
+    u16x4 ah, al, bh, bl;
+    split4(a, ah, al);
+    split4(b, bh, bl);
+    fh[kk] = u16x8{ah[0], ah[1], ah[2], ah[3], bh[0], bh[1], bh[2], bh[3]};
+    fl[kk] = u16x8{al[0], al[1], al[2], al[3], bl[0], bl[1], bl[2], bl[3]};
+  }
+}
+
+// c += a b with a = (ah, al), b = (bh, bl): the three significant partial products
+static __device__ __forceinline__ f32x4 mfma_x3(u16x8 ah, u16x8 al, u16x8 bh, u16x8 bl, f32x4 c) {
+  c = mfma_bf16_16x16x32(al, bh, c);
+  c = mfma_bf16_16x16x32(ah, bl, c);
+  return mfma_bf16_16x16x32(ah, bh, c);
+}
+
+static __device__ __forceinline__ void pack_pair_x3(const f32x4& a, const f32x4& b, u16x8& hi, u16x8& lo) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const bf16_t ha = f2bf(a[r]), hb = f2bf(b[r]);
+    hi[r] = ha; hi[4 + r] = hb;
+    lo[r] = f2bf(a[r] - bf2f(ha)); lo[4 + r] = f2bf(b[r] - bf2f(hb));
+  }
+}
+
+// scores^T of 16 queries against all key tiles (three products per tile and k half), then the softmax over keys -- scores_softmax
+static __device__ __forceinline__ void scores_softmax_x3(const bf16_t* sKh, const bf16_t* sKl, const u16x8 (&qh)[2], const u16x8 (&ql)[2],
+                                                         int nt, int Nk, float scale, int g, int l15, f32x4 (&p)[kNT], float* lse_out = nullptr) {
+#pragma unroll
+  for (int t = 0; t < kNT; ++t) {
+    p[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (t < nt) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        p[t] = mfma_x3(frag_rows(sKh, 16 * t, kk, g, l15), frag_rows(sKl, 16 * t, kk, g, l15), qh[kk], ql[kk], p[t]);
+    }
+  }
+  float m = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < kNT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool live = 16 * t + 4 * g + r < Nk;
+      p[t][r] = live ? p[t][r] * scale : -INFINITY;
+      m = fmaxf(m, p[t][r]);
+    }
+  m = col_max(m);
+  float l = 0.f;
+#pragma unroll
+  for (int t = 0; t < kNT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      p[t][r] = __expf(p[t][r] - m);
+      l += p[t][r];
+    }
+  l = col_sum(l);
+  if (lse_out) *lse_out = m + __logf(l);
+  const float inv = 1.f / l;
+#pragma unroll
+  for (int t = 0; t < kNT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[t][r] *= inv;
+}
+
+__global__ __launch_bounds__(256, 1) void attn_fwd_x3_kernel(AttnX3Params p) {
+  __shared__ __attribute__((aligned(1024))) bf16_t sKh[kMaxK * kHD];
+  __shared__ __attribute__((aligned(1024))) bf16_t sKl[kMaxK * kHD];
+  __shared__ __attribute__((aligned(1024))) bf16_t sVh[kMaxK * kHD];
+  __shared__ __attribute__((aligned(1024))) bf16_t sVl[kMaxK * kHD];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const unsigned nqb = (unsigned)((p.N + p.q_per_block - 1) / p.q_per_block);
+  const unsigned lb = xcd_logical_block(), bh = lb / nqb;
+  const long qblk = lb - bh * nqb;
+  const int h = (int)(bh % (unsigned)p.heads), b = (int)(bh / (unsigned)p.heads);
+  const float* kbase = p.kv + (long)b * p.Nk * 2 * p.C + h * kHD;
+  const int nt = (p.Nk + 15) >> 4;
+  load_split_tile(kbase, 2L * p.C, p.Nk, 16 * nt, sKh, sKl, tid, 256);
+  load_split_tile(kbase + p.C, 2L * p.C, p.Nk, ((16 * nt + 31) >> 5) << 5, sVh, sVl, tid, 256);   // (the P V loop reads key tiles in pairs)
+  __syncthreads();
+  const float* qb = p.q + (long)b * p.N * p.C + h * kHD;
+  float* ob = p.o + (long)b * p.N * p.C + h * kHD;
+  for (int pass = 0; pass < p.q_per_block / 64; ++pass) {
+    const long q0 = qblk * p.q_per_block + pass * 64 + wid * 16;
+    if (q0 >= p.N) break;  // wave-uniform
+    u16x8 qh[2], ql[2];
+    load_qfrag_x3(qb, q0, p.N, p.C, g, l15, qh, ql);
+    f32x4 pr[kNT];
+    scores_softmax_x3(sKh, sKl, qh, ql, nt, p.Nk, p.scale, g, l15, pr);
+    f32x4 oacc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < kNT / 2; ++u) {
+      if (2 * u < nt) {
+        u16x8 ph, pl;
+        pack_pair_x3(pr[2 * u], pr[2 * u + 1], ph, pl);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          oacc[dt] = mfma_x3(frag_cols(sVh, 32 * u + 4 * g, 32 * u + 16 + 4 * g, dt, l15), frag_cols(sVl, 32 * u + 4 * g, 32 * u + 16 + 4 * g, dt, l15),
+                             ph, pl, oacc[dt]);
+      }
+    }
+    if (q0 + l15 < p.N) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const float v[4] = {oacc[dt][0], oacc[dt][1], oacc[dt][2], oacc[dt][3]};
+        st4(ob + (q0 + l15) * p.C + 16 * dt + 4 * g, v);
+      }
+    }
+  }
+}
+
+struct AttnBwdX3Params {
+  const float* q;
+  const float* kv;
+  const float* d_o;
+  float* dq;
+  float* dkv32;    // accumulate mode: fp32 atomics (zero on entry)
+  float* dkv_out;  // direct mode: dK | dV stored
+  float* stats;
+  int B, N, Nk, heads, C, q_per_block;
+  float scale;
+  int fwd_q_per_block;
+  int spans;
+};
+
+__global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(AttnBwdX3Params p) {
+  __shared__ __attribute__((aligned(1024))) bf16_t sKh[kMaxK * kHD];
+  __shared__ __attribute__((aligned(1024))) bf16_t sKl[kMaxK * kHD];
+  __shared__ __attribute__((aligned(1024))) bf16_t sVh[kMaxK * kHD];
+  __shared__ __attribute__((aligned(1024))) bf16_t sVl[kMaxK * kHD];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const unsigned nqb = (unsigned)((p.N + p.fwd_q_per_block - 1) / p.fwd_q_per_block);
+  const unsigned lb = xcd_logical_block(), bh = lb / nqb;
+  const long qblk = lb - bh * nqb;
+  const int h = (int)(bh % (unsigned)p.heads), b = (int)(bh / (unsigned)p.heads);
+  const float* kbase = p.kv + (long)b * p.Nk * 2 * p.C + h * kHD;
+  const int nt = (p.Nk + 15) >> 4;
+  const int rows = ((16 * nt + 31) >> 5) << 5;   // (the dQ loop reads key tiles of K in pairs)
+  load_split_tile(kbase, 2L * p.C, p.Nk, rows, sKh, sKl, tid, 256);
+  load_split_tile(kbase + p.C, 2L * p.C, p.Nk, 16 * nt, sVh, sVl, tid, 256);
+  __syncthreads();
+  const long rowb = (long)b * p.N;
+  const float* qb = p.q + rowb * p.C + h * kHD;
+  const float* dob = p.d_o + rowb * p.C + h * kHD;
+  float* dqb = p.dq + rowb * p.C + h * kHD;
+  float* st = p.stats + ((long)b * p.heads + h) * p.N * 2;
+  for (int pass = 0; pass < p.fwd_q_per_block / 64; ++pass) {
+    const long q0 = qblk * p.fwd_q_per_block + pass * 64 + wid * 16;
+    if (q0 >= p.N) break;  // wave-uniform
+    u16x8 qh[2], ql[2], doh[2], dol[2];
+    load_qfrag_x3(qb, q0, p.N, p.C, g, l15, qh, ql);
+    load_qfrag_x3(dob, q0, p.N, p.C, g, l15, doh, dol);
+    f32x4 pr[kNT], dp[kNT];
+    float lse;
+    scores_softmax_x3(sKh, sKl, qh, ql, nt, p.Nk, p.scale, g, l15, pr, &lse);
+    float dsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < kNT; ++t) {
+      dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (t < nt) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+          dp[t] = mfma_x3(frag_rows(sVh, 16 * t, kk, g, l15), frag_rows(sVl, 16 * t, kk, g, l15), doh[kk], dol[kk], dp[t]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dsum += pr[t][r] * dp[t][r];
+    }
+    dsum = col_sum(dsum);
+#pragma unroll
+    for (int t = 0; t < kNT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dp[t][r] = p.scale * pr[t][r] * (dp[t][r] - dsum);  // dS^T
+    f32x4 dqacc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dqacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < kNT / 2; ++u) {
+      if (2 * u < nt) {
+        u16x8 dh, dl;
+        pack_pair_x3(dp[2 * u], dp[2 * u + 1], dh, dl);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          dqacc[dt] = mfma_x3(frag_cols(sKh, 32 * u + 4 * g, 32 * u + 16 + 4 * g, dt, l15), frag_cols(sKl, 32 * u + 4 * g, 32 * u + 16 + 4 * g, dt, l15),
+                              dh, dl, dqacc[dt]);
+      }
+    }
+    if (q0 + l15 < p.N) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const float v[4] = {dqacc[dt][0], dqacc[dt][1], dqacc[dt][2], dqacc[dt][3]};
+        st4(dqb + (q0 + l15) * p.C + 16 * dt + 4 * g, v);
+      }
+      if (g == 0) {
+        st[(q0 + l15) * 2 + 0] = lse;
+        st[(q0 + l15) * 2 + 1] = dsum;
+      }
+    }
+  }
+}
+
+// dK | dV, split-bf16: four waves per 64-key slice; per wave the 32 x 64 tiles of Q and dO as hi / lo images (4 x 4 KB)
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(AttnBwdX3Params p) {
+  constexpr int NW = 4;
+  __shared__ __attribute__((aligned(1024))) bf16_t sKh[kKS * kHD];
+  __shared__ __attribute__((aligned(1024))) bf16_t sKl[kKS * kHD];
+  __shared__ __attribute__((aligned(1024))) bf16_t sVh[kKS * kHD];
+  __shared__ __attribute__((aligned(1024))) bf16_t sVl[kKS * kHD];
+  constexpr int kStageBytes = NW * 4 * 32 * kHD * 2;          // per wave: Q hi / lo and dO hi / lo tiles of 32 queries
+  constexpr int kRedBytes = 2 * kKS * kRedPitch * 4;          // dK | dV as [key][d] fp32
+  __shared__ __attribute__((aligned(1024))) char sbuf[kStageBytes > kRedBytes ? kStageBytes : kRedBytes];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const unsigned lb = xcd_logical_block();
+  const int ks = (int)(lb & 3);
+  const unsigned span = (lb >> 2) % (unsigned)p.spans, bh = (lb >> 2) / (unsigned)p.spans;
+  const int h = (int)(bh % (unsigned)p.heads), b = (int)(bh / (unsigned)p.heads);
+  const int key0 = ks * kKS;
+  if (key0 >= p.Nk) return;  // block-uniform: this slice holds no key
+  const int nkeys = min(kKS, p.Nk - key0);
+  const float* kbase = p.kv + ((long)b * p.Nk + key0) * 2 * p.C + h * kHD;
+  load_split_tile(kbase, 2L * p.C, nkeys, kKS, sKh, sKl, tid, 64 * NW);
+  load_split_tile(kbase + p.C, 2L * p.C, nkeys, kKS, sVh, sVl, tid, 64 * NW);
+  __syncthreads();
+  const long rowb = (long)b * p.N;
+  const float* qb = p.q + rowb * p.C + h * kHD;
+  const float* dob = p.d_o + rowb * p.C + h * kHD;
+  const float* st = p.stats + ((long)b * p.heads + h) * p.N * 2;
+  bf16_t* sQh = reinterpret_cast<bf16_t*>(sbuf) + wid * 4 * 32 * kHD;
+  bf16_t* sQl = sQh + 32 * kHD;
+  bf16_t* sDh = sQl + 32 * kHD;
+  bf16_t* sDl = sDh + 32 * kHD;
+
+  f32x4 dvacc[4][4], dkacc[4][4];  // [d tile][key tile]: dV^T, dK^T
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) dvacc[dt][kt] = dkacc[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const long qbeg = (long)span * p.q_per_block;
+  const long qend = min((long)p.N, qbeg + p.q_per_block);
+  for (long q32 = qbeg + 32 * wid; q32 < qend; q32 += 32 * NW) {
+    wave_lds_sync();   // the previous trip's fragment reads are done before the tiles are overwritten
+    const int nq = (int)min(32L, p.N - q32);
+    load_split_tile(qb + q32 * p.C, p.C, nq, 32, sQh, sQl, lane, 64);
+    load_split_tile(dob + q32 * p.C, p.C, nq, 32, sDh, sDl, lane, 64);
+    float lse[2][4], dd[2][4];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long qi = q32 + 16 * qt + 4 * g + r;
+        const bool ok = qi < p.N;
+        lse[qt][r] = ok ? st[qi * 2] : INFINITY;  // exp(s - inf) = 0: a missing query contributes nothing
+        dd[qt][r] = ok ? st[qi * 2 + 1] : 0.f;
+      }
+    wave_lds_sync();
+    f32x4 pr[2][4], ds[2][4];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      u16x8 fqh[2], fql[2], fdh[2], fdl[2];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        fqh[kk] = frag_rows(sQh, 16 * qt, kk, g, l15);
+        fql[kk] = frag_rows(sQl, 16 * qt, kk, g, l15);
+        fdh[kk] = frag_rows(sDh, 16 * qt, kk, g, l15);
+        fdl[kk] = frag_rows(sDl, 16 * qt, kk, g, l15);
+      }
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, d = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          s = mfma_x3(fqh[kk], fql[kk], frag_rows(sKh, 16 * kt, kk, g, l15), frag_rows(sKl, 16 * kt, kk, g, l15), s);
+          d = mfma_x3(fdh[kk], fdl[kk], frag_rows(sVh, 16 * kt, kk, g, l15), frag_rows(sVl, 16 * kt, kk, g, l15), d);
+        }
+        const bool live = 16 * kt + l15 < nkeys;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = live ? __expf(s[r] * p.scale - lse[qt][r]) : 0.f;
+          pr[qt][kt][r] = pv;
+          ds[qt][kt][r] = p.scale * pv * (d[r] - dd[qt][r]);
+        }
+      }
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const u16x8 fdoTh = frag_cols(sDh, 4 * g, 16 + 4 * g, dt, l15), fdoTl = frag_cols(sDl, 4 * g, 16 + 4 * g, dt, l15);
+      const u16x8 fqTh = frag_cols(sQh, 4 * g, 16 + 4 * g, dt, l15), fqTl = frag_cols(sQl, 4 * g, 16 + 4 * g, dt, l15);
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        u16x8 ph, pl, dh, dl;
+        pack_pair_x3(pr[0][kt], pr[1][kt], ph, pl);
+        pack_pair_x3(ds[0][kt], ds[1][kt], dh, dl);
+        dvacc[dt][kt] = mfma_x3(fdoTh, fdoTl, ph, pl, dvacc[dt][kt]);
+        dkacc[dt][kt] = mfma_x3(fqTh, fqTl, dh, dl, dkacc[dt][kt]);
+      }
+    }
+  }
+  // ---- fold the four waves' partials through LDS ([key][d], pitch 68), then store (direct mode) or one atomic per element
+  __syncthreads();  // every wave is done with its staging tiles (the buffer is reused)
+  float* red = reinterpret_cast<float*>(sbuf);
+  for (int w = 0; w < NW; ++w) {
+    if (wid == w) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          float* rk = red + (16 * kt + l15) * kRedPitch + 16 * dt + 4 * g;
+          float* rv = rk + kKS * kRedPitch;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            rk[r] = (w ? rk[r] : 0.f) + dkacc[dt][kt][r];
+            rv[r] = (w ? rv[r] : 0.f) + dvacc[dt][kt][r];
+          }
+        }
+    }
+    __syncthreads();
+  }
+  if (p.dkv_out) {
+    float* ob = p.dkv_out + ((long)b * p.Nk + key0) * 2 * p.C + h * kHD;
+    for (int e = tid; e < kKS * kHD; e += 64 * NW) {
+      const int kl = e >> 6, d = e & 63;
+      if (kl < nkeys) {
+        ob[(long)kl * 2 * p.C + d] = red[kl * kRedPitch + d];
+        ob[(long)kl * 2 * p.C + p.C + d] = red[(kKS + kl) * kRedPitch + d];
+      }
+    }
+    return;
+  }
+  float* ob = p.dkv32 + ((long)b * p.Nk + key0) * 2 * p.C + h * kHD;
+  for (int e = tid; e < kKS * kHD; e += 64 * NW) {
+    const int kl = e >> 6, d = e & 63;
+    if (kl < nkeys) {
+      atomicAdd(ob + (long)kl * 2 * p.C + d, red[kl * kRedPitch + d]);
+      atomicAdd(ob + (long)kl * 2 * p.C + p.C + d, red[(kKS + kl) * kRedPitch + d]);
+    }
+  }
+}
+
 }  // namespace
 
 // q [B*N, C] bf16, kv [B*Nk, 2C] bf16 -> o [B*N, C] bf16; head_dim = C / heads must be 64, Nk <= 320 (the backward: 256), C % 8 == 0.
 extern "C" int cmda_attention_fwd(const void* q, const void* kv, void* o, int B, int N, int Nk, int heads, int C,
                                   float scale, int dtype, void* stream) {
   if (B <= 0 || N <= 0) return CMDA_OK;
-  if (dtype != CMDA_BF16) return CMDA_ERR_DTYPE;
+  if (dtype != CMDA_BF16 && dtype != CMDA_F32X3) return CMDA_ERR_DTYPE;
   if (heads <= 0 || C != heads * kHD || Nk <= 0 || Nk > kMaxKFwd) return CMDA_ERR_UNSUPPORTED;
   if (heads > 65535 || B > 65535) return CMDA_ERR_SHAPE;
+  if (dtype == CMDA_F32X3) {   // fp32 storage, split-bf16 products: q / kv / o fp32; all keys as hi + lo images in LDS (<= 256)
+    if (Nk > kMaxK || (C & 3)) return CMDA_ERR_UNSUPPORTED;
+    const int qpb3 = (long)((N + 127) / 128) * heads * B < 256 ? 64 : 128;   // one workgroup per CU: 64 queries while the grid is under ~2 rounds
+    AttnX3Params p3{(const float*)q, (const float*)kv, (float*)o, B, N, Nk, heads, C, scale, qpb3};
+    const long nb3 = (long)((N + qpb3 - 1) / qpb3) * heads * B;
+    if (nb3 > 0x7fffffffL) return CMDA_ERR_SHAPE;
+    CMDA_LAUNCH(attn_fwd_x3_kernel, dim3((unsigned)nb3), dim3(256), 0, stream, p3);
+    CMDA_CHECK_LAUNCH();
+  }
   const int qpb = fwd_queries_per_block(B, N, heads);
   AttnParams p{(const bf16_t*)q, (const bf16_t*)kv, (bf16_t*)o, B, N, Nk, heads, C, scale, qpb};
   const long nblk = (long)((N + qpb - 1) / qpb) * heads * B;
@@ -468,11 +876,28 @@ extern "C" int cmda_attention_bwd_direct(int B, int N, int Nk, int heads) {
 extern "C" int cmda_attention_bwd(const void* q, const void* kv, const void* d_o, void* dq, float* dkv32, void* dkv16,
                                   float* stats, int B, int N, int Nk, int heads, int C, float scale, int dtype, void* stream) {
   if (B <= 0 || N <= 0) return CMDA_OK;
-  if (dtype != CMDA_BF16) return CMDA_ERR_DTYPE;
+  if (dtype != CMDA_BF16 && dtype != CMDA_F32X3) return CMDA_ERR_DTYPE;
   if (heads <= 0 || C != heads * kHD || Nk <= 0 || Nk > kMaxK) return CMDA_ERR_UNSUPPORTED;
   if (heads * 4 > 65535 || B > 65535) return CMDA_ERR_SHAPE;
   const bool direct = cmda_attention_bwd_direct(B, N, Nk, heads) != 0 && dkv16 != nullptr;
   if (!direct && dkv32 == nullptr) return CMDA_ERR_SHAPE;
+  if (dtype == CMDA_F32X3) {   // fp32 storage: q / kv / d_o / dq fp32; direct mode stores fp32 dK | dV into `dkv16`
+    if (C & 3) return CMDA_ERR_UNSUPPORTED;
+    const int fq3 = (long)((N + 127) / 128) * heads * B < 256 ? 64 : 128;
+    AttnBwdX3Params p3{(const float*)q, (const float*)kv, (const float*)d_o, (float*)dq, dkv32, direct ? (float*)dkv16 : nullptr, stats,
+                       B, N, Nk, heads, C, 0, scale, fq3, 1};
+    const long nb1 = (long)((N + fq3 - 1) / fq3) * heads * B;
+    if (nb1 > 0x7fffffffL) return CMDA_ERR_SHAPE;
+    CMDA_LAUNCH(attn_bwd_dq_x3_kernel, dim3((unsigned)nb1), dim3(256), 0, stream, p3);
+    const long slices3 = (long)B * heads * ((Nk + kKS - 1) / kKS);
+    long spans3 = direct ? 1 : std::max<long>(1, 256 / slices3);
+    long qpb3 = ((N + spans3 - 1) / spans3 + 127) / 128 * 128;
+    spans3 = (N + qpb3 - 1) / qpb3;
+    p3.q_per_block = (int)qpb3;
+    p3.spans = (int)spans3;
+    CMDA_LAUNCH(attn_bwd_dkv_x3_kernel, dim3((unsigned)(spans3 * heads * 4 * B)), dim3(256), 0, stream, p3);
+    CMDA_CHECK_LAUNCH();
+  }
   const int fqpb = fwd_queries_per_block(B, N, heads);
   AttnBwdParams p{(const bf16_t*)q, (const bf16_t*)kv, (const bf16_t*)d_o, (bf16_t*)dq, dkv32, direct ? (bf16_t*)dkv16 : nullptr, stats,
                   B, N, Nk, heads, C, 0, scale, fqpb};

@@ -121,8 +121,8 @@ def _conv_bwd(dy, x, weight, bias, B, H, W, stride, pad, dil=1, *, need_dx=True,
 # ------------------------------------------------------------------ attention (scores materialised; v0 path)
 def attention_fwd(q, kv, B, N, Nk, heads, C, scale, need_grad=True):
     """q [B*N,C], kv [B*Nk,2C] -> o [B*N,C]; returns (o, P): P [B,heads,N,Nk] saved for the backward, or None when the fused
-    kernel ran (bf16, head_dim 64, Nk <= 256: the backward recomputes the probabilities in LDS)."""
-    if ops.attention_fused_ok(q, Nk, heads, C, need_grad) and not os.environ.get('CMDA_NO_FUSED_ATTENTION'):
+    kernel ran (bf16 -- or fp32 storage in the split-bf16 mode --, head_dim 64, Nk <= 256: the backward recomputes the probabilities in LDS)."""
+    if ops.attention_fused_ok(q, Nk, heads, C, need_grad, x3=rt.gemm_x3()) and not os.environ.get('CMDA_NO_FUSED_ATTENTION'):
         return ops.attention_fused_fwd(q, kv, B, N, Nk, heads, C, scale), None
     hd = C // heads
     dev = q.device

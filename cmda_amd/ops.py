@@ -742,17 +742,28 @@ def softmax_bwd_(p, dp, rows, L, alpha):
     return dp
 
 
-def attention_fused_ok(q, Nk, heads, C, need_grad=True):
+def attention_fused_ok(q, Nk, heads, C, need_grad=True, x3=False):
     """the fused kernels hold every key of a (batch, head) in LDS: up to 256 with a backward pass to follow, up to 320 forward-only
-    (inference on 440 x 640 frames: 260 / 280 keys, encoder_decoder.py:897-936)"""
+    (inference on 440 x 640 frames: 260 / 280 keys, encoder_decoder.py:897-936).  x3: the split-bf16 mode (fp32 storage, runtime.gemm_x3)
+    has instances of its own -- K / V as hi + lo bf16 images in LDS, up to 256 keys"""
+    if x3 and q.dtype == torch.float32:
+        return C == heads * 64 and 0 < Nk <= 256 and not ATTN_X3_OFF
     return q.dtype == torch.bfloat16 and C == heads * 64 and 0 < Nk <= (256 if need_grad else 320)
+
+
+ATTN_X3_OFF = os.environ.get('CMDA_ATTN_X3', '1') == '0'   # split-bf16 mode on the unfused GEMM + softmax path (same-box A/B)
+
+
+def _attn_tag(q):
+    """cmda dtype of the fused attention entry points: bf16, or CMDA_F32X3 for fp32 storage (the split-bf16 instances)"""
+    return c_i32(2) if q.dtype == torch.float32 else dtype_tag(q)
 
 
 def attention_fused_fwd(q, kv, B, N, Nk, heads, C, scale):
     check_dev(q, kv)
     o = torch.empty(B * N, C, dtype=q.dtype, device=q.device)
     _attn_profile(4.0 * B * N * Nk * C, lambda: call('cmda_attention_fwd', ptr(q), ptr(kv), ptr(o), c_i32(B), c_i32(N), c_i32(Nk),
-                                                     c_i32(heads), c_i32(C), c_f32(scale), dtype_tag(q), stream_of(q)))
+                                                     c_i32(heads), c_i32(C), c_f32(scale), _attn_tag(q), stream_of(q)))
     return o
 
 
@@ -768,7 +779,7 @@ def attention_fused_bwd(q, kv, do, dkv32, B, N, Nk, heads, C, scale, dkv16=None)
     stats = torch.empty(B * N * heads * 2, dtype=torch.float32, device=q.device)
     _attn_profile(10.0 * B * N * Nk * C, lambda: call('cmda_attention_bwd', ptr(q), ptr(kv), ptr(do), ptr(dq), ptr(dkv32), ptr(dkv16),
                                                       ptr(stats), c_i32(B), c_i32(N), c_i32(Nk), c_i32(heads), c_i32(C), c_f32(scale),
-                                                      dtype_tag(q), stream_of(q)))
+                                                      _attn_tag(q), stream_of(q)))
     return dq
 
 

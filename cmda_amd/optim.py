@@ -92,6 +92,8 @@ class FlatAdamW:
 
     def sync_bf16(self):
         """Refresh the bf16 copies after the masters were written by anything but step() (e.g. load_state_dict)."""
+        if hasattr(self, 'segments'):
+            self.synchronize()
         if self.flat_bf16 is not None:
             ops.permute4(self.flat_p, self.flat_bf16, (self.flat_p.numel(), 1, 1, 1), (0, 1, 2, 3))
 
@@ -134,24 +136,51 @@ class FlatAdamW:
         s.wait_stream(torch.cuda.current_stream(self.flat_p.device))
         return torch.cuda.stream(s)
 
+    def flush(self):
+        """launch what an overlapped `step()` / `zero_grad()` postponed (no-op otherwise) -- on the update stream, behind everything the
+        calling stream has enqueued so far.  The postponement exists for ONE reason: the captured DACS iteration stages its inputs
+        (~60 MB of device copies) right after the step boundary, and next to AdamW's 5 TB/s stream those copies took 0.9 ms instead
+        of 0.06 and held back the whole iteration (kernel trace, round 6); uda.DACS.forward_train enqueues the copies first, then flushes."""
+        todo, self._todo = getattr(self, '_todo', None), None
+        if not todo:
+            return
+        with self._on_update_stream():
+            for what, arg in todo:
+                if what == 'step':
+                    self._launch_step(arg)
+                else:
+                    self.flat_g.zero_()
+
     def synchronize(self):
-        """order the current stream behind the overlapped update (no-op otherwise)"""
+        """order the current stream behind the overlapped update, launching it first if it is still postponed (no-op otherwise)"""
+        self.flush()
         if self.overlap and self.flat_p.is_cuda and getattr(self, '_update_stream', None) is not None:
             torch.cuda.current_stream(self.flat_p.device).wait_stream(self._update_stream)
 
+    def _postpone(self):
+        return self.overlap and self.flat_p.is_cuda and not torch.cuda.is_current_stream_capturing()
+
     def zero_grad(self):
+        if self._postpone() and getattr(self, '_todo', None):   # behind a postponed step: AdamW reads these gradients first
+            self._todo.append(('zero', None))
+            return
         with self._on_update_stream():
             self.flat_g.zero_()
 
+    def _launch_step(self, args):
+        lr_scale, step_count = args
+        for start, end, lm, dm in self.segments:
+            ops.adamw_step(self.flat_p[start:end], self.flat_g[start:end], self.flat_m[start:end], self.flat_v[start:end],
+                           self.lr * lm * lr_scale, self.betas[0], self.betas[1], self.eps, self.weight_decay * dm,
+                           step_count, p_bf16=self.flat_bf16[start:end] if self.flat_bf16 is not None else None)
+
     def step(self, lr_scale=1.0):
         self.step_count += 1
-        with self._on_update_stream():
-            for start, end, lm, dm in self.segments:
-                ops.adamw_step(self.flat_p[start:end], self.flat_g[start:end], self.flat_m[start:end], self.flat_v[start:end],
-                               self.lr * lm * lr_scale, self.betas[0], self.betas[1], self.eps, self.weight_decay * dm,
-                               self.step_count, p_bf16=self.flat_bf16[start:end] if self.flat_bf16 is not None else None)
+        if self._postpone():
+            self._todo = (getattr(self, '_todo', None) or []) + [('step', (lr_scale, self.step_count))]
+        else:
+            self._launch_step((lr_scale, self.step_count))
         rt.invalidate()
-
 
     # -- torch.optim.AdamW-compatible state (the layout mmcv's CheckpointHook saves and runner.resume restores) ----------------
     def _slot(self, p):
@@ -180,6 +209,7 @@ class FlatAdamW:
 
     def load_state_dict(self, sd):
         """restores the Adam moments and the step count (same parameter order as state_dict / torch.optim.AdamW)"""
+        self.synchronize()
         steps = set()
         with torch.no_grad():
             for i, p in enumerate(self._order):

@@ -596,11 +596,17 @@ class DACS(nn.Module):
         cb = self._control_block(dev, B, H, W)
         self._stage(cb, draws)
         opt = getattr(self, '_opt', None)
-        with (opt._on_update_stream() if opt is not None else _null_ctx()):   # overlapped update: the EMA follows AdamW on ITS stream
-            if self.local_iter == 0:
-                self._init_ema_weights()
-            if self.local_iter > 0:
-                self._update_ema(self.local_iter)
+
+        def boundary():
+            """the step boundary's device work that precedes this iteration: the (possibly postponed) optimizer update, then the EMA
+            teacher update -- with an overlapped update both on the optimizer's stream"""
+            if opt is not None:
+                opt.flush()
+            with (opt._on_update_stream() if opt is not None else _null_ctx()):
+                if self.local_iter == 0:
+                    self._init_ema_weights()
+                if self.local_iter > 0:
+                    self._update_ema(self.local_iter)
         if tt == 'cs2dz_image+raw-isr':
             second = tgt['warp_img_self_res'] if 'warp_image' in tgt else tgt['night_isr']
         else:
@@ -617,8 +623,11 @@ class DACS(nn.Module):
                 self._graphs = {}
             if key not in self._graphs:
                 # (first replay, another launch structure, or another batch shape: the captured launches are shape-specific)
+                boundary()
+                boundary = lambda: None   # noqa: E731  (done: the capture synchronises the device)
                 self._capture(src, tgt, cb, struct_events, ndir_key)
             G = self._graph = self._graphs[key]
+            # the inputs are staged FIRST, the step boundary's HBM-bound passes (AdamW, EMA) are enqueued behind them on their own stream
             for k, v in G['src'].items():
                 if v.data_ptr() != src[k].data_ptr():
                     v.copy_(src[k])
@@ -626,9 +635,11 @@ class DACS(nn.Module):
                 if v.data_ptr() != tgt[k].data_ptr():
                     v.copy_(tgt[k])
             G['second'].copy_(second)
+            boundary()
             G['graph'].replay()
             log_vars, extras = G['out']
         else:
+            boundary()
             if opt is not None:
                 opt.synchronize()   # eager launches: everything behind the (possibly overlapped) update
             log_vars, extras = self._iteration(src, tgt, cb['d'], struct_events, second, ndir_key)

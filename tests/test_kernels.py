@@ -341,6 +341,54 @@ def test_fused_attention(tgt, B, N, Nk, heads):
         assert_close(dkv16, kvr.grad, 2e-2, name='attention dkv (direct)')
 
 
+@pytest.mark.parametrize('B,N,Nk,heads', [(1, 64, 256, 1), (2, 200, 256, 2), (1, 70, 37, 1), (1, 300, 130, 5), (2, 1100, 256, 1)])
+def test_fused_attention_split_bf16(tgt, B, N, Nk, heads):
+    """the split-bf16 instances of the fused attention kernels (fp32 storage, three bf16 MFMAs per product: the tolerance-meeting
+    mode's mix_transformer.py:97-101): forward, dq, dK | dV in the accumulating and the direct form, against fp32 autograd -- the
+    error of ~16 mantissa bits per product, two orders below the bf16 kernels'"""
+    if B * N > 1500 and tgt.device.type != 'cuda':
+        pytest.skip('query counts beyond the direct mode: GPU only (emulator run time)')
+    torch.manual_seed(N + Nk)
+    C, scale = heads * 64, 0.125
+    q, kv, do = torch.randn(B * N, C), torch.randn(B * Nk, 2 * C), torch.randn(B * N, C)
+    qr, kvr = q.clone().requires_grad_(True), kv.clone().requires_grad_(True)
+    ref = _attention_ref(qr, kvr, B, N, Nk, heads, C, scale)
+    ref.backward(do)
+    qd, kvd, dod = tgt.to(q), tgt.to(kv), tgt.to(do)
+    assert ops.attention_fused_ok(qd, Nk, heads, C, x3=True) and not ops.attention_fused_ok(qd, Nk, heads, C)
+    o = ops.attention_fused_fwd(qd, kvd, B, N, Nk, heads, C, scale)
+    assert o.dtype == torch.float32
+    assert_close(o, ref.detach(), 1e-4, name='split-bf16 attention o')
+    dkv = torch.zeros(B * Nk, 2 * C, device=tgt.device)
+    dq = ops.attention_fused_bwd(qd, kvd, dod, dkv, B, N, Nk, heads, C, scale)   # accumulating form: fp32 atomics
+    assert_close(dq, qr.grad, 2e-4, name='split-bf16 attention dq')
+    assert_close(dkv, kvr.grad, 2e-4, name='split-bf16 attention dkv')
+    if ops.attention_bwd_direct(B, N, Nk, heads):   # few queries: one block per key slice stores dK | dV (fp32)
+        dkv2 = torch.full((B * Nk, 2 * C), float('nan'), device=tgt.device)
+        dq2 = ops.attention_fused_bwd(qd, kvd, dod, None, B, N, Nk, heads, C, scale, dkv16=dkv2)
+        assert_close(dq2, qr.grad, 2e-4, name='split-bf16 attention dq (direct)')
+        assert_close(dkv2, kvr.grad, 2e-4, name='split-bf16 attention dkv (direct)')
+    # through the block-level composite: runtime.gemm_x3 routes fp32 storage to these kernels; same result as the unfused products
+    from cmda_amd import nn as K
+    import cmda_amd.runtime as rt
+    rt.set_compute_dtype(torch.float32)
+    rt.set_gemm_x3(True)
+    try:
+        o1, P1 = K.attention_fwd(qd, kvd, B, N, Nk, heads, C, scale)
+        assert P1 is None
+        dq1, dkv1 = K.attention_bwd(dod, qd, kvd, None, B, N, Nk, heads, C, scale)
+        ops.ATTN_X3_OFF = True
+        o2, P2 = K.attention_fwd(qd, kvd, B, N, Nk, heads, C, scale)
+        assert P2 is not None
+        dq2, dkv2 = K.attention_bwd(dod, qd, kvd, P2, B, N, Nk, heads, C, scale)
+    finally:
+        ops.ATTN_X3_OFF = False
+        rt.set_gemm_x3(False)
+    assert_close(o1, o2, 1e-4, name='fused vs unfused split-bf16 attention')
+    assert_close(dq1, dq2, 2e-4, name='fused vs unfused split-bf16 dq')
+    assert_close(dkv1, dkv2, 2e-4, name='fused vs unfused split-bf16 dkv')
+
+
 @pytest.mark.parametrize('B,N,Nk,heads', [(1, 1120, 280, 2), (2, 280, 260, 5), (1, 70, 320, 8), (1, 300, 257, 1)])
 def test_fused_attention_eval_keys(tgt, B, N, Nk, heads):
     """inference on 440 x 640 frames leaves 260 / 280 keys after the spatial reduction (encoder_decoder.py:897-936, mix_transformer.py
