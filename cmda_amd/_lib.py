@@ -70,7 +70,7 @@ def _load():
             '(python -c "import __graft_entry__ as g; g.build()" or `make hip`). '
             'cmda_amd has no CPU fallback.')
     _lib = _declare(ctypes.CDLL(_LIB_PATH))
-    if _lib.cmda_abi_version() != 7:
+    if _lib.cmda_abi_version() != 8:
         raise CmdaError('libcmda_hip.so ABI version mismatch')
     return _lib
 

@@ -161,7 +161,9 @@ int cmda_layernorm_slots(void);
 int cmda_softmax_fwd(void* s, int64_t rows, int L, float alpha, int dtype, void* stream);
 int cmda_softmax_bwd(const void* p, void* dp, int64_t rows, int L, float alpha, int dtype, void* stream);
 
-/* ---- Fused attention core (bf16, head_dim 64, Nk <= 256) -- Attention.forward mix_transformer.py:86-103:
+/* ---- Fused attention core (head_dim 64, Nk <= 256; dtype CMDA_BF16, or -- ABI 8 -- CMDA_F32X3: q / kv / o / d_o / dq fp32, every
+ * product as three bf16 MFMAs on split operands, K / V held as hi + lo bf16 images in LDS; the direct-mode dK | dV buffer `dkv16` is
+ * then fp32 as well) -- Attention.forward mix_transformer.py:86-103:
  * softmax(q k^T * scale) v per (batch, head) without materialising the [N, Nk] scores.  q [B*N, C] (head h = columns
  * 64h..), kv [B*Nk, 2C] (K at column 64h, V at C + 64h), o [B*N, C].  bwd recomputes the probabilities; dq [B*N, C] is
  * written, dkv32 [B*Nk, 2C] fp32 is ACCUMULATED into (atomics; caller zeroes).  CMDA_ERR_UNSUPPORTED outside these

@@ -21,7 +21,7 @@ def test_header_symbols_exported_by_hip_library():
     assert len(syms) >= 33
     for s in syms:
         assert hasattr(lib, s), f'{s} declared in include/cmda_hip.h but not exported'
-    assert lib.cmda_abi_version() == 7
+    assert lib.cmda_abi_version() == 8
 
 
 def test_every_exported_entry_point_is_declared():
