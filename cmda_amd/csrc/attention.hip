@@ -445,7 +445,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_dkv_kernel(
 // the outputs are stored as fp32.
 struct AttnX3Params {
   const float* q;
-  const float* kv;
+  const bf16_t* kvh;   // kv split ONCE in HBM by the caller (cmda_split_bf16): every query block of a (batch, head) reads the same K / V,
+  const bf16_t* kvl;   // and converting the 128 KB per block in registers cost as much as the block's MFMAs (first version: 116.4 against 116.8 ms)
   float* o;
   int B, N, Nk, heads, C;
   float scale;
@@ -568,10 +569,12 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_x3_kernel(AttnX3Params p) {
   const unsigned lb = xcd_logical_block(), bh = lb / nqb;
   const long qblk = lb - bh * nqb;
   const int h = (int)(bh % (unsigned)p.heads), b = (int)(bh / (unsigned)p.heads);
-  const float* kbase = p.kv + (long)b * p.Nk * 2 * p.C + h * kHD;
+  const long koff = (long)b * p.Nk * 2 * p.C + h * kHD;
   const int nt = (p.Nk + 15) >> 4;
-  load_split_tile(kbase, 2L * p.C, p.Nk, 16 * nt, sKh, sKl, tid, 256);
-  load_split_tile(kbase + p.C, 2L * p.C, p.Nk, ((16 * nt + 31) >> 5) << 5, sVh, sVl, tid, 256);   // (the P V loop reads key tiles in pairs)
+  load_kv_tile(p.kvh + koff, 2 * p.C, p.Nk, sKh, wid, lane, 4);
+  load_kv_tile(p.kvl + koff, 2 * p.C, p.Nk, sKl, wid, lane, 4);
+  load_kv_tile(p.kvh + koff + p.C, 2 * p.C, p.Nk, sVh, wid, lane, 4);
+  load_kv_tile(p.kvl + koff + p.C, 2 * p.C, p.Nk, sVl, wid, lane, 4);
   __syncthreads();
   const float* qb = p.q + (long)b * p.N * p.C + h * kHD;
   float* ob = p.o + (long)b * p.N * p.C + h * kHD;
@@ -608,7 +611,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_x3_kernel(AttnX3Params p) {
 
 struct AttnBwdX3Params {
   const float* q;
-  const float* kv;
+  const bf16_t* kvh;
+  const bf16_t* kvl;
   const float* d_o;
   float* dq;
   float* dkv32;    // accumulate mode: fp32 atomics (zero on entry)
@@ -630,11 +634,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(AttnBwdX3Params 
   const unsigned lb = xcd_logical_block(), bh = lb / nqb;
   const long qblk = lb - bh * nqb;
   const int h = (int)(bh % (unsigned)p.heads), b = (int)(bh / (unsigned)p.heads);
-  const float* kbase = p.kv + (long)b * p.Nk * 2 * p.C + h * kHD;
+  const long koff = (long)b * p.Nk * 2 * p.C + h * kHD;
   const int nt = (p.Nk + 15) >> 4;
-  const int rows = ((16 * nt + 31) >> 5) << 5;   // (the dQ loop reads key tiles of K in pairs)
-  load_split_tile(kbase, 2L * p.C, p.Nk, rows, sKh, sKl, tid, 256);
-  load_split_tile(kbase + p.C, 2L * p.C, p.Nk, 16 * nt, sVh, sVl, tid, 256);
+  load_kv_tile(p.kvh + koff, 2 * p.C, p.Nk, sKh, wid, lane, 4);
+  load_kv_tile(p.kvl + koff, 2 * p.C, p.Nk, sKl, wid, lane, 4);
+  load_kv_tile(p.kvh + koff + p.C, 2 * p.C, p.Nk, sVh, wid, lane, 4);
+  load_kv_tile(p.kvl + koff + p.C, 2 * p.C, p.Nk, sVl, wid, lane, 4);
   __syncthreads();
   const long rowb = (long)b * p.N;
   const float* qb = p.q + rowb * p.C + h * kHD;
@@ -713,9 +718,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(AttnBwdX3Params
   const int key0 = ks * kKS;
   if (key0 >= p.Nk) return;  // block-uniform: this slice holds no key
   const int nkeys = min(kKS, p.Nk - key0);
-  const float* kbase = p.kv + ((long)b * p.Nk + key0) * 2 * p.C + h * kHD;
-  load_split_tile(kbase, 2L * p.C, nkeys, kKS, sKh, sKl, tid, 64 * NW);
-  load_split_tile(kbase + p.C, 2L * p.C, nkeys, kKS, sVh, sVl, tid, 64 * NW);
+  const long koff = ((long)b * p.Nk + key0) * 2 * p.C + h * kHD;
+  for (int i = wid; i < kKS / 8; i += NW) {
+    const int row = 8 * i + (lane >> 3);
+    const int chunk = (lane & 7) ^ (row & 7);
+    const void* zero = static_cast<const void*>(g_attn_zero16);
+    const long so = koff + (long)row * 2 * p.C + chunk * 8;
+    const bool ok = row < nkeys;
+    glds16(ok ? static_cast<const void*>(p.kvh + so) : zero, reinterpret_cast<char*>(sKh) + i * 1024);
+    glds16(ok ? static_cast<const void*>(p.kvl + so) : zero, reinterpret_cast<char*>(sKl) + i * 1024);
+    glds16(ok ? static_cast<const void*>(p.kvh + so + p.C) : zero, reinterpret_cast<char*>(sVh) + i * 1024);
+    glds16(ok ? static_cast<const void*>(p.kvl + so + p.C) : zero, reinterpret_cast<char*>(sVl) + i * 1024);
+  }
   __syncthreads();
   const long rowb = (long)b * p.N;
   const float* qb = p.q + rowb * p.C + h * kHD;
@@ -839,18 +853,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(AttnBwdX3Params
 extern "C" int cmda_attention_fwd(const void* q, const void* kv, void* o, int B, int N, int Nk, int heads, int C,
                                   float scale, int dtype, void* stream) {
   if (B <= 0 || N <= 0) return CMDA_OK;
-  if (dtype != CMDA_BF16 && dtype != CMDA_F32X3) return CMDA_ERR_DTYPE;
+  if (dtype != CMDA_BF16) return CMDA_ERR_DTYPE;
   if (heads <= 0 || C != heads * kHD || Nk <= 0 || Nk > kMaxKFwd) return CMDA_ERR_UNSUPPORTED;
   if (heads > 65535 || B > 65535) return CMDA_ERR_SHAPE;
-  if (dtype == CMDA_F32X3) {   // fp32 storage, split-bf16 products: q / kv / o fp32; all keys as hi + lo images in LDS (<= 256)
-    if (Nk > kMaxK || (C & 3)) return CMDA_ERR_UNSUPPORTED;
-    const int qpb3 = (long)((N + 127) / 128) * heads * B < 256 ? 64 : 128;   // one workgroup per CU: 64 queries while the grid is under ~2 rounds
-    AttnX3Params p3{(const float*)q, (const float*)kv, (float*)o, B, N, Nk, heads, C, scale, qpb3};
-    const long nb3 = (long)((N + qpb3 - 1) / qpb3) * heads * B;
-    if (nb3 > 0x7fffffffL) return CMDA_ERR_SHAPE;
-    CMDA_LAUNCH(attn_fwd_x3_kernel, dim3((unsigned)nb3), dim3(256), 0, stream, p3);
-    CMDA_CHECK_LAUNCH();
-  }
   const int qpb = fwd_queries_per_block(B, N, heads);
   AttnParams p{(const bf16_t*)q, (const bf16_t*)kv, (bf16_t*)o, B, N, Nk, heads, C, scale, qpb};
   const long nblk = (long)((N + qpb - 1) / qpb) * heads * B;
@@ -876,28 +881,11 @@ extern "C" int cmda_attention_bwd_direct(int B, int N, int Nk, int heads) {
 extern "C" int cmda_attention_bwd(const void* q, const void* kv, const void* d_o, void* dq, float* dkv32, void* dkv16,
                                   float* stats, int B, int N, int Nk, int heads, int C, float scale, int dtype, void* stream) {
   if (B <= 0 || N <= 0) return CMDA_OK;
-  if (dtype != CMDA_BF16 && dtype != CMDA_F32X3) return CMDA_ERR_DTYPE;
+  if (dtype != CMDA_BF16) return CMDA_ERR_DTYPE;
   if (heads <= 0 || C != heads * kHD || Nk <= 0 || Nk > kMaxK) return CMDA_ERR_UNSUPPORTED;
   if (heads * 4 > 65535 || B > 65535) return CMDA_ERR_SHAPE;
   const bool direct = cmda_attention_bwd_direct(B, N, Nk, heads) != 0 && dkv16 != nullptr;
   if (!direct && dkv32 == nullptr) return CMDA_ERR_SHAPE;
-  if (dtype == CMDA_F32X3) {   // fp32 storage: q / kv / d_o / dq fp32; direct mode stores fp32 dK | dV into `dkv16`
-    if (C & 3) return CMDA_ERR_UNSUPPORTED;
-    const int fq3 = (long)((N + 127) / 128) * heads * B < 256 ? 64 : 128;
-    AttnBwdX3Params p3{(const float*)q, (const float*)kv, (const float*)d_o, (float*)dq, dkv32, direct ? (float*)dkv16 : nullptr, stats,
-                       B, N, Nk, heads, C, 0, scale, fq3, 1};
-    const long nb1 = (long)((N + fq3 - 1) / fq3) * heads * B;
-    if (nb1 > 0x7fffffffL) return CMDA_ERR_SHAPE;
-    CMDA_LAUNCH(attn_bwd_dq_x3_kernel, dim3((unsigned)nb1), dim3(256), 0, stream, p3);
-    const long slices3 = (long)B * heads * ((Nk + kKS - 1) / kKS);
-    long spans3 = direct ? 1 : std::max<long>(1, 256 / slices3);
-    long qpb3 = ((N + spans3 - 1) / spans3 + 127) / 128 * 128;
-    spans3 = (N + qpb3 - 1) / qpb3;
-    p3.q_per_block = (int)qpb3;
-    p3.spans = (int)spans3;
-    CMDA_LAUNCH(attn_bwd_dkv_x3_kernel, dim3((unsigned)(spans3 * heads * 4 * B)), dim3(256), 0, stream, p3);
-    CMDA_CHECK_LAUNCH();
-  }
   const int fqpb = fwd_queries_per_block(B, N, heads);
   AttnBwdParams p{(const bf16_t*)q, (const bf16_t*)kv, (const bf16_t*)d_o, (bf16_t*)dq, dkv32, direct ? (bf16_t*)dkv16 : nullptr, stats,
                   B, N, Nk, heads, C, 0, scale, fqpb};
@@ -919,3 +907,41 @@ extern "C" int cmda_attention_bwd(const void* q, const void* kv, const void* d_o
   else CMDA_LAUNCH(attn_bwd_dkv_kernel<4>, g2, dim3(256), 0, stream, p);
   CMDA_CHECK_LAUNCH();
 }
+
+// ---- split-bf16 instances (fp32 storage): q / o / d_o / dq / dK | dV fp32; kv_hi / kv_lo = cmda_split_bf16 of the fp32 [B*Nk, 2C] kv
+extern "C" int cmda_attention_fwd_x3(const float* q, const void* kv_hi, const void* kv_lo, float* o, int B, int N, int Nk, int heads, int C,
+                                     float scale, void* stream) {
+  if (B <= 0 || N <= 0) return CMDA_OK;
+  if (heads <= 0 || C != heads * kHD || Nk <= 0 || Nk > kMaxK || (C & 3)) return CMDA_ERR_UNSUPPORTED;
+  if (heads > 65535 || B > 65535) return CMDA_ERR_SHAPE;
+  const int qpb = (long)((N + 127) / 128) * heads * B < 256 ? 64 : 128;   // one workgroup per CU (128 KB of K / V images): 64 queries while the grid is under two rounds
+  AttnX3Params p{q, (const bf16_t*)kv_hi, (const bf16_t*)kv_lo, o, B, N, Nk, heads, C, scale, qpb};
+  const long nblk = (long)((N + qpb - 1) / qpb) * heads * B;
+  if (nblk > 0x7fffffffL) return CMDA_ERR_SHAPE;
+  CMDA_LAUNCH(attn_fwd_x3_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, p);
+  CMDA_CHECK_LAUNCH();
+}
+
+extern "C" int cmda_attention_bwd_x3(const float* q, const void* kv_hi, const void* kv_lo, const float* d_o, float* dq, float* dkv32,
+                                     float* dkv_direct, float* stats, int B, int N, int Nk, int heads, int C, float scale, void* stream) {
+  if (B <= 0 || N <= 0) return CMDA_OK;
+  if (heads <= 0 || C != heads * kHD || Nk <= 0 || Nk > kMaxK || (C & 3)) return CMDA_ERR_UNSUPPORTED;
+  if (heads * 4 > 65535 || B > 65535) return CMDA_ERR_SHAPE;
+  const bool direct = cmda_attention_bwd_direct(B, N, Nk, heads) != 0 && dkv_direct != nullptr;
+  if (!direct && dkv32 == nullptr) return CMDA_ERR_SHAPE;
+  const int fq = (long)((N + 127) / 128) * heads * B < 256 ? 64 : 128;
+  AttnBwdX3Params p{q, (const bf16_t*)kv_hi, (const bf16_t*)kv_lo, d_o, dq, dkv32, direct ? dkv_direct : nullptr, stats,
+                    B, N, Nk, heads, C, 0, scale, fq, 1};
+  const long nb1 = (long)((N + fq - 1) / fq) * heads * B;
+  if (nb1 > 0x7fffffffL) return CMDA_ERR_SHAPE;
+  CMDA_LAUNCH(attn_bwd_dq_x3_kernel, dim3((unsigned)nb1), dim3(256), 0, stream, p);
+  const long slices = (long)B * heads * ((Nk + kKS - 1) / kKS);
+  long spans = direct ? 1 : std::max<long>(1, 256 / slices);
+  long qpb = ((N + spans - 1) / spans + 127) / 128 * 128;
+  spans = (N + qpb - 1) / qpb;
+  p.q_per_block = (int)qpb;
+  p.spans = (int)spans;
+  CMDA_LAUNCH(attn_bwd_dkv_x3_kernel, dim3((unsigned)(spans * heads * 4 * B)), dim3(256), 0, stream, p);
+  CMDA_CHECK_LAUNCH();
+}
+

@@ -754,16 +754,26 @@ def attention_fused_ok(q, Nk, heads, C, need_grad=True, x3=False):
 ATTN_X3_OFF = os.environ.get('CMDA_ATTN_X3', '1') == '0'   # split-bf16 mode on the unfused GEMM + softmax path (same-box A/B)
 
 
-def _attn_tag(q):
-    """cmda dtype of the fused attention entry points: bf16, or CMDA_F32X3 for fp32 storage (the split-bf16 instances)"""
-    return c_i32(2) if q.dtype == torch.float32 else dtype_tag(q)
+def _kv_split(kv):
+    """hi / lo bf16 halves of an fp32 kv tensor, split ONCE per attention call (cmda_split_bf16) and kept on the tensor for the
+    backward pass, which reads the same kv"""
+    pair = getattr(kv, '_cmda_split', None)
+    if pair is None or pair[2] != kv._version:
+        hi, lo = split_bf16(kv)
+        pair = kv._cmda_split = (hi, lo, kv._version)
+    return pair[0], pair[1]
 
 
 def attention_fused_fwd(q, kv, B, N, Nk, heads, C, scale):
     check_dev(q, kv)
     o = torch.empty(B * N, C, dtype=q.dtype, device=q.device)
+    if q.dtype == torch.float32:   # split-bf16 instances (fp32 storage)
+        hi, lo = _kv_split(kv)
+        _attn_profile(4.0 * B * N * Nk * C, lambda: call('cmda_attention_fwd_x3', ptr(q), ptr(hi), ptr(lo), ptr(o), c_i32(B), c_i32(N),
+                                                         c_i32(Nk), c_i32(heads), c_i32(C), c_f32(scale), stream_of(q)))
+        return o
     _attn_profile(4.0 * B * N * Nk * C, lambda: call('cmda_attention_fwd', ptr(q), ptr(kv), ptr(o), c_i32(B), c_i32(N), c_i32(Nk),
-                                                     c_i32(heads), c_i32(C), c_f32(scale), _attn_tag(q), stream_of(q)))
+                                                     c_i32(heads), c_i32(C), c_f32(scale), dtype_tag(q), stream_of(q)))
     return o
 
 
@@ -777,9 +787,15 @@ def attention_fused_bwd(q, kv, do, dkv32, B, N, Nk, heads, C, scale, dkv16=None)
     check_dev(q, kv, do, dkv32, dkv16)
     dq = torch.empty(B * N, C, dtype=q.dtype, device=q.device)
     stats = torch.empty(B * N * heads * 2, dtype=torch.float32, device=q.device)
+    if q.dtype == torch.float32:   # split-bf16 instances: `dkv16` is then the fp32 dK | dV tensor of the direct mode
+        hi, lo = _kv_split(kv)
+        _attn_profile(10.0 * B * N * Nk * C, lambda: call('cmda_attention_bwd_x3', ptr(q), ptr(hi), ptr(lo), ptr(do), ptr(dq), ptr(dkv32),
+                                                          ptr(dkv16), ptr(stats), c_i32(B), c_i32(N), c_i32(Nk), c_i32(heads), c_i32(C),
+                                                          c_f32(scale), stream_of(q)))
+        return dq
     _attn_profile(10.0 * B * N * Nk * C, lambda: call('cmda_attention_bwd', ptr(q), ptr(kv), ptr(do), ptr(dq), ptr(dkv32), ptr(dkv16),
                                                       ptr(stats), c_i32(B), c_i32(N), c_i32(Nk), c_i32(heads), c_i32(C), c_f32(scale),
-                                                      _attn_tag(q), stream_of(q)))
+                                                      dtype_tag(q), stream_of(q)))
     return dq
 
 

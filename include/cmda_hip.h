@@ -161,9 +161,7 @@ int cmda_layernorm_slots(void);
 int cmda_softmax_fwd(void* s, int64_t rows, int L, float alpha, int dtype, void* stream);
 int cmda_softmax_bwd(const void* p, void* dp, int64_t rows, int L, float alpha, int dtype, void* stream);
 
-/* ---- Fused attention core (head_dim 64, Nk <= 256; dtype CMDA_BF16, or -- ABI 8 -- CMDA_F32X3: q / kv / o / d_o / dq fp32, every
- * product as three bf16 MFMAs on split operands, K / V held as hi + lo bf16 images in LDS; the direct-mode dK | dV buffer `dkv16` is
- * then fp32 as well) -- Attention.forward mix_transformer.py:86-103:
+/* ---- Fused attention core (bf16, head_dim 64, Nk <= 256) -- Attention.forward mix_transformer.py:86-103:
  * softmax(q k^T * scale) v per (batch, head) without materialising the [N, Nk] scores.  q [B*N, C] (head h = columns
  * 64h..), kv [B*Nk, 2C] (K at column 64h, V at C + 64h), o [B*N, C].  bwd recomputes the probabilities; dq [B*N, C] is
  * written, dkv32 [B*Nk, 2C] fp32 is ACCUMULATED into (atomics; caller zeroes).  CMDA_ERR_UNSUPPORTED outside these
@@ -176,6 +174,15 @@ int64_t cmda_attention_bwd_ws_floats(int B, int N, int heads);   /* size of `sta
 int cmda_attention_bwd_direct(int B, int N, int Nk, int heads);
 int cmda_attention_bwd(const void* q, const void* kv, const void* d_o, void* dq, float* dkv32, void* dkv16, float* stats, int B,
     int N, int Nk, int heads, int C, float scale, int dtype, void* stream);
+/* (ABI 8) the same three kernels for the SPLIT-bf16 mode (fp32 storage; every product as three bf16 MFMAs on hi / lo operands, the
+ * arithmetic of cmda_gemm with dtype CMDA_F32X3): mix_transformer.py:97-101 of the tolerance-meeting mode without the [N, Nk]
+ * probabilities in HBM.  q / o / d_o / dq fp32 [B*N, C]; kv_hi / kv_lo = cmda_split_bf16 of the fp32 kv [B*Nk, 2C] (split once by the
+ * caller: every query block of a (batch, head) reads the same K / V); dK | dV fp32: accumulated into dkv32 (zero on entry) or, in the
+ * direct mode of cmda_attention_bwd_direct, stored into dkv_direct.  head_dim 64, Nk <= 256, C % 4 == 0. */
+int cmda_attention_fwd_x3(const float* q, const void* kv_hi, const void* kv_lo, float* o, int B, int N, int Nk, int heads, int C,
+    float scale, void* stream);
+int cmda_attention_bwd_x3(const float* q, const void* kv_hi, const void* kv_lo, const float* d_o, float* dq, float* dkv32,
+    float* dkv_direct, float* stats, int B, int N, int Nk, int heads, int C, float scale, void* stream);
 
 /* ---- Depthwise 3x3 convolution, NHWC -- DWConv(+GELU) of MixFFN mix_transformer.py:37-44,443-455 and the dilated depthwise
  * half of the sep-ASPP decode_heads/sep_aspp_head.py:18-27.  `w` is tap-major fp32 [9][C]; dw (gradient) is [C][9]. */
