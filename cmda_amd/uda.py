@@ -380,9 +380,9 @@ class DACS(nn.Module):
         # Schedule.  The reference runs source step, teacher, mixing, mixed step one after the other (dacs.py:489-860), but the
         # only data dependencies are: mixing needs the teacher's pseudo-labels and the generator's events; the student's
         # gradients are the sum over both steps; its BatchNorm running statistics see the source step before the mixed step.
-        # So: teacher -> mixing, the generator queued on the side lane behind the teacher's event encoder, then the student ONCE over
-        # source + mixed samples (lane 'T' -- the teacher on its own lane -- exists as an option and is off: runtime.py).
-        # With the lanes switched off (eager launches) the same code simply runs in program order.
+        # Round-5 schedule (lane 'T' off): teacher -> mixing, the generator queued on the side lane behind the teacher's event encoder,
+        # then the student ONCE over source + mixed samples.  Default since round 6 (lanes 'T', 'Tenc', 'wq' on, uda.GRAPH_LANES): the
+        # EARLY-STUDENT schedule below.  With the lanes switched off (eager launches) the same code simply runs in program order.
 
         def teacher_labels():
             """teacher forward -> pseudo-labels -> ClassMix'd labels / weights (dacs.py:653-711, :716-771 for the targets)"""
