@@ -19,6 +19,7 @@ def main():
     torch.manual_seed(1234)
     dacs = bench.build_dacs(dev)
     opt = optim.FlatAdamW(dacs.model, lr=6e-5, weight_decay=0.01, custom_keys=bench.CUSTOM_KEYS)
+    opt.overlap = os.environ.get('CMDA_OPT_OVERLAP', '1') != '0'   # as bench.py: the step boundary on the optimizer's own stream
     dacs.attach_flat_store(opt)
     batches = [bench.synthetic_pairs(2, 512, 100 + i, dev) for i in range(4)]
     dacs.enable_graph(warmup_iters=2)
