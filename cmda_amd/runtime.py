@@ -456,7 +456,7 @@ def lane_enabled(name):
 # Lanes that REUSE another lane's stream (and with it its hardware queue: HIP has four by default and more cost dearly -- GPU_MAX_HW_QUEUES=8
 # ran the step at 82 ms against 53): the weight-gradient queues of the encoders' backward passes run on the streams the teacher's two
 # encoders used at the head of the iteration, which are joined and idle by then.
-LANE_ALIAS = {'main/wq': 'main/T', 'main/enc/wq': 'main/T/enc'}
+LANE_ALIAS = {'main/wq': 'main/T', 'main/enc/wq': 'main/T/enc', 'main/hw': 'main/T/enc'}
 
 
 class lane:
