@@ -456,7 +456,10 @@ def lane_enabled(name):
 # Lanes that REUSE another lane's stream (and with it its hardware queue: HIP has four by default and more cost dearly -- GPU_MAX_HW_QUEUES=8
 # ran the step at 82 ms against 53): the weight-gradient queues of the encoders' backward passes run on the streams the teacher's two
 # encoders used at the head of the iteration, which are joined and idle by then.
-LANE_ALIAS = {'main/wq': 'main/T', 'main/enc/wq': 'main/T/enc', 'main/hw': 'main/T/enc'}
+# (the decode head's weight gradients on such a queue from the start of the backward phase instead of in the image encoder's tail --
+# lane 'hw' aliased to main/T/enc -- measured 51.53-51.62 against 51.22-51.30 ms, three alternating runs: the 256 x 256-tile kernels
+# stall the encoders' chains, as in round 4; not aliased, not on)
+LANE_ALIAS = {'main/wq': 'main/T', 'main/enc/wq': 'main/T/enc'}
 
 
 class lane:
