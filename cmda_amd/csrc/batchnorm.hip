@@ -368,8 +368,14 @@ extern "C" int cmda_bn_train_fwd(const void* x, const float* gamma, const float*
   if ((C & 3) || (ldy & 3) || (coff & 3) || groups < 1 || groups > 8) return CMDA_ERR_SHAPE;
   BnOrder ord;
   for (int i = 0; i < 8; ++i) ord.g[i] = (order && i < groups) ? order[i] : i;
-  for (int i = 0; i < groups; ++i)
+  unsigned seen = 0;
+  for (int i = 0; i < groups; ++i) {
     if (ord.g[i] < 0 || ord.g[i] >= groups) return CMDA_ERR_SHAPE;
+    seen |= 1u << ord.g[i];
+  }
+  // with the statistics already in the workspace (ws_has_stats) the finalize pass is what hands it back ZEROED, group by group in
+  // `order`: a repeated group would leave another group's sums in place for the next layer on this lane (advisor finding, round 5)
+  if (ws_has_stats && seen != (1u << groups) - 1u) return CMDA_ERR_SHAPE;
   if (!ws_has_stats) cmda_zero_async(ws, sizeof(float) * (size_t)groups * (kBnSlots + 1) * 2 * C, stream);
   const int gx = (C / 4 + 63) / 64;
   const int rpb = rows_per_block(M * groups, gx);
@@ -397,8 +403,14 @@ extern "C" int cmda_bn_train_fwd2(const void* x, int x_dtype, const float* gamma
   if ((x_dtype != CMDA_F32 && x_dtype != CMDA_BF16) || (y_dtype != CMDA_F32 && y_dtype != CMDA_BF16)) return CMDA_ERR_DTYPE;
   BnOrder ord;
   for (int i = 0; i < 8; ++i) ord.g[i] = (order && i < groups) ? order[i] : i;
-  for (int i = 0; i < groups; ++i)
+  unsigned seen = 0;
+  for (int i = 0; i < groups; ++i) {
     if (ord.g[i] < 0 || ord.g[i] >= groups) return CMDA_ERR_SHAPE;
+    seen |= 1u << ord.g[i];
+  }
+  // with the statistics already in the workspace (ws_has_stats) the finalize pass is what hands it back ZEROED, group by group in
+  // `order`: a repeated group would leave another group's sums in place for the next layer on this lane (advisor finding, round 5)
+  if (ws_has_stats && seen != (1u << groups) - 1u) return CMDA_ERR_SHAPE;
   if (!ws_has_stats) cmda_zero_async(ws, sizeof(float) * (size_t)groups * (kBnSlots + 1) * 2 * C, stream);
   const int gx = (C / 4 + 63) / 64;
   const int rpb = rows_per_block(M * groups, gx);

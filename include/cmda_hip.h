@@ -96,7 +96,8 @@ typedef struct cmda_gemm_params_t {
   int32_t res_f32;
   /* colstats != NULL: column statistics of the OUTPUT fused into the epilogue -- the BatchNorm / InstanceNorm behind a convolution
    * (mmcv ConvModule conv -> norm, daformer_head.py:46-62, sep_aspp_head.py:18-27; cyclegan_model.py:339-434) no longer re-reads the
-   * activation for its batch statistics.  For every stored element v = C[m][n] (as computed, before rounding to the storage type):
+   * activation for its batch statistics.  For every stored element v = C[m][n] (the general epilogue and the dilated depthwise walk take the value as computed, before rounding to
+   * the storage type; the 256 x 256 ping-pong kernel takes the rounded bf16 value it stores -- the statistics differ by one rounding of the inputs):
    * colstats[g][slot][0][n] += v and colstats[g][slot][1][n] += v * v with g = m / colstats_rows and an arbitrary slot < 32, i.e. the
    * layout of the BatchNorm workspace (groups x cmda_bn_ws_floats(N) floats, ZERO on entry); cmda_bn_train_fwd / fwd2 with
    * ws_has_stats = 1 finish the normalisation from it.  Requires: forward form (A, B not K-strided outputs of atomics: atomic == 0,

@@ -177,6 +177,11 @@ def test_gemm_fused_column_statistics(tgt, dt, tag, tol, hint):
             for i, nm in enumerate(('y', 'mean', 'rstd', 'running_mean', 'running_var')):
                 assert_close(outs[0][i], outs[1][i], st_tol if i else max(st_tol, tol), atol=st_tol, name=f'BatchNorm from epilogue statistics: {nm}')
             assert ws.abs().max().item() == 0.0, 'the workspace comes back zeroed'
+            # a group order that is not a permutation would leave a group's sums in the workspace: refused when the workspace carries them
+            from cmda_amd._lib import CmdaError
+            with pytest.raises(CmdaError):
+                ops.bn_train_fwd(out, g, be, torch.empty_like(out), torch.zeros(N, device=tgt.device), torch.ones(N, device=tgt.device), rpg, N,
+                                 1e-5, 0.1, True, groups=groups, order=[2, 0, 0], stats_ws=ws)
     finally:
         ops.GEMM_TILE_HINT = prev
 
