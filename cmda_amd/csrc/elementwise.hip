@@ -629,13 +629,26 @@ extern "C" int cmda_copy2d(const void* src, void* dst, int64_t rows, int cols, i
   CMDA_CHECK_LAUNCH();
 }
 
+// Grid cap of the parameter-state passes (EMA, AdamW).  They stream at the HBM rate with far fewer workgroups than wave slots; what
+// the cap decides is how much of the chip is left to kernels of OTHER streams meanwhile: with 4096 grid-stride workgroups every wave slot
+// of every CU was held for the whole pass, and the mixing kernels / the generator's first convolutions that the overlapped step
+// boundary runs beside them (optim.FlatAdamW.overlap) took 4-40 x their time (kernel trace, round 6: class_mix 531 us against 14).
+static long stream_pass_blocks() {
+  static const long v = [] {
+    const char* e = getenv("CMDA_STREAM_BLOCKS");
+    const long b = e ? atol(e) : 1024;
+    return b > 0 ? b : 1024;
+  }();
+  return v;
+}
+
 extern "C" int cmda_ema_update(float* ema, const float* param, float alpha, int64_t n, void* ema_bf16, void* stream) {
   if (n <= 0) return CMDA_OK;
   // (non-temporal accesses: 243 -> 195 us over 85 M parameters, AdamW 472 -> 454; tools/hbm_bench.py, gpurun r04 A/B)
   static const bool nt = getenv("CMDA_STREAM_TEMPORAL") == nullptr;
-  if (nt) CMDA_LAUNCH(ema_kernel<true>, dim3((unsigned)std::max<long>(1, std::min<long>((n + 2047) / 2048, 4096))), dim3(256), 0, stream, ema, param, alpha,
+  if (nt) CMDA_LAUNCH(ema_kernel<true>, dim3((unsigned)std::max<long>(1, std::min<long>((n + 2047) / 2048, stream_pass_blocks()))), dim3(256), 0, stream, ema, param, alpha,
               (long)n, (bf16_t*)ema_bf16);
-  else CMDA_LAUNCH(ema_kernel<false>, dim3((unsigned)std::max<long>(1, std::min<long>((n + 2047) / 2048, 4096))), dim3(256), 0, stream, ema, param, alpha,
+  else CMDA_LAUNCH(ema_kernel<false>, dim3((unsigned)std::max<long>(1, std::min<long>((n + 2047) / 2048, stream_pass_blocks()))), dim3(256), 0, stream, ema, param, alpha,
               (long)n, (bf16_t*)ema_bf16);
   CMDA_CHECK_LAUNCH();
 }
@@ -650,10 +663,10 @@ extern "C" int cmda_adamw_step(float* p, const float* g, float* m, float* v, voi
   const long n4 = aligned ? n / 4 : 0;
   static const bool nt = getenv("CMDA_STREAM_TEMPORAL") == nullptr;   // (A/B switch: plain loads / stores)
   if (n4 > 0 && nt)
-    CMDA_LAUNCH(adamw_vec_kernel<true>, dim3((unsigned)std::max<long>(1, std::min<long>((n4 + 511) / 512, 4096))), dim3(256), 0, stream, p, g, m,
+    CMDA_LAUNCH(adamw_vec_kernel<true>, dim3((unsigned)std::max<long>(1, std::min<long>((n4 + 511) / 512, stream_pass_blocks()))), dim3(256), 0, stream, p, g, m,
                 v, (bf16_t*)p_bf16, n4, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2));
   else if (n4 > 0)
-    CMDA_LAUNCH(adamw_vec_kernel<false>, dim3((unsigned)std::max<long>(1, std::min<long>((n4 + 511) / 512, 4096))), dim3(256), 0, stream, p, g, m,
+    CMDA_LAUNCH(adamw_vec_kernel<false>, dim3((unsigned)std::max<long>(1, std::min<long>((n4 + 511) / 512, stream_pass_blocks()))), dim3(256), 0, stream, p, g, m,
                 v, (bf16_t*)p_bf16, n4, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2));
   if (const long rest = n - 4 * n4) {
     bf16_t* pb = p_bf16 ? (bf16_t*)p_bf16 + 4 * n4 : nullptr;
