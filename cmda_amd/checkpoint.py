@@ -90,6 +90,11 @@ def save_checkpoint(model, filename, optimizer=None, meta=None):
     module = getattr(model, 'module', model)
     if hasattr(module, 'CLASSES') and module.CLASSES is not None:
         meta.setdefault('CLASSES', module.CLASSES)
+    if optimizer is not None and hasattr(optimizer, 'synchronize'):
+        optimizer.synchronize()   # an overlapped (postponed) update lands before the weights are read (optim.FlatAdamW.overlap)
+    opt_of_model = getattr(module, '_opt', None)
+    if opt_of_model is not None and opt_of_model is not optimizer and hasattr(opt_of_model, 'synchronize'):
+        opt_of_model.synchronize()
     ckpt = {'meta': meta, 'state_dict': weights_to_cpu(module.state_dict())}
     if optimizer is not None:
         if not hasattr(optimizer, 'state_dict'):
